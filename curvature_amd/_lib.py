@@ -1,0 +1,112 @@
+"""ctypes binding of ``libcurv_hip.so`` (the C ABI declared in ``include/curv_hip.h``).
+
+The shared library is built in-tree by :func:`build` (``hipcc --offload-arch=gfx950``) and loaded
+lazily by :func:`lib`.  There is no CPU fallback: if the library is missing or a call fails, a
+``RuntimeError`` is raised.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.normpath(os.path.join(_HERE, "..", "include"))
+LIB_PATH = os.path.join(CSRC, "libcurv_hip.so")
+SOURCES = ["api.cpp", "elementwise.hip", "syrk.hip"]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall",
+               "-Wno-unused-function"]
+
+_lock = threading.Lock()
+_lib = None
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
+    deps.append(os.path.join(INCLUDE, "curv_hip.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into ``csrc/libcurv_hip.so``; returns the library path."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + proc.stdout)
+    if verbose and proc.stdout:
+        print(proc.stdout)
+    return LIB_PATH
+
+
+class curv_factor_desc(ctypes.Structure):
+    """Mirror of ``curv_factor_desc`` in include/curv_hip.h."""
+    _fields_ = [
+        ("src", ctypes.c_void_p), ("dst", ctypes.c_void_p),
+        ("N", ctypes.c_int32), ("C", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+        ("kh", ctypes.c_int32), ("kw", ctypes.c_int32), ("sh", ctypes.c_int32), ("sw", ctypes.c_int32),
+        ("ph", ctypes.c_int32), ("pw", ctypes.c_int32),
+        ("has_bias", ctypes.c_int32), ("first", ctypes.c_int32),
+        ("scale", ctypes.c_float), ("reserved", ctypes.c_int32),
+    ]
+
+
+_vp, _i, _ll, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_double, ctypes.c_size_t
+
+# name -> (restype, argtypes); every symbol include/curv_hip.h declares
+SIGNATURES = {
+    "curv_version": (_i, []),
+    "curv_last_error": (ctypes.c_char_p, []),
+    "curv_kfac_workspace_bytes": (_sz, [ctypes.POINTER(curv_factor_desc), _i]),
+    "curv_kfac_plan_info": (_i, [ctypes.POINTER(curv_factor_desc), _i, ctypes.POINTER(ctypes.c_longlong)]),
+    "curv_kfac_accumulate": (_i, [_vp, ctypes.POINTER(curv_factor_desc), _i, _vp, _sz]),
+    "curv_rsqrt_affine": (_i, [_vp, _vp, _d, _d, _vp, _ll]),
+    "curv_sq_accumulate": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _i]),
+    "curv_clamp_min0": (_i, [_vp, _vp, _ll]),
+    "curv_sqrt_scale": (_i, [_vp, _vp, _d, _vp, _ll]),
+    "curv_mul": (_i, [_vp, _vp, _vp, _vp, _ll]),
+}
+
+
+def lib() -> ctypes.CDLL:
+    """Load the HIP library (once).  torch must be imported first so that both share one HIP runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        import torch  # noqa: F401  (binds libamdhip64.so.7 of the torch wheel before our DT_NEEDED resolves)
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if handle.curv_version() != 1:
+            raise RuntimeError("libcurv_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    """Turn a non-zero status of the C ABI into ``RuntimeError`` (error convention)."""
+    if status != 0:
+        msg = lib().curv_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libcurv_hip {what} failed with status {status}: {msg}")
+
+
+def stream_ptr() -> int:
+    """hipStream_t of torch's current stream, so our kernels are ordered after backward()."""
+    import torch
+    return int(torch.cuda.current_stream().cuda_stream)

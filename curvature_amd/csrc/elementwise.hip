@@ -1,0 +1,141 @@
+// HBM-bound elementwise kernels of the Diagonal / EFB / INF estimators.
+// Reference arithmetic: curvature/curvatures.py:141-193 (Diagonal), :431-434 (EFB diags),
+// :449 (EFB invert), :523-526 (INF invert).
+#include "common.h"
+#include "../../include/curv_hip.h"
+
+namespace curv {
+
+// One grid-stride sweep, 16 B per lane where alignment allows.
+static inline dim3 sweep_grid(long long count, int per_thread) {
+  long long blocks = cdivll(count, 256LL * per_thread);
+  if (blocks > 2048) blocks = 2048;   // 256 CUs x 8 blocks, grid-stride the rest
+  if (blocks < 1) blocks = 1;
+  return dim3((unsigned)blocks);
+}
+
+// (s*v + n)^(-1/2) with the reference's rounding sequence: mul, add, reciprocal, sqrt (no fma contraction).
+__device__ __forceinline__ float rsq_aff(float s, float v, float n) {
+  return __fsqrt_rn(__frcp_rn(__fadd_rn(__fmul_rn(s, v), n)));
+}
+
+// out[i] = (s * v[i] + n)^(-1/2)
+__global__ void __launch_bounds__(256)
+rsqrt_affine_kernel(const float* __restrict__ v, float s, float n, float* __restrict__ out,
+                    long long count) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool vec = ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (vec) {
+    const long long nvec = count >> 2;
+    const float4* v4 = reinterpret_cast<const float4*>(v);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    for (long long j = i; j < nvec; j += stride) {
+      float4 a = v4[j];
+      float4 r;
+      // reciprocal().sqrt() in the reference: 1/x then sqrt, both correctly rounded fp32
+      r.x = rsq_aff(s, a.x, n);
+      r.y = rsq_aff(s, a.y, n);
+      r.z = rsq_aff(s, a.z, n);
+      r.w = rsq_aff(s, a.w, n);
+      o4[j] = r;
+    }
+    for (long long j = (nvec << 2) + i; j < count; j += stride) out[j] = rsq_aff(s, v[j], n);
+  } else {
+    for (long long j = i; j < count; j += stride) out[j] = rsq_aff(s, v[j], n);
+  }
+}
+
+// state[r, c] (+)= bs * grad(r, c)^2 where grad = [gw (rows x cols_w) | gb (rows)] (bias column last).
+__global__ void __launch_bounds__(256)
+sq_accumulate_kernel(const float* __restrict__ gw, const float* __restrict__ gb, int rows, int cols_w,
+                     float bs, float* __restrict__ state, int first) {
+  const int cols = cols_w + (gb != nullptr ? 1 : 0);
+  const long long count = (long long)rows * cols;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+    const int r = (int)(j / cols);
+    const int c = (int)(j - (long long)r * cols);
+    const float g = (c < cols_w) ? gw[(long long)r * cols_w + c] : gb[r];
+    const float val = g * g * bs;
+    state[j] = first ? val : state[j] + val;
+  }
+}
+
+// v[i] = max(v[i], 0) in place (INF.invert clamps the correction term on `state`).
+__global__ void __launch_bounds__(256) clamp_min0_kernel(float* __restrict__ v, long long count) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+    const float a = v[j];
+    v[j] = a < 0.0f ? 0.0f : a;
+  }
+}
+
+// out[i] = sqrt(s * v[i])
+__global__ void __launch_bounds__(256)
+sqrt_scale_kernel(const float* __restrict__ v, float s, float* __restrict__ out, long long count) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride)
+    out[j] = sqrtf(s * v[j]);
+}
+
+// out[i] = a[i] * b[i]
+__global__ void __launch_bounds__(256)
+mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+           long long count) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride)
+    out[j] = a[j] * b[j];
+}
+
+}  // namespace curv
+
+using namespace curv;
+
+extern "C" int curv_rsqrt_affine(void* stream, const float* v, double s, double n, float* out,
+                                 long long count) {
+  CURV_REQUIRE(count >= 0, "curv_rsqrt_affine: negative count");
+  if (count == 0) return CURV_OK;
+  CURV_REQUIRE(v && out, "curv_rsqrt_affine: null pointer");
+  hipLaunchKernelGGL(rsqrt_affine_kernel, sweep_grid(count, 4), dim3(256), 0, (hipStream_t)stream, v,
+                     (float)s, (float)n, out, count);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}
+
+extern "C" int curv_sq_accumulate(void* stream, const float* grad_w, const float* grad_b, int rows,
+                                  int cols_w, double batch_size, float* state, int first) {
+  CURV_REQUIRE(rows >= 0 && cols_w >= 0, "curv_sq_accumulate: negative shape");
+  const long long count = (long long)rows * (cols_w + (grad_b ? 1 : 0));
+  if (count == 0) return CURV_OK;
+  CURV_REQUIRE(grad_w && state, "curv_sq_accumulate: null pointer");
+  hipLaunchKernelGGL(sq_accumulate_kernel, sweep_grid(count, 1), dim3(256), 0, (hipStream_t)stream,
+                     grad_w, grad_b, rows, cols_w, (float)batch_size, state, first);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}
+
+extern "C" int curv_clamp_min0(void* stream, float* v, long long count) {
+  if (count <= 0) return CURV_OK;
+  CURV_REQUIRE(v, "curv_clamp_min0: null pointer");
+  hipLaunchKernelGGL(clamp_min0_kernel, sweep_grid(count, 1), dim3(256), 0, (hipStream_t)stream, v, count);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}
+
+extern "C" int curv_sqrt_scale(void* stream, const float* v, double s, float* out, long long count) {
+  if (count <= 0) return CURV_OK;
+  CURV_REQUIRE(v && out, "curv_sqrt_scale: null pointer");
+  hipLaunchKernelGGL(sqrt_scale_kernel, sweep_grid(count, 1), dim3(256), 0, (hipStream_t)stream, v,
+                     (float)s, out, count);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}
+
+extern "C" int curv_mul(void* stream, const float* a, const float* b, float* out, long long count) {
+  if (count <= 0) return CURV_OK;
+  CURV_REQUIRE(a && b && out, "curv_mul: null pointer");
+  hipLaunchKernelGGL(mul_kernel, sweep_grid(count, 1), dim3(256), 0, (hipStream_t)stream, a, b, out, count);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}

@@ -1,0 +1,100 @@
+/*
+ * curv_hip.h -- C ABI of libcurv_hip.so, the gfx950 (MI355X) implementation of the KFAC / EFB / INF
+ * curvature hot path of DLR-RM/curvature.
+ *
+ * Every entry point is what a binding of the reference's `Curvature` plugin API would call for the
+ * arithmetic it performs today through torch (reference file:line cited per function, paths relative
+ * to the reference checkout).  Conventions:
+ *   - plain C types only; all tensors are dense row-major fp32 device buffers unless stated;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls only enqueue work and
+ *     never synchronise the device, so they are ordered after whatever produced their inputs on
+ *     that stream (e.g. torch's backward);
+ *   - the library owns no device memory: scratch comes from the caller (`*_workspace_bytes`);
+ *   - return value 0 = ok, otherwise a CURV_ERR_* code with text in curv_last_error();
+ *     numerical failure ("not positive definite") is reported through caller-provided device
+ *     `info` words so that a whole model can be processed without a host round trip per layer;
+ *   - re-entrant, no global mutable state besides the thread-local error string.
+ */
+#ifndef CURV_HIP_H
+#define CURV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CURV_ABI_VERSION 1
+
+#define CURV_OK 0
+#define CURV_ERR_NOT_PD 1
+#define CURV_ERR_INVALID 2
+#define CURV_ERR_WORKSPACE 3
+#define CURV_ERR_HIP 4
+
+int curv_version(void);
+const char* curv_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * KFAC factor build:  dst (+)= scale * X X^T           (curvature/curvatures.py:312-352)
+ *
+ * One descriptor per Kronecker factor.  X is never materialised: it is the implicit im2col of
+ * `src` (the reference's F.unfold at :329-330, rows ordered (c, kh, kw), columns (n, oh, ow)) plus,
+ * when `has_bias`, the row of ones the reference concatenates at :333-335.
+ *   A-side of Conv2d : src = layer input  (N,C,H,W), kernel/stride/padding of the layer,
+ *                      scale = 1/(N*Ho*Wo)
+ *   G-side of Conv2d : src = grad_output  (N,Cout,Ho,Wo) with kh=kw=1, stride 1, padding 0,
+ *                      has_bias = 0, scale = N/(Ho*Wo)   (the reference scales grad_output by N
+ *                      in its backward hook, :310, and divides by N*Ho*Wo at :343)
+ *   Linear           : src = (N,C) viewed as (N,C,1,1); A: scale = 1/N, G: scale = N
+ * `dst` is the (dim x dim) fp32 factor, dim = C*kh*kw + has_bias.  `first` != 0 overwrites dst
+ * (the reference's `self.state[layer] = [...]` at :350), 0 accumulates (`+=` at :347-348).
+ * The result is exactly symmetric.  Dilation and groups are not representable: the reference
+ * ignores them (:329), callers must reject such layers.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct curv_factor_desc {
+  const float* src;
+  float* dst;
+  int32_t N, C, H, W;
+  int32_t kh, kw, sh, sw, ph, pw;
+  int32_t has_bias;
+  int32_t first;
+  float scale;
+  int32_t reserved;
+} curv_factor_desc;
+
+/* Device scratch needed by curv_kfac_accumulate for this set of factors (bytes). */
+size_t curv_kfac_workspace_bytes(const curv_factor_desc* descs, int n_factors);
+
+/* Host-only introspection of the launch plan (tests, tuning): writes CURV_PLAN_INFO_FIELDS values per
+ * factor: dim, Ho, Wo, chunk samples, chunk rows, chunk cols, n_chunks, LDS row stride, plane stride,
+ * sample stride, channels per panel, n_tiles, chunks per item, k-slices, n_items, item_base. */
+#define CURV_PLAN_INFO_FIELDS 16
+int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors, long long* out);
+
+/* Grouped launch over all factors of a model (one SYRK launch + one reduce launch). `descs` is a
+ * host array; it may be reused as soon as the call returns. */
+int curv_kfac_accumulate(void* stream, const curv_factor_desc* descs, int n_factors, void* workspace,
+                         size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise pieces (Diagonal / EFB / INF)
+ * ---------------------------------------------------------------------------------------------- */
+/* out = (s*v + n)^(-1/2)     curvatures.py:188 (Diagonal.invert), :449 (EFB.invert), :526 (INF) */
+int curv_rsqrt_affine(void* stream, const float* v, double s, double n, float* out, long long count);
+/* state (+)= batch_size * [grad_w | grad_b]^2   curvatures.py:160-165 (Diagonal), :431-434 (EFB diags)
+ * grad_w is (rows x cols_w), grad_b (rows) or NULL; state is (rows x (cols_w + (grad_b != NULL))). */
+int curv_sq_accumulate(void* stream, const float* grad_w, const float* grad_b, int rows, int cols_w,
+                       double batch_size, float* state, int first);
+/* v = max(v, 0) in place      curvatures.py:523 */
+int curv_clamp_min0(void* stream, float* v, long long count);
+/* out = sqrt(s*v)             curvatures.py:525 */
+int curv_sqrt_scale(void* stream, const float* v, double s, float* out, long long count);
+/* out = a*b */
+int curv_mul(void* stream, const float* a, const float* b, float* out, long long count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CURV_HIP_H */

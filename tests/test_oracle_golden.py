@@ -1,0 +1,176 @@
+"""Pin the CPU oracle (oracle/curvature_oracle.py) against outputs of the reference itself.
+
+The golden vectors were produced by tools/make_golden.py importing /root/reference; see that script
+for what each file holds.  These tests run on CPU (`-m "not gpu"`)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle.curvature_oracle as o
+from conftest import rel_fro
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LENET_GEOM = [dict(kernel_size=(5, 5), stride=(1, 1), padding=(2, 2)),
+              dict(kernel_size=(5, 5), stride=(1, 1), padding=(0, 0)),
+              dict(kernel_size=None, stride=None, padding=None),
+              dict(kernel_size=None, stride=None, padding=None),
+              dict(kernel_size=None, stride=None, padding=None)]
+
+
+def load(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, name)).items()}
+
+
+def test_kron_doctest():
+    """The reference's only known-answer test (curvature/utils.py:301-309)."""
+    g = load("g10_kron.npz")
+    assert torch.equal(o.kron(g["a"], g["b"]), g["ab"])
+    assert torch.equal(g["ab"], torch.tensor([[0, 5, 0, 10], [6, 7, 12, 14], [0, 15, 0, 20], [18, 21, 24, 28]]))
+    assert torch.allclose(o.kron(g["c"], g["d"]), g["cd"], rtol=0, atol=0)
+
+
+def test_kfac_update_lenet():
+    g = load("g1_kfac_lenet.npz")
+    for li in range(5):
+        A = G = None
+        for b in range(3):
+            a, gg = o.kfac_factors(g[f"b{b}_l{li}_x"], g[f"b{b}_l{li}_g"], has_bias=True, **LENET_GEOM[li])
+            A, G = (a, gg) if A is None else (A + a, G + gg)
+            if b in (0, 2):
+                assert rel_fro(A, g[f"A_after{b + 1}_l{li}"]) < 1e-6
+                assert rel_fro(G, g[f"G_after{b + 1}_l{li}"]) < 1e-6
+
+
+def test_kfac_update_conv_shapes():
+    g = load("g2_kfac_convshapes.npz")
+    for li in range(5):
+        geom = dict(kernel_size=None, stride=None, padding=None)
+        if f"l{li}_geom" in g:
+            k = g[f"l{li}_geom"].tolist()
+            geom = dict(kernel_size=(k[0], k[1]), stride=(k[2], k[3]), padding=(k[4], k[5]))
+        A, G = o.kfac_factors(g[f"l{li}_x"], g[f"l{li}_g"], has_bias=bool(g[f"l{li}_bias"]), **geom)
+        assert rel_fro(A, g[f"l{li}_A"]) < 1e-6
+        assert rel_fro(G, g[f"l{li}_G"]) < 1e-6
+
+
+def test_diag_update_lenet():
+    g = load("g1_kfac_lenet.npz")
+    for li in range(5):
+        d = sum(o.diag_update(g[f"b{b}_l{li}_gw"], g[f"b{b}_l{li}_gb"], 8) for b in range(3))
+        assert rel_fro(d, g[f"diag_after3_l{li}"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_kfac_invert(tag):
+    g1, g3 = load("g1_kfac_lenet.npz"), load("g3_kfac_invert.npz")
+    hyper = {"a": (0.5, 1), "b": (1.0, 1000.0), "c": (g3["c_add"].tolist(), g3["c_mul"].tolist())}[tag]
+    for li in range(5):
+        n, s = o.layer_hyper(hyper[0], hyper[1], li, 5)
+        A, G = g1[f"A_after3_l{li}"], g1[f"G_after3_l{li}"]
+        LA, LG = o.kfac_invert(A, G, n, s)
+        # same LAPACK path as the reference -> agreement at fp32 rounding level
+        assert rel_fro(LA, g3[f"{tag}_LA_l{li}"]) < 2e-5
+        assert rel_fro(LG, g3[f"{tag}_LG_l{li}"]) < 2e-5
+        if tag in ("a", "b"):
+            LA64, LG64 = o.kfac_invert(A.double(), G.double(), n, s)
+            assert rel_fro(LA64, g3[f"{tag}64_LA_l{li}"]) < 1e-6
+            assert rel_fro(LG64, g3[f"{tag}64_LG_l{li}"]) < 1e-6
+
+
+def test_kfac_sample_and_replace():
+    g1, g3, g4 = load("g1_kfac_lenet.npz"), load("g3_kfac_invert.npz"), load("g4_kfac_sample.npz")
+    for li in range(5):
+        s = o.kfac_sample(g3[f"a_LA_l{li}"], g3[f"a_LG_l{li}"], g4[f"z_l{li}"])
+        assert rel_fro(s, g4[f"sample_l{li}"]) < 1e-6
+        w, b = o.replace(g4[f"sample_l{li}"], g1[f"w_l{li}"], g1[f"bias_l{li}"])
+        assert torch.equal(w, g4[f"w_new_l{li}"]) and torch.equal(b, g4[f"b_new_l{li}"])
+
+
+def test_eigenvectors_span():
+    """Eigenvectors are unique only up to sign / rotation inside degenerate clusters:
+    compare through residual and orthogonality, and through the invariant F U = U diag(w)."""
+    g1, g5 = load("g1_kfac_lenet.npz"), load("g5_eigvecs_lenet.npz")
+    for li in range(5):
+        for side, key in (("A", "UA"), ("G", "UG")):
+            F = g1[f"{side}_after3_l{li}"].double()
+            U = o.eigenvectors(F)
+            Ug = g5[f"{key}_l{li}"].double()
+            n = F.shape[0]
+            for V in (U, Ug):
+                assert torch.linalg.norm(V.t() @ V - torch.eye(n, dtype=V.dtype)) < 1e-4 * n ** 0.5
+                w = torch.diagonal(V.t() @ F @ V)
+                assert torch.linalg.norm(F @ V - V * w) < 1e-4 * torch.linalg.norm(F)
+
+
+def test_efb():
+    g1, g5, g6 = load("g1_kfac_lenet.npz"), load("g5_eigvecs_lenet.npz"), load("g6_efb_lenet.npz")
+    for li in range(5):
+        UA, UG = g5[f"UA_l{li}"], g5[f"UG_l{li}"]
+        lam = sum(o.efb_update(UA, UG, g1[f"b{b}_l{li}_gw"], g1[f"b{b}_l{li}_gb"]) for b in range(2))
+        dia = sum(o.diag_update(g1[f"b{b}_l{li}_gw"], g1[f"b{b}_l{li}_gb"], 8) for b in range(2))
+        assert rel_fro(lam, g6[f"lambda_l{li}"]) < 1e-5
+        assert rel_fro(dia, g6[f"diags_l{li}"]) < 1e-6
+        inv = o.rsqrt_affine(g6[f"lambda_l{li}"], 0.5, 2.0)
+        assert rel_fro(inv, g6[f"inv_l{li}"]) < 1e-6
+        s = o.efb_sample(UA, UG, g6[f"inv_l{li}"], g6[f"z_l{li}"])
+        assert rel_fro(s, g6[f"sample_l{li}"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag,rank", [("r10", 10), ("r100", 100), ("rall", 10 ** 9)])
+def test_inf_update(tag, rank):
+    g5, g6, g7 = load("g5_eigvecs_lenet.npz"), load("g6_efb_lenet.npz"), load("g7_inf_update.npz")
+    for li in range(5):
+        ua, ug, lam, D, I, J = o.inf_update(g5[f"UA_l{li}"], g5[f"UG_l{li}"], g6[f"lambda_l{li}"],
+                                            g6[f"diags_l{li}"], rank)
+        if I is None:
+            I, J = np.arange(ua.shape[1]), np.arange(ug.shape[1])
+        assert np.array_equal(I, g7[f"{tag}_I_l{li}"].numpy())       # bit-exact index sets
+        assert np.array_equal(J, g7[f"{tag}_J_l{li}"].numpy())
+        if f"{tag}_lam_l{li}" in g7:
+            assert torch.equal(lam, g7[f"{tag}_lam_l{li}"])
+        if f"{tag}_D_l{li}" in g7:
+            ref = g7[f"{tag}_D_l{li}"]
+            # D = d - sif_diag cancels heavily; compare against the scale of the minuend
+            scale = torch.linalg.norm(g6[f"diags_l{li}"].double())
+            assert float(torch.linalg.norm(D.double() - ref.double()) / scale) < 1e-5
+
+
+def test_inf_invert_and_sample():
+    g5, g7, g8, g9 = (load("g5_eigvecs_lenet.npz"), load("g7_inf_update.npz"), load("g8_inf_invert.npz"),
+                      load("g9_inf_sample.npz"))
+    add, mul = float(g8["add"]), float(g8["mul"])
+    for li in range(5):
+        I, J = g7[f"r10_I_l{li}"], g7[f"r10_J_l{li}"]
+        ua, ug = g5[f"UA_l{li}"][:, I], g5[f"UG_l{li}"][:, J]
+        Dc, sigma, r, vtv, Pc = o.inf_invert(ua, ug, g7[f"r10_lam_l{li}"], g7[f"r10_D_l{li}"], add, mul)
+        assert torch.equal(Dc, g8[f"Dclamped_l{li}"])
+        assert rel_fro(sigma, g8[f"sigma_l{li}"]) < 1e-6
+        assert rel_fro(r, g8[f"r_l{li}"]) < 1e-6
+        assert rel_fro(vtv, g8[f"vtv_l{li}"]) < 1e-5
+        # the fp32 chain (2 Cholesky + 3 inverses) is noisy in the reference itself: judge the fp32
+        # restatement loosely and the fp64 restatement against the reference's fp64 twin tightly
+        assert rel_fro(Pc, g8[f"Pc_l{li}"]) < 5e-3
+        out64 = o.inf_invert(ua.double(), ug.double(), g7[f"r10_lam_l{li}"].double(),
+                             g7[f"r10_D_l{li}"].double(), add, mul)
+        assert rel_fro(out64[4], g8[f"Pc64_l{li}"]) < 1e-5
+        s = o.inf_sampler(ua, ug, g8[f"r_l{li}"], g8[f"Pc_l{li}"], g9[f"X_l{li}"])
+        assert rel_fro(s, g9[f"sample_l{li}"]) < 1e-5
+
+
+def test_layer_tables_match_models():
+    """Layer order / (n, m, L) of the build's own model definitions == the reference's (bit-exact)."""
+    from curvature_amd import models
+    with open(os.path.join(GOLD, "g11_layer_tables.json")) as fh:
+        tables = json.load(fh)
+    specs = {"lenet5": (models.lenet5(), (1, 28, 28)), "resnet18": (models.resnet18(), (3, 224, 224)),
+             "resnet50": (models.resnet50(), (3, 224, 224))}
+    for name, (model, shape) in specs.items():
+        rows = models.layer_table(model, shape)
+        ref = tables[name]
+        assert len(rows) == len(ref)
+        for a, b in zip(rows, ref):
+            assert (a["index"], a["name"], a["kind"], a["n"], a["m"], a["L"], a["has_bias"]) == \
+                   (b["index"], b["name"], b["kind"], b["n"], b["m"], b["L"], b["has_bias"]), (name, a, b)
