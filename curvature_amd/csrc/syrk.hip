@@ -4,21 +4,24 @@
 //
 // Design (see DESIGN.md section "K1"):
 //   * one launch covers every Kronecker factor of a model.  The work list is implicit:
-//       item -> (factor, k-slice, upper-triangular 64x64 tile), decoded on the device from a
-//     small descriptor table, so nothing but that table is uploaded per call;
-//   * a workgroup stages the RAW activation patch of the channels its two 64-row panels touch in LDS
+//       item -> (factor, k-slice, upper-triangular tile), decoded on the device from a small
+//     descriptor table, so nothing but that table is uploaded per call;
+//   * a workgroup stages the RAW activation patch of the channels its two row panels touch in LDS
 //     (never the unfolded matrix: a 3x3 conv reads each input pixel once per chunk instead of nine
 //     times) and MFMA operands are gathered from the patch with per-lane addresses
 //       addr(i, k) = lane_base(i) + ktab[k],
 //     lane_base encodes (channel, kh, kw), ktab[k] encodes (sample, out row, out col) of the chunk;
 //     row/plane strides are padded so that 32 consecutive unfolded rows hit 32 distinct banks;
 //   * the bias row of ones and the zero padding rows are two constant LDS words;
-//   * the four waves of a workgroup split the K range of a chunk and each owns the full 64x64 tile as
-//     2x2 v_mfma_f32_32x32x2_f32 blocks (diagonal tiles skip the redundant lower-left block);
+//   * global loads of chunk t+1 are issued into registers before the MFMA loop of chunk t and written
+//     to LDS after it, so HBM/L2 latency hides under the matrix pipe; two workgroups per CU cover each
+//     other's LDS-store phases;
+//   * tile 64x64 (four waves split the K range of a chunk, each owning the full tile) for small or
+//     awkward dims, tile 128x128 (2x2 waves of 64x64) for large ones; every wave works on 2x2
+//     v_mfma_f32_32x32x2_f32 blocks and skips the redundant lower-left block on the diagonal;
 //   * partial tiles go to fp32 slabs and a second kernel sums the k-slices in a fixed order, applies
 //     the scale and adds into the factor and its mirror image: deterministic, exactly symmetric.
 #include "common.h"
-#include "../../include/curv_hip.h"
 
 #include <algorithm>
 #include <vector>
@@ -26,19 +29,22 @@
 namespace curv {
 
 constexpr int SYRK_THREADS = 256;
-constexpr int TM = 64;                 // tile edge (rows of X per panel)
 constexpr int XCD_GROUP = 32;          // consecutive items that share an XCD
 constexpr int KTAB_MAX = 1024;         // k values per chunk
 constexpr int ROWTAB_MAX = 512;        // patch rows per panel per chunk
-constexpr int PATCH_WORDS = 16384;     // both panels; also the 4 x (64x64) cross-wave reduce scratch
-constexpr int PANEL_WORDS = PATCH_WORDS / 2;
+constexpr int PANEL_WORDS = 8704;      // LDS words per panel patch
+constexpr int PATCH_WORDS = 2 * PANEL_WORDS;   // >= 4 x (64x64) cross-wave reduce scratch
+constexpr int STAGE_SLOTS = 32;        // staging registers per panel per lane (floats)
+constexpr int PANEL_SLOT_ELEMS = STAGE_SLOTS * SYRK_THREADS;   // padded patch elements per panel
 // LDS word offsets
 constexpr int ZERO_OFF = 0;
 constexpr int ONE_OFF = 1;
 constexpr int KTAB_OFF = 16;
 constexpr int ROWTAB_OFF = KTAB_OFF + KTAB_MAX;
 constexpr int PATCH_OFF = ROWTAB_OFF + 3 * ROWTAB_MAX;
-constexpr int SMEM_WORDS = PATCH_OFF + PATCH_WORDS;   // 18960 words = 75840 B -> 2 workgroups per CU
+constexpr int SMEM_WORDS = PATCH_OFF + PATCH_WORDS;   // 19984 words = 79936 B -> 2 workgroups per CU
+static_assert(PATCH_WORDS >= 4 * 64 * 64, "reduce scratch must fit the patch region");
+static_assert(2 * SMEM_WORDS * 4 <= 160 * 1024, "two workgroups per CU");
 
 struct FactorDev {
   const float* src;
@@ -49,29 +55,33 @@ struct FactorDev {
   int khkw;
   int rows, dim, has_bias;
   int compact;             // kh == kw == 1: patch holds only the sampled pixels
+  int vec4;                // flattened per-pixel factor with 16-B aligned rows: float4 staging
+  int TM;                  // tile edge: 64 or 128
   int NS, R, Wc;           // chunk extent: samples, output rows, output cols
   int n_rg, n_cg;          // chunk grid (rows, cols); samples outermost
   int n_chunks;
   int RS, PS, SS, nch;     // LDS strides in words, channels per panel
+  int cshift;              // log2 of the padded patch row length (lanes along x)
   int P, n_tiles;
   int cpi, n_slices;       // chunks per item, k-slices
   int item_base, n_items;
-  int tile_base;
+  int sub_base, n_sub;     // 64x64 sub-tiles for the reduce kernel
   int first;
   float scale;
   int pad0;
   long long slab_base;     // in floats
 };
+static_assert(sizeof(FactorDev) % 8 == 0, "FactorDev must be 8-byte granular");
 
 __device__ __forceinline__ int find_segment(const FactorDev* __restrict__ descs, int n_factors, int id,
-                                            bool by_tile) {
+                                            bool by_sub) {
   // largest f with base[f] <= id; bases are ascending.  One ballot per 64 factors.
   const int lane = threadIdx.x & 63;
   int count = 0;
   for (int f0 = 0; f0 < n_factors; f0 += 64) {
     const int f = f0 + lane;
     bool le = false;
-    if (f < n_factors) le = (by_tile ? descs[f].tile_base : descs[f].item_base) <= id;
+    if (f < n_factors) le = (by_sub ? descs[f].sub_base : descs[f].item_base) <= id;
     count += __popcll(__ballot(le));
   }
   return __builtin_amdgcn_readfirstlane(count - 1);
@@ -83,10 +93,14 @@ __device__ __forceinline__ void decode_tile(int t, int P, int& ti, int& tj) {
   tj = ti + t;
 }
 
-__global__ void __launch_bounds__(SYRK_THREADS, 2)
-syrk_patch_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_items,
-                  float* __restrict__ slabs) {
-  __shared__ __attribute__((aligned(16))) int smem[SMEM_WORDS];
+// Position and extent of one K chunk.
+struct Chunk {
+  int s0, ns, oh0, ra, ow0, wa, kc, npairs, rows_in, cols_in, ih_base, iw_base;
+};
+
+template <int TMv>
+__device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, float* __restrict__ slabs,
+                                          int* smem) {
   float* fs = reinterpret_cast<float*>(smem);
   int* ktab = smem + KTAB_OFF;
   int* rowtab = smem + ROWTAB_OFF;
@@ -97,48 +111,65 @@ syrk_patch_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_item
   const int r32 = lane & 31;
   const int h = lane >> 5;
 
-  // XCD-aware item order: workgroups that share an XCD (equal blockIdx % 8) take every 8th group of
-  // XCD_GROUP consecutive items, i.e. neighbouring tiles of one k-slice of one factor, so the panels
-  // they stage hit that XCD's L2, while every XCD still sees an even mix of all factors.
-  int item;
-  {
-    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
-    item = ((j / XCD_GROUP) * 8 + xcd) * XCD_GROUP + (j % XCD_GROUP);
-  }
-  if (item >= n_items) return;
-  const int f = find_segment(descs, n_factors, item, false);
-  const FactorDev& d = descs[f];
-
-  const int local = item - d.item_base;
   const int n_tiles = d.n_tiles;
   const int slice = local / n_tiles;
   const int tile = local - slice * n_tiles;
   int ti, tj;
   decode_tile(tile, d.P, ti, tj);
   const bool diag = (ti == tj);
-  const int i0 = ti * TM, j0 = tj * TM;
+  const int i0 = ti * TMv, j0 = tj * TMv;
+
+  // wave roles
+  const int wm = (TMv == 128) ? (wave >> 1) : 0;
+  const int wn = (TMv == 128) ? (wave & 1) : 0;
+  const int kfirst = (TMv == 128) ? 0 : wave;      // first k pair of this wave within a chunk
+  constexpr int KSTRIDE = (TMv == 128) ? 1 : 4;
+  const bool idle = (TMv == 128) && diag && wm == 1 && wn == 0;
+  const bool skip10 = diag && (wm == wn);          // 64x64 block on the diagonal: lower-left redundant
 
   const float* __restrict__ src = d.src;
   const int N = d.N, C = d.C, H = d.H, W = d.W;
   const int kh = d.kh, kw = d.kw, sh = d.sh, sw = d.sw, ph = d.ph, pw = d.pw;
   const int Ho = d.Ho, Wo = d.Wo, khkw = d.khkw, rows = d.rows, has_bias = d.has_bias;
-  const int compact = d.compact;
+  const int compact = d.compact, vec4 = d.vec4;
   const int NS = d.NS, R = d.R, Wc = d.Wc, n_rg = d.n_rg, n_cg = d.n_cg, n_chunks = d.n_chunks;
-  const int RS = d.RS, PS = d.PS, SS = d.SS, nch = d.nch;
+  const int RS = d.RS, PS = d.PS, SS = d.SS, nch = d.nch, cshift = d.cshift;
   const int HW = H * W;
 
   const int c_lo_i = i0 / khkw, c_lo_j = j0 / khkw;
-  const int off_i = 0, off_j = diag ? 0 : PANEL_WORDS;
+  const int nch_i = min(nch, C - c_lo_i), nch_j = min(nch, C - c_lo_j);
+  const int off_j = diag ? 0 : PANEL_WORDS;
+  const int n_panels = diag ? 1 : 2;
+
+  const int cy = compact ? RS : sh * RS;     // LDS step per output row / col
+  const int cx = compact ? 1 : sw;
+  const int gy = compact ? sh : 1;           // source step per patch row / col
+  const int gx = compact ? sw : 1;
+
+  // full-chunk patch extent (tables are built for it once; ragged chunks mask the excess)
+  const int rows_in_full = compact ? R : (R - 1) * sh + kh;
+  const int total_rows_full = NS * nch * rows_in_full;
 
   if (tid == 0) { fs[ZERO_OFF] = 0.0f; fs[ONE_OFF] = 1.0f; }
+  if (!vec4) {
+    for (int p = tid; p < total_rows_full; p += SYRK_THREADS) {
+      const int y = p % rows_in_full;
+      const int t2 = p / rows_in_full;
+      const int cc = t2 % nch;
+      const int s = t2 / nch;
+      rowtab[3 * p + 0] = s * SS + cc * PS + y * RS;
+      rowtab[3 * p + 1] = (s * C + cc) * HW + y * gy * W;
+      rowtab[3 * p + 2] = (s << 24) | (cc << 16) | y;
+    }
+  }
 
-  // Per-lane operand rows: A0/A1 = panel i rows r32, 32 + r32; B0/B1 = panel j.
+  // Per-lane operand rows: A0/A1 = panel i rows (64 wm) + r32, + 32; B0/B1 = panel j rows (64 wn) + ...
   int base[4], kmask[4];
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
-    const int i = ((o < 2) ? i0 : j0) + (o & 1) * 32 + r32;
+    const int i = ((o < 2) ? i0 + 64 * wm : j0 + 64 * wn) + (o & 1) * 32 + r32;
     const int c_lo = (o < 2) ? c_lo_i : c_lo_j;
-    const int poff = (o < 2) ? off_i : off_j;
+    const int poff = (o < 2) ? 0 : off_j;
     if (i < rows) {
       const int c = i / khkw;
       const int rem = i - c * khkw;
@@ -155,163 +186,292 @@ syrk_patch_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_item
     }
   }
 
-  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+  // staging lane geometry (constant per lane: 256 % padded row length == 0)
+  const int cmask = (1 << cshift) - 1;
+  const int lx = tid & cmask;                 // x (general) or x4 (vec4) of this lane
+  const int prow0 = tid >> cshift;
+  const int prow_step = SYRK_THREADS >> cshift;
 
-  const int cy = compact ? RS : sh * RS;     // LDS step per output row / col
-  const int cx = compact ? 1 : sw;
-  const int gy = compact ? sh : 1;           // source step per patch row / col
-  const int gx = compact ? sw : 1;
+  auto decode_chunk = [&](int ch) {
+    Chunk c;
+    const int cg = ch % n_cg;
+    const int t1 = ch / n_cg;
+    const int rg = t1 % n_rg;
+    const int sg = t1 / n_rg;
+    c.s0 = sg * NS; c.ns = min(NS, N - c.s0);
+    c.oh0 = rg * R; c.ra = min(R, Ho - c.oh0);
+    c.ow0 = cg * Wc; c.wa = min(Wc, Wo - c.ow0);
+    c.kc = c.ns * c.ra * c.wa;
+    c.npairs = (c.kc + 1) >> 1;
+    c.rows_in = compact ? c.ra : (c.ra - 1) * sh + kh;
+    c.cols_in = compact ? c.wa : (c.wa - 1) * sw + kw;
+    c.ih_base = c.oh0 * sh - ph;
+    c.iw_base = c.ow0 * sw - pw;
+    return c;
+  };
+
+  float st[2 * STAGE_SLOTS];
+
+  // global -> registers for one chunk (both panels); every slot is written (zero when masked)
+  auto issue_loads = [&](const Chunk& c) {
+#pragma unroll
+    for (int pnl = 0; pnl < 2; ++pnl) {
+      if (pnl < n_panels) {
+        const int c_lo = pnl ? c_lo_j : c_lo_i;
+        const int nch_p = pnl ? nch_j : nch_i;
+        if (vec4) {
+          const int cols4 = c.wa >> 2;
+          const int prow = c.ns * nch_p;
+          const float* g0 = src + ((long long)c.s0 * C + c_lo) * HW + c.iw_base + 4 * lx;
+          const bool colok = lx < cols4;
+#pragma unroll
+          for (int j = 0; j < STAGE_SLOTS / 4; ++j) {
+            const int p = prow0 + j * prow_step;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (colok && p < prow) {
+              const int s = (c.ns == 1) ? 0 : p / nch_p;
+              const int cc = p - s * nch_p;
+              v = *reinterpret_cast<const f32x4*>(g0 + ((long long)s * C + cc) * HW);
+            }
+            st[pnl * STAGE_SLOTS + 4 * j + 0] = v.x;
+            st[pnl * STAGE_SLOTS + 4 * j + 1] = v.y;
+            st[pnl * STAGE_SLOTS + 4 * j + 2] = v.z;
+            st[pnl * STAGE_SLOTS + 4 * j + 3] = v.w;
+          }
+        } else {
+          const float* g0 = src + ((long long)c.s0 * C + c_lo) * HW + (long long)c.ih_base * W + c.iw_base +
+                            lx * gx;
+          const int iw = c.iw_base + lx * gx;
+          const bool colok = lx < c.cols_in && (unsigned)iw < (unsigned)W;
+#pragma unroll
+          for (int j = 0; j < STAGE_SLOTS; ++j) {
+            const int p = prow0 + j * prow_step;
+            float v = 0.0f;
+            if (p < total_rows_full) {
+              const int go = rowtab[3 * p + 1];
+              const int scy = rowtab[3 * p + 2];
+              const int s = scy >> 24, cc = (scy >> 16) & 0xff, y = scy & 0xffff;
+              const int ih = c.ih_base + y * gy;
+              if (colok && s < c.ns && cc < nch_p && y < c.rows_in && (unsigned)ih < (unsigned)H) v = g0[go];
+            }
+            st[pnl * STAGE_SLOTS + j] = v;
+          }
+        }
+      }
+    }
+  };
+
+  // registers -> LDS patch
+  auto store_stage = [&](const Chunk& c) {
+#pragma unroll
+    for (int pnl = 0; pnl < 2; ++pnl) {
+      if (pnl < n_panels) {
+        const int nch_p = pnl ? nch_j : nch_i;
+        float* lbase = fs + PATCH_OFF + (pnl ? off_j : 0);
+        if (vec4) {
+          const int cols4 = c.wa >> 2;
+          const int prow = c.ns * nch_p;
+          if (lx < cols4) {
+#pragma unroll
+            for (int j = 0; j < STAGE_SLOTS / 4; ++j) {
+              const int p = prow0 + j * prow_step;
+              if (p < prow) {
+                const int s = (c.ns == 1) ? 0 : p / nch_p;
+                const int cc = p - s * nch_p;
+                float* l = lbase + s * SS + cc * PS + 4 * lx;
+                l[0] = st[pnl * STAGE_SLOTS + 4 * j + 0];
+                l[1] = st[pnl * STAGE_SLOTS + 4 * j + 1];
+                l[2] = st[pnl * STAGE_SLOTS + 4 * j + 2];
+                l[3] = st[pnl * STAGE_SLOTS + 4 * j + 3];
+              }
+            }
+          }
+        } else {
+          if (lx < c.cols_in) {
+#pragma unroll
+            for (int j = 0; j < STAGE_SLOTS; ++j) {
+              const int p = prow0 + j * prow_step;
+              if (p < total_rows_full) {
+                const int lo = rowtab[3 * p + 0];
+                const int scy = rowtab[3 * p + 2];
+                const int s = scy >> 24, cc = (scy >> 16) & 0xff, y = scy & 0xffff;
+                if (s < c.ns && cc < nch_p && y < c.rows_in) lbase[lo + lx] = st[pnl * STAGE_SLOTS + j];
+              }
+            }
+          }
+        }
+      }
+    }
+  };
+
+  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
 
   const int ch_begin = slice * d.cpi;
   const int ch_end = min(ch_begin + d.cpi, n_chunks);
   int cur_ns = -1, cur_ra = -1, cur_wa = -1;
 
-  for (int ch = ch_begin; ch < ch_end; ++ch) {
-    const int cg = ch % n_cg;
-    const int t1 = ch / n_cg;
-    const int rg = t1 % n_rg;
-    const int sg = t1 / n_rg;
-    const int s0 = sg * NS, ns = min(NS, N - s0);
-    const int oh0 = rg * R, ra = min(R, Ho - oh0);
-    const int ow0 = cg * Wc, wa = min(Wc, Wo - ow0);
-    const int kc = ns * ra * wa;
-    const int npairs = (kc + 1) >> 1;
-    const int rows_in = compact ? ra : (ra - 1) * sh + kh;
-    const int cols_in = compact ? wa : (wa - 1) * sw + kw;
-    const int total_rows = ns * nch * rows_in;
+  __syncthreads();                       // rowtab, ZERO/ONE visible
+  Chunk cur = decode_chunk(min(ch_begin, n_chunks - 1));
+  if (ch_begin < ch_end) issue_loads(cur);
 
-    if (ns != cur_ns || ra != cur_ra || wa != cur_wa) {
-      cur_ns = ns; cur_ra = ra; cur_wa = wa;
-      const int rw = ra * wa;
-      for (int k = tid; k < 2 * npairs; k += SYRK_THREADS) {
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    // (all waves are past the MFMA loop of the previous chunk here)
+    if (cur.ns != cur_ns || cur.ra != cur_ra || cur.wa != cur_wa) {
+      cur_ns = cur.ns; cur_ra = cur.ra; cur_wa = cur.wa;
+      const int rw = cur.ra * cur.wa;
+      for (int k = tid; k < 2 * cur.npairs; k += SYRK_THREADS) {
         int v = 0;
-        if (k < kc) {
+        if (k < cur.kc) {
           const int s = k / rw;
           const int rem = k - s * rw;
-          const int r = rem / wa;
-          const int w = rem - r * wa;
+          const int r = rem / cur.wa;
+          const int w = rem - r * cur.wa;
           v = s * SS + r * cy + w * cx;
         }
         ktab[k] = v;
       }
-      for (int p = tid; p < total_rows; p += SYRK_THREADS) {
-        const int y = p % rows_in;
-        const int t2 = p / rows_in;
-        const int cc = t2 % nch;
-        const int s = t2 / nch;
-        rowtab[3 * p + 0] = s * SS + cc * PS + y * RS;
-        rowtab[3 * p + 1] = (s * C + cc) * HW + y * gy * W;
-        rowtab[3 * p + 2] = (cc << 16) | y;
-      }
-      __syncthreads();
     }
-
-    // ---- stage the raw patch of both panels ----
-    {
-      int lx_shift = 0;
-      while ((1 << lx_shift) < cols_in && lx_shift < 6) ++lx_shift;
-      const int LX = 1 << lx_shift;
-      const int row_step = SYRK_THREADS >> lx_shift;
-      const int x0 = tid & (LX - 1);
-      const int ih_base = oh0 * sh - ph;
-      const int iw_base = ow0 * sw - pw;
-      const int n_panels = diag ? 1 : 2;
-      for (int pnl = 0; pnl < n_panels; ++pnl) {
-        const int c_lo = pnl ? c_lo_j : c_lo_i;
-        const int nch_p = min(nch, C - c_lo);
-        const long long gbase = ((long long)s0 * C + c_lo) * HW + (long long)ih_base * W + iw_base;
-        float* lbase = fs + PATCH_OFF + (pnl ? off_j : off_i);
-        for (int p = tid >> lx_shift; p < total_rows; p += row_step) {
-          const int lo = rowtab[3 * p + 0];
-          const int go = rowtab[3 * p + 1];
-          const int cyv = rowtab[3 * p + 2];
-          const int cc = cyv >> 16;
-          const int y = cyv & 0xffff;
-          if (cc >= nch_p) continue;
-          const int ih = ih_base + y * gy;
-          const bool rowok = (unsigned)ih < (unsigned)H;
-          const float* g = src + gbase + go;
-          float* l = lbase + lo;
-          for (int x = x0; x < cols_in; x += LX) {
-            const int iw = iw_base + x * gx;
-            float v = 0.0f;
-            if (rowok && (unsigned)iw < (unsigned)W) v = g[x * gx];
-            l[x] = v;
-          }
-        }
-      }
-    }
+    store_stage(cur);
     __syncthreads();
 
-    // ---- MFMA over this wave's share of the chunk's k pairs ----
-    for (int p = wave; p < npairs; p += 4) {
-      const int k = 2 * p + h;
-      const int koff = ktab[k];
-      const bool valid = k < kc;
+    const Chunk work = cur;
+    if (ch + 1 < ch_end) {
+      cur = decode_chunk(ch + 1);
+      issue_loads(cur);                  // in flight during the MFMA loop below
+    }
+
+    // ---- MFMA over this wave's share of the chunk's k pairs (operands fetched one step ahead) ----
+    if (!idle && kfirst < work.npairs) {
+      const int klim = 2 * work.npairs - 1;
+      const int kc = work.kc;
+      int pn = kfirst;
+      int kn = 2 * pn + h;
+      int koff = ktab[kn];
       float a0 = fs[base[0] + (koff & kmask[0])];
       float a1 = fs[base[1] + (koff & kmask[1])];
       float b0 = fs[base[2] + (koff & kmask[2])];
       float b1 = fs[base[3] + (koff & kmask[3])];
-      if (!valid) { a0 = 0.0f; a1 = 0.0f; b0 = 0.0f; b1 = 0.0f; }
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-      if (!diag) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+      bool valid = kn < kc;
+      pn += KSTRIDE;
+      kn = 2 * pn + h;
+      int koff_n = ktab[min(kn, klim)];
+      while (true) {
+        const bool has_next = pn < work.npairs;
+        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+        bool nvalid = false;
+        if (has_next) {
+          na0 = fs[base[0] + (koff_n & kmask[0])];
+          na1 = fs[base[1] + (koff_n & kmask[1])];
+          nb0 = fs[base[2] + (koff_n & kmask[2])];
+          nb1 = fs[base[3] + (koff_n & kmask[3])];
+          nvalid = kn < kc;
+          pn += KSTRIDE;
+          kn = 2 * pn + h;
+          koff_n = ktab[min(kn, klim)];
+        }
+        a0 = valid ? a0 : 0.0f;      // zero A is enough: every product of an invalid k vanishes
+        a1 = valid ? a1 : 0.0f;
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+        if (!skip10) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        if (!has_next) break;
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; valid = nvalid;
+      }
     }
     __syncthreads();
   }
 
-  // ---- cross-wave reduction of the four K shares, then one coalesced slab write ----
-  float* red = fs + PATCH_OFF + wave * (TM * TM);
+  float* slab = slabs + d.slab_base + (long long)local * (TMv * TMv);
+  if (TMv == 64) {
+    // cross-wave reduction of the four K shares, then one coalesced slab write
+    float* red = fs + PATCH_OFF + wave * (64 * 64);
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    red[row * TM + r32] = acc00[reg];
-    red[row * TM + 32 + r32] = acc01[reg];
-    red[(32 + row) * TM + r32] = acc10[reg];
-    red[(32 + row) * TM + 32 + r32] = acc11[reg];
-  }
-  __syncthreads();
-  {
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      red[row * 64 + r32] = acc00[reg];
+      red[row * 64 + 32 + r32] = acc01[reg];
+      red[(32 + row) * 64 + r32] = acc10[reg];
+      red[(32 + row) * 64 + 32 + r32] = acc11[reg];
+    }
+    __syncthreads();
     const f32x4* r0 = reinterpret_cast<const f32x4*>(fs + PATCH_OFF);
-    f32x4* slab = reinterpret_cast<f32x4*>(slabs + d.slab_base + (long long)local * (TM * TM));
-    for (int e = tid; e < TM * TM / 4; e += SYRK_THREADS) {
-      f32x4 v = r0[e] + r0[TM * TM / 4 + e] + r0[2 * (TM * TM / 4) + e] + r0[3 * (TM * TM / 4) + e];
-      slab[e] = v;
+    f32x4* slab4 = reinterpret_cast<f32x4*>(slab);
+    for (int e = tid; e < 64 * 64 / 4; e += SYRK_THREADS)
+      slab4[e] = r0[e] + r0[1024 + e] + r0[2048 + e] + r0[3072 + e];
+  } else if (!idle) {
+    // each wave owns one 64x64 quadrant of the 128x128 slab
+    float* q = slab + (64 * wm) * 128 + 64 * wn;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      q[row * 128 + r32] = acc00[reg];
+      q[row * 128 + 32 + r32] = acc01[reg];
+      q[(32 + row) * 128 + r32] = acc10[reg];
+      q[(32 + row) * 128 + 32 + r32] = acc11[reg];
     }
   }
 }
 
-// Sum the k-slices of one tile in slice order, scale, and add into the factor and its mirror.
+__global__ void __launch_bounds__(SYRK_THREADS, 2)
+syrk_patch_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_items,
+                  float* __restrict__ slabs) {
+  __shared__ __attribute__((aligned(16))) int smem[SMEM_WORDS];
+  // XCD-aware item order: workgroups that share an XCD (equal blockIdx % 8) take every 8th group of
+  // XCD_GROUP consecutive items, i.e. neighbouring tiles of one k-slice of one factor, so the panels
+  // they stage hit that XCD's L2, while every XCD still sees an even mix of all factors.
+  int item;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    item = ((j / XCD_GROUP) * 8 + xcd) * XCD_GROUP + (j % XCD_GROUP);
+  }
+  if (item >= n_items) return;
+  const int f = find_segment(descs, n_factors, item, false);
+  const FactorDev& d = descs[f];
+  const int local = item - d.item_base;
+  if (d.TM == 128) syrk_body<128>(d, local, slabs, smem);
+  else syrk_body<64>(d, local, slabs, smem);
+}
+
+// Sum the k-slices of one 64x64 sub-tile in slice order, scale, add into the factor and its mirror.
 __global__ void __launch_bounds__(SYRK_THREADS)
 syrk_reduce_kernel(const FactorDev* __restrict__ descs, int n_factors, const float* __restrict__ slabs) {
-  __shared__ float tile[TM][TM + 1];
+  __shared__ float tile[64][65];
   const int tid = threadIdx.x;
   const int f = find_segment(descs, n_factors, blockIdx.x, true);
   const FactorDev& d = descs[f];
-  const int t = blockIdx.x - d.tile_base;
+  const int TMv = d.TM;
+  const int q = TMv >> 6;                       // sub-tiles per tile edge
+  const int sub = blockIdx.x - d.sub_base;
+  const int t = sub / (q * q);
+  const int qq = sub - t * (q * q);
+  const int qi = qq / q, qj = qq - qi * q;
   int ti, tj;
   decode_tile(t, d.P, ti, tj);
-  const bool diag = (ti == tj);
-  const int i0 = ti * TM, j0 = tj * TM, dim = d.dim;
+  const int bi = ti * q + qi, bj = tj * q + qj;  // 64-granular block coordinates
+  if (bi > bj) return;                          // mirror of (bj, bi)
+  const bool diag = (bi == bj);
+  const int i0 = bi * 64, j0 = bj * 64, dim = d.dim;
+  if (i0 >= dim || j0 >= dim) return;
   const int n_tiles = d.n_tiles, n_slices = d.n_slices;
   const float scale = d.scale;
   const bool first = d.first != 0;
   float* __restrict__ dst = d.dst;
 
-  const f32x4* s4 = reinterpret_cast<const f32x4*>(slabs + d.slab_base + (long long)t * (TM * TM));
-  const long long slice_stride4 = (long long)n_tiles * (TM * TM / 4);
-  for (int e = tid; e < TM * TM / 4; e += SYRK_THREADS) {
-    f32x4 v = s4[e];
-    for (int s = 1; s < n_slices; ++s) v += s4[s * slice_stride4 + e];
+  const float* s0 = slabs + d.slab_base + (long long)t * (TMv * TMv) + (qi * 64) * TMv + qj * 64;
+  const long long slice_stride = (long long)n_tiles * (TMv * TMv);
+  for (int e = tid; e < 64 * 64 / 4; e += SYRK_THREADS) {
     const int r = e >> 4, c = (e & 15) << 2;
+    const float* p = s0 + r * TMv + c;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    for (int s = 1; s < n_slices; ++s) v += *reinterpret_cast<const f32x4*>(p + s * slice_stride);
     tile[r][c + 0] = v.x * scale;
     tile[r][c + 1] = v.y * scale;
     tile[r][c + 2] = v.z * scale;
     tile[r][c + 3] = v.w * scale;
   }
   __syncthreads();
-  for (int e = tid; e < TM * TM; e += SYRK_THREADS) {
+  for (int e = tid; e < 64 * 64; e += SYRK_THREADS) {
     const int r = e >> 6, c = e & 63;
     const int gi = i0 + r, gj = j0 + c;
     if (gi < dim && gj < dim) {
@@ -321,7 +481,7 @@ syrk_reduce_kernel(const FactorDev* __restrict__ descs, int n_factors, const flo
     }
   }
   if (!diag) {
-    for (int e = tid; e < TM * TM; e += SYRK_THREADS) {
+    for (int e = tid; e < 64 * 64; e += SYRK_THREADS) {
       const int r = e >> 6, c = e & 63;      // r indexes panel j, c panel i
       const int gi = j0 + r, gj = i0 + c;
       if (gi < dim && gj < dim) {
@@ -338,7 +498,6 @@ syrk_reduce_kernel(const FactorDev* __restrict__ descs, int n_factors, const flo
 constexpr int UPLOAD_CHUNK = 16;
 struct TableChunk { FactorDev f[UPLOAD_CHUNK]; };
 static_assert(sizeof(TableChunk) <= 3840, "kernel argument block must stay below 4 KB");
-static_assert(sizeof(FactorDev) % 8 == 0, "FactorDev must be 8-byte granular");
 
 __global__ void __launch_bounds__(256)
 upload_table_kernel(FactorDev* __restrict__ table, TableChunk chunk, int count) {
@@ -358,36 +517,111 @@ static int round_mod32(int v, int m) {   // smallest u >= v with u = m (mod 32)
   return u;
 }
 
-struct ChunkGeom { int rows_in, cols_in, RS, PS, SS; };
+static int ceil_log2(int v) {
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return s;
+}
+
+struct ChunkGeom { int rows_in, cols_in, RS, PS, SS, cshift; };
+
+// Bank multiplicity of the per-lane operand gather for LDS strides RS = r, PS = p (mod 32): the 32
+// lanes of a half-wave read rows i .. i+31 of the unfolded matrix, i.e. words c*PS + a*RS + b with
+// (c, a, b) the (channel, kh, kw) digits of i.  (r, p) = (kw, kh*kw) is conflict-free by construction;
+// other residues are accepted when no bank is hit more than twice, which lets small feature maps use
+// tighter strides (a 9-wide patch row padded to 35 words wastes 4x LDS).
+struct ConflictTable {
+  int kh = 0, kw = 0;
+  unsigned char mult[32][32];
+};
+
+static const ConflictTable& conflict_table(int kh, int kw) {
+  static thread_local std::vector<ConflictTable> memo;   // pure function cache
+  for (const auto& t : memo) if (t.kh == kh && t.kw == kw) return t;
+  ConflictTable t;
+  t.kh = kh; t.kw = kw;
+  const int q = kh * kw;
+  for (int r = 0; r < 32; ++r) {
+    for (int p = 0; p < 32; ++p) {
+      int worst = 0;
+      for (int phase = 0; phase < q; ++phase) {
+        int hist[32] = {0};
+        for (int l = 0; l < 32; ++l) {
+          const int i = phase + l;
+          const int c = i / q, rem = i % q, a = rem / kw, b = rem % kw;
+          const int bank = (c * p + a * r + b) & 31;
+          worst = std::max(worst, ++hist[bank]);
+        }
+      }
+      t.mult[r][p] = (unsigned char)std::min(worst, 255);
+    }
+  }
+  memo.push_back(t);
+  return memo.back();
+}
+
+static void pick_strides(const FactorDev& f, int rows_in, int cols_in, int& RS, int& PS) {
+  const ConflictTable& t = conflict_table(f.kh, f.kw);
+  int best_ps[3] = {0, 1 << 30, 1 << 30}, best_rs[3] = {0, 0, 0};
+  for (int r = 0; r < 32; ++r) {
+    const int rs = round_mod32(cols_in, r);
+    for (int p = 0; p < 32; ++p) {
+      const int m = t.mult[r][p];
+      if (m > 2) continue;
+      const int ps = round_mod32(rows_in * rs, p);
+      if (ps < best_ps[m]) { best_ps[m] = ps; best_rs[m] = rs; }
+    }
+  }
+  // prefer conflict-free unless the 2-way layout is markedly smaller
+  const int m = (best_ps[2] * 5 < best_ps[1] * 4) ? 2 : 1;
+  RS = best_rs[m];
+  PS = best_ps[m];
+}
 
 static bool chunk_fits(const FactorDev& f, int NS, int R, int Wc, ChunkGeom& g) {
   g.rows_in = f.compact ? R : (R - 1) * f.sh + f.kh;
   g.cols_in = f.compact ? Wc : (Wc - 1) * f.sw + f.kw;
-  g.RS = f.compact ? g.cols_in : round_mod32(g.cols_in, f.kw);
-  g.PS = round_mod32(g.rows_in * g.RS, f.khkw);
+  if (f.compact) {
+    g.RS = g.cols_in;
+    g.PS = round_mod32(g.rows_in * g.RS, 1);
+  } else {
+    pick_strides(f, g.rows_in, g.cols_in, g.RS, g.PS);
+  }
   g.SS = f.nch * g.PS;
   if ((long long)NS * g.SS > PANEL_WORDS) return false;
-  if ((long long)NS * f.nch * g.rows_in > ROWTAB_MAX) return false;
   if ((long long)NS * R * Wc > KTAB_MAX) return false;
-  if (g.rows_in > 0xffff) return false;
+  if (NS > 127 || g.rows_in > 0xffff) return false;
+  const long long prow = (long long)NS * f.nch * g.rows_in;
+  if (f.vec4) {
+    if (Wc % 4 != 0) return false;
+    g.cshift = ceil_log2(Wc / 4);
+    if (g.cshift > 6) return false;                                    // <= 64 lanes along x4
+    if ((prow << g.cshift) * 4 > PANEL_SLOT_ELEMS) return false;       // float4 slots per lane
+  } else {
+    if (prow > ROWTAB_MAX) return false;
+    g.cshift = ceil_log2(g.cols_in);
+    if (g.cshift > 8) return false;                                    // <= 256 lanes along x
+    if ((prow << g.cshift) > PANEL_SLOT_ELEMS) return false;
+  }
   return true;
 }
 
 struct Plan {
   std::vector<FactorDev> f;
   int n_items = 0;
-  int n_tiles = 0;
+  int n_sub = 0;
   long long slab_floats = 0;
 };
 
 static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
   CURV_REQUIRE(n >= 0 && (n == 0 || descs != nullptr), "curv_kfac: bad descriptor array");
   plan.f.resize(n);
-  std::vector<double> chunk_cost(n);   // MFMA wave-cycles of one (tile, chunk), averaged over tiles
+  std::vector<double> chunk_cost(n);   // MFMA CU-cycles of one (tile, chunk)
   double total_cost = 0.0;
   for (int i = 0; i < n; ++i) {
     const curv_factor_desc& s = descs[i];
     FactorDev& f = plan.f[i];
+    memset(&f, 0, sizeof(f));
     CURV_REQUIRE(s.N > 0 && s.C > 0 && s.H > 0 && s.W > 0, "curv_kfac: factor %d: empty source", i);
     CURV_REQUIRE(s.kh > 0 && s.kw > 0 && s.sh > 0 && s.sw > 0 && s.ph >= 0 && s.pw >= 0,
                  "curv_kfac: factor %d: bad kernel geometry", i);
@@ -400,78 +634,100 @@ static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     f.Wo = (s.W + 2 * s.pw - s.kw) / s.sw + 1;
     f.khkw = s.kh * s.kw;
     f.compact = (s.kh == 1 && s.kw == 1) ? 1 : 0;
+    bool flattened = false;
     if (f.compact && s.sh == 1 && s.sw == 1 && s.ph == 0 && s.pw == 0) {
       // pure per-pixel factor (1x1 conv, grad_output, Linear): one long row per (sample, channel)
       CURV_REQUIRE((long long)s.H * s.W < (1LL << 30), "curv_kfac: factor %d: plane too large", i);
       f.W = s.H * s.W; f.H = 1; f.Ho = 1; f.Wo = f.W;
+      flattened = true;
     }
     f.rows = s.C * f.khkw;
     f.has_bias = s.has_bias ? 1 : 0;
     f.dim = f.rows + f.has_bias;
     f.first = s.first;
     f.scale = s.scale;
-    f.pad0 = 0;
     CURV_REQUIRE((long long)f.N * f.C * f.H * f.W < (1LL << 31), "curv_kfac: factor %d: source too large", i);
-    f.nch = std::min(f.C, (f.khkw + TM - 2) / f.khkw + 1);
+
+    // tile edge: 128 where the padding it adds is small, 64 otherwise
+    f.TM = (f.dim >= 256 && cdiv(f.dim, 128) * 128 <= f.dim + f.dim / 14) ? 128 : 64;
+    f.nch = std::min(f.C, (f.khkw + f.TM - 2) / f.khkw + 1);
+    f.vec4 = (flattened && f.W % 4 == 0 && f.W >= 4 && (reinterpret_cast<uintptr_t>(s.src) & 15) == 0) ? 1 : 0;
 
     // chunk extent: full-width rows if they fit, then as many rows, then as many samples
     ChunkGeom g;
     int Wc = f.Wo, R = 1, NS = 1;
     if (!chunk_fits(f, 1, 1, Wc, g)) {
-      CURV_REQUIRE(chunk_fits(f, 1, 1, 1, g), "curv_kfac: factor %d: no chunk shape fits the LDS budget", i);
-      int lo = 1, hi = Wc;                       // fits(lo), !fits(hi); fits is monotone in Wc
+      if (f.vec4 && !chunk_fits(f, 1, 1, 4, g)) f.vec4 = 0;
+      const int unit = f.vec4 ? 4 : 1;
+      CURV_REQUIRE(chunk_fits(f, 1, 1, unit, g), "curv_kfac: factor %d: no chunk shape fits the LDS budget", i);
+      int lo = 1, hi = cdiv(Wc, unit);           // in units; fits(lo), !fits(hi); monotone
       while (hi - lo > 1) {
         const int mid = (lo + hi) / 2;
-        if (chunk_fits(f, 1, 1, mid, g)) lo = mid; else hi = mid;
+        if (chunk_fits(f, 1, 1, mid * unit, g)) lo = mid; else hi = mid;
       }
-      Wc = lo;
-      if (Wc > 4) Wc &= ~3;                      // keep column groups 16-B aligned
+      Wc = lo * unit;
+      if (!f.vec4 && Wc > 4) Wc &= ~3;
+      const int groups = cdiv(f.Wo, Wc);         // even out the column groups
+      const int even = (cdiv(f.Wo, groups) + 3) & ~3;
+      if (even <= Wc) Wc = even;
     }
     if (Wc == f.Wo) {
       while (R < f.Ho && chunk_fits(f, 1, R + 1, Wc, g)) ++R;
+      if (R < f.Ho) R = cdiv(f.Ho, cdiv(f.Ho, R));          // even out the row groups
       if (R == f.Ho) while (NS < f.N && chunk_fits(f, NS + 1, R, Wc, g)) ++NS;
+      if (NS > 1 && NS < f.N) NS = cdiv(f.N, cdiv(f.N, NS)); // even out the sample groups
     }
-    chunk_fits(f, NS, R, Wc, g);
+    CURV_REQUIRE(chunk_fits(f, NS, R, Wc, g), "curv_kfac: factor %d: internal chunk planning error", i);
     f.NS = NS; f.R = R; f.Wc = Wc;
-    f.RS = g.RS; f.PS = g.PS; f.SS = g.SS;
+    f.RS = g.RS; f.PS = g.PS; f.SS = g.SS; f.cshift = g.cshift;
     f.n_rg = cdiv(f.Ho, R);
     f.n_cg = cdiv(f.Wo, Wc);
     f.n_chunks = cdiv(f.N, NS) * f.n_rg * f.n_cg;
-    f.P = cdiv(f.dim, TM);
+    f.P = cdiv(f.dim, f.TM);
     f.n_tiles = f.P * (f.P + 1) / 2;
     const double kc = (double)NS * R * Wc;
-    const double blocks = (4.0 * (f.n_tiles - f.P) + 3.0 * f.P) / f.n_tiles;
-    chunk_cost[i] = kc / 8.0 * blocks * 64.0 + 600.0;   // + staging / barrier overhead
+    const double q = f.TM / 64.0;
+    chunk_cost[i] = kc * 32.0 * q * q + 1500.0;   // 64x64xk = 32 k CU-cycles; + staging / barriers
     total_cost += chunk_cost[i] * f.n_tiles * f.n_chunks;
   }
   // k-slicing: aim at ~16 items per workgroup slot (2 per CU) so that the tail of the launch is
-  // a few percent, while keeping the slab traffic (16 KB per item) negligible.
+  // a few percent, while keeping the slab traffic negligible.
   const double target = std::max(total_cost / (512.0 * 16.0), 1.0);
-  long long items = 0, tiles = 0, slab = 0;
+  long long items = 0, subs = 0, slab = 0;
   for (int i = 0; i < n; ++i) {
     FactorDev& f = plan.f[i];
     int cpi = (int)(target / chunk_cost[i] + 0.5);
     cpi = std::max(1, std::min(cpi, f.n_chunks));
-    f.cpi = cpi;
     f.n_slices = cdiv(f.n_chunks, cpi);
     f.cpi = cdiv(f.n_chunks, f.n_slices);          // even out the slices
     f.n_slices = cdiv(f.n_chunks, f.cpi);
     f.n_items = f.n_slices * f.n_tiles;
+    f.n_sub = f.n_tiles * (f.TM / 64) * (f.TM / 64);
     f.item_base = (int)items;
-    f.tile_base = (int)tiles;
+    f.sub_base = (int)subs;
     f.slab_base = slab;
     items += f.n_items;
-    tiles += f.n_tiles;
-    slab += (long long)f.n_items * TM * TM;
-    CURV_REQUIRE(items < (1LL << 30) && tiles < (1LL << 30), "curv_kfac: too many work items");
+    subs += f.n_sub;
+    slab += (long long)f.n_items * f.TM * f.TM;
+    CURV_REQUIRE(items < (1LL << 30) && subs < (1LL << 30), "curv_kfac: too many work items");
   }
   plan.n_items = (int)items;
-  plan.n_tiles = (int)tiles;
+  plan.n_sub = (int)subs;
   plan.slab_floats = slab;
   return CURV_OK;
 }
 
 static size_t table_bytes(int n) { return align_up((size_t)std::max(n, 1) * sizeof(FactorDev), 256); }
+
+static int plan_without_pointers(const curv_factor_desc* descs, int n_factors, Plan& plan) {
+  // pointers are not dereferenced by the planner, but it insists on non-null ones
+  std::vector<curv_factor_desc> tmp(descs, descs + (n_factors > 0 ? n_factors : 0));
+  for (auto& t : tmp) {
+    if (!t.src) t.src = reinterpret_cast<const float*>(16);
+    if (!t.dst) t.dst = reinterpret_cast<float*>(16);
+  }
+  return make_plan(tmp.data(), n_factors, plan);
+}
 
 }  // namespace curv
 
@@ -479,24 +735,13 @@ using namespace curv;
 
 extern "C" size_t curv_kfac_workspace_bytes(const curv_factor_desc* descs, int n_factors) {
   Plan plan;
-  // pointers are not dereferenced by the planner, but it insists on non-null ones
-  std::vector<curv_factor_desc> tmp(descs, descs + (n_factors > 0 ? n_factors : 0));
-  for (auto& t : tmp) {
-    if (!t.src) t.src = reinterpret_cast<const float*>(16);
-    if (!t.dst) t.dst = reinterpret_cast<float*>(16);
-  }
-  if (make_plan(tmp.data(), n_factors, plan) != CURV_OK) return 0;
+  if (plan_without_pointers(descs, n_factors, plan) != CURV_OK) return 0;
   return table_bytes(n_factors) + (size_t)plan.slab_floats * sizeof(float);
 }
 
 extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors, long long* out) {
   Plan plan;
-  std::vector<curv_factor_desc> tmp(descs, descs + (n_factors > 0 ? n_factors : 0));
-  for (auto& t : tmp) {
-    if (!t.src) t.src = reinterpret_cast<const float*>(16);
-    if (!t.dst) t.dst = reinterpret_cast<float*>(16);
-  }
-  int rc = make_plan(tmp.data(), n_factors, plan);
+  int rc = plan_without_pointers(descs, n_factors, plan);
   if (rc != CURV_OK) return rc;
   for (int i = 0; i < n_factors; ++i) {
     const FactorDev& f = plan.f[i];
@@ -504,6 +749,7 @@ extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors,
     o[0] = f.dim; o[1] = f.Ho; o[2] = f.Wo; o[3] = f.NS; o[4] = f.R; o[5] = f.Wc;
     o[6] = f.n_chunks; o[7] = f.RS; o[8] = f.PS; o[9] = f.SS; o[10] = f.nch;
     o[11] = f.n_tiles; o[12] = f.cpi; o[13] = f.n_slices; o[14] = f.n_items; o[15] = f.item_base;
+    o[16] = f.TM; o[17] = f.vec4; o[18] = f.cshift; o[19] = f.n_sub;
   }
   return CURV_OK;
 }
@@ -535,7 +781,7 @@ extern "C" int curv_kfac_accumulate(void* stream_, const curv_factor_desc* descs
   hipLaunchKernelGGL(syrk_patch_kernel, dim3(grid), dim3(SYRK_THREADS), 0, stream, table, n_factors,
                      plan.n_items, slabs);
   CURV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_tiles), dim3(SYRK_THREADS), 0, stream, table,
+  hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub), dim3(SYRK_THREADS), 0, stream, table,
                      n_factors, slabs);
   CURV_LAUNCH_CHECK();
   return CURV_OK;
