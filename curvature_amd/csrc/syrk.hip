@@ -24,22 +24,25 @@
 #include "common.h"
 
 #include <algorithm>
+#include <type_traits>
+#include <cstdlib>
 #include <vector>
 
 namespace curv {
 
 constexpr int SYRK_THREADS = 256;
 constexpr int XCD_GROUP = 32;          // consecutive items that share an XCD
-constexpr int KTAB_MAX = 1024;         // k values per chunk
+constexpr int MAX_RL = 2;              // longest k-run (register budget: two operand sets of 4 * RL)
+constexpr int KTAB_MAX = 1024;         // k runs per chunk
 constexpr int ROWTAB_MAX = 512;        // patch rows per panel per chunk
 constexpr int PANEL_WORDS = 8704;      // LDS words per panel patch
 constexpr int PATCH_WORDS = 2 * PANEL_WORDS;   // >= 4 x (64x64) cross-wave reduce scratch
 constexpr int STAGE_SLOTS = 32;        // staging registers per panel per lane (floats)
 constexpr int PANEL_SLOT_ELEMS = STAGE_SLOTS * SYRK_THREADS;   // padded patch elements per panel
 // LDS word offsets
-constexpr int ZERO_OFF = 0;
-constexpr int ONE_OFF = 1;
-constexpr int KTAB_OFF = 16;
+constexpr int ZERO_OFF = 0;            // 16 zero words (padding rows read run elements 0..RL-1 from here)
+constexpr int ONE_OFF = 16;            // 16 one words (the bias row of ones)
+constexpr int KTAB_OFF = 32;
 constexpr int ROWTAB_OFF = KTAB_OFF + KTAB_MAX;
 constexpr int PATCH_OFF = ROWTAB_OFF + 3 * ROWTAB_MAX;
 constexpr int SMEM_WORDS = PATCH_OFF + PATCH_WORDS;   // 19984 words = 79936 B -> 2 workgroups per CU
@@ -62,13 +65,14 @@ struct FactorDev {
   int n_chunks;
   int RS, PS, SS, nch;     // LDS strides in words, channels per panel
   int cshift;              // log2 of the padded patch row length (lanes along x)
+  int RL;                  // k-run length: 1, 2 or 4 LDS-adjacent k values per operand address
   int P, n_tiles;
   int cpi, n_slices;       // chunks per item, k-slices
   int item_base, n_items;
   int sub_base, n_sub;     // 64x64 sub-tiles for the reduce kernel
   int first;
   float scale;
-  int pad0;
+  int pad0, pad1;
   long long slab_base;     // in floats
 };
 static_assert(sizeof(FactorDev) % 8 == 0, "FactorDev must be 8-byte granular");
@@ -93,14 +97,18 @@ __device__ __forceinline__ void decode_tile(int t, int P, int& ti, int& tj) {
   tj = ti + t;
 }
 
+typedef __attribute__((address_space(1))) float gfloat;      // global-address-space views
+typedef __attribute__((address_space(1))) f32x4 gf32x4;
+
 // Position and extent of one K chunk.
 struct Chunk {
-  int s0, ns, oh0, ra, ow0, wa, kc, npairs, rows_in, cols_in, ih_base, iw_base;
+  int s0, ns, oh0, ra, ow0, wa, nruns, niter, rows_in, cols_in, ih_base, iw_base;
 };
 
 template <int TMv>
 __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, float* __restrict__ slabs,
-                                          int* smem) {
+                                          const float* __restrict__ zeros_, int* smem) {
+  const gfloat* zeros = (const gfloat*)zeros_;
   float* fs = reinterpret_cast<float*>(smem);
   int* ktab = smem + KTAB_OFF;
   int* rowtab = smem + ROWTAB_OFF;
@@ -127,13 +135,15 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   const bool idle = (TMv == 128) && diag && wm == 1 && wn == 0;
   const bool skip10 = diag && (wm == wn);          // 64x64 block on the diagonal: lower-left redundant
 
-  const float* __restrict__ src = d.src;
+  // the pointer comes out of the descriptor table, so tell the compiler it is a GLOBAL address:
+  // a flat load would also count on lgkmcnt and serialise the prefetch with the LDS operand reads
+  const gfloat* __restrict__ src = (const gfloat*)d.src;
   const int N = d.N, C = d.C, H = d.H, W = d.W;
   const int kh = d.kh, kw = d.kw, sh = d.sh, sw = d.sw, ph = d.ph, pw = d.pw;
   const int Ho = d.Ho, Wo = d.Wo, khkw = d.khkw, rows = d.rows, has_bias = d.has_bias;
   const int compact = d.compact, vec4 = d.vec4;
   const int NS = d.NS, R = d.R, Wc = d.Wc, n_rg = d.n_rg, n_cg = d.n_cg, n_chunks = d.n_chunks;
-  const int RS = d.RS, PS = d.PS, SS = d.SS, nch = d.nch, cshift = d.cshift;
+  const int RS = d.RS, PS = d.PS, SS = d.SS, nch = d.nch, cshift = d.cshift, RL = d.RL;
   const int HW = H * W;
 
   const int c_lo_i = i0 / khkw, c_lo_j = j0 / khkw;
@@ -150,7 +160,9 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   const int rows_in_full = compact ? R : (R - 1) * sh + kh;
   const int total_rows_full = NS * nch * rows_in_full;
 
-  if (tid == 0) { fs[ZERO_OFF] = 0.0f; fs[ONE_OFF] = 1.0f; }
+  // every LDS word a masked run element may touch must be finite (0 * NaN would poison the tile)
+  for (int w = tid; w < SMEM_WORDS; w += SYRK_THREADS) fs[w] = (w >= ONE_OFF && w < ONE_OFF + 16) ? 1.0f : 0.0f;
+  __syncthreads();
   if (!vec4) {
     for (int p = tid; p < total_rows_full; p += SYRK_THREADS) {
       const int y = p % rows_in_full;
@@ -188,8 +200,8 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
 
   // staging lane geometry (constant per lane: 256 % padded row length == 0)
   const int cmask = (1 << cshift) - 1;
-  const int lx = tid & cmask;                 // x (general) or x4 (vec4) of this lane
-  const int prow0 = tid >> cshift;
+  const int lx_ = tid & cmask;                // x (general) or x4 (vec4) of this lane
+  const int prow0_ = tid >> cshift;
   const int prow_step = SYRK_THREADS >> cshift;
 
   auto decode_chunk = [&](int ch) {
@@ -201,8 +213,8 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
     c.s0 = sg * NS; c.ns = min(NS, N - c.s0);
     c.oh0 = rg * R; c.ra = min(R, Ho - c.oh0);
     c.ow0 = cg * Wc; c.wa = min(Wc, Wo - c.ow0);
-    c.kc = c.ns * c.ra * c.wa;
-    c.npairs = (c.kc + 1) >> 1;
+    c.nruns = c.ns * c.ra * ((c.wa + RL - 1) / RL);   // rows are padded to whole runs
+    c.niter = (c.nruns + 1) >> 1;                      // one run per lane half per iteration
     c.rows_in = compact ? c.ra : (c.ra - 1) * sh + kh;
     c.cols_in = compact ? c.wa : (c.wa - 1) * sw + kw;
     c.ih_base = c.oh0 * sh - ph;
@@ -212,8 +224,14 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
 
   float st[2 * STAGE_SLOTS];
 
-  // global -> registers for one chunk (both panels); every slot is written (zero when masked)
+  // global -> registers for one chunk (both panels).  Branch-free on purpose: a masked slot loads from
+  // a zeroed dummy word instead of being skipped, so every staging register is the direct destination
+  // of exactly one load and the compiler needs no copy (hence no vmcnt wait) before the MFMA loop.
   auto issue_loads = [&](const Chunk& c) {
+    // lane geometry made opaque per call: otherwise every per-slot address is hoisted out of the chunk
+    // loop and pinned in registers, which spills
+    int lx = lx_, prow0 = prow0_;
+    asm volatile("" : "+v"(lx), "+v"(prow0));
 #pragma unroll
     for (int pnl = 0; pnl < 2; ++pnl) {
       if (pnl < n_panels) {
@@ -222,39 +240,38 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
         if (vec4) {
           const int cols4 = c.wa >> 2;
           const int prow = c.ns * nch_p;
-          const float* g0 = src + ((long long)c.s0 * C + c_lo) * HW + c.iw_base + 4 * lx;
+          const gfloat* g0 = src + ((long long)c.s0 * C + c_lo) * HW + c.iw_base + 4 * lx;
           const bool colok = lx < cols4;
 #pragma unroll
           for (int j = 0; j < STAGE_SLOTS / 4; ++j) {
             const int p = prow0 + j * prow_step;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (colok && p < prow) {
-              const int s = (c.ns == 1) ? 0 : p / nch_p;
-              const int cc = p - s * nch_p;
-              v = *reinterpret_cast<const f32x4*>(g0 + ((long long)s * C + cc) * HW);
-            }
+            const bool ok = colok && p < prow;
+            const int s = (c.ns == 1) ? 0 : p / nch_p;
+            const int cc = p - s * nch_p;
+            const gfloat* a = ok ? g0 + ((long long)s * C + cc) * HW : zeros;
+            const f32x4 v = *reinterpret_cast<const gf32x4*>(a);
             st[pnl * STAGE_SLOTS + 4 * j + 0] = v.x;
             st[pnl * STAGE_SLOTS + 4 * j + 1] = v.y;
             st[pnl * STAGE_SLOTS + 4 * j + 2] = v.z;
             st[pnl * STAGE_SLOTS + 4 * j + 3] = v.w;
           }
         } else {
-          const float* g0 = src + ((long long)c.s0 * C + c_lo) * HW + (long long)c.ih_base * W + c.iw_base +
-                            lx * gx;
+          const gfloat* g0 = src + ((long long)c.s0 * C + c_lo) * HW + (long long)c.ih_base * W + c.iw_base +
+                             lx * gx;
           const int iw = c.iw_base + lx * gx;
           const bool colok = lx < c.cols_in && (unsigned)iw < (unsigned)W;
 #pragma unroll
           for (int j = 0; j < STAGE_SLOTS; ++j) {
             const int p = prow0 + j * prow_step;
-            float v = 0.0f;
-            if (p < total_rows_full) {
-              const int go = rowtab[3 * p + 1];
-              const int scy = rowtab[3 * p + 2];
-              const int s = scy >> 24, cc = (scy >> 16) & 0xff, y = scy & 0xffff;
-              const int ih = c.ih_base + y * gy;
-              if (colok && s < c.ns && cc < nch_p && y < c.rows_in && (unsigned)ih < (unsigned)H) v = g0[go];
-            }
-            st[pnl * STAGE_SLOTS + j] = v;
+            const bool in = p < total_rows_full;
+            const int pp = in ? p : 0;
+            const int go = rowtab[3 * pp + 1];
+            const int scy = rowtab[3 * pp + 2];
+            const int s = scy >> 24, cc = (scy >> 16) & 0xff, y = scy & 0xffff;
+            const int ih = c.ih_base + y * gy;
+            const bool ok = in && colok && s < c.ns && cc < nch_p && y < c.rows_in && (unsigned)ih < (unsigned)H;
+            const gfloat* a = ok ? g0 + go : zeros;
+            st[pnl * STAGE_SLOTS + j] = *a;
           }
         }
       }
@@ -263,6 +280,8 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
 
   // registers -> LDS patch
   auto store_stage = [&](const Chunk& c) {
+    int lx = lx_, prow0 = prow0_;
+    asm volatile("" : "+v"(lx), "+v"(prow0));
 #pragma unroll
     for (int pnl = 0; pnl < 2; ++pnl) {
       if (pnl < n_panels) {
@@ -306,6 +325,77 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
 
   f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
 
+  const int cxb = cx * 4;                      // byte step between the elements of a run
+  int bbase[4];                                // operand row bases as LDS byte addresses
+#pragma unroll
+  for (int o = 0; o < 4; ++o) bbase[o] = base[o] * 4;
+
+  struct Ops { float a0[MAX_RL], a1[MAX_RL], b0[MAX_RL], b1[MAX_RL]; int mask; };
+  auto load_ops = [&](auto rl_tag, Ops& op, int e) {
+    constexpr int RLc = decltype(rl_tag)::value;
+    const int koff = (e & 0xfffff) * 4;
+    op.mask = e >> 20;
+    const char* lds = reinterpret_cast<const char*>(fs);
+    const int pa0 = bbase[0] + (koff & kmask[0]);
+    const int pa1 = bbase[1] + (koff & kmask[1]);
+    const int pb0 = bbase[2] + (koff & kmask[2]);
+    const int pb1 = bbase[3] + (koff & kmask[3]);
+#pragma unroll
+    for (int j = 0; j < RLc; ++j) {
+      op.a0[j] = *reinterpret_cast<const float*>(lds + pa0 + j * cxb);
+      op.a1[j] = *reinterpret_cast<const float*>(lds + pa1 + j * cxb);
+      op.b0[j] = *reinterpret_cast<const float*>(lds + pb0 + j * cxb);
+      op.b1[j] = *reinterpret_cast<const float*>(lds + pb1 + j * cxb);
+    }
+  };
+  auto compute_ops = [&](auto rl_tag, Ops& op) {
+    constexpr int RLc = decltype(rl_tag)::value;
+    constexpr int FULL = (1 << RLc) - 1;
+    if (__ballot(op.mask != FULL) != 0ull) {   // some lane half has padded or missing elements: zero its A
+#pragma unroll
+      for (int j = 0; j < RLc; ++j) {
+        const bool v = (op.mask >> j) & 1;
+        op.a0[j] = v ? op.a0[j] : 0.0f;
+        op.a1[j] = v ? op.a1[j] : 0.0f;
+      }
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < RLc; ++j) {
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a0[j], op.b0[j], acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a0[j], op.b1[j], acc01, 0, 0, 0);
+      if (!skip10) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1[j], op.b0[j], acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1[j], op.b1[j], acc11, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // the other operand set was requested before these MFMAs were issued and has long landed: retiring
+    // it here costs nothing and keeps the compiler from waiting on it in front of the next MFMA group
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+  };
+
+  auto mfma_runs = [&](auto rl_tag, int niter) {
+    Ops A, B;
+    const int last = 2 * niter - 1;          // table entries exist up to here
+    int it = kfirst;
+    load_ops(rl_tag, A, ktab[2 * it + h]);
+    int e = ktab[min(2 * (it + KSTRIDE) + h, last)];   // table entry fetched one iteration ahead
+    // retire the prologue's LDS reads here, so that inside the loop the compiler only has to wait for
+    // operands fetched a full MFMA group earlier
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    while (true) {
+      const int it1 = it + KSTRIDE;
+      const bool n1 = it1 < niter;
+      if (n1) { load_ops(rl_tag, B, e); e = ktab[min(2 * (it1 + KSTRIDE) + h, last)]; }
+      compute_ops(rl_tag, A);
+      if (!n1) break;
+      it = it1 + KSTRIDE;
+      const bool n2 = it < niter;
+      if (n2) { load_ops(rl_tag, A, e); e = ktab[min(2 * (it + KSTRIDE) + h, last)]; }
+      compute_ops(rl_tag, B);
+      if (!n2) break;
+    }
+  };
+
   const int ch_begin = slice * d.cpi;
   const int ch_end = min(ch_begin + d.cpi, n_chunks);
   int cur_ns = -1, cur_ra = -1, cur_wa = -1;
@@ -318,71 +408,43 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
     // (all waves are past the MFMA loop of the previous chunk here)
     if (cur.ns != cur_ns || cur.ra != cur_ra || cur.wa != cur_wa) {
       cur_ns = cur.ns; cur_ra = cur.ra; cur_wa = cur.wa;
-      const int rw = cur.ra * cur.wa;
-      for (int k = tid; k < 2 * cur.npairs; k += SYRK_THREADS) {
+      // one entry per k-run: LDS word offset of its first k, validity mask of its RL elements << 20
+      const int rpr = (cur.wa + RL - 1) / RL;          // runs per output row
+      const int rr = cur.ra * rpr;
+      for (int q = tid; q < 2 * cur.niter; q += SYRK_THREADS) {
         int v = 0;
-        if (k < cur.kc) {
-          const int s = k / rw;
-          const int rem = k - s * rw;
-          const int r = rem / cur.wa;
-          const int w = rem - r * cur.wa;
-          v = s * SS + r * cy + w * cx;
+        if (q < cur.nruns) {
+          const int s = q / rr;
+          const int rem = q - s * rr;
+          const int r = rem / rpr;
+          const int w = (rem - r * rpr) * RL;
+          const int nvalid = min(RL, cur.wa - w);
+          v = (s * SS + r * cy + w * cx) | (((1 << nvalid) - 1) << 20);
         }
-        ktab[k] = v;
+        ktab[q] = v;
       }
     }
-    store_stage(cur);
+    if (!(d.pad0 & 2) || ch == ch_begin) store_stage(cur);
     __syncthreads();
 
     const Chunk work = cur;
     if (ch + 1 < ch_end) {
       cur = decode_chunk(ch + 1);
-      issue_loads(cur);                  // in flight during the MFMA loop below
+      if (!(d.pad0 & 2)) issue_loads(cur);                  // in flight during the MFMA loop below
     }
 
-    // ---- MFMA over this wave's share of the chunk's k pairs (operands fetched one step ahead) ----
-    if (!idle && kfirst < work.npairs) {
-      const int klim = 2 * work.npairs - 1;
-      const int kc = work.kc;
-      int pn = kfirst;
-      int kn = 2 * pn + h;
-      int koff = ktab[kn];
-      float a0 = fs[base[0] + (koff & kmask[0])];
-      float a1 = fs[base[1] + (koff & kmask[1])];
-      float b0 = fs[base[2] + (koff & kmask[2])];
-      float b1 = fs[base[3] + (koff & kmask[3])];
-      bool valid = kn < kc;
-      pn += KSTRIDE;
-      kn = 2 * pn + h;
-      int koff_n = ktab[min(kn, klim)];
-      while (true) {
-        const bool has_next = pn < work.npairs;
-        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-        bool nvalid = false;
-        if (has_next) {
-          na0 = fs[base[0] + (koff_n & kmask[0])];
-          na1 = fs[base[1] + (koff_n & kmask[1])];
-          nb0 = fs[base[2] + (koff_n & kmask[2])];
-          nb1 = fs[base[3] + (koff_n & kmask[3])];
-          nvalid = kn < kc;
-          pn += KSTRIDE;
-          kn = 2 * pn + h;
-          koff_n = ktab[min(kn, klim)];
-        }
-        a0 = valid ? a0 : 0.0f;      // zero A is enough: every product of an invalid k vanishes
-        a1 = valid ? a1 : 0.0f;
-        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-        if (!skip10) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
-        if (!has_next) break;
-        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; valid = nvalid;
-      }
+    // ---- MFMA over this wave's share of the chunk's k-runs ----
+    // Per iteration each lane half owns one run of RL LDS-adjacent k values: one table lookup and one
+    // address per operand row feed RL MFMA groups.  Two register sets alternate so that the operand
+    // reads of iteration t+1 are in flight while the 4*RL MFMAs of iteration t issue.
+    if (!idle && kfirst < work.niter && !(d.pad0 & 1)) {
+      if (RL == 2) mfma_runs(std::integral_constant<int, 2>{}, work.niter);
+      else mfma_runs(std::integral_constant<int, 1>{}, work.niter);
     }
     __syncthreads();
   }
 
-  float* slab = slabs + d.slab_base + (long long)local * (TMv * TMv);
+  gfloat* slab = (gfloat*)slabs + d.slab_base + (long long)local * (TMv * TMv);
   if (TMv == 64) {
     // cross-wave reduction of the four K shares, then one coalesced slab write
     float* red = fs + PATCH_OFF + wave * (64 * 64);
@@ -396,12 +458,12 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
     }
     __syncthreads();
     const f32x4* r0 = reinterpret_cast<const f32x4*>(fs + PATCH_OFF);
-    f32x4* slab4 = reinterpret_cast<f32x4*>(slab);
+    gf32x4* slab4 = reinterpret_cast<gf32x4*>(slab);
     for (int e = tid; e < 64 * 64 / 4; e += SYRK_THREADS)
       slab4[e] = r0[e] + r0[1024 + e] + r0[2048 + e] + r0[3072 + e];
   } else if (!idle) {
     // each wave owns one 64x64 quadrant of the 128x128 slab
-    float* q = slab + (64 * wm) * 128 + 64 * wn;
+    gfloat* q = slab + (64 * wm) * 128 + 64 * wn;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -415,7 +477,7 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
 
 __global__ void __launch_bounds__(SYRK_THREADS, 2)
 syrk_patch_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_items,
-                  float* __restrict__ slabs) {
+                  float* __restrict__ slabs, const float* __restrict__ zeros) {
   __shared__ __attribute__((aligned(16))) int smem[SMEM_WORDS];
   // XCD-aware item order: workgroups that share an XCD (equal blockIdx % 8) take every 8th group of
   // XCD_GROUP consecutive items, i.e. neighbouring tiles of one k-slice of one factor, so the panels
@@ -429,8 +491,8 @@ syrk_patch_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_item
   const int f = find_segment(descs, n_factors, item, false);
   const FactorDev& d = descs[f];
   const int local = item - d.item_base;
-  if (d.TM == 128) syrk_body<128>(d, local, slabs, smem);
-  else syrk_body<64>(d, local, slabs, smem);
+  if (d.TM == 128) syrk_body<128>(d, local, slabs, zeros, smem);
+  else syrk_body<64>(d, local, slabs, zeros, smem);
 }
 
 // Sum the k-slices of one 64x64 sub-tile in slice order, scale, add into the factor and its mirror.
@@ -456,7 +518,7 @@ syrk_reduce_kernel(const FactorDev* __restrict__ descs, int n_factors, const flo
   const int n_tiles = d.n_tiles, n_slices = d.n_slices;
   const float scale = d.scale;
   const bool first = d.first != 0;
-  float* __restrict__ dst = d.dst;
+  gfloat* __restrict__ dst = (gfloat*)d.dst;
 
   const float* s0 = slabs + d.slab_base + (long long)t * (TMv * TMv) + (qi * 64) * TMv + qj * 64;
   const long long slice_stride = (long long)n_tiles * (TMv * TMv);
@@ -496,15 +558,17 @@ syrk_reduce_kernel(const FactorDev* __restrict__ descs, int n_factors, const flo
 // The descriptor table travels as kernel arguments (copied by the runtime at launch time), so the
 // call is fully asynchronous and needs neither pinned staging memory nor a stream synchronisation.
 constexpr int UPLOAD_CHUNK = 16;
+constexpr int ZERO_PAD_FLOATS = 64;    // dummy load target of masked staging slots
 struct TableChunk { FactorDev f[UPLOAD_CHUNK]; };
 static_assert(sizeof(TableChunk) <= 3840, "kernel argument block must stay below 4 KB");
 
 __global__ void __launch_bounds__(256)
-upload_table_kernel(FactorDev* __restrict__ table, TableChunk chunk, int count) {
+upload_table_kernel(FactorDev* __restrict__ table, TableChunk chunk, int count, float* __restrict__ zeros) {
   const int words = count * (int)(sizeof(FactorDev) / 4);
   const int* in = reinterpret_cast<const int*>(&chunk);
   int* out = reinterpret_cast<int*>(table);
   for (int w = threadIdx.x; w < words; w += blockDim.x) out[w] = in[w];
+  if (zeros != nullptr && threadIdx.x < ZERO_PAD_FLOATS) zeros[threadIdx.x] = 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -588,8 +652,9 @@ static bool chunk_fits(const FactorDev& f, int NS, int R, int Wc, ChunkGeom& g) 
     pick_strides(f, g.rows_in, g.cols_in, g.RS, g.PS);
   }
   g.SS = f.nch * g.PS;
-  if ((long long)NS * g.SS > PANEL_WORDS) return false;
-  if ((long long)NS * R * Wc > KTAB_MAX) return false;
+  if ((long long)NS * g.SS + 16 > PANEL_WORDS) return false;       // + slack for padded run elements
+  if ((long long)NS * R * cdiv(Wc, f.RL) > KTAB_MAX) return false;
+  if ((long long)NS * R * Wc > 4096) return false;
   if (NS > 127 || g.rows_in > 0xffff) return false;
   const long long prow = (long long)NS * f.nch * g.rows_in;
   if (f.vec4) {
@@ -646,12 +711,27 @@ static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     f.dim = f.rows + f.has_bias;
     f.first = s.first;
     f.scale = s.scale;
+    { const char* ab = getenv("CURV_SYRK_ABLATE"); f.pad0 = ab ? atoi(ab) : 0; }   // diagnostics only
     CURV_REQUIRE((long long)f.N * f.C * f.H * f.W < (1LL << 31), "curv_kfac: factor %d: source too large", i);
 
     // tile edge: 128 where the padding it adds is small, 64 otherwise
     f.TM = (f.dim >= 256 && cdiv(f.dim, 128) * 128 <= f.dim + f.dim / 14) ? 128 : 64;
     f.nch = std::min(f.C, (f.khkw + f.TM - 2) / f.khkw + 1);
     f.vec4 = (flattened && f.W % 4 == 0 && f.W >= 4 && (reinterpret_cast<uintptr_t>(s.src) & 15) == 0) ? 1 : 0;
+
+    // k-run length: 4 LDS-adjacent k values per operand address where the row padding it needs is
+    // cheaper than the address arithmetic it saves
+    {
+      const int cxs = f.compact ? 1 : f.sw;
+      double best = 1e30;
+      f.RL = 1;
+      for (int rl = 1; rl <= MAX_RL; rl *= 2) {
+        if (rl * cxs > 16) break;
+        const double padded = (double)cdiv(f.Wo, rl) * rl / f.Wo;
+        const double cost = padded * (1.0 + 0.5 / rl);
+        if (cost < best - 1e-9) { best = cost; f.RL = rl; }
+      }
+    }
 
     // chunk extent: full-width rows if they fit, then as many rows, then as many samples
     ChunkGeom g;
@@ -685,7 +765,7 @@ static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     f.n_chunks = cdiv(f.N, NS) * f.n_rg * f.n_cg;
     f.P = cdiv(f.dim, f.TM);
     f.n_tiles = f.P * (f.P + 1) / 2;
-    const double kc = (double)NS * R * Wc;
+    const double kc = (double)NS * R * cdiv(Wc, f.RL) * f.RL;
     const double q = f.TM / 64.0;
     chunk_cost[i] = kc * 32.0 * q * q + 1500.0;   // 64x64xk = 32 k CU-cycles; + staging / barriers
     total_cost += chunk_cost[i] * f.n_tiles * f.n_chunks;
@@ -717,7 +797,9 @@ static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
   return CURV_OK;
 }
 
-static size_t table_bytes(int n) { return align_up((size_t)std::max(n, 1) * sizeof(FactorDev), 256); }
+static size_t table_bytes(int n) {   // descriptor table + the zeroed dummy-load pad
+  return align_up((size_t)std::max(n, 1) * sizeof(FactorDev), 256) + 256;
+}
 
 static int plan_without_pointers(const curv_factor_desc* descs, int n_factors, Plan& plan) {
   // pointers are not dereferenced by the planner, but it insists on non-null ones
@@ -749,7 +831,7 @@ extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors,
     o[0] = f.dim; o[1] = f.Ho; o[2] = f.Wo; o[3] = f.NS; o[4] = f.R; o[5] = f.Wc;
     o[6] = f.n_chunks; o[7] = f.RS; o[8] = f.PS; o[9] = f.SS; o[10] = f.nch;
     o[11] = f.n_tiles; o[12] = f.cpi; o[13] = f.n_slices; o[14] = f.n_items; o[15] = f.item_base;
-    o[16] = f.TM; o[17] = f.vec4; o[18] = f.cshift; o[19] = f.n_sub;
+    o[16] = f.TM; o[17] = f.vec4; o[18] = f.cshift; o[19] = f.n_sub; o[20] = f.RL;
   }
   return CURV_OK;
 }
@@ -769,17 +851,19 @@ extern "C" int curv_kfac_accumulate(void* stream_, const curv_factor_desc* descs
   }
   FactorDev* table = reinterpret_cast<FactorDev*>(workspace);
   float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + tb);
+  float* zeros = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + tb - 256);
   for (int b = 0; b < n_factors; b += UPLOAD_CHUNK) {
     TableChunk chunk;
     const int count = std::min(UPLOAD_CHUNK, n_factors - b);
     memset(&chunk, 0, sizeof(chunk));
     memcpy(chunk.f, plan.f.data() + b, (size_t)count * sizeof(FactorDev));
-    hipLaunchKernelGGL(upload_table_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count);
+    hipLaunchKernelGGL(upload_table_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count,
+                       b == 0 ? zeros : nullptr);
     CURV_LAUNCH_CHECK();
   }
   const int grid = cdiv(plan.n_items, 8 * XCD_GROUP) * 8 * XCD_GROUP;
   hipLaunchKernelGGL(syrk_patch_kernel, dim3(grid), dim3(SYRK_THREADS), 0, stream, table, n_factors,
-                     plan.n_items, slabs);
+                     plan.n_items, slabs, zeros);
   CURV_LAUNCH_CHECK();
   hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub), dim3(SYRK_THREADS), 0, stream, table,
                      n_factors, slabs);

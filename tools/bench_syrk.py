@@ -78,17 +78,45 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--per-layer", action="store_true")
+    ap.add_argument("--classes", action="store_true", help="time factor classes (grouped per class)")
+    ap.add_argument("--only", default="", help="restrict to one class, e.g. 3x3s1:2304 or G:1024")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     model, chw = {"lenet5": (models.lenet5, (1, 28, 28)), "resnet18": (models.resnet18, (3, 224, 224)),
                   "resnet50": (models.resnet50, (3, 224, 224))}[args.model]
     model = model()
     jobs, meta = make_jobs(model, chw, args.batch, dev)
+    if args.only:
+        kind_w, dim_w = args.only.split(":")
+        sel, ex = [], 0.0
+        for li, (idx, n, m, K) in enumerate(meta):
+            for side, job, d in (("A", jobs[2 * li], n), ("G", jobs[2 * li + 1], m)):
+                k = job.kernel
+                kind = f"{k[0]}x{k[1]}s{job.stride[0]}" if side == "A" else "G"
+                if kind == kind_w and d == int(dim_w):
+                    sel.append(job)
+                    ex += d * (d + 1.0) * K
+        t = time_jobs(sel, args.iters)
+        print(f"{args.only} x{len(sel)}: {t * 1e6:.1f} us  {ex / t / 1e12:.1f} TF/s exec ({ex / t / PEAK_F32_MFMA * 100:.1f}%)")
+        return
     dense = sum(2.0 * (n * n + m * m) * K for _, n, m, K in meta)
     execd = sum(1.0 * (n * (n + 1) + m * (m + 1)) * K for _, n, m, K in meta)
     t = time_jobs(jobs, args.iters)
     print(f"{args.model} N={args.batch}: {t * 1e3:.3f} ms/update  executed {execd / t / 1e12:.1f} TFLOP/s "
           f"({execd / t / PEAK_F32_MFMA * 100:.1f}% of fp32 MFMA peak)  dense-equivalent {dense / t / 1e12:.1f} TFLOP/s")
+    if args.classes:
+        classes = {}
+        for li, (idx, n, m, K) in enumerate(meta):
+            for side, job, d in (("A", jobs[2 * li], n), ("G", jobs[2 * li + 1], m)):
+                k = job.kernel
+                kind = f"{k[0]}x{k[1]}s{job.stride[0]}" if side == "A" else "G"
+                key = (kind, d, K)
+                classes.setdefault(key, []).append(job)
+        for (kind, d, K), js in sorted(classes.items(), key=lambda kv: -kv[0][1] * kv[0][1] * kv[0][2] * len(kv[1])):
+            tt = time_jobs(js, 3, 1)
+            ex = d * (d + 1.0) * K * len(js)
+            print(f"  {kind:6s} dim={d:5d} K={K:7d} x{len(js):2d}: {tt * 1e6:9.1f} us  {ex / tt / 1e12:6.1f} TF/s exec "
+                  f"({ex / tt / PEAK_F32_MFMA * 100:5.1f}%)  share of flops {ex / execd * 100:4.1f}%")
     if args.per_layer:
         for li, (idx, n, m, K) in enumerate(meta):
             for side, job, d in (("A", jobs[2 * li], n), ("G", jobs[2 * li + 1], m)):
