@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(CSRC, "libcurv_hip.so")
-SOURCES = ["api.cpp", "elementwise.hip", "syrk.hip"]
+SOURCES = ["api.cpp", "elementwise.hip", "syrk.hip", "invert.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall",
                "-Wno-unused-function"]
 
@@ -58,6 +58,12 @@ class curv_factor_desc(ctypes.Structure):
     ]
 
 
+class curv_inv_desc(ctypes.Structure):
+    """Mirror of ``curv_inv_desc`` in include/curv_hip.h."""
+    _fields_ = [("F", ctypes.c_void_p), ("L", ctypes.c_void_p), ("n", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("add", ctypes.c_double), ("multiply", ctypes.c_double)]
+
+
 _vp, _i, _ll, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_double, ctypes.c_size_t
 
 # name -> (restype, argtypes); every symbol include/curv_hip.h declares
@@ -67,6 +73,8 @@ SIGNATURES = {
     "curv_kfac_workspace_bytes": (_sz, [ctypes.POINTER(curv_factor_desc), _i]),
     "curv_kfac_plan_info": (_i, [ctypes.POINTER(curv_factor_desc), _i, ctypes.POINTER(ctypes.c_longlong)]),
     "curv_kfac_accumulate": (_i, [_vp, ctypes.POINTER(curv_factor_desc), _i, _vp, _sz]),
+    "curv_chol_inv_workspace_bytes": (_sz, [ctypes.POINTER(curv_inv_desc), _i]),
+    "curv_chol_inv_lower": (_i, [_vp, ctypes.POINTER(curv_inv_desc), _i, _vp, _vp, _sz]),
     "curv_rsqrt_affine": (_i, [_vp, _vp, _d, _d, _vp, _ll]),
     "curv_sq_accumulate": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _i]),
     "curv_clamp_min0": (_i, [_vp, _vp, _ll]),

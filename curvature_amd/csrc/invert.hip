@@ -1,0 +1,422 @@
+// KFAC.invert on gfx950: L = chol_lower( (sqrt(s) F + sqrt(n) I)^-1 ) for every Kronecker factor of a
+// model in one batched sweep (curvature/curvatures.py:354-385).
+//
+// The reference computes inverse() then cholesky() (getrf + getri + potrf, fp32 LAPACK).  Here:
+//   chol(M^-1) = J * chol(J M J)^-T * J        (J = index reversal)
+// so one Cholesky factorisation C C^T = J M J and one triangular inverse X = C^-1 suffice:
+//   L[i][j] = X[n-1-j][n-1-i].
+// The damped matrix is formed in fp32 exactly as the reference forms it (:368-375) and everything after
+// that runs in fp64 on v_mfma_f64_16x16x4_f64, so the result is the correctly rounded answer for the
+// matrix the reference hands to LAPACK (the reference's own fp32 LAPACK noise is 5e-5 .. 6e-4 here).
+//
+// Batched left-looking blocked algorithm, block 64, all factors of the model advance together:
+//   step k:  (1) A[i][k] -= sum_{j<k} A[i][j] A[k][j]^T          for every block row i >= k
+//            (2) every workgroup of block column k factorises the 64x64 diagonal block in LDS
+//                (redundantly: cheaper than another launch), then A[i][k] <- A[i][k] L_kk^-T;
+//                the workgroup of the diagonal block stores L_kk and X_kk = L_kk^-1
+//   step i:  (3) X[i][j] = -X_ii * sum_{k=j}^{i-1} C[i][k] X[k][j]  for every block j < i
+// Matrices are padded to a multiple of 64 with an identity tail, so no kernel needs bounds checks.
+// "Not positive definite" is reported through a per-factor device info word (0 = ok).
+#include "common.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace curv {
+
+constexpr int NB = 64;                 // block edge
+constexpr int INV_THREADS = 256;
+constexpr int LDA = NB + 1;            // LDS row pitch (doubles) of a [row][k] operand tile: bank spread
+
+struct InvDev {
+  const float* F;       // (n x n) fp32 factor
+  float* L;             // (n x n) fp32 output
+  double* W;            // (np x np) fp64 work matrix: reversed damped factor -> Cholesky factor C
+  double* X;            // (np x np) fp64: C^-1
+  int* info;            // device status word of this factor
+  int n, np, P;
+  float sqrt_s, sqrt_n;
+};
+
+typedef __attribute__((address_space(1))) double gdouble;
+
+// block -> (factor, local tile) for per-factor tile counts cnt(f) that depend on the step
+template <typename CountFn>
+__device__ __forceinline__ bool locate(const InvDev* __restrict__ t, int nf, int bid, CountFn cnt, int& f,
+                                       int& local) {
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  for (int f0 = 0; f0 < nf; f0 += 64) {
+    const int ff = f0 + lane;
+    const int c = (ff < nf) ? cnt(t[ff]) : 0;
+    int incl = c;                       // inclusive wave scan
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    const int total = __shfl(incl, 63, 64);
+    if (bid < base + total) {
+      const unsigned long long m = __ballot(bid < base + incl);
+      const int l = __ffsll((long long)m) - 1;
+      f = f0 + l;
+      local = bid - (base + __shfl(incl - c, l, 64));
+      return true;
+    }
+    base += total;
+  }
+  return false;
+}
+
+// acc(2x2 of 16x16 per wave, 32x32 wave quadrant) += Atile(64 x 64: [row][k]) * Btile
+//   BT = true : B given as [col][k]  (C += A * B^T, both K-contiguous)
+//   BT = false: B given as [k][col]
+// Both tiles live in LDS with pitch LDA doubles.
+template <bool BT>
+__device__ __forceinline__ void mma_64(const double* __restrict__ As, const double* __restrict__ Bs, int wm,
+                                       int wn, int lane, f64x4 (&acc)[2][2]) {
+  const int r16 = lane & 15, kq = lane >> 4;
+#pragma unroll 4
+  for (int ks = 0; ks < NB / 4; ++ks) {
+    const int k = 4 * ks + kq;
+    double a[2], b[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) a[m] = As[(32 * wm + 16 * m + r16) * LDA + k];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+      b[n] = BT ? Bs[(32 * wn + 16 * n + r16) * LDA + k] : Bs[k * LDA + 32 * wn + 16 * n + r16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+  }
+}
+
+// 64x64 block copy global (pitch ld) -> LDS (pitch LDA)
+__device__ __forceinline__ void load_block(const gdouble* __restrict__ g, int ld, double* __restrict__ s) {
+  for (int e = threadIdx.x; e < NB * NB; e += INV_THREADS) {
+    const int r = e >> 6, c = e & 63;
+    s[r * LDA + c] = g[(long long)r * ld + c];
+  }
+}
+
+// wave quadrant accumulators -> LDS tile [row][col] (f64 C/D map: col = lane&15, row = (lane>>4) + 4*reg)
+__device__ __forceinline__ void acc_to_lds(const f64x4 (&acc)[2][2], int wm, int wn, int lane, double* s) {
+  const int c16 = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[(32 * wm + 16 * m + rq + 4 * r) * LDA + 32 * wn + 16 * n + c16] = acc[m][n][r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// (0) W = J (sqrt_s F + sqrt_n I) J in fp64, formed with the reference's fp32 rounding sequence;
+//     identity tail on the padding; lower triangle only.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(INV_THREADS)
+inv_prepare_kernel(const InvDev* __restrict__ t, int nf) {
+  int f, tile;
+  if (!locate(t, nf, blockIdx.x, [](const InvDev& d) { return d.P * (d.P + 1) / 2; }, f, tile)) return;
+  const InvDev& d = t[f];
+  int bi = 0;
+  while (tile > bi) { tile -= bi + 1; ++bi; }       // lower-triangular enumeration: row bi has bi+1 blocks
+  const int bj = tile;
+  const int n = d.n, np = d.np;
+  const float ss = d.sqrt_s, sn = d.sqrt_n;
+  const float* __restrict__ F = d.F;
+  gdouble* W = (gdouble*)d.W;
+  if (bi == 0 && bj == 0 && threadIdx.x == 0) *d.info = 0;
+  for (int e = threadIdx.x; e < NB * NB; e += INV_THREADS) {
+    const int i = bi * NB + (e >> 6), j = bj * NB + (e & 63);
+    double v;
+    if (i < n && j < n) {
+      const int ri = n - 1 - i, rj = n - 1 - j;
+      // reg = s**0.5 * F + diag(n**0.5); reg = (reg + reg.t()) / 2   (curvatures.py:368-375), in fp32
+      float a = __fmul_rn(ss, F[(long long)ri * n + rj]);
+      float b = __fmul_rn(ss, F[(long long)rj * n + ri]);
+      if (i == j) { a = __fadd_rn(a, sn); b = __fadd_rn(b, sn); }
+      v = (double)__fmul_rn(__fadd_rn(a, b), 0.5f);
+    } else {
+      v = (i == j) ? 1.0 : 0.0;
+    }
+    W[(long long)i * np + j] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (1) A[i][k] -= sum_{j<k} A[i][j] A[k][j]^T
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(INV_THREADS)
+chol_update_col_kernel(const InvDev* __restrict__ t, int nf, int k) {
+  __shared__ double As[NB * LDA], Bs[NB * LDA];
+  int f, local;
+  if (!locate(t, nf, blockIdx.x, [k](const InvDev& d) { return max(0, d.P - k); }, f, local)) return;
+  const InvDev& d = t[f];
+  const int i = k + local, np = d.np;
+  gdouble* W = (gdouble*)d.W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  f64x4 acc[2][2] = {};
+  for (int j = 0; j < k; ++j) {
+    load_block(W + (long long)i * NB * np + j * NB, np, As);
+    load_block(W + (long long)k * NB * np + j * NB, np, Bs);
+    __syncthreads();
+    mma_64<true>(As, Bs, wm, wn, lane, acc);
+    __syncthreads();
+  }
+  gdouble* C = W + (long long)i * NB * np + k * NB;
+  const int c16 = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long idx = (long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16;
+        C[idx] -= acc[m][n][r];
+      }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (2) diagonal block factorisation (in LDS, every workgroup of the block column) + panel solve
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(INV_THREADS)
+chol_diag_trsm_kernel(const InvDev* __restrict__ t, int nf, int k) {
+  __shared__ double Ds[NB * LDA];     // A_kk -> L_kk (lower)
+  __shared__ double Is[NB * LDA];     // L_kk^-1 (lower, zeros above)
+  __shared__ double Ts[NB * LDA];     // this workgroup's panel block
+  __shared__ int bad;
+  int f, local;
+  if (!locate(t, nf, blockIdx.x, [k](const InvDev& d) { return max(0, d.P - k); }, f, local)) return;
+  const InvDev& d = t[f];
+  const int i = k + local, np = d.np;
+  gdouble* W = (gdouble*)d.W;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  if (tid == 0) bad = 0;
+  load_block(W + (long long)k * NB * np + k * NB, np, Ds);
+  if (i != k) load_block(W + (long long)i * NB * np + k * NB, np, Ts);
+  __syncthreads();
+
+  // unblocked right-looking Cholesky of the 64x64 block, lower triangle
+  for (int c = 0; c < NB; ++c) {
+    const double piv = Ds[c * LDA + c];
+    const bool ok = piv > 0.0 && piv < 1.0e300;     // also false for NaN
+    const double dinv = ok ? 1.0 / sqrt(piv) : 1.0;
+    if (!ok && tid == 0 && bad == 0) bad = k * NB + c + 1;
+    __syncthreads();                               // everyone has read the pivot
+    if (tid >= c && tid < NB) Ds[tid * LDA + c] *= dinv;          // column c (diag becomes sqrt(piv))
+    __syncthreads();
+    // trailing update of the lower triangle: a[r][q] -= a[r][c] * a[q][c], r >= q > c
+    for (int e = tid; e < NB * NB; e += INV_THREADS) {
+      const int r = e >> 6, q = e & 63;
+      if (q > c && r >= q) Ds[r * LDA + q] -= Ds[r * LDA + c] * Ds[q * LDA + c];
+    }
+    __syncthreads();
+  }
+  // zero the strict upper triangle, then invert: column j of L^-1 by forward substitution (one lane each)
+  for (int e = tid; e < NB * NB; e += INV_THREADS) {
+    const int r = e >> 6, q = e & 63;
+    if (q > r) Ds[r * LDA + q] = 0.0;
+    Is[r * LDA + q] = 0.0;
+  }
+  __syncthreads();
+  if (tid < NB) {
+    const int j = tid;
+    Is[j * LDA + j] = 1.0 / Ds[j * LDA + j];
+    for (int r = j + 1; r < NB; ++r) {
+      double s = 0.0;
+      for (int q = j; q < r; ++q) s += Ds[r * LDA + q] * Is[q * LDA + j];
+      Is[r * LDA + j] = -s / Ds[r * LDA + r];
+    }
+  }
+  __syncthreads();
+
+  if (i == k) {
+    gdouble* Dg = W + (long long)k * NB * np + k * NB;
+    gdouble* Xg = (gdouble*)d.X + (long long)k * NB * np + k * NB;
+    for (int e = tid; e < NB * NB; e += INV_THREADS) {
+      const int r = e >> 6, q = e & 63;
+      Dg[(long long)r * np + q] = Ds[r * LDA + q];
+      Xg[(long long)r * np + q] = Is[r * LDA + q];
+    }
+    if (tid == 0 && bad != 0) atomicCAS(d.info, 0, bad);
+  } else {
+    // A_ik <- A_ik * L_kk^-T  =  Ts * Is^T   (Is rows are the K-contiguous operand)
+    f64x4 acc[2][2] = {};
+    mma_64<true>(Ts, Is, wm, wn, lane, acc);
+    gdouble* C = W + (long long)i * NB * np + k * NB;
+    const int c16 = lane & 15, rq = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          C[(long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16] = acc[m][n][r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (3) X[i][j] = -X_ii * sum_{k=j}^{i-1} C[i][k] X[k][j]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(INV_THREADS)
+trtri_row_kernel(const InvDev* __restrict__ t, int nf, int i) {
+  __shared__ double As[NB * LDA], Bs[NB * LDA];
+  int f, j;
+  if (!locate(t, nf, blockIdx.x, [i](const InvDev& d) { return i < d.P ? i : 0; }, f, j)) return;
+  const InvDev& d = t[f];
+  const int np = d.np;
+  const gdouble* W = (const gdouble*)d.W;
+  gdouble* X = (gdouble*)d.X;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  f64x4 acc[2][2] = {};
+  for (int k = j; k < i; ++k) {
+    load_block(W + (long long)i * NB * np + k * NB, np, As);
+    load_block(X + (long long)k * NB * np + j * NB, np, Bs);
+    __syncthreads();
+    mma_64<false>(As, Bs, wm, wn, lane, acc);
+    __syncthreads();
+  }
+  acc_to_lds(acc, wm, wn, lane, Bs);                                   // Bs = G as [k][col]
+  load_block(X + (long long)i * NB * np + i * NB, np, As);            // As = X_ii as [row][k]
+  __syncthreads();
+  f64x4 out[2][2] = {};
+  mma_64<false>(As, Bs, wm, wn, lane, out);
+  gdouble* C = X + (long long)i * NB * np + j * NB;
+  const int c16 = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        C[(long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16] = -out[m][n][r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// (4) L[i][j] = (float) X[n-1-j][n-1-i] for j <= i, 0 above the diagonal (32x32 tiles via LDS)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(INV_THREADS)
+inv_finalize_kernel(const InvDev* __restrict__ t, int nf) {
+  __shared__ float tile[32][33];
+  int f, local;
+  if (!locate(t, nf, blockIdx.x, [](const InvDev& d) { const int q = (d.n + 31) / 32; return q * q; }, f, local)) return;
+  const InvDev& d = t[f];
+  const int n = d.n, np = d.np, q = (n + 31) / 32;
+  const int ti = local / q, tj = local - ti * q;       // output tile (rows ti*32.., cols tj*32..)
+  const gdouble* X = (const gdouble*)d.X;
+  float* __restrict__ L = d.L;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  if (tj > ti) {
+    for (int r = ty; r < 32; r += 8) {
+      const int i = ti * 32 + r, j = tj * 32 + tx;
+      if (i < n && j < n) L[(long long)i * n + j] = 0.0f;
+    }
+    return;
+  }
+  // source element for output (i, j) is X[n-1-j][n-1-i]: read rows of X coalesced along its columns
+  for (int r = ty; r < 32; r += 8) {
+    const int j = tj * 32 + r;          // output column -> source row n-1-j
+    const int i = ti * 32 + tx;         // output row    -> source col n-1-i
+    float v = 0.0f;
+    if (i < n && j < n && j <= i) v = (float)X[(long long)(n - 1 - j) * np + (n - 1 - i)];
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = ti * 32 + r, j = tj * 32 + tx;
+    if (i < n && j < n) L[(long long)i * n + j] = tile[tx][r];
+  }
+}
+
+constexpr int INV_UPLOAD_CHUNK = 48;
+struct InvChunk { InvDev f[INV_UPLOAD_CHUNK]; };
+static_assert(sizeof(InvChunk) <= 3840, "kernel argument block must stay below 4 KB");
+
+__global__ void __launch_bounds__(256) inv_upload_kernel(InvDev* __restrict__ table, InvChunk chunk, int count) {
+  const int words = count * (int)(sizeof(InvDev) / 4);
+  const int* in = reinterpret_cast<const int*>(&chunk);
+  int* out = reinterpret_cast<int*>(table);
+  for (int w = threadIdx.x; w < words; w += blockDim.x) out[w] = in[w];
+}
+
+static size_t inv_table_bytes(int n) { return align_up((size_t)std::max(n, 1) * sizeof(InvDev), 256); }
+
+}  // namespace curv
+
+using namespace curv;
+
+extern "C" size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int n_factors) {
+  size_t total = inv_table_bytes(n_factors);
+  for (int i = 0; i < n_factors; ++i) {
+    if (descs[i].n <= 0) return 0;
+    const size_t np = (size_t)cdiv(descs[i].n, NB) * NB;
+    total += 2 * np * np * sizeof(double);
+  }
+  return total;
+}
+
+extern "C" int curv_chol_inv_lower(void* stream_, const curv_inv_desc* descs, int n_factors, int* info,
+                                   void* workspace, size_t workspace_bytes) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_factors == 0) return CURV_OK;
+  CURV_REQUIRE(descs != nullptr && info != nullptr, "curv_chol_inv_lower: null argument");
+  const size_t need = curv_chol_inv_workspace_bytes(descs, n_factors);
+  CURV_REQUIRE(need != 0, "curv_chol_inv_lower: empty factor");
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("curv_chol_inv_lower: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+    return CURV_ERR_WORKSPACE;
+  }
+  std::vector<InvDev> tab(n_factors);
+  char* p = reinterpret_cast<char*>(workspace) + inv_table_bytes(n_factors);
+  int Pmax = 0;
+  long long prep_tiles = 0, fin_tiles = 0;
+  for (int i = 0; i < n_factors; ++i) {
+    const curv_inv_desc& s = descs[i];
+    CURV_REQUIRE(s.F != nullptr && s.L != nullptr, "curv_chol_inv_lower: factor %d: null pointer", i);
+    CURV_REQUIRE(s.multiply >= 0.0 && s.add >= 0.0, "curv_chol_inv_lower: factor %d: negative hyper-parameter", i);
+    InvDev& d = tab[i];
+    d.F = s.F; d.L = s.L; d.n = s.n;
+    d.P = cdiv(s.n, NB); d.np = d.P * NB;
+    d.W = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double);
+    d.X = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double);
+    d.info = info + i;
+    d.sqrt_s = (float)sqrt(s.multiply);      // s ** 0.5 in double, then the fp32 tensor multiply
+    d.sqrt_n = (float)sqrt(s.add);
+    Pmax = std::max(Pmax, d.P);
+    prep_tiles += (long long)d.P * (d.P + 1) / 2;
+    const long long q = cdiv(s.n, 32);
+    fin_tiles += q * q;
+  }
+  InvDev* table = reinterpret_cast<InvDev*>(workspace);
+  for (int b = 0; b < n_factors; b += INV_UPLOAD_CHUNK) {
+    InvChunk chunk;
+    const int count = std::min(INV_UPLOAD_CHUNK, n_factors - b);
+    memset(&chunk, 0, sizeof(chunk));
+    memcpy(chunk.f, tab.data() + b, (size_t)count * sizeof(InvDev));
+    hipLaunchKernelGGL(inv_upload_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count);
+    CURV_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(inv_prepare_kernel, dim3((unsigned)prep_tiles), dim3(INV_THREADS), 0, stream, table, n_factors);
+  CURV_LAUNCH_CHECK();
+  for (int k = 0; k < Pmax; ++k) {
+    long long tiles = 0;
+    for (const InvDev& d : tab) tiles += std::max(0, d.P - k);
+    if (k > 0) {
+      hipLaunchKernelGGL(chol_update_col_kernel, dim3((unsigned)tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
+      CURV_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3((unsigned)tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
+    CURV_LAUNCH_CHECK();
+  }
+  for (int i = 1; i < Pmax; ++i) {
+    long long tiles = 0;
+    for (const InvDev& d : tab) tiles += (i < d.P) ? i : 0;
+    hipLaunchKernelGGL(trtri_row_kernel, dim3((unsigned)tiles), dim3(INV_THREADS), 0, stream, table, n_factors, i);
+    CURV_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(inv_finalize_kernel, dim3((unsigned)fin_tiles), dim3(INV_THREADS), 0, stream, table, n_factors);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}

@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import curv_factor_desc
+from ._lib import curv_factor_desc, curv_inv_desc
 
 _workspaces = {}
 
@@ -103,3 +103,36 @@ def sq_accumulate(grad_w: torch.Tensor, grad_b: Optional[torch.Tensor], batch_si
                                              rows, cols_w, float(batch_size), state.data_ptr(), int(first)),
                "curv_sq_accumulate")
     return state
+
+
+def chol_inv_lower(factors: Sequence[torch.Tensor], adds: Sequence[float], multiplies: Sequence[float],
+                   check: bool = True) -> List[torch.Tensor]:
+    """[chol_lower((sqrt(s_i) F_i + sqrt(n_i) I)^-1)] for all factors in one batched sweep.
+
+    Raises ``RuntimeError`` (like torch's cholesky in the reference, curvatures.py:378-380) when a damped
+    factor is not positive definite; set ``check=False`` to skip the host read-back of the status words."""
+    n = len(factors)
+    if n == 0:
+        return []
+    arr = (curv_inv_desc * n)()
+    outs = []
+    for d, F, a, s in zip(arr, factors, adds, multiplies):
+        _require_gpu(F)
+        if F.dim() != 2 or F.shape[0] != F.shape[1]:
+            raise RuntimeError("factor must be a square matrix")
+        out = torch.empty_like(F)
+        outs.append(out)
+        d.F, d.L, d.n, d.add, d.multiply = F.data_ptr(), out.data_ptr(), F.shape[0], float(a), float(s)
+    dev = factors[0].device
+    info = torch.empty(n, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    need = L.curv_chol_inv_workspace_bytes(arr, n)
+    ws = workspace(need, dev, "invert")
+    _lib.check(L.curv_chol_inv_lower(_lib.stream_ptr(), arr, n, info.data_ptr(), ws.data_ptr(), ws.numel()),
+               "curv_chol_inv_lower")
+    if check:
+        bad = torch.nonzero(info).flatten().tolist()
+        if bad:
+            raise RuntimeError(f"cholesky: damped factor(s) {bad} are not positive-definite "
+                               f"(first failing pivot {int(info[bad[0]]) - 1})")
+    return outs

@@ -80,6 +80,29 @@ int curv_kfac_accumulate(void* stream, const curv_factor_desc* descs, int n_fact
                          size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------------
+ * KFAC.invert:  L = lower Cholesky factor of (sqrt(multiply) * F + sqrt(add) * I)^-1
+ *                                                                (curvature/curvatures.py:354-385)
+ * One descriptor per Kronecker factor; all factors of a model are processed by one batched sweep.
+ * F is the (n x n) fp32 factor (read only), L the (n x n) fp32 output (zeros above the diagonal, as
+ * torch's cholesky returns).  The damped matrix is formed in fp32 exactly as the reference does
+ * (:368-375); the factorisation itself runs in fp64.  info[i] (device int32) is 0 on success and
+ * 1 + the index of the failing pivot when factor i is not positive definite, in which case L holds
+ * garbage: the caller raises the reference's RuntimeError (:380, scripts/hyper.py:141).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct curv_inv_desc {
+  const float* F;
+  float* L;
+  int32_t n;
+  int32_t reserved;
+  double add;       /* n of the reference: sqrt(add) goes on the diagonal   */
+  double multiply;  /* s of the reference: the factor is scaled by sqrt(s)   */
+} curv_inv_desc;
+
+size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int n_factors);
+int curv_chol_inv_lower(void* stream, const curv_inv_desc* descs, int n_factors, int* info, void* workspace,
+                        size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------------------------------
  * Elementwise pieces (Diagonal / EFB / INF)
  * ---------------------------------------------------------------------------------------------- */
 /* out = (s*v + n)^(-1/2)     curvatures.py:188 (Diagonal.invert), :449 (EFB.invert), :526 (INF) */
