@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(CSRC, "libcurv_hip.so")
-SOURCES = ["api.cpp", "elementwise.hip", "syrk.hip", "invert.hip"]
+SOURCES = ["api.cpp", "elementwise.hip", "syrk.hip", "invert.hip", "gemm.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall",
                "-Wno-unused-function"]
 
@@ -64,6 +64,14 @@ class curv_inv_desc(ctypes.Structure):
                 ("add", ctypes.c_double), ("multiply", ctypes.c_double)]
 
 
+class curv_gemm_desc(ctypes.Structure):
+    """Mirror of ``curv_gemm_desc`` in include/curv_hip.h."""
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("E", ctypes.c_void_p)] + \
+               [(k, ctypes.c_longlong) for k in ("a_rs", "a_cs", "b_rs", "b_cs", "c_rs", "c_cs", "e_rs", "e_cs")] + \
+               [("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("epilogue", ctypes.c_int32),
+                ("alpha", ctypes.c_float), ("beta", ctypes.c_float)]
+
+
 _vp, _i, _ll, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_double, ctypes.c_size_t
 
 # name -> (restype, argtypes); every symbol include/curv_hip.h declares
@@ -75,6 +83,9 @@ SIGNATURES = {
     "curv_kfac_accumulate": (_i, [_vp, ctypes.POINTER(curv_factor_desc), _i, _vp, _sz]),
     "curv_chol_inv_workspace_bytes": (_sz, [ctypes.POINTER(curv_inv_desc), _i]),
     "curv_chol_inv_lower": (_i, [_vp, ctypes.POINTER(curv_inv_desc), _i, _vp, _vp, _sz]),
+    "curv_gemm_workspace_bytes": (_sz, [_i]),
+    "curv_gemm_batched": (_i, [_vp, ctypes.POINTER(curv_gemm_desc), _i, _vp, _sz]),
+    "curv_randn": (_i, [_vp, _vp, _ll, ctypes.c_ulonglong, ctypes.c_ulonglong]),
     "curv_rsqrt_affine": (_i, [_vp, _vp, _d, _d, _vp, _ll]),
     "curv_sq_accumulate": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _i]),
     "curv_clamp_min0": (_i, [_vp, _vp, _ll]),

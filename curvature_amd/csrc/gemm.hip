@@ -1,0 +1,264 @@
+// Batched, strided fp32 GEMM on the f32 MFMA with the fused epilogues the estimators need, plus the
+// Philox normal generator of the samplers.
+//
+//   C = epilogue( alpha * op(A) op(B) )      op(.) expressed through element strides
+//
+// Used for (reference lines in curvature/curvatures.py):
+//   KFAC.sample   (L_A z L_G^T)^T = L_G z^T L_A^T                      :387-392
+//   EFB.update    Lambda += (U_G^T grad U_A)**2                        :427-431
+//   EFB.sample    (U_A (z * inv^T) U_G^T)^T                            :457-460
+//   INF           the small dense products of update / pre_sampler / sampler   :487-600
+// One launch covers any number of independent products (one per layer): the work list is
+// (descriptor, 64x64 output tile), decoded on the device from the descriptor table.
+#include "common.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace curv {
+
+constexpr int GT = 64;                 // output tile edge
+constexpr int GK = 16;                 // K depth per stage
+constexpr int GEMM_THREADS = 256;
+constexpr int GP = GT + 1;             // LDS pitch of a [k][row] operand image
+
+struct GemmDev {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* E;         // optional elementwise operand of the epilogue
+  long long a_rs, a_cs;   // op(A) is M x K: element (i, k) at A[i*a_rs + k*a_cs]
+  long long b_rs, b_cs;   // op(B) is K x N: element (k, j) at B[k*b_rs + j*b_cs]
+  long long c_rs, c_cs;
+  long long e_rs, e_cs;
+  int M, N, K;
+  int epilogue;
+  float alpha, beta;
+  int tiles_n, tile_base;
+};
+
+typedef __attribute__((address_space(1))) float gfl;
+
+__device__ __forceinline__ int gemm_find(const GemmDev* __restrict__ t, int n, int id) {
+  const int lane = threadIdx.x & 63;
+  int count = 0;
+  for (int f0 = 0; f0 < n; f0 += 64) {
+    const int f = f0 + lane;
+    bool le = false;
+    if (f < n) le = t[f].tile_base <= id;
+    count += __popcll(__ballot(le));
+  }
+  return __builtin_amdgcn_readfirstlane(count - 1);
+}
+
+__global__ void __launch_bounds__(GEMM_THREADS)
+gemm_f32_kernel(const GemmDev* __restrict__ table, int n_desc) {
+  __shared__ float As[2][GK * GP];     // [k][row]
+  __shared__ float Bs[2][GK * GP];     // [k][col]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, h = lane >> 5;
+
+  const int f = gemm_find(table, n_desc, blockIdx.x);
+  const GemmDev& d = table[f];
+  const int local = blockIdx.x - d.tile_base;
+  const int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
+  const int i0 = tm * GT, j0 = tn * GT;
+  const int M = d.M, N = d.N, K = d.K;
+  const gfl* A = (const gfl*)d.A;
+  const gfl* B = (const gfl*)d.B;
+  const long long a_rs = d.a_rs, a_cs = d.a_cs, b_rs = d.b_rs, b_cs = d.b_cs;
+
+  // staging map: 64 x 16 elements per operand per stage = 4 per thread.  Lanes run along the
+  // unit-stride dimension of the operand so that global reads coalesce.
+  const bool a_kfast = (a_cs == 1), b_kfast = (b_rs == 1);
+  int ar[4], ak[4], bc[4], bk[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + u * GEMM_THREADS;           // 0 .. 1023
+    if (a_kfast) { ak[u] = e & 15; ar[u] = e >> 4; } else { ar[u] = e & 63; ak[u] = e >> 6; }
+    if (b_kfast) { bk[u] = e & 15; bc[u] = e >> 4; } else { bc[u] = e & 63; bk[u] = e >> 6; }
+  }
+  float ra[4], rb[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + ar[u], k = k0 + ak[u];
+      ra[u] = (i < M && k < K) ? A[i * a_rs + k * a_cs] : 0.0f;
+      const int j = j0 + bc[u], kk = k0 + bk[u];
+      rb[u] = (j < N && kk < K) ? B[kk * b_rs + j * b_cs] : 0.0f;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      As[buf][ak[u] * GP + ar[u]] = ra[u];
+      Bs[buf][bk[u] * GP + bc[u]] = rb[u];
+    }
+  };
+
+  f32x16 acc = {0};
+  const int nk = (K + GK - 1) / GK;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) fetch((kt + 1) * GK);          // in flight during the MFMAs below
+    const float* as = As[buf] + 32 * wm + r32;
+    const float* bs = Bs[buf] + 32 * wn + r32;
+#pragma unroll
+    for (int kp = 0; kp < GK / 2; ++kp) {
+      const float a = as[(2 * kp + h) * GP];
+      const float b = bs[(2 * kp + h) * GP];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (kt + 1 < nk) stash(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue; C/D map of the 32x32 block: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  gfl* C = (gfl*)d.C;
+  const gfl* E = (const gfl*)d.E;
+  const float alpha = d.alpha, beta = d.beta;
+  const int ep = d.epilogue;
+  const int j = j0 + 32 * wn + r32;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int i = i0 + 32 * wm + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (i < M && j < N) {
+      const long long ci = i * d.c_rs + j * d.c_cs;
+      float v = alpha * acc[reg];
+      if (ep == CURV_EPI_SQUARE) v = alpha * acc[reg] * acc[reg];
+      else if (ep == CURV_EPI_MUL_E) v *= E[i * d.e_rs + j * d.e_cs];
+      else if (ep == CURV_EPI_ADD_E) v += E[i * d.e_rs + j * d.e_cs];
+      if (beta != 0.0f) v += beta * C[ci];
+      C[ci] = v;
+    }
+  }
+}
+
+constexpr int GEMM_UPLOAD_CHUNK = 24;
+struct GemmChunk { GemmDev f[GEMM_UPLOAD_CHUNK]; };
+static_assert(sizeof(GemmChunk) <= 3840, "kernel argument block must stay below 4 KB");
+
+__global__ void __launch_bounds__(256) gemm_upload_kernel(GemmDev* __restrict__ table, GemmChunk chunk, int count) {
+  const int words = count * (int)(sizeof(GemmDev) / 4);
+  const int* in = reinterpret_cast<const int*>(&chunk);
+  int* out = reinterpret_cast<int*>(table);
+  for (int w = threadIdx.x; w < words; w += blockDim.x) out[w] = in[w];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Standard normal noise: Philox4x32-10 counter-based generator + Box-Muller, 4 values per counter.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c[0];
+  const unsigned long long p1 = 0xCD9E8D57ull * c[2];
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0;
+  const unsigned n1 = (unsigned)p1;
+  const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+  const unsigned n3 = (unsigned)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ void __launch_bounds__(256)
+randn_kernel(float* __restrict__ out, long long count, unsigned long long seed, unsigned long long offset) {
+  const long long nquad = (count + 3) >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += stride) {
+    const unsigned long long ctr = offset + (unsigned long long)q;
+    unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u};
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    float z[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const float u1 = ((float)(c[2 * p] >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+      const float u2 = (float)(c[2 * p + 1] >> 8) * (1.0f / 16777216.0f);           // [0, 1)
+      const float r = sqrtf(-2.0f * logf(u1));
+      float sn, cs;
+      sincosf(6.283185307179586f * u2, &sn, &cs);
+      z[2 * p] = r * cs;
+      z[2 * p + 1] = r * sn;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * q + e < count) out[4 * q + e] = z[e];
+  }
+}
+
+}  // namespace curv
+
+using namespace curv;
+
+extern "C" size_t curv_gemm_workspace_bytes(int n_desc) {
+  return align_up((size_t)std::max(n_desc, 1) * sizeof(GemmDev), 256);
+}
+
+extern "C" int curv_gemm_batched(void* stream_, const curv_gemm_desc* descs, int n_desc, void* workspace,
+                                 size_t workspace_bytes) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_desc == 0) return CURV_OK;
+  CURV_REQUIRE(descs != nullptr, "curv_gemm_batched: null descriptor array");
+  if (workspace == nullptr || workspace_bytes < curv_gemm_workspace_bytes(n_desc)) {
+    set_error("curv_gemm_batched: workspace too small");
+    return CURV_ERR_WORKSPACE;
+  }
+  std::vector<GemmDev> tab;
+  tab.reserve(n_desc);
+  long long tiles = 0;
+  for (int i = 0; i < n_desc; ++i) {
+    const curv_gemm_desc& s = descs[i];
+    CURV_REQUIRE(s.M >= 0 && s.N >= 0 && s.K >= 0, "curv_gemm_batched: desc %d: negative shape", i);
+    if (s.M == 0 || s.N == 0) continue;
+    CURV_REQUIRE(s.C != nullptr && (s.K == 0 || (s.A != nullptr && s.B != nullptr)),
+                 "curv_gemm_batched: desc %d: null pointer", i);
+    CURV_REQUIRE(s.epilogue >= 0 && s.epilogue <= CURV_EPI_ADD_E, "curv_gemm_batched: desc %d: bad epilogue", i);
+    CURV_REQUIRE((s.epilogue != CURV_EPI_MUL_E && s.epilogue != CURV_EPI_ADD_E) || s.E != nullptr,
+                 "curv_gemm_batched: desc %d: epilogue needs E", i);
+    GemmDev d;
+    memset(&d, 0, sizeof(d));
+    d.A = s.A; d.B = s.B; d.C = s.C; d.E = s.E;
+    d.a_rs = s.a_rs; d.a_cs = s.a_cs; d.b_rs = s.b_rs; d.b_cs = s.b_cs;
+    d.c_rs = s.c_rs; d.c_cs = s.c_cs; d.e_rs = s.e_rs; d.e_cs = s.e_cs;
+    d.M = s.M; d.N = s.N; d.K = s.K;
+    d.epilogue = s.epilogue; d.alpha = s.alpha; d.beta = s.beta;
+    d.tiles_n = cdiv(s.N, GT);
+    d.tile_base = (int)tiles;
+    tiles += (long long)cdiv(s.M, GT) * d.tiles_n;
+    CURV_REQUIRE(tiles < (1LL << 30), "curv_gemm_batched: too many tiles");
+    tab.push_back(d);
+  }
+  if (tab.empty()) return CURV_OK;
+  GemmDev* table = reinterpret_cast<GemmDev*>(workspace);
+  const int n = (int)tab.size();
+  for (int b = 0; b < n; b += GEMM_UPLOAD_CHUNK) {
+    GemmChunk chunk;
+    const int count = std::min(GEMM_UPLOAD_CHUNK, n - b);
+    memset(&chunk, 0, sizeof(chunk));
+    memcpy(chunk.f, tab.data() + b, (size_t)count * sizeof(GemmDev));
+    hipLaunchKernelGGL(gemm_upload_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count);
+    CURV_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, stream, table, n);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}
+
+extern "C" int curv_randn(void* stream, float* out, long long count, unsigned long long seed,
+                          unsigned long long offset) {
+  if (count <= 0) return CURV_OK;
+  CURV_REQUIRE(out != nullptr, "curv_randn: null pointer");
+  long long blocks = cdivll(cdivll(count, 4), 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, count, seed,
+                     offset);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}

@@ -1,0 +1,276 @@
+"""MI355X-native estimators behind the reference's plugin API.
+
+Same classes, constructor signatures, method names, public attributes (``state``, ``inv_state``,
+``model_state`` ...) and error behaviour as ``curvature/curvatures.py`` of DLR-RM/curvature, so that the
+reference's call sequences run unchanged::
+
+    kfac = KFAC(model)
+    for images, labels in data:                # scripts/test.py:32-47
+        loss = criterion(model(images), sampled_labels); model.zero_grad(); loss.backward()
+        kfac.update(batch_size=images.size(0))
+    kfac.invert(add=0.5, multiply=1)
+    kfac.sample_and_replace()
+
+All arithmetic runs in ``libcurv_hip.so`` (hand-written HIP for gfx950) through the C ABI of
+``include/curv_hip.h``; PyTorch only runs the model's forward/backward and owns the tensors.  There is
+no CPU fallback: CPU models raise ``RuntimeError``.
+"""
+import copy
+import numbers
+from abc import ABC, abstractmethod
+from typing import Any, Dict, List, Optional, Union
+
+import torch
+from torch import Tensor
+from torch.nn import Module, Sequential
+
+from . import ops
+
+SUPPORTED_LAYERS = ['Linear', 'Conv2d', 'MultiheadAttention']
+
+
+def _is_scalar(x) -> bool:
+    """Python / numpy real scalars (a superset of what the reference accepts)."""
+    return isinstance(x, numbers.Real) or (hasattr(x, "ndim") and getattr(x, "ndim") == 0)
+
+
+class Curvature(ABC):
+    """Base class: layer selection, mean weights, `_replace`, `sample_and_replace`.
+
+    Mirrors curvature/curvatures.py:17-129.  Layers are selected by class NAME in ``model.modules()``
+    order; that order is the layer index used by per-layer ``add`` / ``multiply`` lists."""
+
+    def __init__(self, model: Union[Module, Sequential], layer_types: Union[List[str], str] = None):
+        self.model = model
+        self.model_state = copy.deepcopy(model.state_dict())
+        self.layer_types = list()
+        if isinstance(layer_types, str):
+            self.layer_types.append(layer_types)
+        elif isinstance(layer_types, list):
+            self.layer_types.extend(layer_types if layer_types else SUPPORTED_LAYERS)
+        elif layer_types is None:
+            self.layer_types.extend(SUPPORTED_LAYERS)
+        else:
+            raise TypeError
+        for _type in self.layer_types:
+            assert _type in SUPPORTED_LAYERS
+        self.state = dict()
+        self.inv_state = dict()
+        # device-side noise generator of the samplers (Philox): advance `noise_offset` per draw
+        self.noise_seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+        self.noise_offset = 0
+
+    # ------------------------------------------------------------------ helpers
+    def _layers(self) -> List[Module]:
+        """Selected Linear / Conv2d layers in ``model.modules()`` order (curvatures.py:120-122)."""
+        out = []
+        for layer in self.model.modules():
+            name = layer.__class__.__name__
+            if name in self.layer_types:
+                if name in ('Linear', 'Conv2d'):
+                    out.append(layer)
+                elif name == 'MultiheadAttention':
+                    raise NotImplementedError
+        return out
+
+    @staticmethod
+    def _hyper(add, multiply, index: int, count: int):
+        """(n, s) of layer `index`: lists only when BOTH are non-scalars (curvatures.py:361-365)."""
+        if not _is_scalar(add) and not _is_scalar(multiply):
+            assert len(add) == len(multiply) == count
+            return float(add[index]), float(multiply[index])
+        return float(add), float(multiply)
+
+    def _randn(self, *shape, device) -> Tensor:
+        numel = 1
+        for s in shape:
+            numel *= int(s)
+        out = ops.randn(shape, device, self.noise_seed, self.noise_offset)
+        self.noise_offset += (numel + 3) // 4
+        return out
+
+    @staticmethod
+    def _replace(sample: Tensor, weight: Tensor, bias: Tensor = None):
+        """weight += sample[:, :-1], bias += sample[:, -1] (curvatures.py:67-82)."""
+        if bias is not None:
+            bias_sample = sample[:, -1].contiguous().view(*bias.shape)
+            bias.data.add_(bias_sample)
+            sample = sample[:, :-1]
+        weight.data.add_(sample.contiguous().view(*weight.shape))
+
+    # ------------------------------------------------------------------ plugin API
+    @abstractmethod
+    def update(self, *args: Any, **kwargs: Any):
+        raise NotImplementedError
+
+    @abstractmethod
+    def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
+        raise NotImplementedError
+
+    @abstractmethod
+    def sample(self, layer: Module) -> Tensor:
+        raise NotImplementedError
+
+    def sample_and_replace(self):
+        """Reset to the mean weights, then add one posterior sample per selected layer (curvatures.py:117-129)."""
+        self.model.load_state_dict(self.model_state)
+        for layer in self._layers():
+            _sample = self.sample(layer)
+            self._replace(_sample, layer.weight, layer.bias)
+
+
+class Diagonal(Curvature):
+    """Diagonal Fisher: state += grad**2 * batch_size (curvatures.py:132-193)."""
+
+    def update(self, batch_size: int):
+        for layer in self._layers():
+            bias_grad = layer.bias.grad if layer.bias is not None else None
+            self.state[layer] = ops.sq_accumulate(layer.weight.grad.contiguous(), bias_grad, batch_size,
+                                                  self.state.get(layer))
+
+    def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
+        assert self.state, "State dict is empty. Did you call 'update' prior to this?"
+        for index, (layer, value) in enumerate(self.state.items()):
+            # Diagonal uses lists when both are list/tuple (curvatures.py:183); same outcome as _hyper
+            n, s = self._hyper(add, multiply, index, len(self.state))
+            self.inv_state[layer] = ops.rsqrt_affine(value, n, s)
+
+    def sample(self, layer: Union[Module, str], z: Optional[Tensor] = None) -> Tensor:
+        assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
+        inv = self.inv_state[layer]
+        if z is None:
+            z = self._randn(*inv.shape, device=inv.device)
+        return ops.mul(z, inv)
+
+
+class KFAC(Curvature):
+    """Kronecker-factored Fisher (curvatures.py:264-392).
+
+    ``state[layer] = [A, G]`` (fp32, exactly symmetric), ``inv_state[layer] = (L_A, L_G)`` with
+    L = chol_lower((sqrt(s) F + sqrt(n) I)^-1).  ``record[layer] = [input, grad_output]``: unlike the
+    reference the recorded grad_output is NOT pre-multiplied by the batch size (curvatures.py:310); the
+    factor N is folded into the scale of the G-side SYRK, which saves one pass over every gradient."""
+
+    def __init__(self, model: Union[Module, Sequential], layer_types: Union[List[str], str] = None):
+        super().__init__(model, layer_types)
+        self.hooks = list()
+        self.record = dict()
+        for layer in model.modules():
+            name = layer.__class__.__name__
+            if name in self.layer_types:
+                if name in ('Linear', 'Conv2d'):
+                    if name == 'Conv2d' and (tuple(layer.dilation) != (1, 1) or layer.groups != 1):
+                        # the reference silently ignores both (curvatures.py:329)
+                        raise NotImplementedError("KFAC: dilated or grouped convolutions are not supported")
+                    if name == 'Conv2d' and not all(isinstance(p, int) for p in layer.padding):
+                        raise NotImplementedError("KFAC: string padding modes are not supported")
+                    self.record[layer] = [None, None]
+                    self.hooks.append(layer.register_forward_pre_hook(self._save_input))
+                    self.hooks.append(layer.register_forward_hook(self._hook_output))
+                elif name == 'MultiheadAttention':
+                    raise NotImplementedError
+
+    def _save_input(self, module, input):
+        self.record[module][0] = input[0]            # by reference, like curvatures.py:307
+
+    def _hook_output(self, module, input, output):
+        if output.requires_grad:
+            output.register_hook(lambda grad, module=module: self._save_output(module, grad))
+
+    def _save_output(self, module, grad_output):
+        self.record[module][1] = grad_output         # raw; the reference stores grad * N (curvatures.py:310)
+
+    def update(self, batch_size: int = None):
+        """A += X X^T / (N L), G += (N g)(N g)^T / (N L) for every selected layer: one grouped launch."""
+        jobs = []
+        for layer in self._layers():
+            forward, backward = self.record[layer]
+            if forward is None or backward is None:
+                raise RuntimeError("KFAC.update: no recorded forward/backward pass for a selected layer")
+            x = forward.detach()
+            g = backward.detach()
+            if x.dtype != torch.float32 or g.dtype != torch.float32:
+                raise RuntimeError("KFAC.update expects float32 activations and gradients")
+            x, g = x.contiguous(), g.contiguous()
+            has_bias = layer.bias is not None
+            if layer.__class__.__name__ == 'Conv2d':
+                N, C = x.shape[0], x.shape[1]
+                kernel, stride, padding = layer.kernel_size, layer.stride, layer.padding
+                L = g.shape[2] * g.shape[3]
+                n = C * kernel[0] * kernel[1] + int(has_bias)
+            else:
+                if x.dim() != 2:                      # (N, *, in) inputs: flatten the leading dims
+                    x = x.reshape(-1, x.shape[-1])
+                    g = g.reshape(-1, g.shape[-1])
+                N, C = x.shape
+                kernel, stride, padding, L = (1, 1), (1, 1), (0, 0), 1
+                n = C + int(has_bias)
+            m = g.shape[1]
+            first = layer not in self.state
+            if first:
+                self.state[layer] = [torch.empty(n, n, dtype=torch.float32, device=x.device),
+                                     torch.empty(m, m, dtype=torch.float32, device=x.device)]
+            A, G = self.state[layer]
+            jobs.append(ops.FactorJob(x, A, kernel, stride, padding, has_bias, 1.0 / (N * L), first))
+            jobs.append(ops.FactorJob(g, G, (1, 1), (1, 1), (0, 0), False, float(N) / L, first))
+        ops.kfac_accumulate(jobs)
+
+    def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
+        assert self.state, "State dict is empty. Did you call 'update' prior to this?"
+        factors, adds, muls = [], [], []
+        for index, (layer, value) in enumerate(self.state.items()):
+            n, s = self._hyper(add, multiply, index, len(self.state))
+            for factor in value:
+                factors.append(factor)
+                adds.append(n)
+                muls.append(s)
+        chols = ops.chol_inv_lower(factors, adds, muls)      # RuntimeError if not positive definite
+        for index, layer in enumerate(self.state.keys()):
+            self.inv_state[layer] = (chols[2 * index], chols[2 * index + 1])
+
+    def sample(self, layer: Module, z: Optional[Tensor] = None) -> Tensor:
+        """(L_A z L_G^T)^T -> (m, n) (curvatures.py:387-392); `z` (n, m) may be supplied for parity tests."""
+        assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
+        first, second = self.inv_state[layer]
+        n, m = first.size(0), second.size(0)
+        if z is None:
+            z = self._randn(n, m, device=first.device)
+        tmp = torch.empty(m, n, dtype=torch.float32, device=first.device)
+        out = torch.empty(m, n, dtype=torch.float32, device=first.device)
+        ops.gemm_batched([ops.Gemm(second, z.t(), tmp)])
+        ops.gemm_batched([ops.Gemm(tmp, first.t(), out)])
+        return out
+
+    def sample_and_replace(self, noise: Optional[Dict[Module, Tensor]] = None):
+        """Fused form of the base-class loop: two batched GEMM launches for the whole model, the second
+        writing ``mean + sample`` straight into the parameters (same result as curvatures.py:117-129)."""
+        assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
+        self.model.load_state_dict(self.model_state)
+        layers = self._layers()
+        stage1, stage2 = [], []
+        for layer in layers:
+            first, second = self.inv_state[layer]
+            n, m = first.size(0), second.size(0)
+            z = noise[layer] if noise is not None else self._randn(n, m, device=first.device)
+            tmp = torch.empty(m, n, dtype=torch.float32, device=first.device)
+            stage1.append(ops.Gemm(second, z.t(), tmp))
+            n0 = n - int(layer.bias is not None)
+            w = layer.weight.data.view(m, n0)
+            w_mean = self.model_state_of(layer, 'weight').view(m, n0)
+            la_t = first.t()
+            stage2.append(ops.Gemm(tmp, la_t[:, :n0], w, epilogue=ops.EPI_ADD_E, E=w_mean))
+            if layer.bias is not None:
+                b = layer.bias.data.view(m, 1)
+                b_mean = self.model_state_of(layer, 'bias').view(m, 1)
+                stage2.append(ops.Gemm(tmp, la_t[:, n0:], b, epilogue=ops.EPI_ADD_E, E=b_mean))
+        ops.gemm_batched(stage1)
+        ops.gemm_batched(stage2)
+
+    def model_state_of(self, layer: Module, name: str) -> Tensor:
+        """The mean (MAP) tensor of `layer.<name>` inside ``model_state``."""
+        if not hasattr(self, "_state_keys"):
+            self._state_keys = {}
+            for prefix, mod in self.model.named_modules():
+                for pname, _ in mod.named_parameters(recurse=False):
+                    self._state_keys[(mod, pname)] = (prefix + "." if prefix else "") + pname
+        return self.model_state[self._state_keys[(layer, name)]]

@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import curv_factor_desc, curv_inv_desc
+from ._lib import curv_factor_desc, curv_gemm_desc, curv_inv_desc
 
 _workspaces = {}
 
@@ -136,3 +136,69 @@ def chol_inv_lower(factors: Sequence[torch.Tensor], adds: Sequence[float], multi
             raise RuntimeError(f"cholesky: damped factor(s) {bad} are not positive-definite "
                                f"(first failing pivot {int(info[bad[0]]) - 1})")
     return outs
+
+
+EPI_NONE, EPI_SQUARE, EPI_MUL_E, EPI_ADD_E = 0, 1, 2, 3
+
+
+class Gemm:
+    """C = epilogue(alpha * A @ B) [+ beta * C] on 2-D views (any strides: .t() and slices are free)."""
+    __slots__ = ("A", "B", "C", "E", "alpha", "beta", "epilogue")
+
+    def __init__(self, A, B, C, alpha=1.0, beta=0.0, epilogue=EPI_NONE, E=None):
+        self.A, self.B, self.C, self.E = A, B, C, E
+        self.alpha, self.beta, self.epilogue = float(alpha), float(beta), int(epilogue)
+
+
+def _check_view(t: torch.Tensor):
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2:
+        raise RuntimeError("GEMM operands must be 2-D float32 GPU tensors (no CPU fallback)")
+
+
+def gemm_batched(jobs: Sequence[Gemm]) -> None:
+    """All products in one launch (one work item per 64x64 output tile)."""
+    if not jobs:
+        return
+    n = len(jobs)
+    arr = (curv_gemm_desc * n)()
+    for d, j in zip(arr, jobs):
+        for t in (j.A, j.B, j.C):
+            _check_view(t)
+        M, K = j.A.shape
+        K2, N = j.B.shape
+        if K != K2 or tuple(j.C.shape) != (M, N):
+            raise RuntimeError(f"GEMM shape mismatch: {tuple(j.A.shape)} @ {tuple(j.B.shape)} -> {tuple(j.C.shape)}")
+        d.A, d.B, d.C = j.A.data_ptr(), j.B.data_ptr(), j.C.data_ptr()
+        d.a_rs, d.a_cs = j.A.stride()
+        d.b_rs, d.b_cs = j.B.stride()
+        d.c_rs, d.c_cs = j.C.stride()
+        if j.E is not None:
+            _check_view(j.E)
+            if tuple(j.E.shape) != (M, N):
+                raise RuntimeError("GEMM epilogue operand must match the output shape")
+            d.E = j.E.data_ptr()
+            d.e_rs, d.e_cs = j.E.stride()
+        d.M, d.N, d.K = M, N, K
+        d.alpha, d.beta, d.epilogue = j.alpha, j.beta, j.epilogue
+    L = _lib.lib()
+    ws = workspace(L.curv_gemm_workspace_bytes(n), jobs[0].C.device, "gemm")
+    _lib.check(L.curv_gemm_batched(_lib.stream_ptr(), arr, n, ws.data_ptr(), ws.numel()), "curv_gemm_batched")
+
+
+def randn(shape, device, seed: int, offset: int = 0) -> torch.Tensor:
+    """Standard normal noise from the library's Philox generator (counter `offset` in units of 4 values)."""
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    _lib.check(_lib.lib().curv_randn(_lib.stream_ptr(), out.data_ptr(), out.numel(), int(seed) & (2 ** 64 - 1),
+                                     int(offset)), "curv_randn")
+    return out
+
+
+def mul(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _require_gpu(a, b, out)
+    if a.shape != b.shape:
+        raise RuntimeError("mul: shape mismatch")
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(_lib.lib().curv_mul(_lib.stream_ptr(), a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel()),
+               "curv_mul")
+    return out

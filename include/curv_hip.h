@@ -103,6 +103,39 @@ int curv_chol_inv_lower(void* stream, const curv_inv_desc* descs, int n_factors,
                         size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------------
+ * Dense contractions of the samplers and of EFB / INF: a batch of independent strided fp32 GEMMs
+ *     C = epilogue(alpha * op(A) op(B)) [+ beta * C]
+ * op(A) is M x K with element (i,k) at A[i*a_rs + k*a_cs]; op(B) is K x N with (k,j) at
+ * B[k*b_rs + j*b_cs]; C is M x N with (i,j) at C[i*c_rs + j*c_cs] (strides in elements, so transposes
+ * and column slices need no copies).  Epilogues: NONE; SQUARE (alpha*acc^2, EFB.update's (.)**2 at
+ * curvatures.py:427); MUL_E / ADD_E (multiply by / add an elementwise operand E, used for the
+ * lambda scaling of EFB.sample :458 and for writing mean + sample straight into a parameter, :67-82).
+ * ---------------------------------------------------------------------------------------------- */
+#define CURV_EPI_NONE 0
+#define CURV_EPI_SQUARE 1
+#define CURV_EPI_MUL_E 2
+#define CURV_EPI_ADD_E 3
+
+typedef struct curv_gemm_desc {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* E;
+  long long a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, e_rs, e_cs;
+  int32_t M, N, K;
+  int32_t epilogue;
+  float alpha, beta;
+} curv_gemm_desc;
+
+size_t curv_gemm_workspace_bytes(int n_desc);
+int curv_gemm_batched(void* stream, const curv_gemm_desc* descs, int n_desc, void* workspace,
+                      size_t workspace_bytes);
+
+/* out[0..count) ~ N(0,1): Philox4x32-10 keyed by `seed`, counter starting at `offset` (in units of 4
+ * values); the draw of torch.randn at curvatures.py:391, :457, :590 with a device-side generator. */
+int curv_randn(void* stream, float* out, long long count, unsigned long long seed, unsigned long long offset);
+
+/* ------------------------------------------------------------------------------------------------
  * Elementwise pieces (Diagonal / EFB / INF)
  * ---------------------------------------------------------------------------------------------- */
 /* out = (s*v + n)^(-1/2)     curvatures.py:188 (Diagonal.invert), :449 (EFB.invert), :526 (INF) */
