@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Headline benchmark: KFAC factor-build + invert + sample throughput on ResNet-50 (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch whose activations / gradients are already resident
+in HBM: ``KFAC.update()`` (factor build, all layers) + ``KFAC.invert(1.0, 1000.0)`` +
+``KFAC.sample_and_replace()`` on a random-init ImageNet ResNet-50 (54 layers, N = 32, synthetic
+3x224x224 inputs).  With N > 1 GPUs the layers are sharded across ranks (disjoint layer groups, replicated
+forward/backward, one RCCL all-gather of the sampled weights per step): total work is fixed, so scaling is
+"strong".  Rank 0 prints ONE JSON line; see DESIGN.md section "Measurement" for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA = 157.3e12      # /opt/skills/guides/MI355X_MICROARCH.md: f32-input MFMA, dense
+
+
+def layer_dims(layers, record):
+    """(n, m, K) per layer from the recorded activations / gradients."""
+    dims = []
+    for layer in layers:
+        x, g = record[layer]
+        bias = int(layer.bias is not None)
+        if layer.__class__.__name__ == "Conv2d":
+            n = layer.in_channels * layer.kernel_size[0] * layer.kernel_size[1] + bias
+            K = g.shape[0] * g.shape[2] * g.shape[3]
+        else:
+            n = layer.in_features + bias
+            K = g.shape[0]
+        dims.append((n, g.shape[1], K))
+    return dims
+
+
+def cpu_baseline(batch_full, seed):
+    """The oracle (torch-CPU restatement of the reference path) timed on this box's host cores, on a
+    bounded sample of the same workload: ResNet-50 at N = 4 for update (scaled to N = 32), full invert
+    and sample_and_replace of all 54 layers."""
+    import oracle.curvature_oracle as o
+    from curvature_amd import models
+    # a bounded thread count: torch/MKL with hundreds of threads on these matrix sizes runs slower than
+    # with 16, and the sample has to stay within tens of seconds
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    torch.manual_seed(seed)
+    model = models.resnet50().train()
+    n_small = 4
+    x = torch.randn(n_small, 3, 224, 224)
+    rec, _, _ = o.capture(model, x, seed=seed)
+    t0 = time.perf_counter()
+    state = o.model_kfac_update({}, model, rec)
+    t_update = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    inv = o.model_kfac_invert(state, 1.0, 1000.0)
+    t_invert = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    samples = o.model_kfac_sample(inv, model)
+    for layer, s in samples.items():
+        o.replace(s, layer.weight.data, layer.bias.data if layer.bias is not None else None)
+    t_sample = time.perf_counter() - t0
+    step = t_update * (batch_full / n_small) + t_invert + t_sample
+    n_layers = len(state)
+    return {"value": n_layers / step, "unit": "layers/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/curvature_oracle.py on ResNet-50: update at N={n_small} ({t_update:.2f} s, scaled x"
+                      f"{batch_full // n_small}), invert ({t_invert:.2f} s) and sample ({t_sample:.2f} s) of all "
+                      f"{n_layers} layers, torch {torch.get_num_threads()} threads",
+            "update_s": t_update, "invert_s": t_invert, "sample_s": t_sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from curvature_amd import _lib, models, sharding
+    from curvature_amd.curvatures import KFAC
+
+    seed = 0
+    torch.manual_seed(seed)
+    # BatchNorm in batch-statistics mode: a random-init network in eval mode (running stats 0/1) lets the
+    # activations explode with depth, which no trained network does; train mode keeps them O(1)
+    model = models.resnet50().to(dev).train()
+    kfac = KFAC(model)
+    layers = kfac._layers()
+    x = torch.randn(args.batch, 3, 224, 224, device=dev)
+    logits = model(x)
+    labels = torch.distributions.Categorical(logits=logits.detach()).sample()      # scripts/test.py:39-40
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    model.zero_grad()
+    loss.backward()                       # activations / gradients of every layer now resident in HBM
+    dims = layer_dims(layers, kfac.record)
+    if world > 1:
+        kfac.shard = sharding.make_shard([sharding.layer_cost(*d) for d in dims], rank, world)
+    owned = [i for i, _ in kfac._owned()]
+
+    L = _lib.lib()
+    ev = (L.curv_event_create(), L.curv_event_create())
+    kfac._timing_events = ev
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def step(timed):
+        if timed:
+            e[0].record()
+        kfac.update(batch_size=args.batch)
+        if timed:
+            e[1].record()
+        kfac.invert(add=1.0, multiply=1000.0)
+        if timed:
+            e[2].record()
+        kfac.sample_and_replace()
+        if timed:
+            e[3].record()
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    phase = [0.0, 0.0, 0.0]
+    syrk_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+        # event bookkeeping happens after the step's work is enqueued; reading them waits for that step,
+        # which every step does anyway (invert reads its status words back)
+        torch.cuda.synchronize()
+        for p in range(3):
+            phase[p] += e[p].elapsed_time(e[p + 1])
+        ms = __import__("ctypes").c_float(0.0)
+        _lib.check(L.curv_event_elapsed_ms(ev[0], ev[1], ms), "curv_event_elapsed_ms")
+        syrk_ms += ms.value
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    # algorithmic work of the dominant kernel (SYRK) on this rank, symmetric-executed count
+    exec_flops = sum((dims[i][0] * (dims[i][0] + 1.0) + dims[i][1] * (dims[i][1] + 1.0)) * dims[i][2] for i in owned)
+    dense_flops = sum(2.0 * (dims[i][0] ** 2 + dims[i][1] ** 2) * dims[i][2] for i in owned)
+    syrk_s = syrk_ms / args.steps * 1e-3
+    achieved = exec_flops / syrk_s / 1e12
+
+    if rank == 0:
+        n_layers = len(layers)
+        out = {
+            "metric": "KFAC factor-build + invert + sample throughput",
+            "value": n_layers * args.steps / elapsed,
+            "unit": "layers/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "ResNet-50 random-init (seed 0), synthetic 3x224x224 N(0,1) inputs, N=32: "
+                                   "KFAC.update + invert(1.0, 1000.0) + sample_and_replace, 54 layers",
+                       "batch": args.batch, "layers": n_layers,
+                       "parallelism": f"layer-sharded x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "kernel": "curv::syrk_patch_kernel", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_F32_MFMA / 1e12),
+                         "traffic": None,
+                         "flops_counted": "executed symmetric: sum (n(n+1)+m(m+1)) K over the rank's layers",
+                         "dense_equivalent_tflops": dense_flops / syrk_s / 1e12,
+                         "kernel_ms": syrk_s * 1e3},
+            "phases_ms": {"update": phase[0] / args.steps, "invert": phase[1] / args.steps,
+                          "sample_and_replace": phase[2] / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.batch, seed)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

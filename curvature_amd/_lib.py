@@ -81,6 +81,10 @@ SIGNATURES = {
     "curv_kfac_workspace_bytes": (_sz, [ctypes.POINTER(curv_factor_desc), _i]),
     "curv_kfac_plan_info": (_i, [ctypes.POINTER(curv_factor_desc), _i, ctypes.POINTER(ctypes.c_longlong)]),
     "curv_kfac_accumulate": (_i, [_vp, ctypes.POINTER(curv_factor_desc), _i, _vp, _sz]),
+    "curv_kfac_accumulate_timed": (_i, [_vp, ctypes.POINTER(curv_factor_desc), _i, _vp, _sz, _vp, _vp]),
+    "curv_event_create": (_vp, []),
+    "curv_event_destroy": (None, [_vp]),
+    "curv_event_elapsed_ms": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     "curv_chol_inv_workspace_bytes": (_sz, [ctypes.POINTER(curv_inv_desc), _i]),
     "curv_chol_inv_lower": (_i, [_vp, ctypes.POINTER(curv_inv_desc), _i, _vp, _vp, _sz]),
     "curv_gemm_workspace_bytes": (_sz, [_i]),

@@ -15,3 +15,20 @@ void set_error(const char* fmt, ...) {
 
 extern "C" int curv_version(void) { return CURV_ABI_VERSION; }
 extern "C" const char* curv_last_error(void) { return curv::g_error; }
+
+// HIP event helpers so that a host without HIP bindings (Python/ctypes) can time a kernel on the
+// stream it is launched on (bench.py's roofline leg).
+extern "C" void* curv_event_create(void) {
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return (void*)e;
+}
+extern "C" void curv_event_destroy(void* e) {
+  if (e) (void)hipEventDestroy((hipEvent_t)e);
+}
+extern "C" int curv_event_elapsed_ms(void* start, void* stop, float* ms) {
+  CURV_REQUIRE(start && stop && ms, "curv_event_elapsed_ms: null argument");
+  CURV_HIP_CHECK(hipEventSynchronize((hipEvent_t)stop));
+  CURV_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return CURV_OK;
+}

@@ -13,7 +13,7 @@
 //   step k:  (1) A[i][k] -= sum_{j<k} A[i][j] A[k][j]^T          for every block row i >= k
 //            (2) every workgroup of block column k factorises the 64x64 diagonal block in LDS
 //                (redundantly: cheaper than another launch), then A[i][k] <- A[i][k] L_kk^-T;
-//                the workgroup of the diagonal block stores L_kk and X_kk = L_kk^-1
+//                the workgroup of the diagonal block stores X_kk = L_kk^-1 (A_kk stays read-only)
 //   step i:  (3) X[i][j] = -X_ii * sum_{k=j}^{i-1} C[i][k] X[k][j]  for every block j < i
 // Matrices are padded to a multiple of 64 with an identity tail, so no kernel needs bounds checks.
 // "Not positive definite" is reported through a per-factor device info word (0 = ok).
@@ -233,11 +233,11 @@ chol_diag_trsm_kernel(const InvDev* __restrict__ t, int nf, int k) {
   __syncthreads();
 
   if (i == k) {
-    gdouble* Dg = W + (long long)k * NB * np + k * NB;
+    // Only X_kk = L_kk^-1 is kept.  L_kk itself is never needed again, and A_kk must NOT be overwritten
+    // here: the other workgroups of this block column (possibly scheduled later) still read it.
     gdouble* Xg = (gdouble*)d.X + (long long)k * NB * np + k * NB;
     for (int e = tid; e < NB * NB; e += INV_THREADS) {
       const int r = e >> 6, q = e & 63;
-      Dg[(long long)r * np + q] = Ds[r * LDA + q];
       Xg[(long long)r * np + q] = Is[r * LDA + q];
     }
     if (tid == 0 && bad != 0) atomicCAS(d.info, 0, bad);

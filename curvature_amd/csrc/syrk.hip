@@ -836,8 +836,8 @@ extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors,
   return CURV_OK;
 }
 
-extern "C" int curv_kfac_accumulate(void* stream_, const curv_factor_desc* descs, int n_factors,
-                                    void* workspace, size_t workspace_bytes) {
+static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, int n_factors, void* workspace,
+                                size_t workspace_bytes, void* ev_start, void* ev_stop) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_factors == 0) return CURV_OK;
   Plan plan;
@@ -862,11 +862,23 @@ extern "C" int curv_kfac_accumulate(void* stream_, const curv_factor_desc* descs
     CURV_LAUNCH_CHECK();
   }
   const int grid = cdiv(plan.n_items, 8 * XCD_GROUP) * 8 * XCD_GROUP;
+  if (ev_start) CURV_HIP_CHECK(hipEventRecord((hipEvent_t)ev_start, stream));
   hipLaunchKernelGGL(syrk_patch_kernel, dim3(grid), dim3(SYRK_THREADS), 0, stream, table, n_factors,
                      plan.n_items, slabs, zeros);
   CURV_LAUNCH_CHECK();
+  if (ev_stop) CURV_HIP_CHECK(hipEventRecord((hipEvent_t)ev_stop, stream));
   hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub), dim3(SYRK_THREADS), 0, stream, table,
                      n_factors, slabs);
   CURV_LAUNCH_CHECK();
   return CURV_OK;
+}
+
+extern "C" int curv_kfac_accumulate(void* stream, const curv_factor_desc* descs, int n_factors, void* workspace,
+                                    size_t workspace_bytes) {
+  return kfac_accumulate_impl(stream, descs, n_factors, workspace, workspace_bytes, nullptr, nullptr);
+}
+
+extern "C" int curv_kfac_accumulate_timed(void* stream, const curv_factor_desc* descs, int n_factors,
+                                          void* workspace, size_t workspace_bytes, void* ev_start, void* ev_stop) {
+  return kfac_accumulate_impl(stream, descs, n_factors, workspace, workspace_bytes, ev_start, ev_stop);
 }

@@ -56,6 +56,8 @@ class Curvature(ABC):
             assert _type in SUPPORTED_LAYERS
         self.state = dict()
         self.inv_state = dict()
+        # optional layer sharding across ranks (curvature_amd.sharding.Shard); None = own every layer
+        self.shard = None
         # device-side noise generator of the samplers (Philox): advance `noise_offset` per draw
         self.noise_seed = int(torch.initial_seed()) & (2 ** 63 - 1)
         self.noise_offset = 0
@@ -72,6 +74,18 @@ class Curvature(ABC):
                 elif name == 'MultiheadAttention':
                     raise NotImplementedError
         return out
+
+    def _owned(self):
+        """[(global layer index, layer)] of the layers this rank owns (all of them without a shard)."""
+        layers = self._layers()
+        if self.shard is None:
+            return list(enumerate(layers))
+        return [(i, l) for i, l in enumerate(layers) if self.shard.owns(i)]
+
+    def _allgather_sampled(self):
+        """Multi-GPU: the single collective of the path, reassembling every layer's sampled parameters."""
+        if self.shard is not None and self.shard.world > 1:
+            self.shard.allgather_params([[p.data for p in (l.weight, l.bias) if p is not None] for l in self._layers()])
 
     @staticmethod
     def _hyper(add, multiply, index: int, count: int):
@@ -114,9 +128,10 @@ class Curvature(ABC):
     def sample_and_replace(self):
         """Reset to the mean weights, then add one posterior sample per selected layer (curvatures.py:117-129)."""
         self.model.load_state_dict(self.model_state)
-        for layer in self._layers():
+        for _, layer in self._owned():
             _sample = self.sample(layer)
             self._replace(_sample, layer.weight, layer.bias)
+        self._allgather_sampled()
 
 
 class Diagonal(Curvature):
@@ -183,7 +198,7 @@ class KFAC(Curvature):
     def update(self, batch_size: int = None):
         """A += X X^T / (N L), G += (N g)(N g)^T / (N L) for every selected layer: one grouped launch."""
         jobs = []
-        for layer in self._layers():
+        for _, layer in self._owned():
             forward, backward = self.record[layer]
             if forward is None or backward is None:
                 raise RuntimeError("KFAC.update: no recorded forward/backward pass for a selected layer")
@@ -213,13 +228,17 @@ class KFAC(Curvature):
             A, G = self.state[layer]
             jobs.append(ops.FactorJob(x, A, kernel, stride, padding, has_bias, 1.0 / (N * L), first))
             jobs.append(ops.FactorJob(g, G, (1, 1), (1, 1), (0, 0), False, float(N) / L, first))
-        ops.kfac_accumulate(jobs)
+        ops.kfac_accumulate(jobs, events=getattr(self, "_timing_events", None))
 
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
         assert self.state, "State dict is empty. Did you call 'update' prior to this?"
         factors, adds, muls = [], [], []
-        for index, (layer, value) in enumerate(self.state.items()):
-            n, s = self._hyper(add, multiply, index, len(self.state))
+        all_layers = self._layers()
+        gindex = {l: i for i, l in enumerate(all_layers)}
+        for layer, value in self.state.items():
+            # layer index = position among the selected layers in modules() order (== enumerate(state)
+            # of the reference, curvatures.py:360, when every layer is owned)
+            n, s = self._hyper(add, multiply, gindex.get(layer, 0), len(all_layers))
             for factor in value:
                 factors.append(factor)
                 adds.append(n)
@@ -246,9 +265,8 @@ class KFAC(Curvature):
         writing ``mean + sample`` straight into the parameters (same result as curvatures.py:117-129)."""
         assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
         self.model.load_state_dict(self.model_state)
-        layers = self._layers()
         stage1, stage2 = [], []
-        for layer in layers:
+        for _, layer in self._owned():
             first, second = self.inv_state[layer]
             n, m = first.size(0), second.size(0)
             z = noise[layer] if noise is not None else self._randn(n, m, device=first.device)
@@ -265,6 +283,7 @@ class KFAC(Curvature):
                 stage2.append(ops.Gemm(tmp, la_t[:, n0:], b, epilogue=ops.EPI_ADD_E, E=b_mean))
         ops.gemm_batched(stage1)
         ops.gemm_batched(stage2)
+        self._allgather_sampled()
 
     def model_state_of(self, layer: Module, name: str) -> Tensor:
         """The mean (MAP) tensor of `layer.<name>` inside ``model_state``."""

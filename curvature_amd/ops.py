@@ -48,8 +48,11 @@ class FactorJob:
         self.has_bias, self.scale, self.first = bool(has_bias), float(scale), bool(first)
 
 
-def kfac_accumulate(jobs: Sequence[FactorJob]) -> None:
-    """Grouped factor build over any number of factors: one SYRK launch + one reduce launch."""
+def kfac_accumulate(jobs: Sequence[FactorJob], events=None) -> None:
+    """Grouped factor build over any number of factors: one SYRK launch + one reduce launch.
+
+    `events` = (start, stop) handles from ``_lib.lib().curv_event_create()`` are recorded around the SYRK
+    kernel (bench.py's roofline measurement)."""
     if not jobs:
         return
     n = len(jobs)
@@ -76,8 +79,11 @@ def kfac_accumulate(jobs: Sequence[FactorJob]) -> None:
     if need == 0:
         _lib.check(2, "curv_kfac_workspace_bytes")
     ws = workspace(need, jobs[0].src.device, "kfac")
-    _lib.check(L.curv_kfac_accumulate(_lib.stream_ptr(), arr, n, ws.data_ptr(), ws.numel()),
-               "curv_kfac_accumulate")
+    if events is None:
+        rc = L.curv_kfac_accumulate(_lib.stream_ptr(), arr, n, ws.data_ptr(), ws.numel())
+    else:
+        rc = L.curv_kfac_accumulate_timed(_lib.stream_ptr(), arr, n, ws.data_ptr(), ws.numel(), events[0], events[1])
+    _lib.check(rc, "curv_kfac_accumulate")
 
 
 def rsqrt_affine(value: torch.Tensor, add: float, multiply: float, out: Optional[torch.Tensor] = None):

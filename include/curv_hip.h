@@ -79,6 +79,14 @@ int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors, long long*
 int curv_kfac_accumulate(void* stream, const curv_factor_desc* descs, int n_factors, void* workspace,
                          size_t workspace_bytes);
 
+/* Same, recording HIP events (from curv_event_create) on `stream` immediately before and after the
+ * SYRK kernel, so that a benchmark can time exactly that kernel without a profiler. */
+int curv_kfac_accumulate_timed(void* stream, const curv_factor_desc* descs, int n_factors, void* workspace,
+                               size_t workspace_bytes, void* ev_start, void* ev_stop);
+void* curv_event_create(void);
+void curv_event_destroy(void* event);
+int curv_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* waits for ev_stop */
+
 /* ------------------------------------------------------------------------------------------------
  * KFAC.invert:  L = lower Cholesky factor of (sqrt(multiply) * F + sqrt(add) * I)^-1
  *                                                                (curvature/curvatures.py:354-385)

@@ -96,3 +96,21 @@ def test_not_positive_definite_raises(gpu):
     v = torch.ones(40, 1, device=gpu)
     with pytest.raises(RuntimeError):
         ops.chol_inv_lower([(v @ v.t()).contiguous()], [0.0], [1.0])
+
+
+def test_many_large_factors_no_race(gpu):
+    """More block-column workgroups than the chip holds at once: late workgroups must still see the
+    un-factorised diagonal block (regression test for an in-place write-back race)."""
+    import oracle.curvature_oracle as o
+    from curvature_amd import ops
+    torch.manual_seed(5)
+    sizes = [1500] * 6 + [700] * 10 + [64] * 40
+    Fs = []
+    for n in sizes:
+        X = torch.randn(n, n + 8, device=gpu)
+        F = X @ X.t() / X.shape[1]
+        Fs.append(((F + F.t()) / 2).contiguous())
+    outs = ops.chol_inv_lower(Fs, [1.0] * len(Fs), [1000.0] * len(Fs))
+    for idx in (0, 5, 6, 15, 16, 55):
+        exact = o.chol_of_inverse(damp32_then_64(Fs[idx].cpu(), 1.0, 1000.0))
+        assert rel_fro(outs[idx], exact) < 1e-6
