@@ -9,12 +9,16 @@
 // that runs in fp64 on v_mfma_f64_16x16x4_f64, so the result is the correctly rounded answer for the
 // matrix the reference hands to LAPACK (the reference's own fp32 LAPACK noise is 5e-5 .. 6e-4 here).
 //
-// Batched left-looking blocked algorithm, block 64, all factors of the model advance together:
-//   step k:  (1) A[i][k] -= sum_{j<k} A[i][j] A[k][j]^T          for every block row i >= k
-//            (2) every workgroup of block column k factorises the 64x64 diagonal block in LDS
+// Batched right-looking blocked algorithm, block 64, all factors of the model advance together; every
+// launch is a flat list of independent 64x64 tile operations, so the critical path per step is one block
+// operation whatever the matrix size:
+//   step k:  (1) every workgroup of block column k factorises the 64x64 diagonal block in LDS
 //                (redundantly: cheaper than another launch), then A[i][k] <- A[i][k] L_kk^-T;
 //                the workgroup of the diagonal block stores X_kk = L_kk^-1 (A_kk stays read-only)
-//   step i:  (3) X[i][j] = -X_ii * sum_{k=j}^{i-1} C[i][k] X[k][j]  for every block j < i
+//            (2) trailing update  A[i][j] -= A[i][k] A[j][k]^T           for k < j <= i
+//            (3) X[k][j] = -X_kk S[k][j]                                 for j < k   (row k of C^-1 final)
+//            (4) S[i][j] (+)= C[i][k] X[k][j]                            for i > k, j <= k
+//                (S accumulates sum_{k'} C[i][k'] X[k'][j] in the storage of X[i][j])
 // Matrices are padded to a multiple of 64 with an identity tail, so no kernel needs bounds checks.
 // "Not positive definite" is reported through a per-factor device info word (0 = ok).
 #include "common.h"
@@ -146,36 +150,64 @@ inv_prepare_kernel(const InvDev* __restrict__ t, int nf) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// (1) A[i][k] -= sum_{j<k} A[i][j] A[k][j]^T
+// (2) trailing update A[i][j] -= A[i][k] A[j][k]^T for k < j <= i, fused in one launch with
+// (4) S[i][j] (+)= C[i][k] X[k][j] for i > k, j <= k   (both are independent tile updates of step k)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(INV_THREADS)
-chol_update_col_kernel(const InvDev* __restrict__ t, int nf, int k) {
+step_update_kernel(const InvDev* __restrict__ t, int nf, int k) {
   __shared__ double As[NB * LDA], Bs[NB * LDA];
   int f, local;
-  if (!locate(t, nf, blockIdx.x, [k](const InvDev& d) { return max(0, d.P - k); }, f, local)) return;
+  auto count = [k](const InvDev& d) {
+    const int r = d.P - k - 1;                       // block rows below the pivot row
+    return r > 0 ? r * (r + 1) / 2 + r * (k + 1) : 0;
+  };
+  if (!locate(t, nf, blockIdx.x, count, f, local)) return;
   const InvDev& d = t[f];
-  const int i = k + local, np = d.np;
+  const int np = d.np, r = d.P - k - 1;
   gdouble* W = (gdouble*)d.W;
+  gdouble* X = (gdouble*)d.X;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-  f64x4 acc[2][2] = {};
-  for (int j = 0; j < k; ++j) {
-    load_block(W + (long long)i * NB * np + j * NB, np, As);
-    load_block(W + (long long)k * NB * np + j * NB, np, Bs);
-    __syncthreads();
-    mma_64<true>(As, Bs, wm, wn, lane, acc);
-    __syncthreads();
-  }
-  gdouble* C = W + (long long)i * NB * np + k * NB;
   const int c16 = lane & 15, rq = lane >> 4;
+  f64x4 acc[2][2] = {};
+  const int n_trail = r * (r + 1) / 2;
+  if (local < n_trail) {
+    int a = 0, tl = local;
+    while (tl > a) { tl -= a + 1; ++a; }
+    const int i = k + 1 + a, j = k + 1 + tl;
+    load_block(W + (long long)i * NB * np + k * NB, np, As);
+    if (i != j) load_block(W + (long long)j * NB * np + k * NB, np, Bs);
+    __syncthreads();
+    mma_64<true>(As, (i != j) ? Bs : As, wm, wn, lane, acc);
+    gdouble* C = W + (long long)i * NB * np + j * NB;
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+      for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long long idx = (long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16;
-        C[idx] -= acc[m][n][r];
-      }
+        for (int q = 0; q < 4; ++q) {
+          const long long idx = (long long)(32 * wm + 16 * m + rq + 4 * q) * np + 32 * wn + 16 * n + c16;
+          C[idx] -= acc[m][n][q];
+        }
+  } else {
+    const int l2 = local - n_trail;
+    const int a = l2 / (k + 1), j = l2 - a * (k + 1);
+    const int i = k + 1 + a;
+    load_block(W + (long long)i * NB * np + k * NB, np, As);        // C[i][k] as [row][kk]
+    load_block(X + (long long)k * NB * np + j * NB, np, Bs);        // X[k][j] as [kk][col]
+    __syncthreads();
+    mma_64<false>(As, Bs, wm, wn, lane, acc);
+    gdouble* S = X + (long long)i * NB * np + j * NB;
+    const bool first = (j == k);                                    // first contribution to this tile
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const long long idx = (long long)(32 * wm + 16 * m + rq + 4 * q) * np + 32 * wn + 16 * n + c16;
+          S[idx] = first ? acc[m][n][q] : S[idx] + acc[m][n][q];
+        }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -183,10 +215,10 @@ chol_update_col_kernel(const InvDev* __restrict__ t, int nf, int k) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(INV_THREADS)
 chol_diag_trsm_kernel(const InvDev* __restrict__ t, int nf, int k) {
-  __shared__ double Ds[NB * LDA];     // A_kk -> L_kk (lower)
+  __shared__ double Ds[NB * LDA];     // A_kk -> L_kk (lower); afterwards this workgroup's panel block
   __shared__ double Is[NB * LDA];     // L_kk^-1 (lower, zeros above)
-  __shared__ double Ts[NB * LDA];     // this workgroup's panel block
   __shared__ int bad;
+  double* Ts = Ds;                    // two LDS tiles instead of three: two workgroups per CU
   int f, local;
   if (!locate(t, nf, blockIdx.x, [k](const InvDev& d) { return max(0, d.P - k); }, f, local)) return;
   const InvDev& d = t[f];
@@ -195,7 +227,6 @@ chol_diag_trsm_kernel(const InvDev* __restrict__ t, int nf, int k) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   if (tid == 0) bad = 0;
   load_block(W + (long long)k * NB * np + k * NB, np, Ds);
-  if (i != k) load_block(W + (long long)i * NB * np + k * NB, np, Ts);
   __syncthreads();
 
   // unblocked right-looking Cholesky of the 64x64 block, lower triangle
@@ -225,9 +256,17 @@ chol_diag_trsm_kernel(const InvDev* __restrict__ t, int nf, int k) {
     const int j = tid;
     Is[j * LDA + j] = 1.0 / Ds[j * LDA + j];
     for (int r = j + 1; r < NB; ++r) {
-      double s = 0.0;
-      for (int q = j; q < r; ++q) s += Ds[r * LDA + q] * Is[q * LDA + j];
-      Is[r * LDA + j] = -s / Ds[r * LDA + r];
+      // four independent partial sums so that the LDS reads of the dot product pipeline
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int q = j;
+      for (; q + 3 < r; q += 4) {
+        s0 += Ds[r * LDA + q] * Is[q * LDA + j];
+        s1 += Ds[r * LDA + q + 1] * Is[(q + 1) * LDA + j];
+        s2 += Ds[r * LDA + q + 2] * Is[(q + 2) * LDA + j];
+        s3 += Ds[r * LDA + q + 3] * Is[(q + 3) * LDA + j];
+      }
+      for (; q < r; ++q) s0 += Ds[r * LDA + q] * Is[q * LDA + j];
+      Is[r * LDA + j] = -((s0 + s1) + (s2 + s3)) / Ds[r * LDA + r];
     }
   }
   __syncthreads();
@@ -243,6 +282,8 @@ chol_diag_trsm_kernel(const InvDev* __restrict__ t, int nf, int k) {
     if (tid == 0 && bad != 0) atomicCAS(d.info, 0, bad);
   } else {
     // A_ik <- A_ik * L_kk^-T  =  Ts * Is^T   (Is rows are the K-contiguous operand)
+    load_block(W + (long long)i * NB * np + k * NB, np, Ts);      // L_kk is no longer needed
+    __syncthreads();
     f64x4 acc[2][2] = {};
     mma_64<true>(Ts, Is, wm, wn, lane, acc);
     gdouble* C = W + (long long)i * NB * np + k * NB;
@@ -258,32 +299,23 @@ chol_diag_trsm_kernel(const InvDev* __restrict__ t, int nf, int k) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// (3) X[i][j] = -X_ii * sum_{k=j}^{i-1} C[i][k] X[k][j]
+// (3) X[k][j] = -X_kk * S[k][j] for j < k (in place: each workgroup owns its tile; X_kk is read-only)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(INV_THREADS)
-trtri_row_kernel(const InvDev* __restrict__ t, int nf, int i) {
+trtri_finalize_row_kernel(const InvDev* __restrict__ t, int nf, int k) {
   __shared__ double As[NB * LDA], Bs[NB * LDA];
   int f, j;
-  if (!locate(t, nf, blockIdx.x, [i](const InvDev& d) { return i < d.P ? i : 0; }, f, j)) return;
+  if (!locate(t, nf, blockIdx.x, [k](const InvDev& d) { return k < d.P ? k : 0; }, f, j)) return;
   const InvDev& d = t[f];
   const int np = d.np;
-  const gdouble* W = (const gdouble*)d.W;
   gdouble* X = (gdouble*)d.X;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-  f64x4 acc[2][2] = {};
-  for (int k = j; k < i; ++k) {
-    load_block(W + (long long)i * NB * np + k * NB, np, As);
-    load_block(X + (long long)k * NB * np + j * NB, np, Bs);
-    __syncthreads();
-    mma_64<false>(As, Bs, wm, wn, lane, acc);
-    __syncthreads();
-  }
-  acc_to_lds(acc, wm, wn, lane, Bs);                                   // Bs = G as [k][col]
-  load_block(X + (long long)i * NB * np + i * NB, np, As);            // As = X_ii as [row][k]
+  load_block(X + (long long)k * NB * np + k * NB, np, As);            // X_kk as [row][kk]
+  load_block(X + (long long)k * NB * np + j * NB, np, Bs);            // S_kj as [kk][col]
   __syncthreads();
   f64x4 out[2][2] = {};
   mma_64<false>(As, Bs, wm, wn, lane, out);
-  gdouble* C = X + (long long)i * NB * np + j * NB;
+  gdouble* C = X + (long long)k * NB * np + j * NB;
   const int c16 = lane & 15, rq = lane >> 4;
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -295,7 +327,7 @@ trtri_row_kernel(const InvDev* __restrict__ t, int nf, int i) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// (4) L[i][j] = (float) X[n-1-j][n-1-i] for j <= i, 0 above the diagonal (32x32 tiles via LDS)
+// (5) L[i][j] = (float) X[n-1-j][n-1-i] for j <= i, 0 above the diagonal (32x32 tiles via LDS)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(INV_THREADS)
 inv_finalize_kernel(const InvDev* __restrict__ t, int nf) {
@@ -401,20 +433,23 @@ extern "C" int curv_chol_inv_lower(void* stream_, const curv_inv_desc* descs, in
   hipLaunchKernelGGL(inv_prepare_kernel, dim3((unsigned)prep_tiles), dim3(INV_THREADS), 0, stream, table, n_factors);
   CURV_LAUNCH_CHECK();
   for (int k = 0; k < Pmax; ++k) {
-    long long tiles = 0;
-    for (const InvDev& d : tab) tiles += std::max(0, d.P - k);
-    if (k > 0) {
-      hipLaunchKernelGGL(chol_update_col_kernel, dim3((unsigned)tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
+    long long col_tiles = 0, upd_tiles = 0, row_tiles = 0;
+    for (const InvDev& d : tab) {
+      col_tiles += std::max(0, d.P - k);
+      const long long r = d.P - k - 1;
+      if (r > 0) upd_tiles += r * (r + 1) / 2 + r * (k + 1);
+      if (k < d.P) row_tiles += k;
+    }
+    hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3((unsigned)col_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
+    CURV_LAUNCH_CHECK();
+    if (row_tiles > 0) {
+      hipLaunchKernelGGL(trtri_finalize_row_kernel, dim3((unsigned)row_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
       CURV_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3((unsigned)tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
-    CURV_LAUNCH_CHECK();
-  }
-  for (int i = 1; i < Pmax; ++i) {
-    long long tiles = 0;
-    for (const InvDev& d : tab) tiles += (i < d.P) ? i : 0;
-    hipLaunchKernelGGL(trtri_row_kernel, dim3((unsigned)tiles), dim3(INV_THREADS), 0, stream, table, n_factors, i);
-    CURV_LAUNCH_CHECK();
+    if (upd_tiles > 0) {
+      hipLaunchKernelGGL(step_update_kernel, dim3((unsigned)upd_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
+      CURV_LAUNCH_CHECK();
+    }
   }
   hipLaunchKernelGGL(inv_finalize_kernel, dim3((unsigned)fin_tiles), dim3(INV_THREADS), 0, stream, table, n_factors);
   CURV_LAUNCH_CHECK();

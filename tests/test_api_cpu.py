@@ -1,0 +1,74 @@
+"""Plugin-API behaviour that needs no GPU: layer selection, hyper-parameter indexing, error convention
+(mirrors curvature/curvatures.py:38-65, :361-365 of the reference)."""
+import numpy as np
+import pytest
+import torch
+
+from curvature_amd import models
+from curvature_amd.curvatures import Curvature, Diagonal, KFAC
+
+
+def test_layer_types_normalisation():
+    m = models.lenet5()
+    assert KFAC(m).layer_types == ['Linear', 'Conv2d', 'MultiheadAttention']
+    assert KFAC(m, []).layer_types == ['Linear', 'Conv2d', 'MultiheadAttention']
+    assert KFAC(m, 'Conv2d').layer_types == ['Conv2d']
+    assert [l.__class__.__name__ for l in KFAC(m, 'Conv2d')._layers()] == ['Conv2d', 'Conv2d']
+    assert len(KFAC(m, ['Linear'])._layers()) == 3
+    with pytest.raises(AssertionError):
+        KFAC(m, ['Conv3d'])
+    with pytest.raises(TypeError):
+        KFAC(m, 3)
+
+
+def test_layer_order_is_modules_order():
+    m = models.resnet18()
+    layers = Diagonal(m)._layers()
+    ref = [l for l in m.modules() if l.__class__.__name__ in ('Linear', 'Conv2d')]
+    assert layers == ref and len(layers) == 21
+    # the downsample 1x1 conv comes after the block's main convs
+    names = {mod: n for n, mod in m.named_modules()}
+    assert names[layers[7]] == 'layer2.0.downsample.0'
+
+
+def test_hyper_indexing():
+    h = Curvature._hyper
+    assert h(0.5, 1, 3, 5) == (0.5, 1.0)                              # scalars (int accepted)
+    assert h(np.float32(0.5), np.float64(2), 0, 5) == (0.5, 2.0)      # numpy scalars (superset of the reference)
+    assert h([1, 2, 3], (4, 5, 6), 1, 3) == (2.0, 5.0)                # both lists -> per layer
+    with pytest.raises(TypeError):
+        h([1, 2, 3], 7.0, 1, 3)                                        # mixed: float(list), as in the reference
+    with pytest.raises(AssertionError):
+        h([1, 2], [3, 4], 0, 3)                                        # wrong length
+
+
+def test_mha_is_rejected_like_the_reference():
+    m = torch.nn.Sequential(torch.nn.Linear(4, 4))
+    m.add_module("attn", torch.nn.MultiheadAttention(4, 2))
+    with pytest.raises(NotImplementedError):
+        KFAC(m)
+    KFAC(m, 'Linear')                                                 # fine when not selected
+
+
+def test_dilated_conv_rejected():
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, dilation=2))
+    with pytest.raises(NotImplementedError):
+        KFAC(m)
+
+
+def test_invert_and_sample_need_state():
+    k = KFAC(models.lenet5())
+    with pytest.raises(AssertionError):
+        k.invert()
+    with pytest.raises(AssertionError):
+        k.sample(k._layers()[0])
+
+
+def test_model_state_is_a_deep_copy():
+    m = models.lenet5()
+    k = KFAC(m)
+    w0 = k.model_state['0.weight'].clone()
+    with torch.no_grad():
+        m[0].weight.add_(1.0)
+    assert torch.equal(k.model_state['0.weight'], w0)
+    assert k.model_state_of(m[0], 'weight') is k.model_state['0.weight']

@@ -1,0 +1,82 @@
+"""Host-side launch planning of the SYRK kernel (curv_kfac_plan_info): every plan must respect the
+kernel's LDS / staging-register budgets and cover the whole K range."""
+import ctypes
+import itertools
+
+import pytest
+
+from curvature_amd import _lib
+
+NF = 21
+NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub RL".split()
+PANEL_WORDS, ROWTAB_MAX, KTAB_MAX, SLOT_ELEMS = 8704, 512, 1024, 32 * 256
+
+
+def plan(descs):
+    n = len(descs)
+    arr = (_lib.curv_factor_desc * n)()
+    for d, a in zip(descs, arr):
+        for k, v in d.items():
+            setattr(a, k, v)
+        a.scale = 1.0
+    out = (ctypes.c_longlong * (NF * n))()
+    rc = _lib.lib().curv_kfac_plan_info(arr, n, out)
+    assert rc == 0, _lib.lib().curv_last_error()
+    return [dict(zip(NAMES, out[NF * i:NF * i + NF])) for i in range(n)]
+
+
+def geom(N, C, H, W, k, s, p, bias):
+    return dict(N=N, C=C, H=H, W=W, kh=k, kw=k, sh=s, sw=s, ph=p, pw=p, has_bias=bias)
+
+
+CASES = [geom(N, C, H, H, k, s, p, b)
+         for (N, C, H, k, s, p, b) in
+         [(32, 3, 224, 7, 2, 3, 0), (32, 64, 56, 1, 1, 0, 0), (32, 64, 56, 3, 1, 1, 0), (32, 128, 56, 3, 2, 1, 0),
+          (32, 256, 56, 1, 2, 0, 0), (32, 512, 7, 3, 1, 1, 0), (32, 2048, 7, 1, 1, 0, 0), (32, 2048, 1, 1, 1, 0, 1),
+          (100, 1, 28, 5, 1, 2, 1), (100, 6, 14, 5, 1, 0, 1), (100, 400, 1, 1, 1, 0, 1), (1, 1, 1, 1, 1, 0, 0),
+          (7, 33, 17, 3, 3, 0, 1), (2, 5, 300, 11, 4, 5, 0), (3, 700, 5, 1, 1, 0, 0)]]
+
+
+@pytest.mark.parametrize("d", CASES)
+def test_plan_respects_budgets(d):
+    p = plan([d])[0]
+    compact = d["kh"] == 1 and d["kw"] == 1
+    Ho = (d["H"] + 2 * d["ph"] - d["kh"]) // d["sh"] + 1
+    Wo = (d["W"] + 2 * d["pw"] - d["kw"]) // d["sw"] + 1
+    flat = compact and d["sh"] == 1 and d["ph"] == 0
+    assert p["dim"] == d["C"] * d["kh"] * d["kw"] + d["has_bias"]
+    assert (p["Ho"], p["Wo"]) == ((1, Ho * Wo) if flat else (Ho, Wo))
+    assert p["TM"] in (64, 128) and p["RL"] in (1, 2)
+    assert p["NS"] * p["SS"] + 16 <= PANEL_WORDS                      # LDS patch per panel
+    rows_in = p["R"] if compact else (p["R"] - 1) * d["sh"] + d["kh"]
+    cols_in = p["Wc"] if compact else (p["Wc"] - 1) * d["sw"] + d["kw"]
+    assert p["RS"] >= cols_in and p["PS"] >= rows_in * p["RS"] and p["SS"] == p["nch"] * p["PS"]
+    prow = p["NS"] * p["nch"] * rows_in
+    if p["vec4"]:
+        assert p["Wc"] % 4 == 0 and (prow << p["cshift"]) * 4 <= SLOT_ELEMS
+    else:
+        assert prow <= ROWTAB_MAX and (prow << p["cshift"]) <= SLOT_ELEMS and (1 << p["cshift"]) >= cols_in
+    runs = p["NS"] * p["R"] * -(-p["Wc"] // p["RL"])
+    assert runs <= KTAB_MAX
+    # chunk grid covers all of K = N * Ho * Wo
+    n_rg, n_cg, n_sg = -(-p["Ho"] // p["R"]), -(-p["Wo"] // p["Wc"]), -(-d["N"] // p["NS"])
+    assert p["nchunks"] == n_rg * n_cg * n_sg
+    assert p["cpi"] * p["nslices"] >= p["nchunks"] and p["cpi"] * (p["nslices"] - 1) < p["nchunks"]
+    P = -(-p["dim"] // p["TM"])
+    assert p["ntiles"] == P * (P + 1) // 2 and p["nitems"] == p["ntiles"] * p["nslices"]
+
+
+def test_item_bases_are_contiguous():
+    ps = plan(CASES)
+    base = 0
+    for p in ps:
+        assert p["base"] == base
+        base += p["nitems"]
+
+
+def test_invalid_geometry_is_rejected():
+    arr = (_lib.curv_factor_desc * 1)()
+    for k, v in geom(2, 3, 4, 4, 7, 1, 0, 0).items():        # kernel larger than the unpadded input
+        setattr(arr[0], k, v)
+    out = (ctypes.c_longlong * NF)()
+    assert _lib.lib().curv_kfac_plan_info(arr, 1, out) == 2   # CURV_ERR_INVALID
