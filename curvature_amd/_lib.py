@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(CSRC, "libcurv_hip.so")
-SOURCES = ["api.cpp", "elementwise.hip", "syrk.hip", "invert.hip", "gemm.hip"]
+SOURCES = ["api.cpp", "elementwise.hip", "syrk.hip", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall",
                "-Wno-unused-function"]
 
@@ -72,6 +72,29 @@ class curv_gemm_desc(ctypes.Structure):
                 ("alpha", ctypes.c_float), ("beta", ctypes.c_float)]
 
 
+class curv_cholinv_desc(ctypes.Structure):
+    _fields_ = [("M", ctypes.c_void_p), ("X", ctypes.c_void_p), ("n", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("diag_add", ctypes.c_double)]
+
+
+class curv_gemm64_desc(ctypes.Structure):
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p)] + \
+               [(k, ctypes.c_longlong) for k in ("a_rs", "a_cs", "b_rs", "b_cs", "c_rs", "c_cs")] + \
+               [("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("alpha", ctypes.c_double), ("beta", ctypes.c_double)]
+
+
+class curv_eigh_desc(ctypes.Structure):
+    _fields_ = [("F", ctypes.c_void_p), ("U", ctypes.c_void_p), ("w", ctypes.c_void_p), ("n", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+class curv_select_desc(ctypes.Structure):
+    _fields_ = [("lambda_vec", ctypes.c_void_p), ("I", ctypes.c_void_p), ("J", ctypes.c_void_p),
+                ("counts", ctypes.c_void_p), ("n", ctypes.c_int32), ("m", ctypes.c_int32), ("rank", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
 _vp, _i, _ll, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_double, ctypes.c_size_t
 
 # name -> (restype, argtypes); every symbol include/curv_hip.h declares
@@ -87,6 +110,16 @@ SIGNATURES = {
     "curv_event_elapsed_ms": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     "curv_chol_inv_workspace_bytes": (_sz, [ctypes.POINTER(curv_inv_desc), _i]),
     "curv_chol_inv_lower": (_i, [_vp, ctypes.POINTER(curv_inv_desc), _i, _vp, _vp, _sz]),
+    "curv_chol_factor_inverse_workspace_bytes": (_sz, [ctypes.POINTER(curv_cholinv_desc), _i]),
+    "curv_chol_factor_inverse": (_i, [_vp, ctypes.POINTER(curv_cholinv_desc), _i, _vp, _vp, _sz]),
+    "curv_gemm_f64_batched": (_i, [_vp, ctypes.POINTER(curv_gemm64_desc), _i]),
+    "curv_syevd_workspace_bytes": (_sz, [ctypes.POINTER(curv_eigh_desc), _i]),
+    "curv_syevd": (_i, [_vp, ctypes.POINTER(curv_eigh_desc), _i, _vp, _sz, _i, _d, ctypes.POINTER(ctypes.c_int)]),
+    "curv_inf_select": (_i, [_vp, ctypes.POINTER(curv_select_desc), _i]),
+    "curv_colpairs": (_i, [_vp, _vp, _i, _i, _ll, _vp]),
+    "curv_inf_vtv_assemble": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "curv_diag_scale": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i]),
+    "curv_mul2d": (_i, [_vp, _vp, _ll, _ll, _vp, _ll, _ll, _vp, _i, _i]),
     "curv_gemm_workspace_bytes": (_sz, [_i]),
     "curv_gemm_batched": (_i, [_vp, ctypes.POINTER(curv_gemm_desc), _i, _vp, _sz]),
     "curv_randn": (_i, [_vp, _vp, _ll, ctypes.c_ulonglong, ctypes.c_ulonglong]),

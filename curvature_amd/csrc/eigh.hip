@@ -1,0 +1,460 @@
+// Symmetric eigensolver on gfx950 for utils.get_eigenvectors (curvature/utils.py:45-60): a batched
+// two-sided BLOCK JACOBI method in fp64, every heavy step a 64x64x64 tile product on the f64 MFMA.
+//
+//   blocks of 32 indices; one step = a round-robin matching of all N_b blocks into N_b/2 disjoint pairs;
+//   for every pair (p, q):   S = A[{p,q},{p,q}] (64x64)  --Jacobi in LDS-->  S = Q diag Q^T
+//   then                      A <- J^T A J,  V <- V J     with J = the block embedding of all the Q's:
+//       rows  {p,q} of A  <-  Q^T * rows          (tiles of 64 columns, disjoint across pairs)
+//       cols  {p,q} of A,V <- cols * Q            (tiles of 64 rows)
+//   N_b - 1 steps visit every pair once (one sweep); sweeps repeat until off(A) is negligible.
+// All matrices of a model advance together (one launch per phase per step for the whole batch).
+// Eigenvalues are returned ascending with the eigenvectors as columns, like the reference's symeig;
+// signs and the basis inside degenerate clusters are arbitrary there as here.
+#include "common.h"
+#include "mma64.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace curv {
+
+constexpr int JB = 32;                 // block of indices
+constexpr int EIG_THREADS = MMA_THREADS;
+
+struct EighDev {
+  const float* F;       // (n x n) fp32 symmetric input
+  float* U;             // (n x n) fp32 eigenvectors (columns), ascending eigenvalues
+  float* w;             // (n) fp32 eigenvalues or null
+  double* A;            // (np x np) work matrix
+  double* V;            // (np x np) accumulated rotations
+  double* Q;            // (Nb/2) x 64 x 64 rotation blocks of the current step
+  double* norms;        // {off^2, diag^2}
+  int n, np, Nb, pad;
+};
+
+template <typename CountFn>
+__device__ __forceinline__ bool eig_locate(const EighDev* __restrict__ t, int nf, int bid, CountFn cnt, int& f,
+                                           int& local) {
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  for (int f0 = 0; f0 < nf; f0 += 64) {
+    const int ff = f0 + lane;
+    const int c = (ff < nf) ? cnt(t[ff]) : 0;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    const int total = __shfl(incl, 63, 64);
+    if (bid < base + total) {
+      const unsigned long long m = __ballot(bid < base + incl);
+      const int l = __ffsll((long long)m) - 1;
+      f = f0 + l;
+      local = bid - (base + __shfl(incl - c, l, 64));
+      return true;
+    }
+    base += total;
+  }
+  return false;
+}
+
+// round-robin tournament (circle method): pair t of round r among N players (N even)
+__device__ __host__ __forceinline__ void rr_pair(int N, int r, int t, int& p, int& q) {
+  if (N == 2) { p = 0; q = 1; return; }
+  const int M = N - 1;
+  r %= M;
+  if (t == 0) { p = r; q = N - 1; }
+  else { p = (r + t) % M; q = (r - t + M) % M; }
+  if (p > q) { const int s = p; p = q; q = s; }
+}
+
+__device__ __forceinline__ int gidx(int p, int q, int x) { return x < JB ? p * JB + x : q * JB + x - JB; }
+
+__global__ void __launch_bounds__(EIG_THREADS)
+eigh_prepare_kernel(const EighDev* __restrict__ t, int nf) {
+  int f, tile;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { const int P = d.np / NB; return P * P; }, f, tile)) return;
+  const EighDev& d = t[f];
+  const int P = d.np / NB, bi = tile / P, bj = tile - bi * P, n = d.n, np = d.np;
+  const float* __restrict__ F = d.F;
+  gdouble* A = (gdouble*)d.A;
+  gdouble* V = (gdouble*)d.V;
+  for (int e = threadIdx.x; e < NB * NB; e += EIG_THREADS) {
+    const int i = bi * NB + (e >> 6), j = bj * NB + (e & 63);
+    double v = 0.0;
+    if (i < n && j < n) v = 0.5 * ((double)F[(long long)i * n + j] + (double)F[(long long)j * n + i]);
+    A[(long long)i * np + j] = v;
+    V[(long long)i * np + j] = (i == j) ? 1.0 : 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (1) per block pair: diagonalise the 64x64 sub-matrix by cyclic Jacobi in LDS, store Q
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EIG_THREADS)
+jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step) {
+  __shared__ double S[NB * LDA];
+  __shared__ double Qs[NB * LDA];
+  __shared__ double cs[2 * 32];
+  __shared__ int pairs[2 * 32];
+  __shared__ double red[EIG_THREADS];
+  int f, tp;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return d.Nb / 2; }, f, tp)) return;
+  const EighDev& d = t[f];
+  int p, q;
+  rr_pair(d.Nb, step, tp, p, q);
+  const int np = d.np, tid = threadIdx.x;
+  const gdouble* A = (const gdouble*)d.A;
+  for (int e = tid; e < NB * NB; e += EIG_THREADS) {
+    const int x = e >> 6, y = e & 63;
+    S[x * LDA + y] = A[(long long)gidx(p, q, x) * np + gidx(p, q, y)];
+    Qs[x * LDA + y] = (x == y) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  // squared Frobenius norm of S (for the stopping test)
+  double part = 0.0;
+  for (int e = tid; e < NB * NB; e += EIG_THREADS) { const double v = S[(e >> 6) * LDA + (e & 63)]; part += v * v; }
+  red[tid] = part;
+  __syncthreads();
+  for (int o = EIG_THREADS / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  const double fro2 = red[0];
+  __syncthreads();
+
+  for (int sweep = 0; sweep < 10; ++sweep) {
+    for (int rr = 0; rr < NB - 1; ++rr) {
+      if (tid < 32) {
+        int i, j;
+        rr_pair(NB, rr, tid, i, j);
+        const double app = S[i * LDA + i], aqq = S[j * LDA + j], apq = S[i * LDA + j];
+        double c = 1.0, s = 0.0;
+        if (fabs(apq) > 1e-300 && fabs(apq) > 1e-17 * sqrt(fabs(app * aqq))) {
+          const double tau = (aqq - app) / (2.0 * apq);
+          const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+          c = 1.0 / sqrt(1.0 + tt * tt);
+          s = tt * c;
+        }
+        cs[2 * tid] = c; cs[2 * tid + 1] = s;
+        pairs[2 * tid] = i; pairs[2 * tid + 1] = j;
+      }
+      __syncthreads();
+      // S' = J^T S J on 2x2 blocks (pair ka rows x pair kb cols): 1024 blocks, 4 per thread, in place
+      for (int blk = tid; blk < 32 * 32; blk += EIG_THREADS) {
+        const int ka = blk >> 5, kb = blk & 31;
+        const int ia = pairs[2 * ka], ja = pairs[2 * ka + 1], ib = pairs[2 * kb], jb = pairs[2 * kb + 1];
+        const double ca = cs[2 * ka], sa = cs[2 * ka + 1], cb = cs[2 * kb], sb = cs[2 * kb + 1];
+        const double m00 = S[ia * LDA + ib], m01 = S[ia * LDA + jb], m10 = S[ja * LDA + ib], m11 = S[ja * LDA + jb];
+        // rows: R_a^T [m0*; m1*]  with R = [[c, s], [-s, c]]
+        const double r00 = ca * m00 - sa * m10, r01 = ca * m01 - sa * m11;
+        const double r10 = sa * m00 + ca * m10, r11 = sa * m01 + ca * m11;
+        // cols: [.] R_b
+        S[ia * LDA + ib] = r00 * cb - r01 * sb;
+        S[ia * LDA + jb] = r00 * sb + r01 * cb;
+        S[ja * LDA + ib] = r10 * cb - r11 * sb;
+        S[ja * LDA + jb] = r10 * sb + r11 * cb;
+      }
+      // Q' = Q J: 64 rows x 32 pairs
+      for (int e = tid; e < NB * 32; e += EIG_THREADS) {
+        const int r = e >> 5, kb = e & 31;
+        const int ib = pairs[2 * kb], jb = pairs[2 * kb + 1];
+        const double cb = cs[2 * kb], sb = cs[2 * kb + 1];
+        const double qi = Qs[r * LDA + ib], qj = Qs[r * LDA + jb];
+        Qs[r * LDA + ib] = qi * cb - qj * sb;
+        Qs[r * LDA + jb] = qi * sb + qj * cb;
+      }
+      __syncthreads();
+    }
+    // off-diagonal norm after this sweep
+    part = 0.0;
+    for (int e = tid; e < NB * NB; e += EIG_THREADS) {
+      const int x = e >> 6, y = e & 63;
+      if (x != y) { const double v = S[x * LDA + y]; part += v * v; }
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int o = EIG_THREADS / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const double off2 = red[0];
+    __syncthreads();
+    if (off2 <= 1e-26 * fro2) break;
+  }
+  gdouble* Qg = (gdouble*)d.Q + (long long)tp * NB * NB;
+  for (int e = tid; e < NB * NB; e += EIG_THREADS) Qg[e] = Qs[(e >> 6) * LDA + (e & 63)];
+}
+
+// ------------------------------------------------------------------------------------------------
+// (2) rows {p,q} of A <- Q^T rows, one 64-column tile per workgroup
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EIG_THREADS)
+jacobi_rows_kernel(const EighDev* __restrict__ t, int nf, int step) {
+  __shared__ double As[NB * LDA], Bs[NB * LDA];
+  int f, local;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return (d.Nb / 2) * (d.np / NB); }, f, local)) return;
+  const EighDev& d = t[f];
+  const int nct = d.np / NB, tp = local / nct, ct = local - tp * nct, np = d.np, tid = threadIdx.x;
+  int p, q;
+  rr_pair(d.Nb, step, tp, p, q);
+  gdouble* A = (gdouble*)d.A;
+  const gdouble* Qg = (const gdouble*)d.Q + (long long)tp * NB * NB;
+  for (int e = tid; e < NB * NB; e += EIG_THREADS) {
+    const int x = e >> 6, y = e & 63;
+    As[y * LDA + x] = Qg[e];                                            // As[row][k] = Q[k][row]  (Q^T)
+    Bs[x * LDA + y] = A[(long long)gidx(p, q, x) * np + ct * NB + y];   // T as [k][col]
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  f64x4 acc[2][2] = {};
+  mma_64<false>(As, Bs, wm, wn, lane, acc);
+  const int c16 = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int x = 32 * wm + 16 * m + rq + 4 * r, y = 32 * wn + 16 * n + c16;
+        A[(long long)gidx(p, q, x) * np + ct * NB + y] = acc[m][n][r];
+      }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (3) cols {p,q} of A and of V <- cols * Q, one 64-row tile per workgroup
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EIG_THREADS)
+jacobi_cols_kernel(const EighDev* __restrict__ t, int nf, int step) {
+  __shared__ double As[NB * LDA], Bs[NB * LDA];
+  int f, local;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return (d.Nb / 2) * (d.np / NB) * 2; }, f, local)) return;
+  const EighDev& d = t[f];
+  const int nrt = d.np / NB, np = d.np, tid = threadIdx.x;
+  const int which = local / ((d.Nb / 2) * nrt);                     // 0: A, 1: V
+  const int l2 = local - which * (d.Nb / 2) * nrt;
+  const int tp = l2 / nrt, rt = l2 - tp * nrt;
+  int p, q;
+  rr_pair(d.Nb, step, tp, p, q);
+  gdouble* Mx = which ? (gdouble*)d.V : (gdouble*)d.A;
+  const gdouble* Qg = (const gdouble*)d.Q + (long long)tp * NB * NB;
+  for (int e = tid; e < NB * NB; e += EIG_THREADS) {
+    const int x = e >> 6, y = e & 63;
+    As[x * LDA + y] = Mx[(long long)(rt * NB + x) * np + gidx(p, q, y)];   // T as [row][k]
+    Bs[x * LDA + y] = Qg[e];                                               // Q as [k][col]
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  f64x4 acc[2][2] = {};
+  mma_64<false>(As, Bs, wm, wn, lane, acc);
+  const int c16 = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int x = 32 * wm + 16 * m + rq + 4 * r, y = 32 * wn + 16 * n + c16;
+        Mx[(long long)(rt * NB + x) * np + gidx(p, q, y)] = acc[m][n][r];
+      }
+}
+
+// off-diagonal / diagonal squared norms of A (convergence test)
+__global__ void __launch_bounds__(EIG_THREADS)
+eigh_norms_kernel(const EighDev* __restrict__ t, int nf) {
+  __shared__ double r0[EIG_THREADS], r1[EIG_THREADS];
+  int f, tile;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { const int P = d.np / NB; return P * P; }, f, tile)) return;
+  const EighDev& d = t[f];
+  const int P = d.np / NB, bi = tile / P, bj = tile - bi * P, np = d.np, tid = threadIdx.x;
+  const gdouble* A = (const gdouble*)d.A;
+  double off = 0.0, dg = 0.0;
+  for (int e = tid; e < NB * NB; e += EIG_THREADS) {
+    const int i = bi * NB + (e >> 6), j = bj * NB + (e & 63);
+    const double v = A[(long long)i * np + j];
+    if (i == j) dg += v * v; else off += v * v;
+  }
+  r0[tid] = off; r1[tid] = dg;
+  __syncthreads();
+  for (int o = EIG_THREADS / 2; o > 0; o >>= 1) {
+    if (tid < o) { r0[tid] += r0[tid + o]; r1[tid] += r1[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) { atomicAdd(d.norms, r0[0]); atomicAdd(d.norms + 1, r1[0]); }
+}
+
+// eigenvalues ascending (bitonic sort of (value, index) in LDS) and the permuted eigenvectors, fp32
+constexpr int SORT_MAX = 8192;
+__global__ void __launch_bounds__(1024)
+eigh_sort_kernel(const EighDev* __restrict__ t, int* __restrict__ perm_all, int perm_stride) {
+  __shared__ double key[SORT_MAX];
+  __shared__ int idx[SORT_MAX];
+  const EighDev& d = t[blockIdx.x];
+  const int n = d.n, np = d.np, tid = threadIdx.x;
+  const gdouble* A = (const gdouble*)d.A;
+  int len = 1;
+  while (len < n) len <<= 1;
+  for (int i = tid; i < len; i += 1024) {
+    key[i] = (i < n) ? A[(long long)i * np + i] : 1.0e308;
+    idx[i] = i;
+  }
+  __syncthreads();
+  for (int k = 2; k <= len; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < len; i += 1024) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = ((i & k) == 0);
+          const double a = key[i], b = key[l];
+          const bool swap = up ? (a > b || (a == b && idx[i] > idx[l])) : (a < b || (a == b && idx[i] < idx[l]));
+          if (swap) { key[i] = b; key[l] = a; const int s = idx[i]; idx[i] = idx[l]; idx[l] = s; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  int* perm = perm_all + (long long)blockIdx.x * perm_stride;
+  for (int i = tid; i < n; i += 1024) {
+    perm[i] = idx[i];
+    if (d.w) d.w[i] = (float)key[i];
+  }
+}
+
+__global__ void __launch_bounds__(EIG_THREADS)
+eigh_gather_kernel(const EighDev* __restrict__ t, int nf, const int* __restrict__ perm_all, int perm_stride) {
+  int f, tile;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { const int P = (d.n + NB - 1) / NB; return P * P; }, f, tile)) return;
+  const EighDev& d = t[f];
+  const int P = (d.n + NB - 1) / NB, bi = tile / P, bj = tile - bi * P, n = d.n, np = d.np;
+  const gdouble* V = (const gdouble*)d.V;
+  const int* perm = perm_all + (long long)f * perm_stride;
+  float* __restrict__ U = d.U;
+  for (int e = threadIdx.x; e < NB * NB; e += EIG_THREADS) {
+    const int i = bi * NB + (e >> 6), j = bj * NB + (e & 63);
+    if (i < n && j < n) U[(long long)i * n + j] = (float)V[(long long)i * np + perm[j]];
+  }
+}
+
+constexpr int EIG_UPLOAD_CHUNK = 48;
+struct EighChunk { EighDev f[EIG_UPLOAD_CHUNK]; };
+static_assert(sizeof(EighChunk) <= 3840, "kernel argument block must stay below 4 KB");
+
+__global__ void __launch_bounds__(256) eigh_upload_kernel(EighDev* __restrict__ table, EighChunk chunk, int count) {
+  const int words = count * (int)(sizeof(EighDev) / 4);
+  const int* in = reinterpret_cast<const int*>(&chunk);
+  int* out = reinterpret_cast<int*>(table);
+  for (int w = threadIdx.x; w < words; w += blockDim.x) out[w] = in[w];
+}
+
+struct EighLayout {
+  size_t table, norms, perm, total;
+  std::vector<size_t> a_off, v_off, q_off;
+  int perm_stride;
+};
+
+static bool eigh_layout(const curv_eigh_desc* descs, int n, EighLayout& L) {
+  L.table = align_up((size_t)std::max(n, 1) * sizeof(EighDev), 256);
+  L.norms = align_up((size_t)std::max(n, 1) * 2 * sizeof(double), 256);
+  int nmax = 1;
+  for (int i = 0; i < n; ++i) { if (descs[i].n <= 0 || descs[i].n > SORT_MAX) return false; nmax = std::max(nmax, descs[i].n); }
+  L.perm_stride = nmax;
+  L.perm = align_up((size_t)std::max(n, 1) * nmax * sizeof(int), 256);
+  size_t off = L.table + L.norms + L.perm;
+  L.a_off.resize(n); L.v_off.resize(n); L.q_off.resize(n);
+  for (int i = 0; i < n; ++i) {
+    const size_t np = (size_t)cdiv(descs[i].n, NB) * NB;
+    L.a_off[i] = off; off += np * np * sizeof(double);
+    L.v_off[i] = off; off += np * np * sizeof(double);
+    L.q_off[i] = off; off += (np / NB) * NB * NB * sizeof(double);
+  }
+  L.total = off;
+  return true;
+}
+
+}  // namespace curv
+
+using namespace curv;
+
+extern "C" size_t curv_syevd_workspace_bytes(const curv_eigh_desc* descs, int n_mats) {
+  EighLayout L;
+  if (!eigh_layout(descs, n_mats, L)) return 0;
+  return L.total;
+}
+
+extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats, void* workspace,
+                          size_t workspace_bytes, int max_sweeps, double tol, int* sweeps_done) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_mats == 0) return CURV_OK;
+  CURV_REQUIRE(descs != nullptr, "curv_syevd: null descriptor array");
+  EighLayout L;
+  CURV_REQUIRE(eigh_layout(descs, n_mats, L), "curv_syevd: matrix size out of range (1 .. %d)", SORT_MAX);
+  if (workspace == nullptr || workspace_bytes < L.total) {
+    set_error("curv_syevd: workspace too small (%zu < %zu bytes)", workspace_bytes, L.total);
+    return CURV_ERR_WORKSPACE;
+  }
+  if (max_sweeps <= 0) max_sweeps = 15;
+  if (tol <= 0.0) tol = 1e-9;
+  char* base = reinterpret_cast<char*>(workspace);
+  EighDev* table = reinterpret_cast<EighDev*>(base);
+  double* norms = reinterpret_cast<double*>(base + L.table);
+  int* perm = reinterpret_cast<int*>(base + L.table + L.norms);
+  std::vector<EighDev> tab(n_mats);
+  long long prep_tiles = 0, pair_wgs = 0, row_tiles = 0, gather_tiles = 0;
+  int maxNb = 2;
+  for (int i = 0; i < n_mats; ++i) {
+    const curv_eigh_desc& s = descs[i];
+    CURV_REQUIRE(s.F != nullptr && s.U != nullptr, "curv_syevd: matrix %d: null pointer", i);
+    EighDev& d = tab[i];
+    memset(&d, 0, sizeof(d));
+    d.F = s.F; d.U = s.U; d.w = s.w; d.n = s.n;
+    d.np = cdiv(s.n, NB) * NB;
+    d.Nb = d.np / JB;
+    d.A = reinterpret_cast<double*>(base + L.a_off[i]);
+    d.V = reinterpret_cast<double*>(base + L.v_off[i]);
+    d.Q = reinterpret_cast<double*>(base + L.q_off[i]);
+    d.norms = norms + 2 * i;
+    maxNb = std::max(maxNb, d.Nb);
+    const long long P = d.np / NB;
+    prep_tiles += P * P;
+    pair_wgs += d.Nb / 2;
+    row_tiles += (long long)(d.Nb / 2) * P;
+    const long long Pg = cdiv(s.n, NB);
+    gather_tiles += Pg * Pg;
+  }
+  for (int b = 0; b < n_mats; b += EIG_UPLOAD_CHUNK) {
+    EighChunk chunk;
+    const int count = std::min(EIG_UPLOAD_CHUNK, n_mats - b);
+    memset(&chunk, 0, sizeof(chunk));
+    memcpy(chunk.f, tab.data() + b, (size_t)count * sizeof(EighDev));
+    hipLaunchKernelGGL(eigh_upload_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count);
+    CURV_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(eigh_prepare_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats);
+  CURV_LAUNCH_CHECK();
+  std::vector<double> host_norms(2 * n_mats);
+  int step = 0, sweeps = 0;
+  const int steps_per_sweep = std::max(1, maxNb - 1);
+  for (; sweeps < max_sweeps; ++sweeps) {
+    for (int s = 0; s < steps_per_sweep; ++s, ++step) {
+      hipLaunchKernelGGL(jacobi_pair_kernel, dim3((unsigned)pair_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, step);
+      CURV_LAUNCH_CHECK();
+      hipLaunchKernelGGL(jacobi_rows_kernel, dim3((unsigned)row_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, step);
+      CURV_LAUNCH_CHECK();
+      hipLaunchKernelGGL(jacobi_cols_kernel, dim3((unsigned)(2 * row_tiles)), dim3(EIG_THREADS), 0, stream, table, n_mats, step);
+      CURV_LAUNCH_CHECK();
+    }
+    // convergence test (one host round trip per sweep)
+    CURV_HIP_CHECK(hipMemsetAsync(norms, 0, (size_t)n_mats * 2 * sizeof(double), stream));
+    hipLaunchKernelGGL(eigh_norms_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats);
+    CURV_LAUNCH_CHECK();
+    CURV_HIP_CHECK(hipMemcpyAsync(host_norms.data(), norms, (size_t)n_mats * 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    CURV_HIP_CHECK(hipStreamSynchronize(stream));
+    bool done = true;
+    for (int i = 0; i < n_mats; ++i) {
+      const double off2 = host_norms[2 * i], dg2 = host_norms[2 * i + 1];
+      if (!(off2 <= tol * tol * (off2 + dg2))) { done = false; break; }
+    }
+    if (done) { ++sweeps; break; }
+  }
+  if (sweeps_done) *sweeps_done = sweeps;
+  hipLaunchKernelGGL(eigh_sort_kernel, dim3(n_mats), dim3(1024), 0, stream, table, perm, L.perm_stride);
+  CURV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(eigh_gather_kernel, dim3((unsigned)gather_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, perm, L.perm_stride);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}

@@ -138,6 +138,86 @@ gemm_f32_kernel(const GemmDev* __restrict__ table, int n_desc) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same batched strided GEMM in fp64 (v_mfma_f64_16x16x4_f64) for the ill-conditioned products of
+// INF.pre_sampler (L_c = A^-T (I - B^-1) A^-1).  alpha/beta only, no fused epilogue.
+// ------------------------------------------------------------------------------------------------
+struct Gemm64Dev {
+  const double* A;
+  const double* B;
+  double* C;
+  long long a_rs, a_cs, b_rs, b_cs, c_rs, c_cs;
+  int M, N, K;
+  int tiles_n, tile_base, pad;
+  double alpha, beta;
+};
+
+typedef __attribute__((address_space(1))) double gdbl;
+
+__global__ void __launch_bounds__(GEMM_THREADS)
+gemm_f64_kernel(Gemm64Dev d0, Gemm64Dev d1, Gemm64Dev d2, Gemm64Dev d3, int n_desc) {
+  __shared__ double As[GK * GP];     // [k][row]
+  __shared__ double Bs[GK * GP];     // [k][col]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, kq = lane >> 4;
+  int f = 0;
+  if (n_desc > 1 && (int)blockIdx.x >= d1.tile_base) f = 1;
+  if (n_desc > 2 && (int)blockIdx.x >= d2.tile_base) f = 2;
+  if (n_desc > 3 && (int)blockIdx.x >= d3.tile_base) f = 3;
+  const Gemm64Dev d = f == 0 ? d0 : f == 1 ? d1 : f == 2 ? d2 : d3;
+  const int local = blockIdx.x - d.tile_base;
+  const int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
+  const int i0 = tm * GT, j0 = tn * GT;
+  const int M = d.M, N = d.N, K = d.K;
+  const gdbl* A = (const gdbl*)d.A;
+  const gdbl* B = (const gdbl*)d.B;
+  const bool a_kfast = (d.a_cs == 1), b_kfast = (d.b_rs == 1);
+  f64x4 acc[2][2] = {};
+  for (int k0 = 0; k0 < K; k0 += GK) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + u * GEMM_THREADS;
+      int ar, ak, bc, bk;
+      if (a_kfast) { ak = e & 15; ar = e >> 4; } else { ar = e & 63; ak = e >> 6; }
+      if (b_kfast) { bk = e & 15; bc = e >> 4; } else { bc = e & 63; bk = e >> 6; }
+      const int i = i0 + ar, k = k0 + ak, j = j0 + bc, kk = k0 + bk;
+      As[ak * GP + ar] = (i < M && k < K) ? A[i * d.a_rs + k * d.a_cs] : 0.0;
+      Bs[bk * GP + bc] = (j < N && kk < K) ? B[kk * d.b_rs + j * d.b_cs] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < GK / 4; ++ks) {
+      const int k = 4 * ks + kq;
+      double a[2], b[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m] = As[k * GP + 32 * wm + 16 * m + r16];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) b[n] = Bs[k * GP + 32 * wn + 16 * n + r16];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  gdbl* C = (gdbl*)d.C;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 32 * wm + 16 * m + kq + 4 * r, j = j0 + 32 * wn + 16 * n + r16;
+        if (i < M && j < N) {
+          const long long ci = i * d.c_rs + j * d.c_cs;
+          double v = d.alpha * acc[m][n][r];
+          if (d.beta != 0.0) v += d.beta * C[ci];
+          C[ci] = v;
+        }
+      }
+}
+
 constexpr int GEMM_UPLOAD_CHUNK = 24;
 struct GemmChunk { GemmDev f[GEMM_UPLOAD_CHUNK]; };
 static_assert(sizeof(GemmChunk) <= 3840, "kernel argument block must stay below 4 KB");
@@ -260,5 +340,29 @@ extern "C" int curv_randn(void* stream, float* out, long long count, unsigned lo
   hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, count, seed,
                      offset);
   CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}
+
+extern "C" int curv_gemm_f64_batched(void* stream_, const curv_gemm64_desc* descs, int n_desc) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CURV_REQUIRE(n_desc >= 0 && (n_desc == 0 || descs), "curv_gemm_f64_batched: bad arguments");
+  for (int base = 0; base < n_desc; base += 4) {
+    Gemm64Dev d[4];
+    memset(d, 0, sizeof(d));
+    const int cnt = std::min(4, n_desc - base);
+    long long tiles = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const curv_gemm64_desc& s = descs[base + i];
+      CURV_REQUIRE(s.M > 0 && s.N > 0 && s.K >= 0 && s.A && s.B && s.C, "curv_gemm_f64_batched: desc %d invalid", base + i);
+      d[i].A = s.A; d[i].B = s.B; d[i].C = s.C;
+      d[i].a_rs = s.a_rs; d[i].a_cs = s.a_cs; d[i].b_rs = s.b_rs; d[i].b_cs = s.b_cs; d[i].c_rs = s.c_rs; d[i].c_cs = s.c_cs;
+      d[i].M = s.M; d[i].N = s.N; d[i].K = s.K; d[i].alpha = s.alpha; d[i].beta = s.beta;
+      d[i].tiles_n = cdiv(s.N, GT);
+      d[i].tile_base = (int)tiles;
+      tiles += (long long)cdiv(s.M, GT) * d[i].tiles_n;
+    }
+    hipLaunchKernelGGL(gemm_f64_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, stream, d[0], d[1], d[2], d[3], cnt);
+    CURV_LAUNCH_CHECK();
+  }
   return CURV_OK;
 }

@@ -22,15 +22,14 @@
 // Matrices are padded to a multiple of 64 with an identity tail, so no kernel needs bounds checks.
 // "Not positive definite" is reported through a per-factor device info word (0 = ok).
 #include "common.h"
+#include "mma64.h"
 
 #include <algorithm>
 #include <vector>
 
 namespace curv {
 
-constexpr int NB = 64;                 // block edge
-constexpr int INV_THREADS = 256;
-constexpr int LDA = NB + 1;            // LDS row pitch (doubles) of a [row][k] operand tile: bank spread
+constexpr int INV_THREADS = MMA_THREADS;
 
 struct InvDev {
   const float* F;       // (n x n) fp32 factor
@@ -40,9 +39,10 @@ struct InvDev {
   int* info;            // device status word of this factor
   int n, np, P;
   float sqrt_s, sqrt_n;
+  int reverse;          // 1: factor J M J and emit L = J X^T J (KFAC.invert); 0: plain M, emit X = chol(M)^-1
+  int pad;
+  double* Xout;         // reverse == 0: (n x n) fp64 output, lower triangular
 };
-
-typedef __attribute__((address_space(1))) double gdouble;
 
 // block -> (factor, local tile) for per-factor tile counts cnt(f) that depend on the step
 template <typename CountFn>
@@ -72,49 +72,6 @@ __device__ __forceinline__ bool locate(const InvDev* __restrict__ t, int nf, int
   return false;
 }
 
-// acc(2x2 of 16x16 per wave, 32x32 wave quadrant) += Atile(64 x 64: [row][k]) * Btile
-//   BT = true : B given as [col][k]  (C += A * B^T, both K-contiguous)
-//   BT = false: B given as [k][col]
-// Both tiles live in LDS with pitch LDA doubles.
-template <bool BT>
-__device__ __forceinline__ void mma_64(const double* __restrict__ As, const double* __restrict__ Bs, int wm,
-                                       int wn, int lane, f64x4 (&acc)[2][2]) {
-  const int r16 = lane & 15, kq = lane >> 4;
-#pragma unroll 4
-  for (int ks = 0; ks < NB / 4; ++ks) {
-    const int k = 4 * ks + kq;
-    double a[2], b[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) a[m] = As[(32 * wm + 16 * m + r16) * LDA + k];
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-      b[n] = BT ? Bs[(32 * wn + 16 * n + r16) * LDA + k] : Bs[k * LDA + 32 * wn + 16 * n + r16];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
-  }
-}
-
-// 64x64 block copy global (pitch ld) -> LDS (pitch LDA)
-__device__ __forceinline__ void load_block(const gdouble* __restrict__ g, int ld, double* __restrict__ s) {
-  for (int e = threadIdx.x; e < NB * NB; e += INV_THREADS) {
-    const int r = e >> 6, c = e & 63;
-    s[r * LDA + c] = g[(long long)r * ld + c];
-  }
-}
-
-// wave quadrant accumulators -> LDS tile [row][col] (f64 C/D map: col = lane&15, row = (lane>>4) + 4*reg)
-__device__ __forceinline__ void acc_to_lds(const f64x4 (&acc)[2][2], int wm, int wn, int lane, double* s) {
-  const int c16 = lane & 15, rq = lane >> 4;
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s[(32 * wm + 16 * m + rq + 4 * r) * LDA + 32 * wn + 16 * n + c16] = acc[m][n][r];
-}
-
 // ------------------------------------------------------------------------------------------------
 // (0) W = J (sqrt_s F + sqrt_n I) J in fp64, formed with the reference's fp32 rounding sequence;
 //     identity tail on the padding; lower triangle only.
@@ -136,7 +93,7 @@ inv_prepare_kernel(const InvDev* __restrict__ t, int nf) {
     const int i = bi * NB + (e >> 6), j = bj * NB + (e & 63);
     double v;
     if (i < n && j < n) {
-      const int ri = n - 1 - i, rj = n - 1 - j;
+      const int ri = d.reverse ? n - 1 - i : i, rj = d.reverse ? n - 1 - j : j;
       // reg = s**0.5 * F + diag(n**0.5); reg = (reg + reg.t()) / 2   (curvatures.py:368-375), in fp32
       float a = __fmul_rn(ss, F[(long long)ri * n + rj]);
       float b = __fmul_rn(ss, F[(long long)rj * n + ri]);
@@ -340,6 +297,14 @@ inv_finalize_kernel(const InvDev* __restrict__ t, int nf) {
   const gdouble* X = (const gdouble*)d.X;
   float* __restrict__ L = d.L;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  if (!d.reverse) {                                          // plain copy of the lower triangle, fp64
+    gdouble* Xo = (gdouble*)d.Xout;
+    for (int r = ty; r < 32; r += 8) {
+      const int i = ti * 32 + r, j = tj * 32 + tx;
+      if (i < n && j < n) Xo[(long long)i * n + j] = (j <= i) ? X[(long long)i * np + j] : 0.0;
+    }
+    return;
+  }
   if (tj > ti) {
     for (int r = ty; r < 32; r += 8) {
       const int i = ti * 32 + r, j = tj * 32 + tx;
@@ -389,36 +354,24 @@ extern "C" size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int 
   return total;
 }
 
-extern "C" int curv_chol_inv_lower(void* stream_, const curv_inv_desc* descs, int n_factors, int* info,
-                                   void* workspace, size_t workspace_bytes) {
-  hipStream_t stream = (hipStream_t)stream_;
-  if (n_factors == 0) return CURV_OK;
-  CURV_REQUIRE(descs != nullptr && info != nullptr, "curv_chol_inv_lower: null argument");
-  const size_t need = curv_chol_inv_workspace_bytes(descs, n_factors);
-  CURV_REQUIRE(need != 0, "curv_chol_inv_lower: empty factor");
+static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* workspace, size_t workspace_bytes,
+                      const char* who) {
+  const int n_factors = (int)tab.size();
+  size_t need = inv_table_bytes(n_factors);
+  for (const InvDev& d : tab) need += 2 * (size_t)d.np * d.np * sizeof(double);
   if (workspace == nullptr || workspace_bytes < need) {
-    set_error("curv_chol_inv_lower: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+    set_error("%s: workspace too small (%zu < %zu bytes)", who, workspace_bytes, need);
     return CURV_ERR_WORKSPACE;
   }
-  std::vector<InvDev> tab(n_factors);
   char* p = reinterpret_cast<char*>(workspace) + inv_table_bytes(n_factors);
   int Pmax = 0;
   long long prep_tiles = 0, fin_tiles = 0;
-  for (int i = 0; i < n_factors; ++i) {
-    const curv_inv_desc& s = descs[i];
-    CURV_REQUIRE(s.F != nullptr && s.L != nullptr, "curv_chol_inv_lower: factor %d: null pointer", i);
-    CURV_REQUIRE(s.multiply >= 0.0 && s.add >= 0.0, "curv_chol_inv_lower: factor %d: negative hyper-parameter", i);
-    InvDev& d = tab[i];
-    d.F = s.F; d.L = s.L; d.n = s.n;
-    d.P = cdiv(s.n, NB); d.np = d.P * NB;
+  for (InvDev& d : tab) {
     d.W = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double);
     d.X = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double);
-    d.info = info + i;
-    d.sqrt_s = (float)sqrt(s.multiply);      // s ** 0.5 in double, then the fp32 tensor multiply
-    d.sqrt_n = (float)sqrt(s.add);
     Pmax = std::max(Pmax, d.P);
     prep_tiles += (long long)d.P * (d.P + 1) / 2;
-    const long long q = cdiv(s.n, 32);
+    const long long q = cdiv(d.n, 32);
     fin_tiles += q * q;
   }
   InvDev* table = reinterpret_cast<InvDev*>(workspace);
@@ -454,4 +407,56 @@ extern "C" int curv_chol_inv_lower(void* stream_, const curv_inv_desc* descs, in
   hipLaunchKernelGGL(inv_finalize_kernel, dim3((unsigned)fin_tiles), dim3(INV_THREADS), 0, stream, table, n_factors);
   CURV_LAUNCH_CHECK();
   return CURV_OK;
+}
+
+extern "C" int curv_chol_inv_lower(void* stream_, const curv_inv_desc* descs, int n_factors, int* info,
+                                   void* workspace, size_t workspace_bytes) {
+  if (n_factors == 0) return CURV_OK;
+  CURV_REQUIRE(descs != nullptr && info != nullptr, "curv_chol_inv_lower: null argument");
+  std::vector<InvDev> tab(n_factors);
+  for (int i = 0; i < n_factors; ++i) {
+    const curv_inv_desc& s = descs[i];
+    CURV_REQUIRE(s.n > 0, "curv_chol_inv_lower: factor %d: empty", i);
+    CURV_REQUIRE(s.F != nullptr && s.L != nullptr, "curv_chol_inv_lower: factor %d: null pointer", i);
+    CURV_REQUIRE(s.multiply >= 0.0 && s.add >= 0.0, "curv_chol_inv_lower: factor %d: negative hyper-parameter", i);
+    InvDev& d = tab[i];
+    memset(&d, 0, sizeof(d));
+    d.F = s.F; d.L = s.L; d.n = s.n;
+    d.P = cdiv(s.n, NB); d.np = d.P * NB;
+    d.info = info + i;
+    d.sqrt_s = (float)sqrt(s.multiply);      // s ** 0.5 in double, then the fp32 tensor multiply
+    d.sqrt_n = (float)sqrt(s.add);
+    d.reverse = 1;
+  }
+  return chol_sweep((hipStream_t)stream_, tab, workspace, workspace_bytes, "curv_chol_inv_lower");
+}
+
+extern "C" size_t curv_chol_factor_inverse_workspace_bytes(const curv_cholinv_desc* descs, int n) {
+  size_t total = inv_table_bytes(n);
+  for (int i = 0; i < n; ++i) {
+    if (descs[i].n <= 0) return 0;
+    const size_t np = (size_t)cdiv(descs[i].n, NB) * NB;
+    total += 2 * np * np * sizeof(double);
+  }
+  return total;
+}
+
+extern "C" int curv_chol_factor_inverse(void* stream_, const curv_cholinv_desc* descs, int n_mats, int* info,
+                                        void* workspace, size_t workspace_bytes) {
+  if (n_mats == 0) return CURV_OK;
+  CURV_REQUIRE(descs != nullptr && info != nullptr, "curv_chol_factor_inverse: null argument");
+  std::vector<InvDev> tab(n_mats);
+  for (int i = 0; i < n_mats; ++i) {
+    const curv_cholinv_desc& s = descs[i];
+    CURV_REQUIRE(s.n > 0 && s.M != nullptr && s.X != nullptr, "curv_chol_factor_inverse: matrix %d invalid", i);
+    InvDev& d = tab[i];
+    memset(&d, 0, sizeof(d));
+    d.F = s.M; d.Xout = s.X; d.n = s.n;
+    d.P = cdiv(s.n, NB); d.np = d.P * NB;
+    d.info = info + i;
+    d.sqrt_s = 1.0f;
+    d.sqrt_n = (float)s.diag_add;            // added in fp32 like the reference's `vtv + eye` (:567)
+    d.reverse = 0;
+  }
+  return chol_sweep((hipStream_t)stream_, tab, workspace, workspace_bytes, "curv_chol_factor_inverse");
 }

@@ -1,0 +1,58 @@
+// 64x64 fp64 tile building blocks on v_mfma_f64_16x16x4_f64, shared by the blocked Cholesky / triangular
+// inverse (invert.hip) and the block-Jacobi eigensolver (eigh.hip).
+#pragma once
+#include "common.h"
+
+namespace curv {
+
+constexpr int NB = 64;                 // block edge
+constexpr int MMA_THREADS = 256;       // 4 waves, each owning a 32x32 quadrant (2x2 MFMA tiles of 16x16)
+constexpr int LDA = NB + 1;            // LDS row pitch (doubles) of an operand tile: bank spread
+
+typedef __attribute__((address_space(1))) double gdouble;
+
+// acc(2x2 of 16x16 per wave, 32x32 wave quadrant) += Atile(64 x 64: [row][k]) * Btile
+//   BT = true : B given as [col][k]  (C += A * B^T, both K-contiguous)
+//   BT = false: B given as [k][col]
+// Both tiles live in LDS with pitch LDA doubles.  Operand maps of v_mfma_f64_16x16x4_f64:
+// A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], C/D col = lane & 15, row = (lane >> 4) + 4 reg.
+template <bool BT>
+__device__ __forceinline__ void mma_64(const double* __restrict__ As, const double* __restrict__ Bs, int wm,
+                                       int wn, int lane, f64x4 (&acc)[2][2]) {
+  const int r16 = lane & 15, kq = lane >> 4;
+#pragma unroll 4
+  for (int ks = 0; ks < NB / 4; ++ks) {
+    const int k = 4 * ks + kq;
+    double a[2], b[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) a[m] = As[(32 * wm + 16 * m + r16) * LDA + k];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+      b[n] = BT ? Bs[(32 * wn + 16 * n + r16) * LDA + k] : Bs[k * LDA + 32 * wn + 16 * n + r16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+  }
+}
+
+// 64x64 block copy global (pitch ld) -> LDS (pitch LDA)
+__device__ __forceinline__ void load_block(const gdouble* __restrict__ g, int ld, double* __restrict__ s) {
+  for (int e = threadIdx.x; e < NB * NB; e += MMA_THREADS) {
+    const int r = e >> 6, c = e & 63;
+    s[r * LDA + c] = g[(long long)r * ld + c];
+  }
+}
+
+// wave quadrant accumulators -> LDS tile [row][col]
+__device__ __forceinline__ void acc_to_lds(const f64x4 (&acc)[2][2], int wm, int wn, int lane, double* s) {
+  const int c16 = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[(32 * wm + 16 * m + rq + 4 * r) * LDA + 32 * wn + 16 * n + c16] = acc[m][n][r];
+}
+
+}  // namespace curv

@@ -293,3 +293,165 @@ class KFAC(Curvature):
                 for pname, _ in mod.named_parameters(recurse=False):
                     self._state_keys[(mod, pname)] = (prefix + "." if prefix else "") + pname
         return self.model_state[self._state_keys[(layer, name)]]
+
+
+class EFB(Curvature):
+    """Eigenvalue-corrected Kronecker factorisation (curvatures.py:395-460).
+
+    ``state[layer]`` = Lambda (m, n) accumulating (U_G^T grad U_A)**2, ``diags[layer]`` the diagonal Fisher
+    grad**2 * batch_size, ``eigvecs[layer] = (U_A, U_G)``, ``inv_state[layer] = (s Lambda + n)^-1/2``."""
+
+    def __init__(self, model: Union[Module, Sequential], factors: Dict[Module, Tensor],
+                 layer_types: Union[List[str], str] = None):
+        super().__init__(model, layer_types)
+        from .utils import get_eigenvectors
+        self.eigvecs = get_eigenvectors(factors)
+        self.diags = dict()
+
+    def update(self, batch_size: int):
+        stage1, stage2 = [], []
+        for layer in self._layers():
+            gw = layer.weight.grad.contiguous()
+            m = gw.shape[0]
+            gw2 = gw.view(m, -1)
+            n0 = gw2.shape[1]
+            gb = layer.bias.grad if layer.bias is not None else None
+            n = n0 + int(gb is not None)
+            U_A, U_G = self.eigvecs[layer]
+            tmp = torch.empty(m, n, dtype=torch.float32, device=gw.device)
+            stage1.append(ops.Gemm(U_G.t(), gw2, tmp[:, :n0]))                      # U_G^T [W.grad | b.grad]
+            if gb is not None:
+                stage1.append(ops.Gemm(U_G.t(), gb.view(m, 1), tmp[:, n0:]))
+            first = layer not in self.state
+            if first:
+                self.state[layer] = torch.empty(m, n, dtype=torch.float32, device=gw.device)
+            stage2.append(ops.Gemm(tmp, U_A, self.state[layer], beta=0.0 if first else 1.0,
+                                   epilogue=ops.EPI_SQUARE))                        # Lambda (+)= (. U_A)**2
+            self.diags[layer] = ops.sq_accumulate(gw, gb, batch_size, self.diags.get(layer))
+        ops.gemm_batched(stage1)
+        ops.gemm_batched(stage2)
+
+    def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
+        assert self.state, "State dict is empty. Did you call 'update' prior to this?"
+        for index, (layer, value) in enumerate(self.state.items()):
+            n, s = self._hyper(add, multiply, index, len(self.state))
+            self.inv_state[layer] = ops.rsqrt_affine(value, n, s)
+
+    def sample(self, layer: Module, z: Optional[Tensor] = None) -> Tensor:
+        """(U_A (z * inv^T) U_G^T)^T = U_G (z^T * inv) U_A^T -> (m, n) (curvatures.py:453-460)."""
+        assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
+        first, second = self.eigvecs[layer]
+        lambdas = self.inv_state[layer]
+        n, m = first.size(0), second.size(0)
+        if z is None:
+            z = self._randn(n, m, device=first.device)
+        zt = ops.mul2d(z.t(), lambdas)                                    # (m, n)
+        tmp = torch.empty(m, n, dtype=torch.float32, device=first.device)
+        out = torch.empty(m, n, dtype=torch.float32, device=first.device)
+        ops.gemm_batched([ops.Gemm(second, zt, tmp)])
+        ops.gemm_batched([ops.Gemm(tmp, first.t(), out)])
+        return out
+
+
+class INF(Curvature):
+    """Sparse information form: low-rank eigen subset + diagonal correction (curvatures.py:463-672).
+
+    ``state[layer] = (U_A[:, I], U_G[:, J], lambda[I x J], D)``; ``inv_state[layer] = (U_A_lr, U_G_lr, r, P_c)``.
+    The (n m) x (a b) Kronecker matrix V_s of the reference's pre_sampler is never formed: V_s^T V_s is
+    computed in closed form from Khatri-Rao squares, and the dense chain after it,
+    L_c = (C^-1 + vtv)^-1 with C = A^-T (B - I) A^-1, A = chol(vtv), B = chol(vtv + I), is evaluated as the
+    algebraically identical A^-T (I - B^-1) A^-1 in fp64 (no symmetry is assumed; P_c stays non-symmetric)."""
+
+    def __init__(self, model: Union[Module, Sequential], diags: Dict[Module, Tensor],
+                 factors: Dict[Module, Tensor], lambdas: Dict[Module, Tensor],
+                 layer_types: Union[List[str], str] = None):
+        super().__init__(model, layer_types)
+        assert diags.keys() == factors.keys() == lambdas.keys()
+        from .utils import get_eigenvectors
+        self.eigvecs = get_eigenvectors(factors)
+        self.lambdas = lambdas
+        self.diags = diags
+
+    def update(self, rank: int = 100):
+        for layer in list(self.diags.keys()):
+            xxt_eigvecs, ggt_eigvecs = self.eigvecs[layer]
+            lambdas, diags = self.lambdas[layer], self.diags[layer]
+            n, m = xxt_eigvecs.shape[0], ggt_eigvecs.shape[0]
+            lambda_vec = lambdas.t().contiguous().view(-1)             # index i*m + j
+            diag_vec = diags.t().contiguous().view(-1)
+            if rank >= lambda_vec.shape[0]:
+                ua, ug, lam = xxt_eigvecs, ggt_eigvecs, lambda_vec
+            else:
+                I, J = ops.inf_select(lambda_vec, n, m, rank)
+                ua = xxt_eigvecs.index_select(1, I).contiguous()
+                ug = ggt_eigvecs.index_select(1, J).contiguous()
+                lam = lambda_vec.view(n, m).index_select(0, I).index_select(1, J).contiguous().view(-1)
+            a, b = ua.shape[1], ug.shape[1]
+            # D = diag_vec - ((U_A**2) Lambda_lr (U_G**2)^T).flatten()
+            ua2, ug2 = ops.mul(ua, ua), ops.mul(ug, ug)
+            tmp = torch.empty(n, b, dtype=torch.float32, device=ua.device)
+            corr = torch.empty(n, m, dtype=torch.float32, device=ua.device)
+            ops.gemm_batched([ops.Gemm(ua2, lam.view(a, b), tmp)])
+            ops.gemm_batched([ops.Gemm(tmp, ug2.t(), corr, alpha=-1.0, epilogue=ops.EPI_ADD_E, E=diag_vec.view(n, m))])
+            self.state[layer] = (ua, ug, lam, corr.view(-1))
+
+    def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
+        assert self.state, "State dict is empty. Did you call 'update' prior to this?"
+        for index, (layer, value) in enumerate(self.state.items()):
+            n, s = self._hyper(add, multiply, index, len(self.state))
+            lr_frst_eigvecs, lr_scnd_eigvecs, lr_lambda, correction = value
+            ops.clamp_min0_(correction)                                  # in place on `state`, like :523
+            reg_lr_lambda = ops.sqrt_scale(lr_lambda, s)
+            reg_inv_correction = ops.rsqrt_affine(correction, n, s)
+            pre_sample = self.pre_sampler(lr_frst_eigvecs, lr_scnd_eigvecs, reg_lr_lambda, reg_inv_correction)
+            self.inv_state[layer] = (lr_frst_eigvecs, lr_scnd_eigvecs, reg_inv_correction, pre_sample)
+
+    @staticmethod
+    def vtv(frst_eigvecs: Tensor, scnd_eigvecs: Tensor, reg_lambda: Tensor, reg_inv_correction: Tensor) -> Tensor:
+        """V_s^T V_s, symmetrised, in closed form (no Kronecker matrix)."""
+        (n, a), (m, b) = frst_eigvecs.shape, scnd_eigvecs.shape
+        PA, PG = ops.colpairs(frst_eigvecs), ops.colpairs(scnd_eigvecs)      # (n, a*a), (m, b*b)
+        r2 = ops.mul(reg_inv_correction, reg_inv_correction).view(n, m)
+        M = torch.empty(a * a, m, dtype=torch.float32, device=PA.device)
+        V4 = torch.empty(a * a, b * b, dtype=torch.float32, device=PA.device)
+        ops.gemm_batched([ops.Gemm(PA.t(), r2, M)])
+        ops.gemm_batched([ops.Gemm(M, PG, V4)])
+        return ops.inf_vtv_assemble(V4, reg_lambda, a, b)
+
+    @staticmethod
+    def pre_sampler(frst_eigvecs: Tensor, scnd_eigvecs: Tensor, reg_lambda: Tensor,
+                    reg_inv_correction: Tensor) -> Tensor:
+        vtv = INF.vtv(frst_eigvecs, scnd_eigvecs, reg_lambda, reg_inv_correction)
+        A_inv, B_inv = ops.chol_factor_inverse([vtv, vtv], [0.0, 1.0])        # float64, lower triangular
+        T = ops.gemm_f64(B_inv, A_inv, alpha=-1.0, beta=1.0, C=A_inv.clone())      # (I - B^-1) A^-1
+        L_c = ops.gemm_f64(A_inv.t(), T)
+        return ops.diag_scale(L_c, reg_lambda, reg_lambda)
+
+    def sample(self, layer: Module, X: Optional[Tensor] = None) -> Tensor:
+        assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
+        a, b, c, d = self.inv_state[layer]
+        return self.sampler(a, b, c, d, X=X, randn=self._randn).t()
+
+    @staticmethod
+    def sampler(frst_eigvecs: Tensor, scnd_eigvecs: Tensor, reg_inv_correction: Tensor, pre_sample: Tensor,
+                X: Optional[Tensor] = None, randn=None) -> Tensor:
+        """(Y_l - Y_r) as an (n, m) matrix (the reference returns it flat and reshapes in `sample`,
+        curvatures.py:532-536, 574-600; reshape conventions reproduced literally)."""
+        (n, a), (m, b) = frst_eigvecs.shape, scnd_eigvecs.shape
+        dev = frst_eigvecs.device
+        if X is None:
+            X = randn(n * m, device=dev) if randn is not None else ops.randn((n * m,), dev, 0)
+        Y_l = ops.mul(reg_inv_correction, X)                                   # (n*m,)
+        t1 = torch.empty(b, n, dtype=torch.float32, device=dev)
+        ops.gemm_batched([ops.Gemm(scnd_eigvecs.t(), Y_l.view(m, n), t1)])      # U_G^T unvec(Y_l): (b, n)
+        xq_t = torch.empty(a, b, dtype=torch.float32, device=dev)               # Xq^T, so that its flat order is k*b + l
+        ops.gemm_batched([ops.Gemm(t1, frst_eigvecs, xq_t.t())])
+        qx = torch.empty(a * b, 1, dtype=torch.float32, device=dev)
+        ops.gemm_batched([ops.Gemm(pre_sample, xq_t.view(a * b, 1), qx)])
+        t2 = torch.empty(m, a, dtype=torch.float32, device=dev)
+        ops.gemm_batched([ops.Gemm(scnd_eigvecs, qx.view(b, a), t2)])           # U_G unvec(Qx): (m, a)
+        out = Y_l.clone().view(n, m)                                           # becomes Y_l - Y_r
+        r2 = ops.mul(reg_inv_correction, reg_inv_correction).view(n, m)
+        # X_p_s = t2 U_A^T (m, n); Y_r[i*m + q] = r^2[i*m + q] X_p_s[q, i]: write X_p_s^T through the strides
+        ops.gemm_batched([ops.Gemm(frst_eigvecs, t2.t(), out, alpha=-1.0, beta=1.0, epilogue=ops.EPI_MUL_E, E=r2)])
+        return out

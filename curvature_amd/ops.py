@@ -208,3 +208,151 @@ def mul(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
     _lib.check(_lib.lib().curv_mul(_lib.stream_ptr(), a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel()),
                "curv_mul")
     return out
+
+
+# ---------------------------------------------------------------------------------------------- EFB / INF helpers
+from ._lib import curv_cholinv_desc, curv_gemm64_desc, curv_select_desc  # noqa: E402
+
+
+def mul2d(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Contiguous a * b for two strided 2-D float32 views of equal shape."""
+    _check_view(a)
+    _check_view(b)
+    if a.shape != b.shape:
+        raise RuntimeError("mul2d: shape mismatch")
+    out = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().curv_mul2d(_lib.stream_ptr(), a.data_ptr(), a.stride(0), a.stride(1), b.data_ptr(),
+                                     b.stride(0), b.stride(1), out.data_ptr(), a.shape[0], a.shape[1]), "curv_mul2d")
+    return out
+
+
+def clamp_min0_(v: torch.Tensor) -> torch.Tensor:
+    _require_gpu(v)
+    _lib.check(_lib.lib().curv_clamp_min0(_lib.stream_ptr(), v.data_ptr(), v.numel()), "curv_clamp_min0")
+    return v
+
+
+def sqrt_scale(v: torch.Tensor, s: float) -> torch.Tensor:
+    _require_gpu(v)
+    out = torch.empty_like(v)
+    _lib.check(_lib.lib().curv_sqrt_scale(_lib.stream_ptr(), v.data_ptr(), float(s), out.data_ptr(), v.numel()),
+               "curv_sqrt_scale")
+    return out
+
+
+def inf_select(lambda_vec: torch.Tensor, n: int, m: int, rank: int):
+    """(I, J) int64 index tensors of INF._dim_reduction (exact integers, ascending)."""
+    _require_gpu(lambda_vec)
+    dev = lambda_vec.device
+    I = torch.empty(n, dtype=torch.int64, device=dev)
+    J = torch.empty(m, dtype=torch.int64, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    d = (curv_select_desc * 1)()
+    d[0].lambda_vec, d[0].I, d[0].J, d[0].counts = lambda_vec.data_ptr(), I.data_ptr(), J.data_ptr(), counts.data_ptr()
+    d[0].n, d[0].m, d[0].rank = n, m, int(rank)
+    _lib.check(_lib.lib().curv_inf_select(_lib.stream_ptr(), d, 1), "curv_inf_select")
+    a, b = counts.tolist()                     # host read-back: sizes of the low-rank factors
+    return I[:a], J[:b]
+
+
+def colpairs(U: torch.Tensor) -> torch.Tensor:
+    """(n, a) -> (n, a*a) with out[p, i*a+k] = U[p,i] U[p,k]."""
+    _require_gpu(U)
+    n, a = U.shape
+    out = torch.empty(n, a * a, dtype=torch.float32, device=U.device)
+    _lib.check(_lib.lib().curv_colpairs(_lib.stream_ptr(), U.data_ptr(), n, a, U.stride(0), out.data_ptr()),
+               "curv_colpairs")
+    return out
+
+
+def inf_vtv_assemble(V4: torch.Tensor, sigma: torch.Tensor, a: int, b: int) -> torch.Tensor:
+    _require_gpu(V4, sigma)
+    out = torch.empty(a * b, a * b, dtype=torch.float32, device=V4.device)
+    _lib.check(_lib.lib().curv_inf_vtv_assemble(_lib.stream_ptr(), V4.data_ptr(), sigma.data_ptr(), a, b,
+                                                out.data_ptr()), "curv_inf_vtv_assemble")
+    return out
+
+
+def diag_scale(src: torch.Tensor, dl: torch.Tensor, dr: torch.Tensor) -> torch.Tensor:
+    """float32 out[i,j] = src[i,j] dl[i] dr[j]; src float32 or float64, contiguous."""
+    if not src.is_cuda or not src.is_contiguous() or src.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("diag_scale: bad source")
+    _require_gpu(dl, dr)
+    out = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    _lib.check(_lib.lib().curv_diag_scale(_lib.stream_ptr(), src.data_ptr(), int(src.dtype == torch.float64),
+                                          out.data_ptr(), dl.data_ptr(), dr.data_ptr(), src.shape[0], src.shape[1]),
+               "curv_diag_scale")
+    return out
+
+
+def chol_factor_inverse(mats: Sequence[torch.Tensor], diag_adds: Sequence[float]) -> List[torch.Tensor]:
+    """[chol_lower(M + d I)^-1] in float64 for symmetric float32 matrices (batched)."""
+    n = len(mats)
+    arr = (curv_cholinv_desc * n)()
+    outs = []
+    for d, M, da in zip(arr, mats, diag_adds):
+        _require_gpu(M)
+        X = torch.empty(M.shape, dtype=torch.float64, device=M.device)
+        outs.append(X)
+        d.M, d.X, d.n, d.diag_add = M.data_ptr(), X.data_ptr(), M.shape[0], float(da)
+    dev = mats[0].device
+    info = torch.empty(n, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    ws = workspace(L.curv_chol_factor_inverse_workspace_bytes(arr, n), dev, "invert")
+    _lib.check(L.curv_chol_factor_inverse(_lib.stream_ptr(), arr, n, info.data_ptr(), ws.data_ptr(), ws.numel()),
+               "curv_chol_factor_inverse")
+    bad = torch.nonzero(info).flatten().tolist()
+    if bad:
+        raise RuntimeError(f"cholesky: matrix/matrices {bad} are not positive-definite")
+    return outs
+
+
+def eigh(mats: Sequence[torch.Tensor], with_values: bool = False, max_sweeps: int = 0, tol: float = 0.0):
+    """Eigenvectors (columns, ascending eigenvalues) of symmetric float32 matrices, batched block-Jacobi."""
+    from ._lib import curv_eigh_desc
+    n = len(mats)
+    if n == 0:
+        return []
+    arr = (curv_eigh_desc * n)()
+    vecs, vals = [], []
+    for d, F in zip(arr, mats):
+        _require_gpu(F)
+        if F.dim() != 2 or F.shape[0] != F.shape[1]:
+            raise RuntimeError("eigh: square matrices expected")
+        U = torch.empty_like(F)
+        w = torch.empty(F.shape[0], dtype=torch.float32, device=F.device)
+        vecs.append(U)
+        vals.append(w)
+        d.F, d.U, d.w, d.n = F.data_ptr(), U.data_ptr(), w.data_ptr(), F.shape[0]
+    L = _lib.lib()
+    need = L.curv_syevd_workspace_bytes(arr, n)
+    if need == 0:
+        raise RuntimeError("eigh: matrix size out of range")
+    ws = workspace(need, mats[0].device, "eigh")
+    sweeps = ctypes.c_int(0)
+    _lib.check(L.curv_syevd(_lib.stream_ptr(), arr, n, ws.data_ptr(), ws.numel(), int(max_sweeps), float(tol),
+                            ctypes.byref(sweeps)), "curv_syevd")
+    eigh.last_sweeps = sweeps.value
+    return (vecs, vals) if with_values else vecs
+
+
+def gemm_f64(A: torch.Tensor, B: torch.Tensor, alpha: float = 1.0, beta: float = 0.0,
+             C: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """float64 C = alpha * A @ B [+ beta * C] on strided 2-D GPU views."""
+    for t in (A, B):
+        if not t.is_cuda or t.dtype != torch.float64 or t.dim() != 2:
+            raise RuntimeError("gemm_f64 operands must be 2-D float64 GPU tensors")
+    M, K = A.shape
+    K2, N = B.shape
+    if K != K2:
+        raise RuntimeError("gemm_f64: shape mismatch")
+    if C is None:
+        C = torch.empty(M, N, dtype=torch.float64, device=A.device)
+    d = (curv_gemm64_desc * 1)()
+    d[0].A, d[0].B, d[0].C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+    d[0].a_rs, d[0].a_cs = A.stride()
+    d[0].b_rs, d[0].b_cs = B.stride()
+    d[0].c_rs, d[0].c_cs = C.stride()
+    d[0].M, d[0].N, d[0].K, d[0].alpha, d[0].beta = M, N, K, float(alpha), float(beta)
+    _lib.check(_lib.lib().curv_gemm_f64_batched(_lib.stream_ptr(), d, 1), "curv_gemm_f64_batched")
+    return C

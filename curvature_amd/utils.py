@@ -1,0 +1,28 @@
+"""`get_eigenvectors` and `kron` of the reference (curvature/utils.py:45-60, 288-310)."""
+from typing import Dict
+
+import torch
+from torch import Tensor
+from torch.nn import Module
+
+from . import ops
+
+
+def get_eigenvectors(factors: Dict[Module, Tensor]) -> Dict[Module, Tensor]:
+    """Eigenvectors (columns, eigenvalues ascending) of both Kronecker factors of every layer.
+
+    The reference decomposes F + F^T (utils.py:55-58); F is exactly symmetric here, so F itself has the
+    same eigenvectors.  Computed by the library's batched block-Jacobi eigensolver (curv_syevd)."""
+    layers = list(factors.keys())
+    mats = []
+    for layer in layers:
+        xxt, ggt = factors[layer]
+        mats.extend([xxt, ggt])
+    vecs = ops.eigh(mats)
+    return {layer: (vecs[2 * i], vecs[2 * i + 1]) for i, layer in enumerate(layers)}
+
+
+def kron(a: Tensor, b: Tensor) -> Tensor:
+    """Kronecker product with the reference's index convention (utils.py:310).  Only used by tests and
+    callers that want the explicit matrix: the estimators never materialise it."""
+    return torch.einsum("ab,cd->acbd", a, b).contiguous().view(a.size(0) * b.size(0), a.size(1) * b.size(1))

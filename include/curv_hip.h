@@ -110,6 +110,21 @@ size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int n_factors);
 int curv_chol_inv_lower(void* stream, const curv_inv_desc* descs, int n_factors, int* info, void* workspace,
                         size_t workspace_bytes);
 
+/* X = chol_lower(M + diag_add * I)^-1 in fp64 for a batch of symmetric fp32 matrices (same blocked sweep,
+ * no index reversal): the A_c^-1 and B_c^-1 of INF.pre_sampler (curvatures.py:566-567).  X is (n x n)
+ * fp64, lower triangular with zeros above.  info as for curv_chol_inv_lower. */
+typedef struct curv_cholinv_desc {
+  const float* M;
+  double* X;
+  int32_t n;
+  int32_t reserved;
+  double diag_add;
+} curv_cholinv_desc;
+
+size_t curv_chol_factor_inverse_workspace_bytes(const curv_cholinv_desc* descs, int n_mats);
+int curv_chol_factor_inverse(void* stream, const curv_cholinv_desc* descs, int n_mats, int* info, void* workspace,
+                             size_t workspace_bytes);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense contractions of the samplers and of EFB / INF: a batch of independent strided fp32 GEMMs
  *     C = epilogue(alpha * op(A) op(B)) [+ beta * C]
@@ -139,6 +154,18 @@ size_t curv_gemm_workspace_bytes(int n_desc);
 int curv_gemm_batched(void* stream, const curv_gemm_desc* descs, int n_desc, void* workspace,
                       size_t workspace_bytes);
 
+/* fp64 variant (alpha/beta only) for the ill-conditioned products of INF.pre_sampler. */
+typedef struct curv_gemm64_desc {
+  const double* A;
+  const double* B;
+  double* C;
+  long long a_rs, a_cs, b_rs, b_cs, c_rs, c_cs;
+  int32_t M, N, K;
+  int32_t reserved;
+  double alpha, beta;
+} curv_gemm64_desc;
+int curv_gemm_f64_batched(void* stream, const curv_gemm64_desc* descs, int n_desc);
+
 /* out[0..count) ~ N(0,1): Philox4x32-10 keyed by `seed`, counter starting at `offset` (in units of 4
  * values); the draw of torch.randn at curvatures.py:391, :457, :590 with a device-side generator. */
 int curv_randn(void* stream, float* out, long long count, unsigned long long seed, unsigned long long offset);
@@ -158,6 +185,54 @@ int curv_clamp_min0(void* stream, float* v, long long count);
 int curv_sqrt_scale(void* stream, const float* v, double s, float* out, long long count);
 /* out = a*b */
 int curv_mul(void* stream, const float* a, const float* b, float* out, long long count);
+
+/* ------------------------------------------------------------------------------------------------
+ * utils.get_eigenvectors (curvature/utils.py:45-60): symmetric eigendecomposition F = U diag(w) U^T of a
+ * batch of fp32 matrices by a two-sided block-Jacobi method in fp64.  U (n x n, fp32) holds the
+ * eigenvectors as columns in ascending eigenvalue order (the reference's symeig order); w (n, fp32,
+ * optional) the eigenvalues of F (the reference decomposes F + F^T: same vectors, doubled values, and it
+ * discards the values).  Signs / bases of degenerate clusters are arbitrary, as with LAPACK.
+ * The call synchronises the stream once per sweep to test convergence (off(A) <= tol * ||A||_F);
+ * max_sweeps <= 0 and tol <= 0 select the defaults (15, 1e-9).  n <= 8192.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct curv_eigh_desc {
+  const float* F;
+  float* U;
+  float* w;
+  int32_t n;
+  int32_t reserved;
+} curv_eigh_desc;
+
+size_t curv_syevd_workspace_bytes(const curv_eigh_desc* descs, int n_mats);
+int curv_syevd(void* stream, const curv_eigh_desc* descs, int n_mats, void* workspace, size_t workspace_bytes,
+               int max_sweeps, double tol, int* sweeps_done);
+
+/* ------------------------------------------------------------------------------------------------
+ * INF (sparse information form), curvature/curvatures.py:463-672
+ * ---------------------------------------------------------------------------------------------- */
+/* _dim_reduction's index work (:617-634): indices of the `rank` largest |lambda_vec| (length n*m, index
+ * i*m + j) -> I = unique(idx / m), J = unique(idx % m), ascending int64, and counts = {|I|, |J|}.
+ * Exact integer results; ties at the threshold magnitude are broken deterministically. n, m <= 8192. */
+typedef struct curv_select_desc {
+  const float* lambda_vec;
+  int64_t* I;
+  int64_t* J;
+  int32_t* counts;
+  int32_t n, m, rank, reserved;
+} curv_select_desc;
+int curv_inf_select(void* stream, const curv_select_desc* descs, int n_desc);
+
+/* out[p][i*a + k] = U[p][i] * U[p][k]: rows of the Khatri-Rao square in the closed form of V_s^T V_s
+ * (pre_sampler :556-564 without the (n m) x (a b) Kronecker matrix). U is n x a with row stride u_rs. */
+int curv_colpairs(void* stream, const float* U, int n, int a, long long u_row_stride, float* out);
+/* vtv[(i,j),(k,l)] = (w + w^T)/2, w = sigma_ij sigma_kl V4[(i,k),(j,l)]   (:564-565) */
+int curv_inf_vtv_assemble(void* stream, const float* V4, const float* sigma, int a, int b, float* vtv);
+/* dst[i][j] = src[i][j] * dl[i] * dr[j] (src fp32 or fp64, dst fp32): P_c = diag(s) L_c diag(s) (:570) */
+int curv_diag_scale(void* stream, const void* src, int src_is_f64, float* dst, const float* dl, const float* dr,
+                    int rows, int cols);
+/* out[i][j] = A(i,j) * B(i,j) for strided 2-D views (EFB.sample's z * inv^T, :458) */
+int curv_mul2d(void* stream, const float* A, long long a_rs, long long a_cs, const float* B, long long b_rs,
+               long long b_cs, float* out, int rows, int cols);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,168 @@
+"""EFB, INF and the eigensolver against the reference's golden vectors (g5-g9).
+
+Eigenvectors are unique only up to sign / rotation inside degenerate clusters, so the
+eigensolver is judged by residual and orthogonality, and EFB / INF parity feeds the REFERENCE's
+eigenvectors in, exactly as the reference's own EFB -> INF chain does."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_fro
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-4
+
+
+def load(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, name)).items()}
+
+
+def lenet(gpu, g1):
+    from curvature_amd import models
+    model = models.lenet5()
+    layers = [m for m in model.modules() if m.__class__.__name__ in ("Conv2d", "Linear")]
+    with torch.no_grad():
+        for li, layer in enumerate(layers):
+            layer.weight.copy_(g1[f"w_l{li}"])
+            layer.bias.copy_(g1[f"bias_l{li}"])
+    return model.to(gpu).eval(), layers
+
+
+def backward(model, g1, b, gpu):
+    x, labels = g1[f"b{b}_x"].to(gpu), g1[f"b{b}_labels"].to(gpu)
+    loss = torch.nn.functional.cross_entropy(model(x), labels)
+    model.zero_grad()
+    loss.backward()
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 64, 65, 150, 401])
+def test_eigh_residual_and_orthogonality(gpu, n):
+    from curvature_amd import ops
+    torch.manual_seed(n)
+    X = torch.randn(n, max(n // 2, 1))                 # rank-deficient PSD, like a KFAC factor
+    F = (X @ X.t() / X.shape[1]).float()
+    F = ((F + F.t()) / 2).contiguous()
+    (U,), (w,) = ops.eigh([F.to(gpu)], with_values=True)
+    U, w, Fd = U.double().cpu(), w.double().cpu(), F.double()
+    assert torch.all(w[1:] >= w[:-1] - 1e-9)                                  # ascending
+    assert torch.linalg.norm(U.t() @ U - torch.eye(n, dtype=torch.float64)) < 1e-5 * n ** 0.5
+    assert torch.linalg.norm(Fd @ U - U * w) < 1e-5 * max(float(torch.linalg.norm(Fd)), 1e-30)
+    ref = torch.linalg.eigvalsh(Fd)
+    assert torch.linalg.norm(w - ref) < 1e-5 * max(float(torch.linalg.norm(ref)), 1e-30)
+
+
+def test_eigh_lenet_factors_batched(gpu):
+    """All ten LeNet factors in one batched call; invariants of the golden eigenvectors hold for ours."""
+    from curvature_amd import ops
+    g1 = load("g1_kfac_lenet.npz")
+    mats = [g1[f"{s}_after3_l{li}"].to(gpu) for li in range(5) for s in ("A", "G")]
+    vecs, vals = ops.eigh(mats, with_values=True)
+    for F, U, w in zip(mats, vecs, vals):
+        F, U, w = F.double().cpu(), U.double().cpu(), w.double().cpu()
+        n = F.shape[0]
+        assert torch.linalg.norm(U.t() @ U - torch.eye(n, dtype=torch.float64)) < 1e-5 * n ** 0.5
+        assert torch.linalg.norm(F @ U - U * w) < 1e-5 * torch.linalg.norm(F)
+        assert rel_fro(w, torch.linalg.eigvalsh(F)) < 1e-5
+
+
+def test_efb_chain(gpu):
+    from curvature_amd.curvatures import EFB
+    g1, g5, g6 = load("g1_kfac_lenet.npz"), load("g5_eigvecs_lenet.npz"), load("g6_efb_lenet.npz")
+    model, layers = lenet(gpu, g1)
+    factors = {l: [g1[f"A_after3_l{li}"].to(gpu), g1[f"G_after3_l{li}"].to(gpu)] for li, l in enumerate(layers)}
+    efb = EFB(model, factors)                                         # runs our eigensolver
+    for li, layer in enumerate(layers):                               # own eigvecs: valid decomposition
+        UA, UG = efb.eigvecs[layer]
+        assert UA.shape == g5[f"UA_l{li}"].shape and UG.shape == g5[f"UG_l{li}"].shape
+    # parity: the reference's eigenvectors in (as its own chain has them)
+    efb.eigvecs = {l: (g5[f"UA_l{li}"].to(gpu), g5[f"UG_l{li}"].to(gpu)) for li, l in enumerate(layers)}
+    for b in range(2):
+        backward(model, g1, b, gpu)
+        efb.update(batch_size=8)
+    for li, layer in enumerate(layers):
+        assert rel_fro(efb.state[layer], g6[f"lambda_l{li}"]) < TOL
+        assert rel_fro(efb.diags[layer], g6[f"diags_l{li}"]) < TOL
+    efb.invert(add=0.5, multiply=2.0)
+    for li, layer in enumerate(layers):
+        assert rel_fro(efb.inv_state[layer], g6[f"inv_l{li}"]) < TOL
+        s = efb.sample(layer, z=g6[f"z_l{li}"].to(gpu))
+        assert rel_fro(s, g6[f"sample_l{li}"]) < TOL
+    efb.sample_and_replace()
+    assert all(torch.isfinite(l.weight).all() for l in layers)
+
+
+def inf_from_golden(gpu, rank):
+    from curvature_amd.curvatures import INF
+    g1, g5, g6 = load("g1_kfac_lenet.npz"), load("g5_eigvecs_lenet.npz"), load("g6_efb_lenet.npz")
+    model, layers = lenet(gpu, g1)
+    factors = {l: [g1[f"A_after3_l{li}"].to(gpu), g1[f"G_after3_l{li}"].to(gpu)] for li, l in enumerate(layers)}
+    lambdas = {l: g6[f"lambda_l{li}"].to(gpu) for li, l in enumerate(layers)}
+    diags = {l: g6[f"diags_l{li}"].to(gpu) for li, l in enumerate(layers)}
+    inf = INF(model, diags, factors, lambdas)
+    inf.eigvecs = {l: (g5[f"UA_l{li}"].to(gpu), g5[f"UG_l{li}"].to(gpu)) for li, l in enumerate(layers)}
+    inf.update(rank=rank)
+    return inf, layers, g5, g6
+
+
+@pytest.mark.parametrize("tag,rank", [("r10", 10), ("r100", 100), ("rall", 10 ** 9)])
+def test_inf_update(gpu, tag, rank):
+    g7 = load("g7_inf_update.npz")
+    inf, layers, g5, g6 = inf_from_golden(gpu, rank)
+    for li, layer in enumerate(layers):
+        ua, ug, lam, D = inf.state[layer]
+        I, J = g7[f"{tag}_I_l{li}"], g7[f"{tag}_J_l{li}"]
+        # bit-exact index sets: the selected columns are exactly the reference's
+        assert torch.equal(ua.cpu(), g5[f"UA_l{li}"][:, I]) and torch.equal(ug.cpu(), g5[f"UG_l{li}"][:, J])
+        if f"{tag}_lam_l{li}" in g7:
+            assert torch.equal(lam.cpu(), g7[f"{tag}_lam_l{li}"])
+        if f"{tag}_D_l{li}" in g7:
+            scale = torch.linalg.norm(g6[f"diags_l{li}"].double())
+            assert float(torch.linalg.norm(D.double().cpu() - g7[f"{tag}_D_l{li}"].double()) / scale) < 1e-5
+
+
+def test_inf_select_exact_and_ties(gpu):
+    import oracle.curvature_oracle as o
+    from curvature_amd import ops
+    torch.manual_seed(0)
+    for n, m, rank in [(7, 5, 3), (401, 120, 100), (26, 6, 10), (300, 200, 1), (64, 64, 4095)]:
+        lam = torch.randn(n * m) ** 3
+        I, J = ops.inf_select(lam.to(gpu), n, m, rank)
+        Ir, Jr = o.inf_select(lam, m, rank)
+        assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(J.cpu().numpy(), Jr)
+    lam = torch.zeros(12 * 8)
+    lam[[5, 17, 40]] = torch.tensor([3.0, -2.0, 1.0])
+    I, J = ops.inf_select(lam.to(gpu), 12, 8, 5)          # ties at |0|: exactly 5 elements selected, any 2 zeros
+    assert set([0, 2, 5]).issubset(set(I.tolist())) and len(I) <= 5 and len(J) <= 5
+
+
+def test_inf_invert_and_sample(gpu):
+    g8, g9 = load("g8_inf_invert.npz"), load("g9_inf_sample.npz")
+    inf, layers, g5, g6 = inf_from_golden(gpu, 10)
+    from curvature_amd.curvatures import INF
+    add, mul = float(g8["add"]), float(g8["mul"])
+    inf.invert(add=add, multiply=mul)
+    for li, layer in enumerate(layers):
+        ua, ug, r, Pc = inf.inv_state[layer]
+        assert torch.equal(inf.state[layer][3].cpu(), g8[f"Dclamped_l{li}"]) or \
+            rel_fro(inf.state[layer][3], g8[f"Dclamped_l{li}"]) < 1e-5          # clamped in place on `state`
+        assert rel_fro(r, g8[f"r_l{li}"]) < TOL
+        vtv = INF.vtv(ua, ug, g8[f"sigma_l{li}"].to(gpu), g8[f"r_l{li}"].to(gpu))
+        assert rel_fro(vtv, g8[f"vtv_l{li}"]) < TOL
+        # P_c: the reference's fp32 chain is itself noisy (2 Cholesky + 3 inverses in fp32); the bar is the
+        # reference code run in fp64 (golden Pc64), and the fp32 reference within its own noise
+        assert rel_fro(Pc, g8[f"Pc64_l{li}"]) < 1e-3, rel_fro(Pc, g8[f"Pc64_l{li}"])
+        noise = rel_fro(g8[f"Pc_l{li}"], g8[f"Pc64_l{li}"])
+        assert rel_fro(Pc, g8[f"Pc_l{li}"]) < max(1e-3, 3 * noise)
+        assert not torch.allclose(Pc, Pc.t())                                   # non-symmetric, as in the reference
+    # sampler with the reference's inverse state and noise
+    for li, layer in enumerate(layers):
+        ua, ug = inf.inv_state[layer][0], inf.inv_state[layer][1]
+        inf.inv_state[layer] = (ua, ug, g8[f"r_l{li}"].to(gpu), g8[f"Pc_l{li}"].to(gpu))
+        s = inf.sample(layer, X=g9[f"X_l{li}"].to(gpu))
+        assert s.shape == g9[f"sample_l{li}"].shape
+        assert rel_fro(s, g9[f"sample_l{li}"]) < TOL, (li, rel_fro(s, g9[f"sample_l{li}"]))
+    inf.sample_and_replace()
+    assert all(torch.isfinite(l.weight).all() for l in layers)
