@@ -107,63 +107,221 @@ inv_prepare_kernel(const InvDev* __restrict__ t, int nf) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// (2) trailing update A[i][j] -= A[i][k] A[j][k]^T for k < j <= i, fused in one launch with
-// (4) S[i][j] (+)= C[i][k] X[k][j] for i > k, j <= k   (both are independent tile updates of step k)
+// (2) trailing update A[i][j] -= A[i][k] A[j][k]^T for k < j <= i and
+// (4) S[i][j] (+)= C[i][k] X[k][j] for i > k, j <= k, as two-level (inner / outer panel) tile lists
 // ------------------------------------------------------------------------------------------------
+// Tile sets of the two-level sweep.  Outer panels of NBO block columns: inside a panel the updates of
+// step k are restricted to the panel (K = 64 products), everything beyond the panel is updated once per
+// panel with K = NBO * 64, which divides the read-modify-write traffic of the trailing matrix by NBO.
+__device__ __host__ __forceinline__ long long inner_tiles(int P, int k, int kend) {
+  const int ke = kend < P ? kend : P;
+  long long tr = 0;
+  for (int j = k + 1; j < ke; ++j) tr += P - j;
+  const long long sr = (ke - k - 1 > 0) ? (long long)(ke - k - 1) * (k + 1) : 0;
+  return tr + sr;
+}
+__device__ __host__ __forceinline__ long long outer_tiles(int P, int kend) {
+  const long long r = P - kend;
+  return r > 0 ? r * (r + 1) / 2 + r * kend : 0;
+}
+
+__device__ __forceinline__ void store_sub(gdouble* C, int np, const f64x4 (&acc)[2][2], int wm, int wn, int lane,
+                                          int mode) {   // mode 0: C -= acc, 1: C = acc, 2: C += acc
+  const int c16 = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long long idx = (long long)(32 * wm + 16 * m + rq + 4 * q) * np + 32 * wn + 16 * n + c16;
+        const double v = acc[m][n][q];
+        C[idx] = mode == 0 ? C[idx] - v : (mode == 1 ? v : C[idx] + v);
+      }
+}
+
+// (2i)/(4i) inner updates of step k, restricted to the outer panel [.., kend)
 __global__ void __launch_bounds__(INV_THREADS)
-step_update_kernel(const InvDev* __restrict__ t, int nf, int k) {
+inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int kend) {
   __shared__ double As[NB * LDA], Bs[NB * LDA];
   int f, local;
-  auto count = [k](const InvDev& d) {
-    const int r = d.P - k - 1;                       // block rows below the pivot row
-    return r > 0 ? r * (r + 1) / 2 + r * (k + 1) : 0;
-  };
-  if (!locate(t, nf, blockIdx.x, count, f, local)) return;
+  if (!locate(t, nf, blockIdx.x, [k, kend](const InvDev& d) { return (int)inner_tiles(d.P, k, kend); }, f, local)) return;
   const InvDev& d = t[f];
-  const int np = d.np, r = d.P - k - 1;
+  const int np = d.np, P = d.P, ke = kend < P ? kend : P;
   gdouble* W = (gdouble*)d.W;
   gdouble* X = (gdouble*)d.X;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-  const int c16 = lane & 15, rq = lane >> 4;
+  f64x4 acc[2][2] = {};
+  int j = k + 1;
+  bool trailing = false;
+  for (; j < ke; ++j) {
+    if (local < P - j) { trailing = true; break; }
+    local -= P - j;
+  }
+  if (trailing) {
+    const int i = j + local;                                       // A[i][j] -= A[i][k] A[j][k]^T
+    load_block(W + (long long)i * NB * np + k * NB, np, As);
+    if (i != j) load_block(W + (long long)j * NB * np + k * NB, np, Bs);
+    __syncthreads();
+    mma_64<true>(As, (i != j) ? Bs : As, wm, wn, lane, acc);
+    store_sub(W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);
+  } else {
+    const int a = local / (k + 1), jj = local - a * (k + 1);       // S[i][jj] (+)= C[i][k] X[k][jj]
+    const int i = k + 1 + a;
+    load_block(W + (long long)i * NB * np + k * NB, np, As);
+    load_block(X + (long long)k * NB * np + jj * NB, np, Bs);
+    __syncthreads();
+    mma_64<false>(As, Bs, wm, wn, lane, acc);
+    store_sub(X + (long long)i * NB * np + jj * NB, np, acc, wm, wn, lane, jj == k ? 1 : 2);
+  }
+}
+
+// (2o)/(4o) once per outer panel [k0, kend): everything beyond the panel, K = (kend - k0) * 64
+__global__ void __launch_bounds__(INV_THREADS)
+outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
+  __shared__ double As[NB * LDA], Bs[NB * LDA];
+  int f, local;
+  if (!locate(t, nf, blockIdx.x, [kend](const InvDev& d) { return (int)outer_tiles(d.P, kend); }, f, local)) return;
+  const InvDev& d = t[f];
+  const int np = d.np, r = d.P - kend;
+  gdouble* W = (gdouble*)d.W;
+  gdouble* X = (gdouble*)d.X;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
   f64x4 acc[2][2] = {};
   const int n_trail = r * (r + 1) / 2;
   if (local < n_trail) {
     int a = 0, tl = local;
     while (tl > a) { tl -= a + 1; ++a; }
-    const int i = k + 1 + a, j = k + 1 + tl;
-    load_block(W + (long long)i * NB * np + k * NB, np, As);
-    if (i != j) load_block(W + (long long)j * NB * np + k * NB, np, Bs);
-    __syncthreads();
-    mma_64<true>(As, (i != j) ? Bs : As, wm, wn, lane, acc);
-    gdouble* C = W + (long long)i * NB * np + j * NB;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const long long idx = (long long)(32 * wm + 16 * m + rq + 4 * q) * np + 32 * wn + 16 * n + c16;
-          C[idx] -= acc[m][n][q];
-        }
+    const int i = kend + a, j = kend + tl;
+    for (int kk = k0; kk < kend; ++kk) {
+      load_block(W + (long long)i * NB * np + kk * NB, np, As);
+      if (i != j) load_block(W + (long long)j * NB * np + kk * NB, np, Bs);
+      __syncthreads();
+      mma_64<true>(As, (i != j) ? Bs : As, wm, wn, lane, acc);
+      __syncthreads();
+    }
+    store_sub(W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);
   } else {
     const int l2 = local - n_trail;
-    const int a = l2 / (k + 1), j = l2 - a * (k + 1);
-    const int i = k + 1 + a;
-    load_block(W + (long long)i * NB * np + k * NB, np, As);        // C[i][k] as [row][kk]
-    load_block(X + (long long)k * NB * np + j * NB, np, Bs);        // X[k][j] as [kk][col]
+    const int a = l2 / kend, j = l2 - a * kend;
+    const int i = kend + a;
+    for (int kk = (j > k0 ? j : k0); kk < kend; ++kk) {
+      load_block(W + (long long)i * NB * np + kk * NB, np, As);       // C[i][kk]
+      load_block(X + (long long)kk * NB * np + j * NB, np, Bs);       // X[kk][j]
+      __syncthreads();
+      mma_64<false>(As, Bs, wm, wn, lane, acc);
+      __syncthreads();
+    }
+    store_sub(X + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, j >= k0 ? 1 : 2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 64x64 block in LDS: Ds <- L (lower Cholesky factor, zeros above), Is <- L^-1.  Blocked by 16:
+//   panel factorisation by ONE wave with the 64 rows in registers (lane = row) and v_readlane
+//   broadcasts: no barriers inside a panel; trailing updates and the block forward substitution of the
+//   inverse are 16x16x16 f64-MFMA tile products.  ~10 barriers in total instead of ~200.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// acc += A (16x16, element (i,k) at Ap[i*lda + k]) * B; BT: B element (k,j) at Bp[j*ldb + k], else Bp[k*ldb + j]
+template <bool BT>
+__device__ __forceinline__ void mma16(const double* Ap, int lda, const double* Bp, int ldb, int lane, f64x4& acc) {
+  const int r16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int kk = 4 * ks + kq;
+    const double a = Ap[r16 * lda + kk];
+    const double b = BT ? Bp[r16 * ldb + kk] : Bp[kk * ldb + r16];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base) {
+  __shared__ double Sc[4][16 * 17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int c0 = 16 * p;
+    if (wave == 0) {
+      double row[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) row[c] = Ds[lane * LDA + c0 + c];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double piv = readlane_f64(row[c], c0 + c);
+        const bool ok = piv > 0.0 && piv < 1.0e300;               // also false for NaN
+        const double dinv = ok ? 1.0 / sqrt(piv) : 1.0;
+        if (!ok && lane == 0 && *bad == 0) *bad = pivot_base + c0 + c + 1;
+        row[c] *= dinv;
+#pragma unroll
+        for (int q = c + 1; q < 16; ++q) row[q] -= row[c] * readlane_f64(row[c], c0 + q);
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) Ds[lane * LDA + c0 + c] = row[c];
+    }
     __syncthreads();
-    mma_64<false>(As, Bs, wm, wn, lane, acc);
-    gdouble* S = X + (long long)i * NB * np + j * NB;
-    const bool first = (j == k);                                    // first contribution to this tile
+    // trailing update of the 16x16 tiles (ti, tj), p < tj <= ti: T -= A21_ti A21_tj^T  (K = 16)
+    {
+      int tcount = 0;
+      for (int ti = p + 1; ti < 4; ++ti)
+        for (int tj = p + 1; tj <= ti; ++tj, ++tcount) {
+          if ((tcount & 3) != wave) continue;
+          f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+          mma16<true>(Ds + 16 * ti * LDA + c0, LDA, Ds + 16 * tj * LDA + c0, LDA, lane, acc);
+          double* C = Ds + 16 * ti * LDA + 16 * tj;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const long long idx = (long long)(32 * wm + 16 * m + rq + 4 * q) * np + 32 * wn + 16 * n + c16;
-          S[idx] = first ? acc[m][n][q] : S[idx] + acc[m][n][q];
+          for (int r = 0; r < 4; ++r) C[(kq + 4 * r) * LDA + r16] -= acc[r];
         }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < NB * NB; e += MMA_THREADS) {
+    const int r = e >> 6, q = e & 63;
+    if (q > r) Ds[r * LDA + q] = 0.0;
+    Is[r * LDA + q] = 0.0;
+  }
+  __syncthreads();
+  // diagonal 16x16 blocks of the inverse: wave w, lane j < 16 owns column j (forward substitution)
+  if (lane < 16) {
+    const double* Lb = Ds + 16 * wave * LDA + 16 * wave;
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double sum = 0.0;
+#pragma unroll
+      for (int q = 0; q < r; ++q) sum += Lb[r * LDA + q] * x[q];
+      x[r] = ((r == lane ? 1.0 : 0.0) - sum) / Lb[r * LDA + r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Is[(16 * wave + r) * LDA + 16 * wave + lane] = x[r];
+  }
+  __syncthreads();
+  // off-diagonal blocks by distance d from the diagonal: X_ib = -X_ii * sum_{k=b}^{i-1} L_ik X_kb
+#pragma unroll
+  for (int dgl = 1; dgl < 4; ++dgl) {
+    const int i = dgl + wave, b = wave;               // wave w < 4 - dgl handles block (dgl + w, w)
+    const bool active = wave < 4 - dgl;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    if (active) {
+      for (int kk = b; kk < i; ++kk)
+        mma16<false>(Ds + 16 * i * LDA + 16 * kk, LDA, Is + 16 * kk * LDA + 16 * b, LDA, lane, acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Sc[wave][(kq + 4 * r) * 17 + r16] = acc[r];
+    }
+    __syncthreads();
+    if (active) {
+      f64x4 out = {0.0, 0.0, 0.0, 0.0};
+      mma16<false>(Is + 16 * i * LDA + 16 * i, LDA, Sc[wave], 17, lane, out);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Is[(16 * i + kq + 4 * r) * LDA + 16 * b + r16] = -out[r];
+    }
+    __syncthreads();
   }
 }
 
@@ -186,47 +344,7 @@ chol_diag_trsm_kernel(const InvDev* __restrict__ t, int nf, int k) {
   load_block(W + (long long)k * NB * np + k * NB, np, Ds);
   __syncthreads();
 
-  // unblocked right-looking Cholesky of the 64x64 block, lower triangle
-  for (int c = 0; c < NB; ++c) {
-    const double piv = Ds[c * LDA + c];
-    const bool ok = piv > 0.0 && piv < 1.0e300;     // also false for NaN
-    const double dinv = ok ? 1.0 / sqrt(piv) : 1.0;
-    if (!ok && tid == 0 && bad == 0) bad = k * NB + c + 1;
-    __syncthreads();                               // everyone has read the pivot
-    if (tid >= c && tid < NB) Ds[tid * LDA + c] *= dinv;          // column c (diag becomes sqrt(piv))
-    __syncthreads();
-    // trailing update of the lower triangle: a[r][q] -= a[r][c] * a[q][c], r >= q > c
-    for (int e = tid; e < NB * NB; e += INV_THREADS) {
-      const int r = e >> 6, q = e & 63;
-      if (q > c && r >= q) Ds[r * LDA + q] -= Ds[r * LDA + c] * Ds[q * LDA + c];
-    }
-    __syncthreads();
-  }
-  // zero the strict upper triangle, then invert: column j of L^-1 by forward substitution (one lane each)
-  for (int e = tid; e < NB * NB; e += INV_THREADS) {
-    const int r = e >> 6, q = e & 63;
-    if (q > r) Ds[r * LDA + q] = 0.0;
-    Is[r * LDA + q] = 0.0;
-  }
-  __syncthreads();
-  if (tid < NB) {
-    const int j = tid;
-    Is[j * LDA + j] = 1.0 / Ds[j * LDA + j];
-    for (int r = j + 1; r < NB; ++r) {
-      // four independent partial sums so that the LDS reads of the dot product pipeline
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int q = j;
-      for (; q + 3 < r; q += 4) {
-        s0 += Ds[r * LDA + q] * Is[q * LDA + j];
-        s1 += Ds[r * LDA + q + 1] * Is[(q + 1) * LDA + j];
-        s2 += Ds[r * LDA + q + 2] * Is[(q + 2) * LDA + j];
-        s3 += Ds[r * LDA + q + 3] * Is[(q + 3) * LDA + j];
-      }
-      for (; q < r; ++q) s0 += Ds[r * LDA + q] * Is[q * LDA + j];
-      Is[r * LDA + j] = -((s0 + s1) + (s2 + s3)) / Ds[r * LDA + r];
-    }
-  }
-  __syncthreads();
+  factor_invert_64(Ds, Is, &bad, k * NB);
 
   if (i == k) {
     // Only X_kk = L_kk^-1 is kept.  L_kk itself is never needed again, and A_kk must NOT be overwritten
@@ -385,22 +503,31 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   }
   hipLaunchKernelGGL(inv_prepare_kernel, dim3((unsigned)prep_tiles), dim3(INV_THREADS), 0, stream, table, n_factors);
   CURV_LAUNCH_CHECK();
-  for (int k = 0; k < Pmax; ++k) {
-    long long col_tiles = 0, upd_tiles = 0, row_tiles = 0;
-    for (const InvDev& d : tab) {
-      col_tiles += std::max(0, d.P - k);
-      const long long r = d.P - k - 1;
-      if (r > 0) upd_tiles += r * (r + 1) / 2 + r * (k + 1);
-      if (k < d.P) row_tiles += k;
-    }
-    hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3((unsigned)col_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
-    CURV_LAUNCH_CHECK();
-    if (row_tiles > 0) {
-      hipLaunchKernelGGL(trtri_finalize_row_kernel, dim3((unsigned)row_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
+  constexpr int NBO = 4;                       // outer panel: 4 block columns = 256
+  for (int k0 = 0; k0 < Pmax; k0 += NBO) {
+    const int kend = k0 + NBO;
+    for (int k = k0; k < std::min(kend, Pmax); ++k) {
+      long long col_tiles = 0, upd_tiles = 0, row_tiles = 0;
+      for (const InvDev& d : tab) {
+        col_tiles += std::max(0, d.P - k);
+        upd_tiles += inner_tiles(d.P, k, kend);
+        if (k < d.P) row_tiles += k;
+      }
+      hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3((unsigned)col_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
       CURV_LAUNCH_CHECK();
+      if (row_tiles > 0) {
+        hipLaunchKernelGGL(trtri_finalize_row_kernel, dim3((unsigned)row_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
+        CURV_LAUNCH_CHECK();
+      }
+      if (upd_tiles > 0) {
+        hipLaunchKernelGGL(inner_update_kernel, dim3((unsigned)upd_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, kend);
+        CURV_LAUNCH_CHECK();
+      }
     }
-    if (upd_tiles > 0) {
-      hipLaunchKernelGGL(step_update_kernel, dim3((unsigned)upd_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
+    long long out_tiles = 0;
+    for (const InvDev& d : tab) out_tiles += outer_tiles(d.P, kend);
+    if (out_tiles > 0) {
+      hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)out_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend);
       CURV_LAUNCH_CHECK();
     }
   }
