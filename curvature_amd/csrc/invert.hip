@@ -120,9 +120,14 @@ __device__ __host__ __forceinline__ long long inner_tiles(int P, int k, int kend
   const long long sr = (ke - k - 1 > 0) ? (long long)(ke - k - 1) * (k + 1) : 0;
   return tr + sr;
 }
+// Outer tile lists are enumerated in 8x8 super-blocks (64 consecutive work items = one super-block, mapped
+// to one XCD): the 16 operand panels of a super-block (2 MB) stay in that XCD's L2 for its 64 tiles.
+constexpr int SB = 8;
 __device__ __host__ __forceinline__ long long outer_tiles(int P, int kend) {
   const long long r = P - kend;
-  return r > 0 ? r * (r + 1) / 2 + r * kend : 0;
+  if (r <= 0) return 0;
+  const long long nsb = (r + SB - 1) / SB, ncb = (kend + SB - 1) / SB;
+  return (nsb * (nsb + 1) / 2 + nsb * ncb) * (SB * SB);
 }
 
 __device__ __forceinline__ void store_sub(gdouble* C, int np, const f64x4 (&acc)[2][2], int wm, int wn, int lane,
@@ -176,44 +181,75 @@ inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int kend) {
   }
 }
 
-// (2o)/(4o) once per outer panel [k0, kend): everything beyond the panel, K = (kend - k0) * 64
+// (2o)/(4o) once per outer panel [k0, kend): everything beyond the panel, K = (kend - k0) * 64.
+// The next K block is fetched into registers while the MFMAs of the current one run.
 __global__ void __launch_bounds__(INV_THREADS)
-outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
+outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int n_items) {
   __shared__ double As[NB * LDA], Bs[NB * LDA];
+  // XCD grouping: workgroups with equal blockIdx % 8 share an XCD; give each XCD whole super-blocks
+  int item;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3;
+    item = ((jj / (SB * SB)) * 8 + xcd) * (SB * SB) + (jj % (SB * SB));
+  }
+  if (item >= n_items) return;
   int f, local;
-  if (!locate(t, nf, blockIdx.x, [kend](const InvDev& d) { return (int)outer_tiles(d.P, kend); }, f, local)) return;
+  if (!locate(t, nf, item, [kend](const InvDev& d) { return (int)outer_tiles(d.P, kend); }, f, local)) return;
   const InvDev& d = t[f];
   const int np = d.np, r = d.P - kend;
-  gdouble* W = (gdouble*)d.W;
-  gdouble* X = (gdouble*)d.X;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-  f64x4 acc[2][2] = {};
-  const int n_trail = r * (r + 1) / 2;
-  if (local < n_trail) {
-    int a = 0, tl = local;
+  const int nsb = (r + SB - 1) / SB;
+  const int sb = local / (SB * SB), in = local - sb * (SB * SB);
+  const int di = in / SB, dj = in - di * SB;
+  const int n_trail_sb = nsb * (nsb + 1) / 2;
+  bool trailing;
+  int i, j;
+  if (sb < n_trail_sb) {
+    int a = 0, tl = sb;
     while (tl > a) { tl -= a + 1; ++a; }
-    const int i = kend + a, j = kend + tl;
-    for (int kk = k0; kk < kend; ++kk) {
-      load_block(W + (long long)i * NB * np + kk * NB, np, As);
-      if (i != j) load_block(W + (long long)j * NB * np + kk * NB, np, Bs);
-      __syncthreads();
-      mma_64<true>(As, (i != j) ? Bs : As, wm, wn, lane, acc);
-      __syncthreads();
-    }
-    store_sub(W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);
+    const int ri = a * SB + di, rj = tl * SB + dj;          // relative to kend
+    if (ri >= r || rj > ri) return;
+    trailing = true; i = kend + ri; j = kend + rj;
   } else {
-    const int l2 = local - n_trail;
-    const int a = l2 / kend, j = l2 - a * kend;
-    const int i = kend + a;
-    for (int kk = (j > k0 ? j : k0); kk < kend; ++kk) {
-      load_block(W + (long long)i * NB * np + kk * NB, np, As);       // C[i][kk]
-      load_block(X + (long long)kk * NB * np + j * NB, np, Bs);       // X[kk][j]
-      __syncthreads();
-      mma_64<false>(As, Bs, wm, wn, lane, acc);
-      __syncthreads();
-    }
-    store_sub(X + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, j >= k0 ? 1 : 2);
+    const int s2 = sb - n_trail_sb;
+    const int ncb = (kend + SB - 1) / SB;
+    const int a = s2 / ncb, cb = s2 - a * ncb;
+    const int ri = a * SB + di; j = cb * SB + dj;
+    if (ri >= r || j >= kend) return;
+    trailing = false; i = kend + ri;
   }
+  const gdouble* W = (const gdouble*)d.W;
+  gdouble* X = (gdouble*)d.X;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int kk_first = trailing ? k0 : (j > k0 ? j : k0);
+  const bool same = trailing && i == j;
+  double ra[16], rb[16];
+  auto fetch = [&](int kk) {
+    const gdouble* ga = W + (long long)i * NB * np + kk * NB;
+    const gdouble* gb = trailing ? W + (long long)j * NB * np + kk * NB : X + (long long)kk * NB * np + j * NB;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + u * INV_THREADS, rr = e >> 6, cc = e & 63;
+      ra[u] = ga[(long long)rr * np + cc];
+      rb[u] = same ? 0.0 : gb[(long long)rr * np + cc];
+    }
+  };
+  f64x4 acc[2][2] = {};
+  fetch(kk_first);
+  for (int kk = kk_first; kk < kend; ++kk) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + u * INV_THREADS, rr = e >> 6, cc = e & 63;
+      As[rr * LDA + cc] = ra[u];
+      if (!same) Bs[rr * LDA + cc] = rb[u];
+    }
+    __syncthreads();
+    if (kk + 1 < kend) fetch(kk + 1);
+    if (trailing) mma_64<true>(As, same ? As : Bs, wm, wn, lane, acc);
+    else mma_64<false>(As, Bs, wm, wn, lane, acc);
+    __syncthreads();
+  }
+  if (trailing) store_sub((gdouble*)d.W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);
+  else store_sub(X + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, j >= k0 ? 1 : 2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -527,7 +563,8 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
     long long out_tiles = 0;
     for (const InvDev& d : tab) out_tiles += outer_tiles(d.P, kend);
     if (out_tiles > 0) {
-      hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)out_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend);
+      const long long grid = cdivll(out_tiles, 8 * SB * SB) * 8 * SB * SB;
+      hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend, (int)out_tiles);
       CURV_LAUNCH_CHECK();
     }
   }
