@@ -348,32 +348,33 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
       op.b1[j] = *reinterpret_cast<const float*>(lds + pb1 + j * cxb);
     }
   };
-  auto compute_ops = [&](auto rl_tag, Ops& op) {
+  // SKIP: the wave sits on the diagonal (lower-left 32x32 block redundant); CHECK: some run of the chunk
+  // is padded or missing, so validity masks must be honoured.  Both are wave-uniform per chunk and
+  // compiled as separate loop bodies: the common body is branch-free between its MFMAs.
+  auto compute_ops = [&](auto rl_tag, auto skip_tag, auto check_tag, Ops& op) {
     constexpr int RLc = decltype(rl_tag)::value;
+    constexpr bool SKIP = decltype(skip_tag)::value, CHECK = decltype(check_tag)::value;
     constexpr int FULL = (1 << RLc) - 1;
-    if (__ballot(op.mask != FULL) != 0ull) {   // some lane half has padded or missing elements: zero its A
+    if (CHECK) {
+      if (__ballot(op.mask != FULL) != 0ull) {   // some lane half has padded or missing elements: zero its A
 #pragma unroll
-      for (int j = 0; j < RLc; ++j) {
-        const bool v = (op.mask >> j) & 1;
-        op.a0[j] = v ? op.a0[j] : 0.0f;
-        op.a1[j] = v ? op.a1[j] : 0.0f;
+        for (int j = 0; j < RLc; ++j) {
+          const bool v = (op.mask >> j) & 1;
+          op.a0[j] = v ? op.a0[j] : 0.0f;
+          op.a1[j] = v ? op.a1[j] : 0.0f;
+        }
       }
     }
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < RLc; ++j) {
       acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a0[j], op.b0[j], acc00, 0, 0, 0);
       acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a0[j], op.b1[j], acc01, 0, 0, 0);
-      if (!skip10) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1[j], op.b0[j], acc10, 0, 0, 0);
+      if (!SKIP) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1[j], op.b0[j], acc10, 0, 0, 0);
       acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1[j], op.b1[j], acc11, 0, 0, 0);
     }
-    __builtin_amdgcn_s_setprio(0);
-    // the other operand set was requested before these MFMAs were issued and has long landed: retiring
-    // it here costs nothing and keeps the compiler from waiting on it in front of the next MFMA group
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
   };
 
-  auto mfma_runs = [&](auto rl_tag, int niter) {
+  auto mfma_runs = [&](auto rl_tag, auto skip_tag, auto check_tag, int niter) {
     Ops A, B;
     const int last = 2 * niter - 1;          // table entries exist up to here
     int it = kfirst;
@@ -386,12 +387,12 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
       const int it1 = it + KSTRIDE;
       const bool n1 = it1 < niter;
       if (n1) { load_ops(rl_tag, B, e); e = ktab[min(2 * (it1 + KSTRIDE) + h, last)]; }
-      compute_ops(rl_tag, A);
+      compute_ops(rl_tag, skip_tag, check_tag, A);
       if (!n1) break;
       it = it1 + KSTRIDE;
       const bool n2 = it < niter;
       if (n2) { load_ops(rl_tag, A, e); e = ktab[min(2 * (it + KSTRIDE) + h, last)]; }
-      compute_ops(rl_tag, B);
+      compute_ops(rl_tag, skip_tag, check_tag, B);
       if (!n2) break;
     }
   };
@@ -438,8 +439,15 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
     // address per operand row feed RL MFMA groups.  Two register sets alternate so that the operand
     // reads of iteration t+1 are in flight while the 4*RL MFMAs of iteration t issue.
     if (!idle && kfirst < work.niter && !(d.pad0 & 1)) {
-      if (RL == 2) mfma_runs(std::integral_constant<int, 2>{}, work.niter);
-      else mfma_runs(std::integral_constant<int, 1>{}, work.niter);
+      using T = std::true_type;
+      using F = std::false_type;
+      const bool check = (work.wa % RL != 0) || (work.nruns & 1);
+      auto go = [&](auto rl_tag) {
+        if (skip10) { if (check) mfma_runs(rl_tag, T{}, T{}, work.niter); else mfma_runs(rl_tag, T{}, F{}, work.niter); }
+        else { if (check) mfma_runs(rl_tag, F{}, T{}, work.niter); else mfma_runs(rl_tag, F{}, F{}, work.niter); }
+      };
+      if (RL == 2) go(std::integral_constant<int, 2>{});
+      else go(std::integral_constant<int, 1>{});
     }
     __syncthreads();
   }
