@@ -69,7 +69,8 @@ class curv_gemm_desc(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("E", ctypes.c_void_p)] + \
                [(k, ctypes.c_longlong) for k in ("a_rs", "a_cs", "b_rs", "b_cs", "c_rs", "c_cs", "e_rs", "e_cs")] + \
                [("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("epilogue", ctypes.c_int32),
-                ("alpha", ctypes.c_float), ("beta", ctypes.c_float)]
+                ("alpha", ctypes.c_float), ("beta", ctypes.c_float), ("tri", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 class curv_cholinv_desc(ctypes.Structure):

@@ -35,6 +35,8 @@ struct GemmDev {
   int epilogue;
   float alpha, beta;
   int tiles_n, tile_base;
+  int tm;                 // tile edge: 64 or 128
+  int tri;                // CURV_TRI_*: triangular operand -> shorter K range per tile
 };
 
 typedef __attribute__((address_space(1))) float gfl;
@@ -51,38 +53,39 @@ __device__ __forceinline__ int gemm_find(const GemmDev* __restrict__ t, int n, i
   return __builtin_amdgcn_readfirstlane(count - 1);
 }
 
-__global__ void __launch_bounds__(GEMM_THREADS)
-gemm_f32_kernel(const GemmDev* __restrict__ table, int n_desc) {
-  __shared__ float As[2][GK * GP];     // [k][row]
-  __shared__ float Bs[2][GK * GP];     // [k][col]
+// One output tile of TMv x TMv: 4 waves as 2 x 2, each wave (TMv/2) x (TMv/2) = BL x BL blocks of 32x32.
+template <int TMv>
+__device__ __forceinline__ void gemm_tile(const GemmDev& d, int local, float* lds) {
+  constexpr int BL = TMv / 64;                 // 32x32 blocks per wave edge
+  constexpr int PITCH = TMv + 1;
+  constexpr int PER_T = TMv * GK / GEMM_THREADS;   // staged elements per thread per operand
+  float* As0 = lds;                            // [2][GK * PITCH]
+  float* Bs0 = lds + 2 * GK * PITCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, h = lane >> 5;
-
-  const int f = gemm_find(table, n_desc, blockIdx.x);
-  const GemmDev& d = table[f];
-  const int local = blockIdx.x - d.tile_base;
   const int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
-  const int i0 = tm * GT, j0 = tn * GT;
-  const int M = d.M, N = d.N, K = d.K;
+  const int i0 = tm * TMv, j0 = tn * TMv;
+  const int M = d.M, N = d.N;
+  int K = d.K;
+  if (d.tri == CURV_TRI_A_LOWER) K = min(K, i0 + TMv);        // A[i][k] = 0 for k > i
+  else if (d.tri == CURV_TRI_B_UPPER) K = min(K, j0 + TMv);   // B[k][j] = 0 for k > j
   const gfl* A = (const gfl*)d.A;
   const gfl* B = (const gfl*)d.B;
   const long long a_rs = d.a_rs, a_cs = d.a_cs, b_rs = d.b_rs, b_cs = d.b_cs;
-
-  // staging map: 64 x 16 elements per operand per stage = 4 per thread.  Lanes run along the
-  // unit-stride dimension of the operand so that global reads coalesce.
+  // staging map: lanes run along the unit-stride dimension of the operand so that global reads coalesce
   const bool a_kfast = (a_cs == 1), b_kfast = (b_rs == 1);
-  int ar[4], ak[4], bc[4], bk[4];
+  int ar[PER_T], ak[PER_T], bc[PER_T], bk[PER_T];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int e = tid + u * GEMM_THREADS;           // 0 .. 1023
-    if (a_kfast) { ak[u] = e & 15; ar[u] = e >> 4; } else { ar[u] = e & 63; ak[u] = e >> 6; }
-    if (b_kfast) { bk[u] = e & 15; bc[u] = e >> 4; } else { bc[u] = e & 63; bk[u] = e >> 6; }
+  for (int u = 0; u < PER_T; ++u) {
+    const int e = tid + u * GEMM_THREADS;
+    if (a_kfast) { ak[u] = e & 15; ar[u] = e >> 4; } else { ar[u] = e % TMv; ak[u] = e / TMv; }
+    if (b_kfast) { bk[u] = e & 15; bc[u] = e >> 4; } else { bc[u] = e % TMv; bk[u] = e / TMv; }
   }
-  float ra[4], rb[4];
+  float ra[PER_T], rb[PER_T];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PER_T; ++u) {
       const int i = i0 + ar[u], k = k0 + ak[u];
       ra[u] = (i < M && k < K) ? A[i * a_rs + k * a_cs] : 0.0f;
       const int j = j0 + bc[u], kk = k0 + bk[u];
@@ -91,13 +94,17 @@ gemm_f32_kernel(const GemmDev* __restrict__ table, int n_desc) {
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      As[buf][ak[u] * GP + ar[u]] = ra[u];
-      Bs[buf][bk[u] * GP + bc[u]] = rb[u];
+    for (int u = 0; u < PER_T; ++u) {
+      As0[buf * GK * PITCH + ak[u] * PITCH + ar[u]] = ra[u];
+      Bs0[buf * GK * PITCH + bk[u] * PITCH + bc[u]] = rb[u];
     }
   };
 
-  f32x16 acc = {0};
+  f32x16 acc[BL][BL];
+#pragma unroll
+  for (int m = 0; m < BL; ++m)
+#pragma unroll
+    for (int n = 0; n < BL; ++n) acc[m][n] = f32x16{0};
   const int nk = (K + GK - 1) / GK;
   fetch(0);
   stash(0);
@@ -105,13 +112,19 @@ gemm_f32_kernel(const GemmDev* __restrict__ table, int n_desc) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) fetch((kt + 1) * GK);          // in flight during the MFMAs below
-    const float* as = As[buf] + 32 * wm + r32;
-    const float* bs = Bs[buf] + 32 * wn + r32;
+    const float* as = As0 + buf * GK * PITCH + (TMv / 2) * wm + r32;
+    const float* bs = Bs0 + buf * GK * PITCH + (TMv / 2) * wn + r32;
 #pragma unroll
     for (int kp = 0; kp < GK / 2; ++kp) {
-      const float a = as[(2 * kp + h) * GP];
-      const float b = bs[(2 * kp + h) * GP];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      float a[BL], b[BL];
+#pragma unroll
+      for (int m = 0; m < BL; ++m) a[m] = as[(2 * kp + h) * PITCH + 32 * m];
+#pragma unroll
+      for (int n = 0; n < BL; ++n) b[n] = bs[(2 * kp + h) * PITCH + 32 * n];
+#pragma unroll
+      for (int m = 0; m < BL; ++m)
+#pragma unroll
+        for (int n = 0; n < BL; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
     }
     if (kt + 1 < nk) stash(buf ^ 1);
     __syncthreads();
@@ -122,20 +135,35 @@ gemm_f32_kernel(const GemmDev* __restrict__ table, int n_desc) {
   const gfl* E = (const gfl*)d.E;
   const float alpha = d.alpha, beta = d.beta;
   const int ep = d.epilogue;
-  const int j = j0 + 32 * wn + r32;
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int i = i0 + 32 * wm + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    if (i < M && j < N) {
-      const long long ci = i * d.c_rs + j * d.c_cs;
-      float v = alpha * acc[reg];
-      if (ep == CURV_EPI_SQUARE) v = alpha * acc[reg] * acc[reg];
-      else if (ep == CURV_EPI_MUL_E) v *= E[i * d.e_rs + j * d.e_cs];
-      else if (ep == CURV_EPI_ADD_E) v += E[i * d.e_rs + j * d.e_cs];
-      if (beta != 0.0f) v += beta * C[ci];
-      C[ci] = v;
+  for (int m = 0; m < BL; ++m)
+#pragma unroll
+    for (int n = 0; n < BL; ++n) {
+      const int j = j0 + (TMv / 2) * wn + 32 * n + r32;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = i0 + (TMv / 2) * wm + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (i < M && j < N) {
+          const long long ci = i * d.c_rs + j * d.c_cs;
+          float v = alpha * acc[m][n][reg];
+          if (ep == CURV_EPI_SQUARE) v = alpha * acc[m][n][reg] * acc[m][n][reg];
+          else if (ep == CURV_EPI_MUL_E) v *= E[i * d.e_rs + j * d.e_cs];
+          else if (ep == CURV_EPI_ADD_E) v += E[i * d.e_rs + j * d.e_cs];
+          if (beta != 0.0f) v += beta * C[ci];
+          C[ci] = v;
+        }
+      }
     }
-  }
+}
+
+__global__ void __launch_bounds__(GEMM_THREADS)
+gemm_f32_kernel(const GemmDev* __restrict__ table, int n_desc) {
+  __shared__ float lds[4 * GK * (128 + 1)];     // A and B images, double buffered, sized for the 128 tile
+  const int f = gemm_find(table, n_desc, blockIdx.x);
+  const GemmDev& d = table[f];
+  const int local = blockIdx.x - d.tile_base;
+  if (d.tm == 128) gemm_tile<128>(d, local, lds);
+  else gemm_tile<64>(d, local, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -309,9 +337,12 @@ extern "C" int curv_gemm_batched(void* stream_, const curv_gemm_desc* descs, int
     d.c_rs = s.c_rs; d.c_cs = s.c_cs; d.e_rs = s.e_rs; d.e_cs = s.e_cs;
     d.M = s.M; d.N = s.N; d.K = s.K;
     d.epilogue = s.epilogue; d.alpha = s.alpha; d.beta = s.beta;
-    d.tiles_n = cdiv(s.N, GT);
+    CURV_REQUIRE(s.tri >= 0 && s.tri <= CURV_TRI_B_UPPER, "curv_gemm_batched: desc %d: bad tri flag", i);
+    d.tri = s.tri;
+    d.tm = (s.M >= 96 && s.N >= 96) ? 128 : 64;
+    d.tiles_n = cdiv(s.N, d.tm);
     d.tile_base = (int)tiles;
-    tiles += (long long)cdiv(s.M, GT) * d.tiles_n;
+    tiles += (long long)cdiv(s.M, d.tm) * d.tiles_n;
     CURV_REQUIRE(tiles < (1LL << 30), "curv_gemm_batched: too many tiles");
     tab.push_back(d);
   }

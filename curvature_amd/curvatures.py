@@ -256,8 +256,8 @@ class KFAC(Curvature):
             z = self._randn(n, m, device=first.device)
         tmp = torch.empty(m, n, dtype=torch.float32, device=first.device)
         out = torch.empty(m, n, dtype=torch.float32, device=first.device)
-        ops.gemm_batched([ops.Gemm(second, z.t(), tmp)])
-        ops.gemm_batched([ops.Gemm(tmp, first.t(), out)])
+        ops.gemm_batched([ops.Gemm(second, z.t(), tmp, tri=ops.TRI_A_LOWER)])       # L_G lower triangular
+        ops.gemm_batched([ops.Gemm(tmp, first.t(), out, tri=ops.TRI_B_UPPER)])      # L_A^T upper triangular
         return out
 
     def sample_and_replace(self, noise: Optional[Dict[Module, Tensor]] = None):
@@ -266,17 +266,27 @@ class KFAC(Curvature):
         assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
         self.model.load_state_dict(self.model_state)
         stage1, stage2 = [], []
-        for _, layer in self._owned():
+        owned = self._owned()
+        flat, pos = None, 0
+        if noise is None and owned:        # one generator launch for the whole model
+            dev = self.inv_state[owned[0][1]][0].device
+            total = sum(self.inv_state[l][0].size(0) * self.inv_state[l][1].size(0) for _, l in owned)
+            flat = self._randn(total, device=dev)
+        for _, layer in owned:
             first, second = self.inv_state[layer]
             n, m = first.size(0), second.size(0)
-            z = noise[layer] if noise is not None else self._randn(n, m, device=first.device)
+            if noise is not None:
+                z = noise[layer]
+            else:
+                z = flat[pos:pos + n * m].view(n, m)
+                pos += n * m
             tmp = torch.empty(m, n, dtype=torch.float32, device=first.device)
-            stage1.append(ops.Gemm(second, z.t(), tmp))
+            stage1.append(ops.Gemm(second, z.t(), tmp, tri=ops.TRI_A_LOWER))
             n0 = n - int(layer.bias is not None)
             w = layer.weight.data.view(m, n0)
             w_mean = self.model_state_of(layer, 'weight').view(m, n0)
             la_t = first.t()
-            stage2.append(ops.Gemm(tmp, la_t[:, :n0], w, epilogue=ops.EPI_ADD_E, E=w_mean))
+            stage2.append(ops.Gemm(tmp, la_t[:, :n0], w, epilogue=ops.EPI_ADD_E, E=w_mean, tri=ops.TRI_B_UPPER))
             if layer.bias is not None:
                 b = layer.bias.data.view(m, 1)
                 b_mean = self.model_state_of(layer, 'bias').view(m, 1)

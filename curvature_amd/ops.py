@@ -145,15 +145,16 @@ def chol_inv_lower(factors: Sequence[torch.Tensor], adds: Sequence[float], multi
 
 
 EPI_NONE, EPI_SQUARE, EPI_MUL_E, EPI_ADD_E = 0, 1, 2, 3
+TRI_NONE, TRI_A_LOWER, TRI_B_UPPER = 0, 1, 2
 
 
 class Gemm:
     """C = epilogue(alpha * A @ B) [+ beta * C] on 2-D views (any strides: .t() and slices are free)."""
-    __slots__ = ("A", "B", "C", "E", "alpha", "beta", "epilogue")
+    __slots__ = ("A", "B", "C", "E", "alpha", "beta", "epilogue", "tri")
 
-    def __init__(self, A, B, C, alpha=1.0, beta=0.0, epilogue=EPI_NONE, E=None):
+    def __init__(self, A, B, C, alpha=1.0, beta=0.0, epilogue=EPI_NONE, E=None, tri=0):
         self.A, self.B, self.C, self.E = A, B, C, E
-        self.alpha, self.beta, self.epilogue = float(alpha), float(beta), int(epilogue)
+        self.alpha, self.beta, self.epilogue, self.tri = float(alpha), float(beta), int(epilogue), int(tri)
 
 
 def _check_view(t: torch.Tensor):
@@ -185,7 +186,7 @@ def gemm_batched(jobs: Sequence[Gemm]) -> None:
             d.E = j.E.data_ptr()
             d.e_rs, d.e_cs = j.E.stride()
         d.M, d.N, d.K = M, N, K
-        d.alpha, d.beta, d.epilogue = j.alpha, j.beta, j.epilogue
+        d.alpha, d.beta, d.epilogue, d.tri = j.alpha, j.beta, j.epilogue, j.tri
     L = _lib.lib()
     ws = workspace(L.curv_gemm_workspace_bytes(n), jobs[0].C.device, "gemm")
     _lib.check(L.curv_gemm_batched(_lib.stream_ptr(), arr, n, ws.data_ptr(), ws.numel()), "curv_gemm_batched")

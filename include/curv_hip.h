@@ -138,6 +138,10 @@ int curv_chol_factor_inverse(void* stream, const curv_cholinv_desc* descs, int n
 #define CURV_EPI_SQUARE 1
 #define CURV_EPI_MUL_E 2
 #define CURV_EPI_ADD_E 3
+/* triangular-operand hints: the K range of every output tile is cut where the operand is known to be 0 */
+#define CURV_TRI_NONE 0
+#define CURV_TRI_A_LOWER 1   /* op(A)(i,k) = 0 for k > i  (e.g. A = L_G) */
+#define CURV_TRI_B_UPPER 2   /* op(B)(k,j) = 0 for k > j  (e.g. B = L_A^T) */
 
 typedef struct curv_gemm_desc {
   const float* A;
@@ -148,6 +152,8 @@ typedef struct curv_gemm_desc {
   int32_t M, N, K;
   int32_t epilogue;
   float alpha, beta;
+  int32_t tri;
+  int32_t reserved;
 } curv_gemm_desc;
 
 size_t curv_gemm_workspace_bytes(int n_desc);
