@@ -387,8 +387,8 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
     set_error("curv_syevd: workspace too small (%zu < %zu bytes)", workspace_bytes, L.total);
     return CURV_ERR_WORKSPACE;
   }
-  if (max_sweeps <= 0) max_sweeps = 15;
-  if (tol <= 0.0) tol = 1e-9;
+  if (max_sweeps <= 0) max_sweeps = 30;
+  if (tol <= 0.0) tol = 1e-8;
   char* base = reinterpret_cast<char*>(workspace);
   EighDev* table = reinterpret_cast<EighDev*>(base);
   double* norms = reinterpret_cast<double*>(base + L.table);

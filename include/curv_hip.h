@@ -199,7 +199,7 @@ int curv_mul(void* stream, const float* a, const float* b, float* out, long long
  * optional) the eigenvalues of F (the reference decomposes F + F^T: same vectors, doubled values, and it
  * discards the values).  Signs / bases of degenerate clusters are arbitrary, as with LAPACK.
  * The call synchronises the stream once per sweep to test convergence (off(A) <= tol * ||A||_F);
- * max_sweeps <= 0 and tol <= 0 select the defaults (15, 1e-9).  n <= 8192.
+ * max_sweeps <= 0 and tol <= 0 select the defaults (30, 1e-8).  n <= 8192.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct curv_eigh_desc {
   const float* F;

@@ -140,3 +140,30 @@ def test_cpu_model_is_rejected():
     loss.backward()
     with pytest.raises(RuntimeError):
         kfac.update(batch_size=2)
+
+
+def test_sharded_ranks_cover_the_unsharded_result(gpu):
+    """Layer sharding without the collective: every rank's update/invert/sample touches only its
+    layers and the union over ranks equals the single-process result (the all-gather itself is covered by
+    tests/test_sharding_gloo.py)."""
+    from curvature_amd import sharding
+    from curvature_amd.curvatures import KFAC
+    g1 = load("g1_kfac_lenet.npz")
+    results = {}
+    for world, rank in [(1, 0), (2, 0), (2, 1)]:
+        model, layers = lenet_with_golden_weights(gpu, g1)
+        kfac = KFAC(model)
+        costs = [sharding.layer_cost(n, m, K) for n, m, K in [(26, 6, 6272), (151, 16, 800), (401, 120, 8), (121, 84, 8), (85, 10, 8)]]
+        if world > 1:
+            kfac.shard = sharding.Shard(sharding.lpt_partition(costs, world), rank, 1)   # world=1 inside: no collective
+            kfac.shard.world = 1
+        list(run_batches(model, [kfac], g1, gpu, nb=1))
+        kfac.invert(0.5, 1)
+        results[(world, rank)] = {li: kfac.inv_state[l] for li, l in enumerate(layers) if l in kfac.inv_state}
+    full = results[(1, 0)]
+    assert len(full) == 5
+    owned0, owned1 = set(results[(2, 0)]), set(results[(2, 1)])
+    assert owned0 and owned1 and owned0.isdisjoint(owned1) and owned0 | owned1 == set(range(5))
+    for part in (results[(2, 0)], results[(2, 1)]):
+        for li, (LA, LG) in part.items():
+            assert torch.equal(LA, full[li][0]) and torch.equal(LG, full[li][1])     # bitwise: same kernels, same inputs
