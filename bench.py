@@ -170,6 +170,17 @@ def main():
     syrk_s = syrk_ms / args.steps * 1e-3
     achieved = exec_flops / syrk_s / 1e12
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they are
+    # collected by tools/collect_profiles.sh (rocprofv3, separate FETCH_SIZE / WRITE_SIZE passes, gfx950
+    # correction of MI355X_MICROARCH.md) on this same workload and committed under profiles/
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_syrk_pmc.json")
+    if world == 1 and args.batch == 32 and os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
     if rank == 0:
         n_layers = len(layers)
         out = {
@@ -191,7 +202,7 @@ def main():
                        "parallelism": f"layer-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "curv::syrk_patch_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_F32_MFMA / 1e12),
-                         "traffic": None,
+                         "traffic": traffic,
                          "flops_counted": "executed symmetric: sum (n(n+1)+m(m+1)) K over the rank's layers",
                          "dense_equivalent_tflops": dense_flops / syrk_s / 1e12,
                          "kernel_ms": syrk_s * 1e3},
