@@ -59,7 +59,13 @@ class Shard:
                     mine[pos:pos + p.numel()].copy_(p.detach().reshape(-1))
                     pos += p.numel()
         gathered = torch.empty(self.world * cap, dtype=ref.dtype, device=ref.device)
-        dist.all_gather(list(gathered.chunk(self.world)), mine, group=self.group)   # the one collective
+        if mine.is_cuda and dist.get_backend(self.group) == "gloo":
+            # test configurations only (several ranks sharing one GPU over gloo): stage through the host
+            host = torch.empty(self.world * cap, dtype=ref.dtype)
+            dist.all_gather(list(host.chunk(self.world)), mine.cpu(), group=self.group)
+            gathered.copy_(host)
+        else:
+            dist.all_gather(list(gathered.chunk(self.world)), mine, group=self.group)   # the one collective
         cursor = [r * cap for r in range(self.world)]
         for i, ps in enumerate(params_per_layer):
             r = self.owner[i]
