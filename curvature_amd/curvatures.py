@@ -260,11 +260,22 @@ class KFAC(Curvature):
         ops.gemm_batched([ops.Gemm(tmp, first.t(), out, tri=ops.TRI_B_UPPER)])      # L_A^T upper triangular
         return out
 
+    def _reload_mean(self):
+        """``model.load_state_dict(model_state)`` (curvatures.py:119) as ONE multi-tensor copy instead of a
+        few hundred small ones: same tensors, same values."""
+        if not hasattr(self, "_reload_lists"):
+            live = self.model.state_dict(keep_vars=True)
+            if list(live.keys()) != list(self.model_state.keys()):
+                raise RuntimeError("model structure changed since the estimator was created")
+            dst = [live[k].data if hasattr(live[k], "data") else live[k] for k in live]
+            self._reload_lists = (dst, [self.model_state[k] for k in live])
+        torch._foreach_copy_(self._reload_lists[0], self._reload_lists[1])
+
     def sample_and_replace(self, noise: Optional[Dict[Module, Tensor]] = None):
         """Fused form of the base-class loop: two batched GEMM launches for the whole model, the second
         writing ``mean + sample`` straight into the parameters (same result as curvatures.py:117-129)."""
         assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
-        self.model.load_state_dict(self.model_state)
+        self._reload_mean()
         stage1, stage2 = [], []
         owned = self._owned()
         flat, pos = None, 0
