@@ -34,7 +34,6 @@ constexpr int SYRK_THREADS = 256;
 constexpr int XCD_GROUP = 32;          // consecutive items that share an XCD
 constexpr int MAX_RL = 2;              // longest k-run (register budget: two operand sets of 4 * RL)
 constexpr int KTAB_MAX = 1024;         // k runs per chunk
-constexpr int ROWTAB_MAX = 512;        // patch rows per panel per chunk
 constexpr int PANEL_WORDS = 8704;      // LDS words per panel patch
 constexpr int PATCH_WORDS = 2 * PANEL_WORDS;   // >= 4 x (64x64) cross-wave reduce scratch
 constexpr int STAGE_SLOTS = 32;        // staging registers per panel per lane (floats)
@@ -43,9 +42,8 @@ constexpr int PANEL_SLOT_ELEMS = STAGE_SLOTS * SYRK_THREADS;   // padded patch e
 constexpr int ZERO_OFF = 0;            // 16 zero words (padding rows read run elements 0..RL-1 from here)
 constexpr int ONE_OFF = 16;            // 16 one words (the bias row of ones)
 constexpr int KTAB_OFF = 32;
-constexpr int ROWTAB_OFF = KTAB_OFF + KTAB_MAX;
-constexpr int PATCH_OFF = ROWTAB_OFF + 3 * ROWTAB_MAX;
-constexpr int SMEM_WORDS = PATCH_OFF + PATCH_WORDS;   // 19984 words = 79936 B -> 2 workgroups per CU
+constexpr int PATCH_OFF = KTAB_OFF + KTAB_MAX;
+constexpr int SMEM_WORDS = PATCH_OFF + PATCH_WORDS;   // 18464 words = 73856 B -> 2 workgroups per CU
 static_assert(PATCH_WORDS >= 4 * 64 * 64, "reduce scratch must fit the patch region");
 static_assert(2 * SMEM_WORDS * 4 <= 160 * 1024, "two workgroups per CU");
 
@@ -72,7 +70,10 @@ struct FactorDev {
   int sub_base, n_sub;     // 64x64 sub-tiles for the reduce kernel
   int first;
   float scale;
-  int pad0, pad1;
+  int pad0;
+  int rshift;              // general staging: a lane group of 2^rshift folded rows; the other row lanes split channels
+  int flat;                // flattened per-pixel factor whose (sample, channel) rows are staged slot-regularly
+  unsigned rmagic;         // ceil(2^32 / patch rows per sample): folded (sample, row) index -> sample
   long long slab_base;     // in floats
 };
 static_assert(sizeof(FactorDev) % 8 == 0, "FactorDev must be 8-byte granular");
@@ -99,6 +100,7 @@ __device__ __forceinline__ void decode_tile(int t, int P, int& ti, int& tj) {
 
 typedef __attribute__((address_space(1))) float gfloat;      // global-address-space views
 typedef __attribute__((address_space(1))) f32x4 gf32x4;
+typedef __attribute__((address_space(1))) char gchar;
 
 // Position and extent of one K chunk.
 struct Chunk {
@@ -111,7 +113,6 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   const gfloat* zeros = (const gfloat*)zeros_;
   float* fs = reinterpret_cast<float*>(smem);
   int* ktab = smem + KTAB_OFF;
-  int* rowtab = smem + ROWTAB_OFF;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -142,7 +143,7 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   const int kh = d.kh, kw = d.kw, sh = d.sh, sw = d.sw, ph = d.ph, pw = d.pw;
   const int Ho = d.Ho, Wo = d.Wo, khkw = d.khkw, rows = d.rows, has_bias = d.has_bias;
   const int compact = d.compact, vec4 = d.vec4;
-  const bool flat1 = compact && !vec4 && d.H == 1;   // flattened per-pixel factor staged with scalar loads
+  const bool flat1 = d.flat && !vec4;                // flattened per-pixel factor staged with scalar loads
   const int NS = d.NS, R = d.R, Wc = d.Wc, n_rg = d.n_rg, n_cg = d.n_cg, n_chunks = d.n_chunks;
   const int RS = d.RS, PS = d.PS, SS = d.SS, nch = d.nch, cshift = d.cshift, RL = d.RL;
   const int HW = H * W;
@@ -159,25 +160,9 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
 
   // full-chunk patch extent (tables are built for it once; ragged chunks mask the excess)
   const int rows_in_full = compact ? R : (R - 1) * sh + kh;
-  const int total_rows_full = NS * nch * rows_in_full;
 
   // every LDS word a masked run element may touch must be finite (0 * NaN would poison the tile)
   for (int w = tid; w < SMEM_WORDS; w += SYRK_THREADS) fs[w] = (w >= ONE_OFF && w < ONE_OFF + 16) ? 1.0f : 0.0f;
-  __syncthreads();
-  if (!vec4 && !flat1) {
-    for (int p = tid; p < total_rows_full; p += SYRK_THREADS) {
-      const int y = p % rows_in_full;
-      const int t2 = p / rows_in_full;
-      const int cc = t2 % nch;
-      const int s = t2 / nch;
-      rowtab[3 * p + 0] = s * SS + cc * PS + y * RS;
-      // with full-height chunks (n_rg == 1) the halo rows are the same in every chunk: mark them once
-      const int ih_static = -ph + y * gy;
-      const bool halo = (n_rg == 1) && !((unsigned)ih_static < (unsigned)H);
-      rowtab[3 * p + 1] = halo ? -1 : (s * C + cc) * HW + y * gy * W;
-      rowtab[3 * p + 2] = (s << 24) | (cc << 16) | y;
-    }
-  }
 
   // Per-lane operand rows: A0/A1 = panel i rows (64 wm) + r32, + 32; B0/B1 = panel j rows (64 wn) + ...
   int base[4], kmask[4];
@@ -226,87 +211,156 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
     return c;
   };
 
+  // ---- staging: global -> registers (before the MFMA loop) -> LDS (after it) ----
+  // All source reads are raw buffer loads against a descriptor of the chunk's samples:
+  //   address = base + soffset (SGPR: channel plane, advanced by SALU per slot) + voffset (VGPR: the
+  //   lane's position inside a plane, constant across the channels it walks),
+  // and a lane that holds padding, or lies outside a ragged chunk, carries voffset = OOB: the range
+  // check returns 0 for it, so halo zeros cost no instruction and no read ever leaves the tensor.
+  // A slot is therefore ~2 instructions on either side (s_add + buffer_load, v_add + ds_write); the
+  // wave issues one instruction every ~4 cycles, so this count is what the staging phase costs.
+  constexpr int OOB = (int)0x80000000;
+  const int sample_bytes = C * HW * 4;
+  auto make_rsrc = [&](const Chunk& c) {
+    const long long left = (long long)(N - c.s0) * sample_bytes;
+    const unsigned nrec = (unsigned)min(left, 0x7ffff000ll);   // < OOB marker, >= any offset of the chunk
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(d.src + (long long)c.s0 * C * HW), 0, nrec, 0x00020000);
+  };
+  auto bload = [&](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  };
+
+  // general path: a lane owns (folded row, x) positions of the patch plane and walks channel groups
+  struct RowGeo { int voff, laddr; bool inr; };
+  const unsigned rmagic = d.rmagic;
+  const int rshift = d.rshift;
+  const int rstep = 1 << rshift;                       // folded rows per pass
+  const int CL = prow_step >> rshift;                  // channels staged side by side by the row lanes
+  const int n_cgs = (nch + CL - 1) / CL;               // channel groups = slots per row pass; the sample
+                                                       // stride SS covers n_cgs * CL planes
+  auto row_geo = [&](const Chunk& c, int k, int lx, int prow0) {
+    RowGeo g;
+    const int ccl = prow0 >> rshift;
+    const int rr = (prow0 & (rstep - 1)) + k * rstep;
+    const int s = (rows_in_full == 1) ? rr : (int)__umulhi((unsigned)rr, rmagic);
+    const int y = rr - s * rows_in_full;
+    const int ih = c.ih_base + y * gy;
+    const int iw = c.iw_base + lx * gx;
+    g.inr = s < c.ns && y < c.rows_in && lx < c.cols_in;
+    const bool ok = g.inr && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    g.voff = ok ? ((s * C + ccl) * HW + ih * W + iw) * 4 : OOB;
+    g.laddr = s * SS + ccl * PS + y * RS + lx;
+    return g;
+  };
+
   float st[2 * STAGE_SLOTS];
 
-  // global -> registers for one chunk (both panels).  Branch-free on purpose: a masked slot loads from
-  // a zeroed dummy word instead of being skipped, so every staging register is the direct destination
-  // of exactly one load and the compiler needs no copy (hence no vmcnt wait) before the MFMA loop.
+  // NCG > 0: channel groups per row pass known at compile time (slot -> (pass, group) is static and the
+  // loop is straight-line); NCG == 0: run-time counters with a uniform branch per slot.
+  auto issue_general = [&](auto ncg_tag, const Chunk& c, __amdgpu_buffer_rsrc_t rs, int pnl, int c_lo, int lx,
+                           int prow0) {
+    constexpr int NCG = decltype(ncg_tag)::value;
+    const int step = CL * HW * 4;
+    int soff0 = c_lo * HW * 4;
+    asm volatile("" : "+s"(soff0));   // keep the per-slot offsets out of loop-invariant hoisting
+    if constexpr (NCG > 0) {
+#pragma unroll
+      for (int k = 0; k < STAGE_SLOTS / NCG; ++k) {
+        const RowGeo g = row_geo(c, k, lx, prow0);
+        int soff = soff0;
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg) {
+          st[pnl * STAGE_SLOTS + k * NCG + cg] = bload(rs, g.voff, soff);
+          soff += step;
+        }
+      }
+    } else {
+      int cg = 0, k = 0, soff = soff0;
+      RowGeo g = row_geo(c, 0, lx, prow0);
+#pragma unroll
+      for (int j = 0; j < STAGE_SLOTS; ++j) {
+        st[pnl * STAGE_SLOTS + j] = bload(rs, g.voff, soff);
+        soff += step;
+        if (++cg == n_cgs) { cg = 0; soff = soff0; ++k; g = row_geo(c, k, lx, prow0); }
+      }
+    }
+  };
+  auto store_general = [&](auto ncg_tag, const Chunk& c, float* lbase, int pnl, int lx, int prow0) {
+    constexpr int NCG = decltype(ncg_tag)::value;
+    int lstep = CL * PS;
+    asm volatile("" : "+s"(lstep));
+    if constexpr (NCG > 0) {
+#pragma unroll
+      for (int k = 0; k < STAGE_SLOTS / NCG; ++k) {
+        const RowGeo g = row_geo(c, k, lx, prow0);
+        if (g.inr) {
+          float* l = lbase + g.laddr;
+#pragma unroll
+          for (int cg = 0; cg < NCG; ++cg) { *l = st[pnl * STAGE_SLOTS + k * NCG + cg]; l += lstep; }
+        }
+      }
+    } else {
+      int cg = 0, k = 0;
+      RowGeo g = row_geo(c, 0, lx, prow0);
+#pragma unroll
+      for (int j = 0; j < STAGE_SLOTS; ++j) {
+        if (g.inr) lbase[g.laddr + cg * lstep] = st[pnl * STAGE_SLOTS + j];
+        if (++cg == n_cgs) { cg = 0; ++k; g = row_geo(c, k, lx, prow0); }
+      }
+    }
+  };
+
+  // flattened per-pixel factors: patch rows are (sample, channel) pairs, lanes run along the pixels.
+  // Slot j holds rows j * prow_step + prow0; the planner guarantees prow_step | nch, so the sample and
+  // the first channel of a slot are wave-uniform.
+  const int flat_rows = NS * nch;
+
   auto issue_loads = [&](const Chunk& c) {
-    // lane geometry made opaque per call: otherwise every per-slot address is hoisted out of the chunk
-    // loop and pinned in registers, which spills
+    // lane geometry made opaque per call: otherwise per-slot values are hoisted out of the chunk loop
+    // and pinned in registers, which spills
     int lx = lx_, prow0 = prow0_;
     asm volatile("" : "+v"(lx), "+v"(prow0));
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(c);
 #pragma unroll
     for (int pnl = 0; pnl < 2; ++pnl) {
       if (pnl < n_panels) {
         const int c_lo = pnl ? c_lo_j : c_lo_i;
-        const int nch_p = pnl ? nch_j : nch_i;
         if (vec4) {
-          const int cols4 = c.wa >> 2;
-          const int prow = c.ns * nch_p;
-          const gfloat* g0 = src + ((long long)c.s0 * C + c_lo) * HW + c.iw_base + 4 * lx;
-          const bool colok = lx < cols4;
+          const int voff = (lx < (c.wa >> 2)) ? (prow0 * HW + c.iw_base + 4 * lx) * 4 : OOB;
+          int srow = 0, cb = 0;                          // uniform (sample, first channel) of the slot
+          asm volatile("" : "+s"(srow), "+s"(cb));
 #pragma unroll
           for (int j = 0; j < STAGE_SLOTS / 4; ++j) {
-            const int p = prow0 + j * prow_step;
-            const bool ok = colok && p < prow;
-            const int s = (c.ns == 1) ? 0 : p / nch_p;
-            const int cc = p - s * nch_p;
-            const gfloat* a = ok ? g0 + ((long long)s * C + cc) * HW : zeros;
-            const f32x4 v = *reinterpret_cast<const gf32x4*>(a);
-            st[pnl * STAGE_SLOTS + 4 * j + 0] = v.x;
-            st[pnl * STAGE_SLOTS + 4 * j + 1] = v.y;
-            st[pnl * STAGE_SLOTS + 4 * j + 2] = v.z;
-            st[pnl * STAGE_SLOTS + 4 * j + 3] = v.w;
+            if (j * prow_step < flat_rows) {
+              const int soff = ((srow * C + c_lo + cb) * HW) * 4;
+              const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+              st[pnl * STAGE_SLOTS + 4 * j + 0] = v.x;
+              st[pnl * STAGE_SLOTS + 4 * j + 1] = v.y;
+              st[pnl * STAGE_SLOTS + 4 * j + 2] = v.z;
+              st[pnl * STAGE_SLOTS + 4 * j + 3] = v.w;
+            }
+            cb += prow_step;
+            if (cb == nch) { cb = 0; ++srow; }
           }
         } else if (flat1) {
-          // flattened per-pixel factor without 16-B alignment (e.g. 7x7 maps): rows = (sample, channel)
-          const int prow = c.ns * nch_p;
-          const gfloat* g0 = src + ((long long)c.s0 * C + c_lo) * HW + c.iw_base + lx;
-          const bool colok = lx < c.wa;
+          const int voff = (lx < c.wa) ? (prow0 * HW + c.iw_base + lx) * 4 : OOB;
+          int srow = 0, cb = 0;
+          asm volatile("" : "+s"(srow), "+s"(cb));
 #pragma unroll
           for (int j = 0; j < STAGE_SLOTS; ++j) {
-            const int p = prow0 + j * prow_step;
-            const bool ok = colok && p < prow;
-            const int s = (c.ns == 1) ? 0 : p / nch_p;
-            const int cc = p - s * nch_p;
-            const gfloat* a = ok ? g0 + ((long long)s * C + cc) * HW : zeros;
-            st[pnl * STAGE_SLOTS + j] = *a;
+            if (j * prow_step < flat_rows) {
+              const int soff = ((srow * C + c_lo + cb) * HW) * 4;
+              st[pnl * STAGE_SLOTS + j] = bload(rs, voff, soff);
+            }
+            cb += prow_step;
+            if (cb == nch) { cb = 0; ++srow; }
           }
+        } else if (n_cgs == 16) {
+          issue_general(std::integral_constant<int, 16>{}, c, rs, pnl, c_lo, lx, prow0);
+        } else if (n_cgs == 8) {
+          issue_general(std::integral_constant<int, 8>{}, c, rs, pnl, c_lo, lx, prow0);
         } else {
-          const gfloat* g0 = src + ((long long)c.s0 * C + c_lo) * HW + (long long)c.ih_base * W + c.iw_base +
-                             lx * gx;
-          const int iw = c.iw_base + lx * gx;
-          const bool colok = lx < c.cols_in && (unsigned)iw < (unsigned)W;
-          // Row validity is static when the chunk has the full extent and either spans the whole height
-          // (halo rows pre-marked in the row table) or touches no image border: one table read per slot.
-          const bool interior = c.ih_base >= 0 && c.ih_base + (rows_in_full - 1) * gy < H;
-          const bool fast = c.ns == NS && c.ra == R && nch_p == nch && (n_rg == 1 || interior);
-          if (fast) {
-#pragma unroll
-            for (int j = 0; j < STAGE_SLOTS; ++j) {
-              const int p = prow0 + j * prow_step;
-              const bool in = p < total_rows_full;
-              const int go = rowtab[3 * (in ? p : 0) + 1];
-              const gfloat* a = (in && colok && go >= 0) ? g0 + go : zeros;
-              st[pnl * STAGE_SLOTS + j] = *a;
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < STAGE_SLOTS; ++j) {
-              const int p = prow0 + j * prow_step;
-              const bool in = p < total_rows_full;
-              const int pp = in ? p : 0;
-              const int go = rowtab[3 * pp + 1];
-              const int scy = rowtab[3 * pp + 2];
-              const int s = scy >> 24, cc = (scy >> 16) & 0xff, y = scy & 0xffff;
-              const int ih = c.ih_base + y * gy;
-              const bool ok = in && colok && s < c.ns && cc < nch_p && y < c.rows_in && (unsigned)ih < (unsigned)H;
-              (void)go;                    // may be the halo marker here: rebuild the offset from (s, cc, y)
-              const gfloat* a = ok ? g0 + ((s * C + cc) * HW + y * gy * W) : zeros;
-              st[pnl * STAGE_SLOTS + j] = *a;
-            }
-          }
+          issue_general(std::integral_constant<int, 0>{}, c, rs, pnl, c_lo, lx, prow0);
         }
       }
     }
@@ -319,61 +373,43 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
 #pragma unroll
     for (int pnl = 0; pnl < 2; ++pnl) {
       if (pnl < n_panels) {
-        const int nch_p = pnl ? nch_j : nch_i;
         float* lbase = fs + PATCH_OFF + (pnl ? off_j : 0);
         if (vec4) {
-          const int cols4 = c.wa >> 2;
-          const int prow = c.ns * nch_p;
-          if (lx < cols4) {
+          if (lx < (c.wa >> 2)) {
+            float* l0 = lbase + prow0 * PS + 4 * lx;
+            int srow = 0, cb = 0;
+          asm volatile("" : "+s"(srow), "+s"(cb));
 #pragma unroll
             for (int j = 0; j < STAGE_SLOTS / 4; ++j) {
-              const int p = prow0 + j * prow_step;
-              if (p < prow) {
-                const int s = (c.ns == 1) ? 0 : p / nch_p;
-                const int cc = p - s * nch_p;
-                float* l = lbase + s * SS + cc * PS + 4 * lx;
+              if (j * prow_step < flat_rows) {
+                float* l = l0 + srow * SS + cb * PS;
                 l[0] = st[pnl * STAGE_SLOTS + 4 * j + 0];
                 l[1] = st[pnl * STAGE_SLOTS + 4 * j + 1];
                 l[2] = st[pnl * STAGE_SLOTS + 4 * j + 2];
                 l[3] = st[pnl * STAGE_SLOTS + 4 * j + 3];
               }
+              cb += prow_step;
+              if (cb == nch) { cb = 0; ++srow; }
             }
           }
         } else if (flat1) {
-          const int prow = c.ns * nch_p;
           if (lx < c.wa) {
+            float* l0 = lbase + prow0 * PS + lx;
+            int srow = 0, cb = 0;
+          asm volatile("" : "+s"(srow), "+s"(cb));
 #pragma unroll
             for (int j = 0; j < STAGE_SLOTS; ++j) {
-              const int p = prow0 + j * prow_step;
-              if (p < prow) {
-                const int s = (c.ns == 1) ? 0 : p / nch_p;
-                const int cc = p - s * nch_p;
-                lbase[s * SS + cc * PS + lx] = st[pnl * STAGE_SLOTS + j];
-              }
+              if (j * prow_step < flat_rows) l0[srow * SS + cb * PS] = st[pnl * STAGE_SLOTS + j];
+              cb += prow_step;
+              if (cb == nch) { cb = 0; ++srow; }
             }
           }
+        } else if (n_cgs == 16) {
+          store_general(std::integral_constant<int, 16>{}, c, lbase, pnl, lx, prow0);
+        } else if (n_cgs == 8) {
+          store_general(std::integral_constant<int, 8>{}, c, lbase, pnl, lx, prow0);
         } else {
-          const bool full = c.ns == NS && c.ra == R && nch_p == nch;
-          if (lx < c.cols_in) {
-            if (full) {
-#pragma unroll
-              for (int j = 0; j < STAGE_SLOTS; ++j) {
-                const int p = prow0 + j * prow_step;
-                if (p < total_rows_full) lbase[rowtab[3 * p + 0] + lx] = st[pnl * STAGE_SLOTS + j];
-              }
-            } else {
-#pragma unroll
-              for (int j = 0; j < STAGE_SLOTS; ++j) {
-                const int p = prow0 + j * prow_step;
-                if (p < total_rows_full) {
-                  const int lo = rowtab[3 * p + 0];
-                  const int scy = rowtab[3 * p + 2];
-                  const int s = scy >> 24, cc = (scy >> 16) & 0xff, y = scy & 0xffff;
-                  if (s < c.ns && cc < nch_p && y < c.rows_in) lbase[lo + lx] = st[pnl * STAGE_SLOTS + j];
-                }
-              }
-            }
-          }
+          store_general(std::integral_constant<int, 0>{}, c, lbase, pnl, lx, prow0);
         }
       }
     }
@@ -457,7 +493,7 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   const int ch_end = min(ch_begin + d.cpi, n_chunks);
   int cur_ns = -1, cur_ra = -1, cur_wa = -1;
 
-  __syncthreads();                       // rowtab, ZERO/ONE visible
+  __syncthreads();                       // ZERO/ONE visible
   Chunk cur = decode_chunk(min(ch_begin, n_chunks - 1));
   if (ch_begin < ch_end) issue_loads(cur);
 
@@ -651,7 +687,7 @@ static int ceil_log2(int v) {
   return s;
 }
 
-struct ChunkGeom { int rows_in, cols_in, RS, PS, SS, cshift; };
+struct ChunkGeom { int rows_in, cols_in, RS, PS, SS, cshift, rshift; };
 
 // Bank multiplicity of the per-lane operand gather for LDS strides RS = r, PS = p (mod 32): the 32
 // lanes of a half-wave read rows i .. i+31 of the unfolded matrix, i.e. words c*PS + a*RS + b with
@@ -716,21 +752,37 @@ static bool chunk_fits(const FactorDev& f, int NS, int R, int Wc, ChunkGeom& g) 
     pick_strides(f, g.rows_in, g.cols_in, g.RS, g.PS);
   }
   g.SS = f.nch * g.PS;
+  g.rshift = 0;
   if ((long long)NS * g.SS + 16 > PANEL_WORDS) return false;       // + slack for padded run elements
   if ((long long)NS * R * cdiv(Wc, f.RL) > KTAB_MAX) return false;
   if ((long long)NS * R * Wc > 4096) return false;
   if (NS > 127 || g.rows_in > 0xffff) return false;
+  if ((long long)NS * f.C * f.H * f.W * 4 > 0x7fff0000ll) return false;   // buffer offsets of a chunk: 31 bits
   const long long prow = (long long)NS * f.nch * g.rows_in;
+  // flat modes: a slot covers 256 >> cshift (sample, channel) rows and must not straddle samples:
+  // nch is a power of two there, so it is enough to keep at least 256 / nch lanes along the pixels
+  const int min_cshift = f.flat ? std::max(0, 8 - ceil_log2(f.nch)) : 0;
   if (f.vec4) {
     if (Wc % 4 != 0) return false;
-    g.cshift = ceil_log2(Wc / 4);
+    g.cshift = std::max(ceil_log2(Wc / 4), min_cshift);
     if (g.cshift > 6) return false;                                    // <= 64 lanes along x4
     if ((prow << g.cshift) * 4 > PANEL_SLOT_ELEMS) return false;       // float4 slots per lane
   } else {
-    if (prow > ROWTAB_MAX) return false;
-    g.cshift = ceil_log2(g.cols_in);
+    g.cshift = std::max(ceil_log2(g.cols_in), min_cshift);
     if (g.cshift > 8) return false;                                    // <= 256 lanes along x
-    if ((prow << g.cshift) > PANEL_SLOT_ELEMS) return false;
+    if (f.flat) {
+      if ((prow << g.cshift) > PANEL_SLOT_ELEMS) return false;         // rows = (sample, channel)
+    } else {
+      // row lanes = 256 >> cshift: 2^rshift of them walk the folded (sample, row) index, the rest
+      // stage that many channels side by side; slots = row passes x channel groups
+      const int rl = SYRK_THREADS >> g.cshift;
+      g.rshift = std::min(ceil_log2(NS * g.rows_in), ceil_log2(rl));
+      const int CL = rl >> g.rshift;
+      const int n_cgs = cdiv(f.nch, CL);
+      if ((long long)cdiv(NS * g.rows_in, 1 << g.rshift) * n_cgs > STAGE_SLOTS) return false;
+      g.SS = n_cgs * CL * g.PS;                                          // planes of the last, partial group
+      if ((long long)NS * g.SS + 16 > PANEL_WORDS) return false;
+    }
   }
   return true;
 }
@@ -781,7 +833,8 @@ static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     // tile edge: 128 where the padding it adds is small, 64 otherwise
     f.TM = (f.dim >= 256 && cdiv(f.dim, 128) * 128 <= f.dim + f.dim / 14) ? 128 : 64;
     f.nch = std::min(f.C, (f.khkw + f.TM - 2) / f.khkw + 1);
-    f.vec4 = (flattened && f.W % 4 == 0 && f.W >= 4 && (reinterpret_cast<uintptr_t>(s.src) & 15) == 0) ? 1 : 0;
+    f.flat = (flattened && (f.nch & (f.nch - 1)) == 0) ? 1 : 0;
+    f.vec4 = (f.flat && f.W % 4 == 0 && f.W >= 4 && (reinterpret_cast<uintptr_t>(s.src) & 15) == 0) ? 1 : 0;
 
     // k-run length: 4 LDS-adjacent k values per operand address where the row padding it needs is
     // cheaper than the address arithmetic it saves
@@ -802,6 +855,7 @@ static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     int Wc = f.Wo, R = 1, NS = 1;
     if (!chunk_fits(f, 1, 1, Wc, g)) {
       if (f.vec4 && !chunk_fits(f, 1, 1, 4, g)) f.vec4 = 0;
+      if (f.flat && !f.vec4 && !chunk_fits(f, 1, 1, 1, g)) f.flat = 0;
       const int unit = f.vec4 ? 4 : 1;
       CURV_REQUIRE(chunk_fits(f, 1, 1, unit, g), "curv_kfac: factor %d: no chunk shape fits the LDS budget", i);
       int lo = 1, hi = cdiv(Wc, unit);           // in units; fits(lo), !fits(hi); monotone
@@ -823,7 +877,8 @@ static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     }
     CURV_REQUIRE(chunk_fits(f, NS, R, Wc, g), "curv_kfac: factor %d: internal chunk planning error", i);
     f.NS = NS; f.R = R; f.Wc = Wc;
-    f.RS = g.RS; f.PS = g.PS; f.SS = g.SS; f.cshift = g.cshift;
+    f.RS = g.RS; f.PS = g.PS; f.SS = g.SS; f.cshift = g.cshift; f.rshift = g.rshift;
+    f.rmagic = (unsigned)(((1ull << 32) + (unsigned)g.rows_in - 1) / (unsigned)g.rows_in);   // unused when rows_in == 1
     f.n_rg = cdiv(f.Ho, R);
     f.n_cg = cdiv(f.Wo, Wc);
     f.n_chunks = cdiv(f.N, NS) * f.n_rg * f.n_cg;
@@ -895,7 +950,7 @@ extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors,
     o[0] = f.dim; o[1] = f.Ho; o[2] = f.Wo; o[3] = f.NS; o[4] = f.R; o[5] = f.Wc;
     o[6] = f.n_chunks; o[7] = f.RS; o[8] = f.PS; o[9] = f.SS; o[10] = f.nch;
     o[11] = f.n_tiles; o[12] = f.cpi; o[13] = f.n_slices; o[14] = f.n_items; o[15] = f.item_base;
-    o[16] = f.TM; o[17] = f.vec4; o[18] = f.cshift; o[19] = f.n_sub; o[20] = f.RL;
+    o[16] = f.TM; o[17] = f.vec4; o[18] = f.cshift; o[19] = f.n_sub; o[20] = f.RL; o[21] = f.rshift;
   }
   return CURV_OK;
 }

@@ -7,9 +7,9 @@ import pytest
 
 from curvature_amd import _lib
 
-NF = 21
-NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub RL".split()
-PANEL_WORDS, ROWTAB_MAX, KTAB_MAX, SLOT_ELEMS = 8704, 512, 1024, 32 * 256
+NF = 22
+NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub RL rshift".split()
+PANEL_WORDS, KTAB_MAX, SLOTS, THREADS = 8704, 1024, 32, 256
 
 
 def plan(descs):
@@ -34,7 +34,8 @@ CASES = [geom(N, C, H, H, k, s, p, b)
          [(32, 3, 224, 7, 2, 3, 0), (32, 64, 56, 1, 1, 0, 0), (32, 64, 56, 3, 1, 1, 0), (32, 128, 56, 3, 2, 1, 0),
           (32, 256, 56, 1, 2, 0, 0), (32, 512, 7, 3, 1, 1, 0), (32, 2048, 7, 1, 1, 0, 0), (32, 2048, 1, 1, 1, 0, 1),
           (100, 1, 28, 5, 1, 2, 1), (100, 6, 14, 5, 1, 0, 1), (100, 400, 1, 1, 1, 0, 1), (1, 1, 1, 1, 1, 0, 0),
-          (7, 33, 17, 3, 3, 0, 1), (2, 5, 300, 11, 4, 5, 0), (3, 700, 5, 1, 1, 0, 0)]]
+          (7, 33, 17, 3, 3, 0, 1), (2, 5, 300, 11, 4, 5, 0), (3, 700, 5, 1, 1, 0, 0), (3, 37, 28, 1, 1, 0, 0),
+          (3, 37, 1, 1, 1, 0, 0), (2, 37, 9, 1, 2, 0, 0)]]
 
 
 @pytest.mark.parametrize("d", CASES)
@@ -50,12 +51,19 @@ def test_plan_respects_budgets(d):
     assert p["NS"] * p["SS"] + 16 <= PANEL_WORDS                      # LDS patch per panel
     rows_in = p["R"] if compact else (p["R"] - 1) * d["sh"] + d["kh"]
     cols_in = p["Wc"] if compact else (p["Wc"] - 1) * d["sw"] + d["kw"]
-    assert p["RS"] >= cols_in and p["PS"] >= rows_in * p["RS"] and p["SS"] == p["nch"] * p["PS"]
+    assert p["RS"] >= cols_in and p["PS"] >= rows_in * p["RS"] and p["SS"] >= p["nch"] * p["PS"]
     prow = p["NS"] * p["nch"] * rows_in
     if p["vec4"]:
-        assert p["Wc"] % 4 == 0 and (prow << p["cshift"]) * 4 <= SLOT_ELEMS
+        assert p["Wc"] % 4 == 0 and (prow << p["cshift"]) * 4 <= SLOTS * THREADS
+    elif flat and p["nch"] & (p["nch"] - 1) == 0:
+        assert (prow << p["cshift"]) <= SLOTS * THREADS and (1 << p["cshift"]) >= cols_in
     else:
-        assert prow <= ROWTAB_MAX and (prow << p["cshift"]) <= SLOT_ELEMS and (1 << p["cshift"]) >= cols_in
+        # general staging: 2^rshift row lanes walk the folded (sample, row) index, the others split channels
+        row_lanes = THREADS >> p["cshift"]
+        assert (1 << p["cshift"]) >= cols_in and (1 << p["rshift"]) <= row_lanes
+        passes = -(-(p["NS"] * rows_in) // (1 << p["rshift"]))
+        groups = -(-p["nch"] // (row_lanes >> p["rshift"]))
+        assert passes * groups <= SLOTS and p["SS"] == groups * (row_lanes >> p["rshift"]) * p["PS"]
     runs = p["NS"] * p["R"] * -(-p["Wc"] // p["RL"])
     assert runs <= KTAB_MAX
     # chunk grid covers all of K = N * Ho * Wo

@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Build tools/micro/libcurv_prof.so: the library with clock64() probes patched into syrk_body (phase
+breakdown for tools/prof_syrk.py).  Diagnostics only; the patched source lives in /tmp."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "curvature_amd", "csrc")
+
+
+def sub(s, a, b):
+    assert a in s, a
+    return s.replace(a, b, 1)
+
+
+def main():
+    s = open(os.path.join(CSRC, "syrk.hip")).read()
+    s = sub(s, "namespace curv {\n", "namespace curv {\n__device__ unsigned long long g_prof[16];\n"
+            "#define PROF(k) { long long t_ = clock64(); pacc[k] += (unsigned)(t_ - tprev); tprev = t_; }\n")
+    s = sub(s, "  const int h = lane >> 5;\n", "  const int h = lane >> 5;\n  long long tprev = clock64();\n"
+            "  unsigned pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned nmf = 0;\n")
+    s = sub(s, "  for (int ch = ch_begin; ch < ch_end; ++ch) {\n", "  PROF(0)\n  for (int ch = ch_begin; ch < ch_end; ++ch) {\n")
+    s = sub(s, "    if (!(d.pad0 & 2) || ch == ch_begin) store_stage(cur);\n    __syncthreads();\n",
+            "    PROF(1)\n    if (!(d.pad0 & 2) || ch == ch_begin) store_stage(cur);\n    PROF(2)\n    __syncthreads();\n    PROF(3)\n")
+    s = sub(s, "    // ---- MFMA over this wave's share of the chunk's k-runs ----", "    PROF(4)")
+    s = sub(s, "      else go(std::integral_constant<int, 1>{});\n    }\n    __syncthreads();\n",
+            "      else go(std::integral_constant<int, 1>{});\n"
+            "      nmf += (work.niter - kfirst + KSTRIDE - 1) / KSTRIDE * (skip10 ? 3 : 4) * RL;\n    }\n"
+            "    PROF(5)\n    __syncthreads();\n    PROF(6)\n")
+    s = sub(s, "      q[(32 + row) * 128 + 32 + r32] = acc11[reg];\n    }\n  }\n}\n",
+            "      q[(32 + row) * 128 + 32 + r32] = acc11[reg];\n    }\n  }\n  PROF(7)\n"
+            "  if (lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&g_prof[k], (unsigned long long)pacc[k]);"
+            " atomicAdd(&g_prof[10], (unsigned long long)nmf); atomicAdd(&g_prof[11], 1ull); }\n}\n")
+    s += '''
+extern "C" int curv_debug_syrk_prof(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(curv::g_prof), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(curv::g_prof), 16 * sizeof(unsigned long long));
+}
+'''
+    src = "/tmp/syrk_prof.hip"
+    open(src, "w").write(s)
+    out = os.path.join(ROOT, "tools", "micro", "libcurv_prof.so")
+    others = ["api.cpp", "elementwise.hip", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+           "-I" + CSRC, "-o", out, src] + [os.path.join(CSRC, o) for o in others]
+    subprocess.check_call(cmd)
+    print("built", out)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

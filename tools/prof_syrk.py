@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Phase-cycle breakdown of syrk_patch_kernel from an instrumented build (tools/micro/libcurv_prof.so,
+built from syrk.hip + clock64() probes; diagnostics only, never shipped)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from curvature_amd import _lib  # noqa: E402
+
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "libcurv_prof.so")
+from curvature_amd import models, ops  # noqa: E402
+import bench_syrk  # noqa: E402
+
+NAMES = ["prologue", "ktab", "store_stage", "sync1", "decode+issue_loads", "mfma_loop", "sync2", "epilogue"]
+
+
+def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    dev = torch.device("cuda:0")
+    model = models.resnet50()
+    jobs, meta = bench_syrk.make_jobs(model, (3, 224, 224), 32, dev)
+    if only:
+        kind, dim = only.split(":")     # e.g. 3x3:2304, 1x1:1024
+        k = int(kind[0])
+        jobs = [j for j in jobs if j.dst.shape[0] == int(dim) and j.kernel[0] == k]
+    h = _lib.lib()
+    h.curv_debug_syrk_prof.restype = ctypes.c_int
+    h.curv_debug_syrk_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    ops.kfac_accumulate(jobs)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 16)()
+    h.curv_debug_syrk_prof(buf, 1)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    ops.kfac_accumulate(jobs)
+    ev1.record()
+    torch.cuda.synchronize()
+    h.curv_debug_syrk_prof(buf, 0)
+    v = list(buf)
+    tot = sum(v[:8])
+    print(f"launch {ev0.elapsed_time(ev1):.3f} ms; wave-cycles total {tot:.3e}; items(waves) {v[11]}; MFMA {v[10]}")
+    for n, c in zip(NAMES, v[:8]):
+        print(f"  {n:20s} {c:.3e}  {100.0 * c / tot:5.1f}%")
+    print(f"  cycles per MFMA inside the loop: {v[5] / max(v[10], 1):.1f}  (64 = pipe-bound for one wave, "
+          f"128 = two waves sharing a SIMD)")
+
+
+if __name__ == "__main__":
+    main()
