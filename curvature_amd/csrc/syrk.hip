@@ -517,13 +517,13 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
         ktab[q] = v;
       }
     }
-    if (!(d.pad0 & 2) || ch == ch_begin) store_stage(cur);
+    if (!(d.pad0 & 10) || ch == ch_begin) store_stage(cur);
     __syncthreads();
 
     const Chunk work = cur;
     if (ch + 1 < ch_end) {
       cur = decode_chunk(ch + 1);
-      if (!(d.pad0 & 2)) issue_loads(cur);                  // in flight during the MFMA loop below
+      if (!(d.pad0 & 6)) issue_loads(cur);                  // in flight during the MFMA loop below
     }
 
     // ---- MFMA over this wave's share of the chunk's k-runs ----
@@ -788,7 +788,8 @@ static bool chunk_fits(const FactorDev& f, int NS, int R, int Wc, ChunkGeom& g) 
 }
 
 struct Plan {
-  std::vector<FactorDev> f;
+  std::vector<FactorDev> f;             // caller order
+  std::vector<int> order;               // device-table order: factors by descending work per item
   int n_items = 0;
   int n_sub = 0;
   long long slab_floats = 0;
@@ -893,6 +894,7 @@ static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
   // a few percent, while keeping the slab traffic negligible.
   const double target = std::max(total_cost / (512.0 * 16.0), 1.0);
   long long items = 0, subs = 0, slab = 0;
+  std::vector<double> item_cost(n);
   for (int i = 0; i < n; ++i) {
     FactorDev& f = plan.f[i];
     int cpi = (int)(target / chunk_cost[i] + 0.5);
@@ -902,6 +904,15 @@ static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     f.n_slices = cdiv(f.n_chunks, f.cpi);
     f.n_items = f.n_slices * f.n_tiles;
     f.n_sub = f.n_tiles * (f.TM / 64) * (f.TM / 64);
+    item_cost[i] = chunk_cost[i] * f.cpi;
+  }
+  // Work items are dispatched in index order: the longest items go first, so that the tail of the
+  // launch is made of the shortest ones (the resident workgroups drain within one short item).
+  plan.order.resize(n);
+  for (int i = 0; i < n; ++i) plan.order[i] = i;
+  std::stable_sort(plan.order.begin(), plan.order.end(), [&](int a, int b) { return item_cost[a] > item_cost[b]; });
+  for (int k = 0; k < n; ++k) {
+    FactorDev& f = plan.f[plan.order[k]];
     f.item_base = (int)items;
     f.sub_base = (int)subs;
     f.slab_base = slab;
@@ -975,7 +986,7 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
     TableChunk chunk;
     const int count = std::min(UPLOAD_CHUNK, n_factors - b);
     memset(&chunk, 0, sizeof(chunk));
-    memcpy(chunk.f, plan.f.data() + b, (size_t)count * sizeof(FactorDev));
+    for (int k = 0; k < count; ++k) chunk.f[k] = plan.f[plan.order[b + k]];
     hipLaunchKernelGGL(upload_table_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count,
                        b == 0 ? zeros : nullptr);
     CURV_LAUNCH_CHECK();

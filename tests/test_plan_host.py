@@ -74,8 +74,10 @@ def test_plan_respects_budgets(d):
     assert p["ntiles"] == P * (P + 1) // 2 and p["nitems"] == p["ntiles"] * p["nslices"]
 
 
-def test_item_bases_are_contiguous():
-    ps = plan(CASES)
+def test_item_bases_tile_the_work_list():
+    """Factors are laid out in the work list by descending work per item; together their
+    [base, base + nitems) ranges cover the list exactly once."""
+    ps = sorted(plan(CASES), key=lambda p: p["base"])
     base = 0
     for p in ps:
         assert p["base"] == base

@@ -40,10 +40,13 @@ def main():
     torch.cuda.synchronize()
     h.curv_debug_syrk_prof(buf, 0)
     v = list(buf)
-    tot = sum(v[:8])
+    tot = sum(v[:8]) + v[8]
     print(f"launch {ev0.elapsed_time(ev1):.3f} ms; wave-cycles total {tot:.3e}; items(waves) {v[11]}; MFMA {v[10]}")
     for n, c in zip(NAMES, v[:8]):
         print(f"  {n:20s} {c:.3e}  {100.0 * c / tot:5.1f}%")
+    print(f"  wait for staged loads (vmcnt) before the store phase: {v[8]:.3e}  {100.0 * v[8] / tot:5.1f}%")
+    nch = max(v[12], 1)
+    print(f"  wave-chunks {v[12]}; per wave-chunk cycles: " + ", ".join(f"{n}={c / nch:.0f}" for n, c in zip(NAMES, v[:8])))
     print(f"  cycles per MFMA inside the loop: {v[5] / max(v[10], 1):.1f}  (64 = pipe-bound for one wave, "
           f"128 = two waves sharing a SIMD)")
 
