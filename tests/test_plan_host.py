@@ -7,8 +7,8 @@ import pytest
 
 from curvature_amd import _lib
 
-NF = 22
-NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub RL rshift".split()
+NF = 23
+NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub RL rshift lin".split()
 PANEL_WORDS, KTAB_MAX, SLOTS, THREADS = 8704, 1024, 32, 256
 
 
@@ -55,6 +55,11 @@ def test_plan_respects_budgets(d):
     prow = p["NS"] * p["nch"] * rows_in
     if p["vec4"]:
         assert p["Wc"] % 4 == 0 and (prow << p["cshift"]) * 4 <= SLOTS * THREADS
+    elif p["lin"]:
+        # linear staging of full-width chunks: V floats per lane over the contiguous rows x W source range
+        assert not compact and p["Wc"] == Wo and p["lin"] == (2 if d["W"] % 2 == 0 else 1)
+        lanes = p["NS"] * rows_in * d["W"] // p["lin"]
+        assert -(-lanes // THREADS) * p["nch"] * p["lin"] <= SLOTS
     elif flat and p["nch"] & (p["nch"] - 1) == 0:
         assert (prow << p["cshift"]) <= SLOTS * THREADS and (1 << p["cshift"]) >= cols_in
     else:

@@ -49,6 +49,33 @@ def main():
     print(f"  wave-chunks {v[12]}; per wave-chunk cycles: " + ", ".join(f"{n}={c / nch:.0f}" for n, c in zip(NAMES, v[:8])))
     print(f"  cycles per MFMA inside the loop: {v[5] / max(v[10], 1):.1f}  (64 = pipe-bound for one wave, "
           f"128 = two waves sharing a SIMD)")
+    timeline(h)
+
+
+def timeline(h):
+    import numpy as np
+    buf = (ctypes.c_ulonglong * (3 * 16384))()
+    h.curv_debug_syrk_times.restype = ctypes.c_int
+    h.curv_debug_syrk_times.argtypes = [ctypes.c_void_p]
+    h.curv_debug_syrk_times(buf)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 3)
+    a = a[a[:, 1] > 0]
+    t0 = a[:, 0].min()
+    st, en = (a[:, 0] - t0).astype(np.float64) / 100.0, (a[:, 1] - t0).astype(np.float64) / 100.0   # us (100 MHz)
+    span = en.max()
+    print(f"  timeline: {len(a)} items, span {span:.0f} us, sum of item time {np.sum(en - st) / 512:.0f} us per slot "
+          f"(occupancy {np.sum(en - st) / 512 / span:.2f})")
+    for frac in (0.5, 0.8, 0.9, 0.95, 1.0):
+        t = span * frac
+        print(f"    active items at {frac:.2f} span: {int(np.sum((st <= t) & (en > t)))}")
+    keys = {}
+    for (s0, e0, k) in zip(st, en, a[:, 2]):
+        keys.setdefault(int(k), []).append(e0 - s0)
+    print("    item duration by (dim, kh, TM):")
+    for k in sorted(keys, key=lambda k: -np.sum(keys[k])):
+        v = np.array(keys[k])
+        print(f"      dim {k >> 32:5d} k{(k & 0xffffffff) // 100} TM{(k & 0xffffffff) % 100:3d}: n={len(v):5d} mean {v.mean():7.1f} us  "
+              f"max {v.max():7.1f}  total/512 {v.sum() / 512:7.1f} us")
 
 
 if __name__ == "__main__":
