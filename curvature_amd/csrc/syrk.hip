@@ -74,6 +74,9 @@ struct FactorDev {
   int rshift;              // general staging: a lane group of 2^rshift folded rows; the other row lanes split channels
   int flat;                // flattened per-pixel factor whose (sample, channel) rows are staged slot-regularly
   unsigned rmagic;         // ceil(2^32 / patch rows per sample): folded (sample, row) index -> sample
+  int lin;                 // linear staging: lanes walk the contiguous rows x W source range, `lin` floats each
+  unsigned pmagic, wmagic; // linear staging: ceil(2^32 / lanes per sample), ceil(2^32 / W)
+  int pad2;
   long long slab_base;     // in floats
 };
 static_assert(sizeof(FactorDev) % 8 == 0, "FactorDev must be 8-byte granular");
@@ -101,6 +104,7 @@ __device__ __forceinline__ void decode_tile(int t, int P, int& ti, int& tj) {
 typedef __attribute__((address_space(1))) float gfloat;      // global-address-space views
 typedef __attribute__((address_space(1))) f32x4 gf32x4;
 typedef __attribute__((address_space(1))) char gchar;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Position and extent of one K chunk.
 struct Chunk {
@@ -253,7 +257,101 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
     return g;
   };
 
+  // linear path (chunks spanning the full width): the patch rows of one channel are ONE contiguous
+  // source range of rows_in * W floats, so lanes walk it linearly, V floats per lane: every wave load is
+  // a fully coalesced 256 * V bytes (a (row, x)-mapped load touches 2 cache lines per 56-byte row), and
+  // V = 2 halves the load and the LDS-store instruction counts.  The left/right halo columns are never
+  // written and stay zero from the fill above; rows above/below the image come back 0 from the range
+  // check.
+  const int lin = d.lin;                               // 0, or V
+  const unsigned pmagic = d.pmagic, wmagic = d.wmagic;
+  const int lin_P = lin ? rows_in_full * W / lin : 1;  // lanes per sample
+  auto lin_geo = [&](const Chunk& c, int k, int t) {
+    RowGeo g;
+    const int q = t + k * SYRK_THREADS;
+    const int s = (NS == 1) ? 0 : (lin_P == 1) ? q : (int)__umulhi((unsigned)q, pmagic);
+    const int e0 = (q - s * lin_P) * lin;              // first element of the lane inside the sample's range
+    const int y = (W == 1) ? e0 : (int)__umulhi((unsigned)e0, wmagic);
+    const int x = e0 - y * W;
+    const int ih = c.ih_base + y;
+    g.inr = q < NS * lin_P && s < c.ns && y < c.rows_in && x + pw < c.cols_in;
+    const bool ok = g.inr && (unsigned)ih < (unsigned)H;
+    g.voff = ok ? (s * C * HW + ih * W + x) * 4 : OOB;
+    g.laddr = s * SS + y * RS + x + pw;
+    return g;
+  };
+
   float st[2 * STAGE_SLOTS];
+
+  auto lin_load = [&](auto v_tag, __amdgpu_buffer_rsrc_t rs, int voff, int soff, int slot) {
+    constexpr int V = decltype(v_tag)::value;
+    if constexpr (V == 2) {
+      const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+      st[slot] = v.x; st[slot + 1] = v.y;
+    } else {
+      st[slot] = bload(rs, voff, soff);
+    }
+  };
+  auto issue_lin = [&](auto ncg_tag, auto v_tag, const Chunk& c, __amdgpu_buffer_rsrc_t rs, int pnl, int c_lo, int t) {
+    constexpr int NCG = decltype(ncg_tag)::value;
+    constexpr int V = decltype(v_tag)::value;
+    const int step = HW * 4;
+    int soff0 = c_lo * HW * 4;
+    asm volatile("" : "+s"(soff0));
+    if constexpr (NCG > 0) {
+#pragma unroll
+      for (int k = 0; k < STAGE_SLOTS / V / NCG; ++k) {
+        const RowGeo g = lin_geo(c, k, t);
+        int soff = soff0;
+#pragma unroll
+        for (int cc = 0; cc < NCG; ++cc) {
+          lin_load(v_tag, rs, g.voff, soff, pnl * STAGE_SLOTS + (k * NCG + cc) * V);
+          soff += step;
+        }
+      }
+    } else {
+      int cc = 0, k = 0, soff = soff0;
+      RowGeo g = lin_geo(c, 0, t);
+#pragma unroll
+      for (int j = 0; j < STAGE_SLOTS / V; ++j) {
+        lin_load(v_tag, rs, g.voff, soff, pnl * STAGE_SLOTS + j * V);
+        soff += step;
+        if (++cc == nch) { cc = 0; soff = soff0; ++k; g = lin_geo(c, k, t); }
+      }
+    }
+  };
+  auto store_lin = [&](auto ncg_tag, auto v_tag, const Chunk& c, float* lbase, int pnl, int t) {
+    constexpr int NCG = decltype(ncg_tag)::value;
+    constexpr int V = decltype(v_tag)::value;
+    int lstep = PS;
+    asm volatile("" : "+s"(lstep));
+    if constexpr (NCG > 0) {
+#pragma unroll
+      for (int k = 0; k < STAGE_SLOTS / V / NCG; ++k) {
+        const RowGeo g = lin_geo(c, k, t);
+        if (g.inr) {
+          float* l = lbase + g.laddr;
+#pragma unroll
+          for (int cc = 0; cc < NCG; ++cc) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) l[v] = st[pnl * STAGE_SLOTS + (k * NCG + cc) * V + v];
+            l += lstep;
+          }
+        }
+      }
+    } else {
+      int cc = 0, k = 0;
+      RowGeo g = lin_geo(c, 0, t);
+#pragma unroll
+      for (int j = 0; j < STAGE_SLOTS / V; ++j) {
+        if (g.inr) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) lbase[g.laddr + cc * lstep + v] = st[pnl * STAGE_SLOTS + j * V + v];
+        }
+        if (++cc == nch) { cc = 0; ++k; g = lin_geo(c, k, t); }
+      }
+    }
+  };
 
   // NCG > 0: channel groups per row pass known at compile time (slot -> (pass, group) is static and the
   // loop is straight-line); NCG == 0: run-time counters with a uniform branch per slot.
@@ -355,6 +453,19 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
             cb += prow_step;
             if (cb == nch) { cb = 0; ++srow; }
           }
+        } else if (lin) {
+          int t = tid;
+          asm volatile("" : "+v"(t));
+          using I2 = std::integral_constant<int, 2>;
+          using I1 = std::integral_constant<int, 1>;
+          if (lin == 2) {
+            if (nch == 16) issue_lin(std::integral_constant<int, 16>{}, I2{}, c, rs, pnl, c_lo, t);
+            else if (nch == 8) issue_lin(std::integral_constant<int, 8>{}, I2{}, c, rs, pnl, c_lo, t);
+            else issue_lin(std::integral_constant<int, 0>{}, I2{}, c, rs, pnl, c_lo, t);
+          } else {
+            if (nch == 16) issue_lin(std::integral_constant<int, 16>{}, I1{}, c, rs, pnl, c_lo, t);
+            else issue_lin(std::integral_constant<int, 0>{}, I1{}, c, rs, pnl, c_lo, t);
+          }
         } else if (n_cgs == 16) {
           issue_general(std::integral_constant<int, 16>{}, c, rs, pnl, c_lo, lx, prow0);
         } else if (n_cgs == 8) {
@@ -403,6 +514,19 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
               cb += prow_step;
               if (cb == nch) { cb = 0; ++srow; }
             }
+          }
+        } else if (lin) {
+          int t = tid;
+          asm volatile("" : "+v"(t));
+          using I2 = std::integral_constant<int, 2>;
+          using I1 = std::integral_constant<int, 1>;
+          if (lin == 2) {
+            if (nch == 16) store_lin(std::integral_constant<int, 16>{}, I2{}, c, lbase, pnl, t);
+            else if (nch == 8) store_lin(std::integral_constant<int, 8>{}, I2{}, c, lbase, pnl, t);
+            else store_lin(std::integral_constant<int, 0>{}, I2{}, c, lbase, pnl, t);
+          } else {
+            if (nch == 16) store_lin(std::integral_constant<int, 16>{}, I1{}, c, lbase, pnl, t);
+            else store_lin(std::integral_constant<int, 0>{}, I1{}, c, lbase, pnl, t);
           }
         } else if (n_cgs == 16) {
           store_general(std::integral_constant<int, 16>{}, c, lbase, pnl, lx, prow0);
@@ -687,7 +811,7 @@ static int ceil_log2(int v) {
   return s;
 }
 
-struct ChunkGeom { int rows_in, cols_in, RS, PS, SS, cshift, rshift; };
+struct ChunkGeom { int rows_in, cols_in, RS, PS, SS, cshift, rshift, lin; };
 
 // Bank multiplicity of the per-lane operand gather for LDS strides RS = r, PS = p (mod 32): the 32
 // lanes of a half-wave read rows i .. i+31 of the unfolded matrix, i.e. words c*PS + a*RS + b with
@@ -753,6 +877,7 @@ static bool chunk_fits(const FactorDev& f, int NS, int R, int Wc, ChunkGeom& g) 
   }
   g.SS = f.nch * g.PS;
   g.rshift = 0;
+  g.lin = 0;
   if ((long long)NS * g.SS + 16 > PANEL_WORDS) return false;       // + slack for padded run elements
   if ((long long)NS * R * cdiv(Wc, f.RL) > KTAB_MAX) return false;
   if ((long long)NS * R * Wc > 4096) return false;
@@ -768,6 +893,15 @@ static bool chunk_fits(const FactorDev& f, int NS, int R, int Wc, ChunkGeom& g) 
     if (g.cshift > 6) return false;                                    // <= 64 lanes along x4
     if ((prow << g.cshift) * 4 > PANEL_SLOT_ELEMS) return false;       // float4 slots per lane
   } else {
+    if (!f.compact && Wc == f.Wo) {
+      // full-width chunk: linear staging, V floats per lane (V = 2 keeps both in one image row)
+      const int V = (f.W % 2 == 0) ? 2 : 1;
+      const long long lanes = (long long)NS * g.rows_in * f.W / V;
+      if (cdivll(lanes, SYRK_THREADS) * f.nch * V > STAGE_SLOTS) return false;
+      g.lin = V;
+      g.cshift = 0;
+      return true;
+    }
     g.cshift = std::max(ceil_log2(g.cols_in), min_cshift);
     if (g.cshift > 8) return false;                                    // <= 256 lanes along x
     if (f.flat) {
@@ -878,7 +1012,12 @@ static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     }
     CURV_REQUIRE(chunk_fits(f, NS, R, Wc, g), "curv_kfac: factor %d: internal chunk planning error", i);
     f.NS = NS; f.R = R; f.Wc = Wc;
-    f.RS = g.RS; f.PS = g.PS; f.SS = g.SS; f.cshift = g.cshift; f.rshift = g.rshift;
+    f.RS = g.RS; f.PS = g.PS; f.SS = g.SS; f.cshift = g.cshift; f.rshift = g.rshift; f.lin = g.lin;
+    if (f.lin) {
+      const unsigned lanes_per_sample = (unsigned)(g.rows_in * f.W / f.lin);
+      f.pmagic = (unsigned)(((1ull << 32) + lanes_per_sample - 1) / lanes_per_sample);
+      f.wmagic = (unsigned)(((1ull << 32) + (unsigned)f.W - 1) / (unsigned)f.W);
+    }
     f.rmagic = (unsigned)(((1ull << 32) + (unsigned)g.rows_in - 1) / (unsigned)g.rows_in);   // unused when rows_in == 1
     f.n_rg = cdiv(f.Ho, R);
     f.n_cg = cdiv(f.Wo, Wc);
@@ -961,7 +1100,7 @@ extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors,
     o[0] = f.dim; o[1] = f.Ho; o[2] = f.Wo; o[3] = f.NS; o[4] = f.R; o[5] = f.Wc;
     o[6] = f.n_chunks; o[7] = f.RS; o[8] = f.PS; o[9] = f.SS; o[10] = f.nch;
     o[11] = f.n_tiles; o[12] = f.cpi; o[13] = f.n_slices; o[14] = f.n_items; o[15] = f.item_base;
-    o[16] = f.TM; o[17] = f.vec4; o[18] = f.cshift; o[19] = f.n_sub; o[20] = f.RL; o[21] = f.rshift;
+    o[16] = f.TM; o[17] = f.vec4; o[18] = f.cshift; o[19] = f.n_sub; o[20] = f.RL; o[21] = f.rshift; o[22] = f.lin;
   }
   return CURV_OK;
 }
