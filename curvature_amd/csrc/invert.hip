@@ -12,9 +12,8 @@
 // Batched right-looking blocked algorithm, block 64, all factors of the model advance together; every
 // launch is a flat list of independent 64x64 tile operations, so the critical path per step is one block
 // operation whatever the matrix size:
-//   step k:  (1) every workgroup of block column k factorises the 64x64 diagonal block in LDS
-//                (redundantly: cheaper than another launch), then A[i][k] <- A[i][k] L_kk^-T;
-//                the workgroup of the diagonal block stores X_kk = L_kk^-1 (A_kk stays read-only)
+//   step k:  (1) one workgroup per factor factorises the 64x64 diagonal block in LDS and stores
+//                X_kk = L_kk^-1; then, in one launch with (3), A[i][k] <- A[i][k] X_kk^T
 //            (2) trailing update  A[i][j] -= A[i][k] A[j][k]^T           for k < j <= i
 //            (3) X[k][j] = -X_kk S[k][j]                                 for j < k   (row k of C^-1 final)
 //            (4) S[i][j] (+)= C[i][k] X[k][j]                            for i > k, j <= k
@@ -123,11 +122,21 @@ __device__ __host__ __forceinline__ long long inner_tiles(int P, int k, int kend
 // Outer tile lists are enumerated in 8x8 super-blocks (64 consecutive work items = one super-block, mapped
 // to one XCD): the 16 operand panels of a super-block (2 MB) stay in that XCD's L2 for its 64 tiles.
 constexpr int SB = 8;
-__device__ __host__ __forceinline__ long long outer_tiles(int P, int kend) {
-  const long long r = P - kend;
+// far part of an outer update: rows/cols from row0 on (trailing) and rows from row0 on x cols < kend (S)
+__device__ __host__ __forceinline__ long long outer_tiles(int P, int kend, int row0) {
+  const long long r = P - row0;
   if (r <= 0) return 0;
   const long long nsb = (r + SB - 1) / SB, ncb = (kend + SB - 1) / SB;
   return (nsb * (nsb + 1) / 2 + nsb * ncb) * (SB * SB);
+}
+// near part ("strip"): what the next panel's chain of diagonal steps needs first: trailing tiles of the
+// block columns [kend, row0) and S tiles of the block rows [kend, row0)
+__device__ __host__ __forceinline__ long long strip_tiles(int P, int kend, int row0) {
+  const int re = row0 < P ? row0 : P;
+  long long n = 0;
+  for (int j = kend; j < re; ++j) n += P - j;
+  if (re > kend) n += (long long)(re - kend) * kend;
+  return n;
 }
 
 __device__ __forceinline__ void store_sub(gdouble* C, int np, const f64x4 (&acc)[2][2], int wm, int wn, int lane,
@@ -184,39 +193,58 @@ inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int kend) {
 // (2o)/(4o) once per outer panel [k0, kend): everything beyond the panel, K = (kend - k0) * 64.
 // The next K block is fetched into registers while the MFMAs of the current one run.
 __global__ void __launch_bounds__(INV_THREADS)
-outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int n_items) {
+outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int row0, int strip, int n_items) {
   __shared__ double As[NB * LDA], Bs[NB * LDA];
-  // XCD grouping: workgroups with equal blockIdx % 8 share an XCD; give each XCD whole super-blocks
-  int item;
-  {
-    const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3;
-    item = ((jj / (SB * SB)) * 8 + xcd) * (SB * SB) + (jj % (SB * SB));
-  }
-  if (item >= n_items) return;
-  int f, local;
-  if (!locate(t, nf, item, [kend](const InvDev& d) { return (int)outer_tiles(d.P, kend); }, f, local)) return;
-  const InvDev& d = t[f];
-  const int np = d.np, r = d.P - kend;
-  const int nsb = (r + SB - 1) / SB;
-  const int sb = local / (SB * SB), in = local - sb * (SB * SB);
-  const int di = in / SB, dj = in - di * SB;
-  const int n_trail_sb = nsb * (nsb + 1) / 2;
   bool trailing;
-  int i, j;
-  if (sb < n_trail_sb) {
-    int a = 0, tl = sb;
-    while (tl > a) { tl -= a + 1; ++a; }
-    const int ri = a * SB + di, rj = tl * SB + dj;          // relative to kend
-    if (ri >= r || rj > ri) return;
-    trailing = true; i = kend + ri; j = kend + rj;
+  int i, j, f, local;
+  if (strip) {
+    // near part: block columns / rows [kend, row0)
+    if (!locate(t, nf, blockIdx.x, [kend, row0](const InvDev& d) { return (int)strip_tiles(d.P, kend, row0); }, f, local))
+      return;
+    const int P = t[f].P, re = row0 < P ? row0 : P;
+    trailing = false;
+    j = kend;
+    for (; j < re; ++j) {
+      if (local < P - j) { trailing = true; break; }
+      local -= P - j;
+    }
+    if (trailing) {
+      i = j + local;
+    } else {
+      const int a = local / kend;
+      i = kend + a; j = local - a * kend;
+    }
   } else {
-    const int s2 = sb - n_trail_sb;
-    const int ncb = (kend + SB - 1) / SB;
-    const int a = s2 / ncb, cb = s2 - a * ncb;
-    const int ri = a * SB + di; j = cb * SB + dj;
-    if (ri >= r || j >= kend) return;
-    trailing = false; i = kend + ri;
+    // far part.  XCD grouping: workgroups with equal blockIdx % 8 share an XCD; give each XCD whole super-blocks
+    int item;
+    {
+      const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3;
+      item = ((jj / (SB * SB)) * 8 + xcd) * (SB * SB) + (jj % (SB * SB));
+    }
+    if (item >= n_items) return;
+    if (!locate(t, nf, item, [kend, row0](const InvDev& d) { return (int)outer_tiles(d.P, kend, row0); }, f, local)) return;
+    const int r = t[f].P - row0;
+    const int nsb = (r + SB - 1) / SB;
+    const int sb = local / (SB * SB), in = local - sb * (SB * SB);
+    const int di = in / SB, dj = in - di * SB;
+    const int n_trail_sb = nsb * (nsb + 1) / 2;
+    if (sb < n_trail_sb) {
+      int a = 0, tl = sb;
+      while (tl > a) { tl -= a + 1; ++a; }
+      const int ri = a * SB + di, rj = tl * SB + dj;          // relative to row0
+      if (ri >= r || rj > ri) return;
+      trailing = true; i = row0 + ri; j = row0 + rj;
+    } else {
+      const int s2 = sb - n_trail_sb;
+      const int ncb = (kend + SB - 1) / SB;
+      const int a = s2 / ncb, cb = s2 - a * ncb;
+      const int ri = a * SB + di; j = cb * SB + dj;
+      if (ri >= r || j >= kend) return;
+      trailing = false; i = row0 + ri;
+    }
   }
+  const InvDev& d = t[f];
+  const int np = d.np;
   const gdouble* W = (const gdouble*)d.W;
   gdouble* X = (gdouble*)d.X;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -362,43 +390,55 @@ __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* ba
 }
 
 // ------------------------------------------------------------------------------------------------
-// (2) diagonal block factorisation (in LDS, every workgroup of the block column) + panel solve
+// (1a) diagonal block of step k: one workgroup per factor factorises A_kk in LDS and stores
+//      X_kk = L_kk^-1 (the only thing steps (1b) and (3) need; L_kk itself is never used again)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(INV_THREADS)
-chol_diag_trsm_kernel(const InvDev* __restrict__ t, int nf, int k) {
-  __shared__ double Ds[NB * LDA];     // A_kk -> L_kk (lower); afterwards this workgroup's panel block
+chol_diag_kernel(const InvDev* __restrict__ t, int nf, int k) {
+  __shared__ double Ds[NB * LDA];     // A_kk -> L_kk (lower)
   __shared__ double Is[NB * LDA];     // L_kk^-1 (lower, zeros above)
   __shared__ int bad;
-  double* Ts = Ds;                    // two LDS tiles instead of three: two workgroups per CU
   int f, local;
-  if (!locate(t, nf, blockIdx.x, [k](const InvDev& d) { return max(0, d.P - k); }, f, local)) return;
+  if (!locate(t, nf, blockIdx.x, [k](const InvDev& d) { return d.P > k ? 1 : 0; }, f, local)) return;
   const InvDev& d = t[f];
-  const int i = k + local, np = d.np;
+  const int np = d.np, tid = threadIdx.x;
   gdouble* W = (gdouble*)d.W;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   if (tid == 0) bad = 0;
   load_block(W + (long long)k * NB * np + k * NB, np, Ds);
   __syncthreads();
-
   factor_invert_64(Ds, Is, &bad, k * NB);
+  gdouble* Xg = (gdouble*)d.X + (long long)k * NB * np + k * NB;
+  for (int e = tid; e < NB * NB; e += INV_THREADS) {
+    const int r = e >> 6, q = e & 63;
+    Xg[(long long)r * np + q] = Is[r * LDA + q];
+  }
+  if (tid == 0 && bad != 0) atomicCAS(d.info, 0, bad);
+}
 
-  if (i == k) {
-    // Only X_kk = L_kk^-1 is kept.  L_kk itself is never needed again, and A_kk must NOT be overwritten
-    // here: the other workgroups of this block column (possibly scheduled later) still read it.
-    gdouble* Xg = (gdouble*)d.X + (long long)k * NB * np + k * NB;
-    for (int e = tid; e < NB * NB; e += INV_THREADS) {
-      const int r = e >> 6, q = e & 63;
-      Xg[(long long)r * np + q] = Is[r * LDA + q];
-    }
-    if (tid == 0 && bad != 0) atomicCAS(d.info, 0, bad);
-  } else {
-    // A_ik <- A_ik * L_kk^-T  =  Ts * Is^T   (Is rows are the K-contiguous operand)
-    load_block(W + (long long)i * NB * np + k * NB, np, Ts);      // L_kk is no longer needed
+// ------------------------------------------------------------------------------------------------
+// (1b) panel solve  A[i][k] <- A[i][k] X_kk^T            for i > k   (P - k - 1 tiles per factor), and
+// (3)  row k of the inverse  X[k][j] = -X_kk S[k][j]      for j < k   (k tiles per factor),
+//      one launch: both need nothing but X_kk from (1a); every workgroup owns the tile it rewrites
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(INV_THREADS)
+chol_panel_kernel(const InvDev* __restrict__ t, int nf, int k) {
+  __shared__ double As[NB * LDA], Bs[NB * LDA];
+  int f, local;
+  if (!locate(t, nf, blockIdx.x, [k](const InvDev& d) { return d.P > k ? d.P - 1 : 0; }, f, local)) return;
+  const InvDev& d = t[f];
+  const int np = d.np, n_solve = d.P - k - 1;
+  gdouble* W = (gdouble*)d.W;
+  gdouble* X = (gdouble*)d.X;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  const int c16 = lane & 15, rq = lane >> 4;
+  f64x4 acc[2][2] = {};
+  if (local < n_solve) {
+    const int i = k + 1 + local;
+    load_block(W + (long long)i * NB * np + k * NB, np, As);            // A_ik as [row][kk]
+    load_block(X + (long long)k * NB * np + k * NB, np, Bs);            // X_kk rows are the K-contiguous operand
     __syncthreads();
-    f64x4 acc[2][2] = {};
-    mma_64<true>(Ts, Is, wm, wn, lane, acc);
+    mma_64<true>(As, Bs, wm, wn, lane, acc);
     gdouble* C = W + (long long)i * NB * np + k * NB;
-    const int c16 = lane & 15, rq = lane >> 4;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -406,35 +446,21 @@ chol_diag_trsm_kernel(const InvDev* __restrict__ t, int nf, int k) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           C[(long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16] = acc[m][n][r];
+  } else {
+    const int j = local - n_solve;
+    load_block(X + (long long)k * NB * np + k * NB, np, As);            // X_kk as [row][kk]
+    load_block(X + (long long)k * NB * np + j * NB, np, Bs);            // S_kj as [kk][col]
+    __syncthreads();
+    mma_64<false>(As, Bs, wm, wn, lane, acc);
+    gdouble* C = X + (long long)k * NB * np + j * NB;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          C[(long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16] = -acc[m][n][r];
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// (3) X[k][j] = -X_kk * S[k][j] for j < k (in place: each workgroup owns its tile; X_kk is read-only)
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(INV_THREADS)
-trtri_finalize_row_kernel(const InvDev* __restrict__ t, int nf, int k) {
-  __shared__ double As[NB * LDA], Bs[NB * LDA];
-  int f, j;
-  if (!locate(t, nf, blockIdx.x, [k](const InvDev& d) { return k < d.P ? k : 0; }, f, j)) return;
-  const InvDev& d = t[f];
-  const int np = d.np;
-  gdouble* X = (gdouble*)d.X;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-  load_block(X + (long long)k * NB * np + k * NB, np, As);            // X_kk as [row][kk]
-  load_block(X + (long long)k * NB * np + j * NB, np, Bs);            // S_kj as [kk][col]
-  __syncthreads();
-  f64x4 out[2][2] = {};
-  mma_64<false>(As, Bs, wm, wn, lane, out);
-  gdouble* C = X + (long long)k * NB * np + j * NB;
-  const int c16 = lane & 15, rq = lane >> 4;
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        C[(long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16] = -out[m][n][r];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -494,6 +520,29 @@ __global__ void __launch_bounds__(256) inv_upload_kernel(InvDev* __restrict__ ta
 
 static size_t inv_table_bytes(int n) { return align_up((size_t)std::max(n, 1) * sizeof(InvDev), 256); }
 
+// Second stream for the far part of the outer updates (runs beside the next panel's chain of small
+// diagonal-step launches), with the fork/join events; one set per device, created on first use.
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_main[2] = {nullptr, nullptr};
+  hipEvent_t ev_side[2] = {nullptr, nullptr};
+};
+static int side_stream(SideStream** out) {
+  static thread_local std::vector<std::pair<int, SideStream>> cache;
+  int dev = 0;
+  CURV_HIP_CHECK(hipGetDevice(&dev));
+  for (auto& e : cache) if (e.first == dev) { *out = &e.second; return CURV_OK; }
+  SideStream s;
+  CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_main[i], hipEventDisableTiming));
+    CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_side[i], hipEventDisableTiming));
+  }
+  cache.emplace_back(dev, s);
+  *out = &cache.back().second;
+  return CURV_OK;
+}
+
 }  // namespace curv
 
 using namespace curv;
@@ -540,19 +589,26 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   hipLaunchKernelGGL(inv_prepare_kernel, dim3((unsigned)prep_tiles), dim3(INV_THREADS), 0, stream, table, n_factors);
   CURV_LAUNCH_CHECK();
   constexpr int NBO = 4;                       // outer panel: 4 block columns = 256
-  for (int k0 = 0; k0 < Pmax; k0 += NBO) {
-    const int kend = k0 + NBO;
+  // Per panel: the chain of diagonal steps (small, latency-bound launches) runs on the caller's stream,
+  // then the near part of the outer update (the block columns / rows the NEXT chain touches).  The far
+  // part goes to a second stream and overlaps the next chain; the two only meet again at the next near
+  // part, which updates tiles the far part has written.
+  SideStream* side = nullptr;
+  { const int rc = side_stream(&side); if (rc != CURV_OK) return rc; }
+  bool far_pending = false;
+  int panel = 0;
+  for (int k0 = 0; k0 < Pmax; k0 += NBO, ++panel) {
+    const int kend = k0 + NBO, row0 = kend + NBO;
     for (int k = k0; k < std::min(kend, Pmax); ++k) {
-      long long col_tiles = 0, upd_tiles = 0, row_tiles = 0;
+      long long diag_tiles = 0, panel_tiles = 0, upd_tiles = 0;
       for (const InvDev& d : tab) {
-        col_tiles += std::max(0, d.P - k);
+        if (d.P > k) { ++diag_tiles; panel_tiles += d.P - 1; }
         upd_tiles += inner_tiles(d.P, k, kend);
-        if (k < d.P) row_tiles += k;
       }
-      hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3((unsigned)col_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
+      hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)diag_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
       CURV_LAUNCH_CHECK();
-      if (row_tiles > 0) {
-        hipLaunchKernelGGL(trtri_finalize_row_kernel, dim3((unsigned)row_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
+      if (panel_tiles > 0) {
+        hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)panel_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
         CURV_LAUNCH_CHECK();
       }
       if (upd_tiles > 0) {
@@ -560,14 +616,35 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
         CURV_LAUNCH_CHECK();
       }
     }
-    long long out_tiles = 0;
-    for (const InvDev& d : tab) out_tiles += outer_tiles(d.P, kend);
-    if (out_tiles > 0) {
-      const long long grid = cdivll(out_tiles, 8 * SB * SB) * 8 * SB * SB;
-      hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend, (int)out_tiles);
+    long long near_tiles = 0, far_tiles = 0;
+    for (const InvDev& d : tab) {
+      near_tiles += strip_tiles(d.P, kend, row0);
+      far_tiles += outer_tiles(d.P, kend, row0);
+    }
+    if (far_tiles > 0) {
+      // fork: the far part needs this panel's chain, and follows the previous far part in stream order
+      CURV_HIP_CHECK(hipEventRecord(side->ev_main[panel & 1], stream));
+      CURV_HIP_CHECK(hipStreamWaitEvent(side->stream, side->ev_main[panel & 1], 0));
+    }
+    if (near_tiles > 0) {
+      if (far_pending) {                       // join: the previous far part wrote the tiles updated here
+        CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_side[(panel + 1) & 1], 0));
+        far_pending = false;
+      }
+      hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)near_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0,
+                         kend, row0, 1, (int)near_tiles);
       CURV_LAUNCH_CHECK();
     }
+    if (far_tiles > 0) {
+      const long long grid = cdivll(far_tiles, 8 * SB * SB) * 8 * SB * SB;
+      hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, side->stream, table, n_factors, k0,
+                         kend, row0, 0, (int)far_tiles);
+      CURV_LAUNCH_CHECK();
+      CURV_HIP_CHECK(hipEventRecord(side->ev_side[panel & 1], side->stream));
+      far_pending = true;
+    }
   }
+  if (far_pending) CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_side[(panel + 1) & 1], 0));
   hipLaunchKernelGGL(inv_finalize_kernel, dim3((unsigned)fin_tiles), dim3(INV_THREADS), 0, stream, table, n_factors);
   CURV_LAUNCH_CHECK();
   return CURV_OK;
