@@ -154,7 +154,12 @@ __device__ __forceinline__ void store_sub(gdouble* C, int np, const f64x4 (&acc)
       }
 }
 
-// (2i)/(4i) inner updates of step k, restricted to the outer panel [.., kend)
+__device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base);
+
+// (2i)/(4i) inner updates of step k, restricted to the outer panel [.., kend).  The workgroup that
+// finishes the next diagonal block A[k+1][k+1] factorises it on the spot and stores X_{k+1,k+1}: step
+// k + 1 then starts with its panel solve, one launch (and one 64x64 factorisation latency) less on the
+// critical path of every step that is not the first of an outer panel.
 __global__ void __launch_bounds__(INV_THREADS)
 inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int kend) {
   __shared__ double As[NB * LDA], Bs[NB * LDA];
@@ -178,7 +183,34 @@ inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int kend) {
     if (i != j) load_block(W + (long long)j * NB * np + k * NB, np, Bs);
     __syncthreads();
     mma_64<true>(As, (i != j) ? Bs : As, wm, wn, lane, acc);
-    store_sub(W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);
+    if (i == j && j == k + 1) {
+      // next diagonal block: A_jj - acc is final.  Factorise it here (As/Bs become the two work tiles).
+      __shared__ int bad;
+      __syncthreads();                                             // all waves are done reading As
+      if (threadIdx.x == 0) bad = 0;
+      load_block(W + (long long)j * NB * np + j * NB, np, As);
+      __syncthreads();
+      {
+        const int c16 = lane & 15, rq = lane >> 4;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              As[(32 * wm + 16 * m + rq + 4 * q) * LDA + 32 * wn + 16 * n + c16] -= acc[m][n][q];
+      }
+      __syncthreads();
+      factor_invert_64(As, Bs, &bad, j * NB);
+      gdouble* Xg = X + (long long)j * NB * np + j * NB;
+      for (int e = threadIdx.x; e < NB * NB; e += INV_THREADS) {
+        const int r = e >> 6, q = e & 63;
+        Xg[(long long)r * np + q] = Bs[r * LDA + q];
+      }
+      if (threadIdx.x == 0 && bad != 0) atomicCAS(d.info, 0, bad);
+    } else {
+      store_sub(W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);
+    }
   } else {
     const int a = local / (k + 1), jj = local - a * (k + 1);       // S[i][jj] (+)= C[i][k] X[k][jj]
     const int i = k + 1 + a;
@@ -605,8 +637,10 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
         if (d.P > k) { ++diag_tiles; panel_tiles += d.P - 1; }
         upd_tiles += inner_tiles(d.P, k, kend);
       }
-      hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)diag_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
-      CURV_LAUNCH_CHECK();
+      if (k == k0) {    // later diagonal blocks of the panel are factorised by inner_update_kernel of step k - 1
+        hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)diag_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
+        CURV_LAUNCH_CHECK();
+      }
       if (panel_tiles > 0) {
         hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)panel_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
         CURV_LAUNCH_CHECK();
