@@ -337,8 +337,21 @@ __device__ __forceinline__ void mma16(const double* Ap, int lda, const double* B
   }
 }
 
+// 1 / sqrt(x) for a positive finite double: hardware estimate (v_rsq_f64, ~2^-26) + two Newton steps.
+// The library sqrt() and division it replaces sit on the serial pivot chain of every column (~400 cycles
+// there, ~100 here); the result is within an ulp or two of the correctly rounded one, five orders of
+// magnitude below the parity tolerance.
+__device__ __forceinline__ double rsqrt_pos(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
+}
+
 __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base) {
   __shared__ double Sc[4][16 * 17];
+  __shared__ double dinv_s[NB];        // 1 / L_cc: the triangular inverse divides by the same pivots
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -352,8 +365,9 @@ __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* ba
       for (int c = 0; c < 16; ++c) {
         const double piv = readlane_f64(row[c], c0 + c);
         const bool ok = piv > 0.0 && piv < 1.0e300;               // also false for NaN
-        const double dinv = ok ? 1.0 / sqrt(piv) : 1.0;
+        const double dinv = ok ? rsqrt_pos(piv) : 1.0;
         if (!ok && lane == 0 && *bad == 0) *bad = pivot_base + c0 + c + 1;
+        if (lane == c0 + c) dinv_s[c0 + c] = dinv;
         row[c] *= dinv;
 #pragma unroll
         for (int q = c + 1; q < 16; ++q) row[q] -= row[c] * readlane_f64(row[c], c0 + q);
@@ -392,7 +406,7 @@ __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* ba
       double sum = 0.0;
 #pragma unroll
       for (int q = 0; q < r; ++q) sum += Lb[r * LDA + q] * x[q];
-      x[r] = ((r == lane ? 1.0 : 0.0) - sum) / Lb[r * LDA + r];
+      x[r] = ((r == lane ? 1.0 : 0.0) - sum) * dinv_s[16 * wave + r];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) Is[(16 * wave + r) * LDA + 16 * wave + lane] = x[r];
@@ -552,23 +566,35 @@ __global__ void __launch_bounds__(256) inv_upload_kernel(InvDev* __restrict__ ta
 
 static size_t inv_table_bytes(int n) { return align_up((size_t)std::max(n, 1) * sizeof(InvDev), 256); }
 
-// Second stream for the far part of the outer updates (runs beside the next panel's chain of small
-// diagonal-step launches), with the fork/join events; one set per device, created on first use.
+// Extra streams of a sweep, one set per device, created on first use:
+//   side[g]  far part of the outer updates of factor group g (runs beside the next panel's chain of
+//            small diagonal-step launches), with its fork/join events;
+//   aux      the sweep of the second factor group (see chol_sweep).
 struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t ev_main[2] = {nullptr, nullptr};
   hipEvent_t ev_side[2] = {nullptr, nullptr};
 };
-static int side_stream(SideStream** out) {
-  static thread_local std::vector<std::pair<int, SideStream>> cache;
+struct StreamSet {
+  SideStream side[2];
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+static int stream_set(StreamSet** out) {
+  static thread_local std::vector<std::pair<int, StreamSet>> cache;
   int dev = 0;
   CURV_HIP_CHECK(hipGetDevice(&dev));
   for (auto& e : cache) if (e.first == dev) { *out = &e.second; return CURV_OK; }
-  SideStream s;
-  CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-  for (int i = 0; i < 2; ++i) {
-    CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_main[i], hipEventDisableTiming));
-    CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_side[i], hipEventDisableTiming));
+  StreamSet s;
+  CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.aux, hipStreamNonBlocking));
+  CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
+  CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
+  for (int g = 0; g < 2; ++g) {
+    CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.side[g].stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_main[i], hipEventDisableTiming));
+      CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_side[i], hipEventDisableTiming));
+    }
   }
   cache.emplace_back(dev, s);
   *out = &cache.back().second;
@@ -580,7 +606,7 @@ static int side_stream(SideStream** out) {
 using namespace curv;
 
 extern "C" size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int n_factors) {
-  size_t total = inv_table_bytes(n_factors);
+  size_t total = 2 * inv_table_bytes(n_factors);
   for (int i = 0; i < n_factors; ++i) {
     if (descs[i].n <= 0) return 0;
     const size_t np = (size_t)cdiv(descs[i].n, NB) * NB;
@@ -589,27 +615,18 @@ extern "C" size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int 
   return total;
 }
 
-static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* workspace, size_t workspace_bytes,
-                      const char* who) {
+// One batched sweep over the factors of `tab` (work matrices already assigned), everything enqueued on
+// `stream` except the far outer updates, which go to side->stream.
+static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vector<InvDev>& tab, InvDev* table) {
   const int n_factors = (int)tab.size();
-  size_t need = inv_table_bytes(n_factors);
-  for (const InvDev& d : tab) need += 2 * (size_t)d.np * d.np * sizeof(double);
-  if (workspace == nullptr || workspace_bytes < need) {
-    set_error("%s: workspace too small (%zu < %zu bytes)", who, workspace_bytes, need);
-    return CURV_ERR_WORKSPACE;
-  }
-  char* p = reinterpret_cast<char*>(workspace) + inv_table_bytes(n_factors);
   int Pmax = 0;
   long long prep_tiles = 0, fin_tiles = 0;
-  for (InvDev& d : tab) {
-    d.W = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double);
-    d.X = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double);
+  for (const InvDev& d : tab) {
     Pmax = std::max(Pmax, d.P);
     prep_tiles += (long long)d.P * (d.P + 1) / 2;
     const long long q = cdiv(d.n, 32);
     fin_tiles += q * q;
   }
-  InvDev* table = reinterpret_cast<InvDev*>(workspace);
   for (int b = 0; b < n_factors; b += INV_UPLOAD_CHUNK) {
     InvChunk chunk;
     const int count = std::min(INV_UPLOAD_CHUNK, n_factors - b);
@@ -625,8 +642,6 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   // then the near part of the outer update (the block columns / rows the NEXT chain touches).  The far
   // part goes to a second stream and overlaps the next chain; the two only meet again at the next near
   // part, which updates tiles the far part has written.
-  SideStream* side = nullptr;
-  { const int rc = side_stream(&side); if (rc != CURV_OK) return rc; }
   bool far_pending = false;
   int panel = 0;
   for (int k0 = 0; k0 < Pmax; k0 += NBO, ++panel) {
@@ -684,6 +699,45 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   return CURV_OK;
 }
 
+// Factors advance in lock step (step k touches every factor with more than k blocks), so a sweep over
+// all of them has the launch count of the largest factor and, in its first panels, kernels as wide as
+// the whole model.  The large factors (more than SPLIT_P blocks: their chain of ~85 us steps is the
+// critical path) and the many small ones are therefore swept as two groups on two streams; the GPU
+// interleaves the small group's wide, throughput-bound kernels with the large group's short ones.
+constexpr int SPLIT_P = 16;
+
+static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* workspace, size_t workspace_bytes,
+                      const char* who) {
+  const int n_factors = (int)tab.size();
+  size_t need = 2 * inv_table_bytes(n_factors);
+  for (const InvDev& d : tab) need += 2 * (size_t)d.np * d.np * sizeof(double);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("%s: workspace too small (%zu < %zu bytes)", who, workspace_bytes, need);
+    return CURV_ERR_WORKSPACE;
+  }
+  char* p = reinterpret_cast<char*>(workspace) + 2 * inv_table_bytes(n_factors);
+  std::vector<InvDev> big, small;
+  for (InvDev& d : tab) {
+    d.W = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double);
+    d.X = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double);
+    (d.P > SPLIT_P ? big : small).push_back(d);
+  }
+  StreamSet* ss = nullptr;
+  { const int rc = stream_set(&ss); if (rc != CURV_OK) return rc; }
+  InvDev* table0 = reinterpret_cast<InvDev*>(workspace);
+  InvDev* table1 = reinterpret_cast<InvDev*>(reinterpret_cast<char*>(workspace) + inv_table_bytes(n_factors));
+  if (big.empty() || small.empty()) return chol_sweep_group(stream, &ss->side[0], big.empty() ? small : big, table0);
+  CURV_HIP_CHECK(hipEventRecord(ss->ev_fork, stream));
+  CURV_HIP_CHECK(hipStreamWaitEvent(ss->aux, ss->ev_fork, 0));
+  int rc = chol_sweep_group(stream, &ss->side[0], big, table0);
+  if (rc != CURV_OK) return rc;
+  rc = chol_sweep_group(ss->aux, &ss->side[1], small, table1);
+  if (rc != CURV_OK) return rc;
+  CURV_HIP_CHECK(hipEventRecord(ss->ev_join, ss->aux));
+  CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->ev_join, 0));
+  return CURV_OK;
+}
+
 extern "C" int curv_chol_inv_lower(void* stream_, const curv_inv_desc* descs, int n_factors, int* info,
                                    void* workspace, size_t workspace_bytes) {
   if (n_factors == 0) return CURV_OK;
@@ -707,7 +761,7 @@ extern "C" int curv_chol_inv_lower(void* stream_, const curv_inv_desc* descs, in
 }
 
 extern "C" size_t curv_chol_factor_inverse_workspace_bytes(const curv_cholinv_desc* descs, int n) {
-  size_t total = inv_table_bytes(n);
+  size_t total = 2 * inv_table_bytes(n);
   for (int i = 0; i < n; ++i) {
     if (descs[i].n <= 0) return 0;
     const size_t np = (size_t)cdiv(descs[i].n, NB) * NB;
