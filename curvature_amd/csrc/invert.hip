@@ -112,11 +112,11 @@ inv_prepare_kernel(const InvDev* __restrict__ t, int nf) {
 // Tile sets of the two-level sweep.  Outer panels of NBO block columns: inside a panel the updates of
 // step k are restricted to the panel (K = 64 products), everything beyond the panel is updated once per
 // panel with K = NBO * 64, which divides the read-modify-write traffic of the trailing matrix by NBO.
-__device__ __host__ __forceinline__ long long inner_tiles(int P, int k, int kend) {
+__device__ __host__ __forceinline__ long long inner_tiles(int P, int k, int k0, int kend) {
   const int ke = kend < P ? kend : P;
   long long tr = 0;
-  for (int j = k + 1; j < ke; ++j) tr += P - j;
-  const long long sr = (ke - k - 1 > 0) ? (long long)(ke - k - 1) * (k + 1) : 0;
+  for (int j = k + 1; j < ke; ++j) tr += ke - j;
+  const long long sr = (ke - k - 1 > 0) ? (long long)(ke - k - 1) * (k - k0 + 1) : 0;
   return tr + sr;
 }
 // Outer tile lists are enumerated in 8x8 super-blocks (64 consecutive work items = one super-block, mapped
@@ -161,10 +161,10 @@ __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* ba
 // k + 1 then starts with its panel solve, one launch (and one 64x64 factorisation latency) less on the
 // critical path of every step that is not the first of an outer panel.
 __global__ void __launch_bounds__(INV_THREADS)
-inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int kend) {
+inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int kend) {
   __shared__ double As[NB * LDA], Bs[NB * LDA];
   int f, local;
-  if (!locate(t, nf, blockIdx.x, [k, kend](const InvDev& d) { return (int)inner_tiles(d.P, k, kend); }, f, local)) return;
+  if (!locate(t, nf, blockIdx.x, [k, k0, kend](const InvDev& d) { return (int)inner_tiles(d.P, k, k0, kend); }, f, local)) return;
   const InvDev& d = t[f];
   const int np = d.np, P = d.P, ke = kend < P ? kend : P;
   gdouble* W = (gdouble*)d.W;
@@ -174,8 +174,8 @@ inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int kend) {
   int j = k + 1;
   bool trailing = false;
   for (; j < ke; ++j) {
-    if (local < P - j) { trailing = true; break; }
-    local -= P - j;
+    if (local < ke - j) { trailing = true; break; }
+    local -= ke - j;
   }
   if (trailing) {
     const int i = j + local;                                       // A[i][j] -= A[i][k] A[j][k]^T
@@ -212,7 +212,8 @@ inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int kend) {
       store_sub(W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);
     }
   } else {
-    const int a = local / (k + 1), jj = local - a * (k + 1);       // S[i][jj] (+)= C[i][k] X[k][jj]
+    const int w = k - k0 + 1;                                      // S[i][jj] (+)= C[i][k] X[k][jj], k0 <= jj <= k
+    const int a = local / w, jj = k0 + local - a * w;
     const int i = k + 1 + a;
     load_block(W + (long long)i * NB * np + k * NB, np, As);
     load_block(X + (long long)k * NB * np + jj * NB, np, Bs);
@@ -467,12 +468,14 @@ chol_diag_kernel(const InvDev* __restrict__ t, int nf, int k) {
 //      one launch: both need nothing but X_kk from (1a); every workgroup owns the tile it rewrites
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(INV_THREADS)
-chol_panel_kernel(const InvDev* __restrict__ t, int nf, int k) {
+chol_panel_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int kend) {
   __shared__ double As[NB * LDA], Bs[NB * LDA];
   int f, local;
-  if (!locate(t, nf, blockIdx.x, [k](const InvDev& d) { return d.P > k ? d.P - 1 : 0; }, f, local)) return;
+  if (!locate(t, nf, blockIdx.x,
+              [k, k0, kend](const InvDev& d) { return d.P > k ? (kend < d.P ? kend : d.P) - k0 - 1 : 0; }, f, local))
+    return;
   const InvDev& d = t[f];
-  const int np = d.np, n_solve = d.P - k - 1;
+  const int np = d.np, n_solve = (kend < d.P ? kend : d.P) - k - 1;
   gdouble* W = (gdouble*)d.W;
   gdouble* X = (gdouble*)d.X;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
@@ -493,7 +496,7 @@ chol_panel_kernel(const InvDev* __restrict__ t, int nf, int k) {
         for (int r = 0; r < 4; ++r)
           C[(long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16] = acc[m][n][r];
   } else {
-    const int j = local - n_solve;
+    const int j = k0 + local - n_solve;
     load_block(X + (long long)k * NB * np + k * NB, np, As);            // X_kk as [row][kk]
     load_block(X + (long long)k * NB * np + j * NB, np, Bs);            // S_kj as [kk][col]
     __syncthreads();
@@ -506,6 +509,59 @@ chol_panel_kernel(const InvDev* __restrict__ t, int nf, int k) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           C[(long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16] = -acc[m][n][r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// After the chain of diagonal steps has factorised the nb x nb block square of outer panel [k0, kend)
+// (L_sq in W, X_sq = L_sq^-1 in X), everything else of the panel is two triangular products:
+//   (1c) rows below the square:   W[i][k0 + c] <- sum_{k <= c} W[i][k0 + k] X_sq[c][k]^T      i >= kend
+//   (3c) columns left of it:      X[k0 + r][j] <- - sum_{k <= r} X_sq[r][k] S[k0 + k][j]      j <  k0
+// One workgroup per row block / column block walks its nb outputs in DESCENDING order: output c only
+// reads inputs k <= c, so the in-place update never overwrites something still needed.  Compared with
+// doing these rows step by step (nb panel solves + nb (nb - 1) / 2 rank-64 updates, each a read-modify-
+// write of 64x64 tiles) the row panel is read and written once.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(INV_THREADS)
+panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
+  __shared__ double As[NB * LDA], Bs[NB * LDA];
+  int f, local;
+  if (!locate(t, nf, blockIdx.x,
+              [k0, kend](const InvDev& d) { return d.P > k0 ? (d.P > kend ? d.P - kend : 0) + k0 : 0; }, f, local))
+    return;
+  const InvDev& d = t[f];
+  const int np = d.np, nb = (kend < d.P ? kend : d.P) - k0;
+  const int n_below = d.P > kend ? d.P - kend : 0;
+  gdouble* W = (gdouble*)d.W;
+  gdouble* X = (gdouble*)d.X;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  const int c16 = lane & 15, rq = lane >> 4;
+  const bool below = local < n_below;
+  const int i = kend + local, j = local - n_below;
+  for (int c = nb - 1; c >= 0; --c) {
+    f64x4 acc[2][2] = {};
+    for (int k = 0; k <= c; ++k) {
+      if (below) {
+        load_block(W + (long long)i * NB * np + (k0 + k) * NB, np, As);              // A_ik as [row][kk]
+        load_block(X + (long long)(k0 + c) * NB * np + (k0 + k) * NB, np, Bs);       // X_sq[c][k] as [col][kk]
+      } else {
+        load_block(X + (long long)(k0 + c) * NB * np + (k0 + k) * NB, np, As);       // X_sq[c][k] as [row][kk]
+        load_block(X + (long long)(k0 + k) * NB * np + j * NB, np, Bs);              // S_kj as [kk][col]
+      }
+      __syncthreads();
+      if (below) mma_64<true>(As, Bs, wm, wn, lane, acc);
+      else mma_64<false>(As, Bs, wm, wn, lane, acc);
+      __syncthreads();
+    }
+    gdouble* C = below ? W + (long long)i * NB * np + (k0 + c) * NB : X + (long long)(k0 + c) * NB * np + j * NB;
+    const double sgn = below ? 1.0 : -1.0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          C[(long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16] = sgn * acc[m][n][r];
   }
 }
 
@@ -646,24 +702,31 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
   int panel = 0;
   for (int k0 = 0; k0 < Pmax; k0 += NBO, ++panel) {
     const int kend = k0 + NBO, row0 = kend + NBO;
+    long long prod_tiles = 0;
     for (int k = k0; k < std::min(kend, Pmax); ++k) {
       long long diag_tiles = 0, panel_tiles = 0, upd_tiles = 0;
       for (const InvDev& d : tab) {
-        if (d.P > k) { ++diag_tiles; panel_tiles += d.P - 1; }
-        upd_tiles += inner_tiles(d.P, k, kend);
+        if (d.P > k) { ++diag_tiles; panel_tiles += std::min(kend, d.P) - k0 - 1; }
+        upd_tiles += inner_tiles(d.P, k, k0, kend);
       }
       if (k == k0) {    // later diagonal blocks of the panel are factorised by inner_update_kernel of step k - 1
         hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)diag_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
         CURV_LAUNCH_CHECK();
       }
       if (panel_tiles > 0) {
-        hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)panel_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
+        hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)panel_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, k0, kend);
         CURV_LAUNCH_CHECK();
       }
       if (upd_tiles > 0) {
-        hipLaunchKernelGGL(inner_update_kernel, dim3((unsigned)upd_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, kend);
+        hipLaunchKernelGGL(inner_update_kernel, dim3((unsigned)upd_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, k0, kend);
         CURV_LAUNCH_CHECK();
       }
+    }
+    for (const InvDev& d : tab)
+      if (d.P > k0) prod_tiles += std::max(0, d.P - kend) + k0;
+    if (prod_tiles > 0) {   // rows below / columns left of the square: one triangular product each
+      hipLaunchKernelGGL(panel_product_kernel, dim3((unsigned)prod_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend);
+      CURV_LAUNCH_CHECK();
     }
     long long near_tiles = 0, far_tiles = 0;
     for (const InvDev& d : tab) {
