@@ -534,34 +534,63 @@ panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
   const int n_below = d.P > kend ? d.P - kend : 0;
   gdouble* W = (gdouble*)d.W;
   gdouble* X = (gdouble*)d.X;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int c16 = lane & 15, rq = lane >> 4;
   const bool below = local < n_below;
   const int i = kend + local, j = local - n_below;
-  for (int c = nb - 1; c >= 0; --c) {
-    f64x4 acc[2][2] = {};
-    for (int k = 0; k <= c; ++k) {
-      if (below) {
-        load_block(W + (long long)i * NB * np + (k0 + k) * NB, np, As);              // A_ik as [row][kk]
-        load_block(X + (long long)(k0 + c) * NB * np + (k0 + k) * NB, np, Bs);       // X_sq[c][k] as [col][kk]
-      } else {
-        load_block(X + (long long)(k0 + c) * NB * np + (k0 + k) * NB, np, As);       // X_sq[c][k] as [row][kk]
-        load_block(X + (long long)(k0 + k) * NB * np + j * NB, np, Bs);              // S_kj as [kk][col]
-      }
-      __syncthreads();
-      if (below) mma_64<true>(As, Bs, wm, wn, lane, acc);
-      else mma_64<false>(As, Bs, wm, wn, lane, acc);
-      __syncthreads();
+  // Loop order: input block k outermost, so the workgroup's own tile (A_ik / S_kj) is loaded once per k;
+  // all nb outputs accumulate in registers and are written after the last read (hence in place).  The
+  // X_sq tile of the next (k, c) pair is fetched into registers while the MFMAs of the current one run.
+  constexpr int NBO_MAX = 4;
+  f64x4 acc[NBO_MAX][2][2] = {};
+  double* own = below ? As : Bs;                    // A_ik as [row][kk]  /  S_kj as [kk][col]
+  double* var = below ? Bs : As;                    // X_sq[c][k] as [col][kk]  /  as [row][kk]
+  double rv[16];
+  auto fetch_var = [&](int c, int k) {
+    const gdouble* g = X + (long long)(k0 + c) * NB * np + (k0 + k) * NB;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + u * INV_THREADS;
+      rv[u] = g[(long long)(e >> 6) * np + (e & 63)];
     }
-    gdouble* C = below ? W + (long long)i * NB * np + (k0 + c) * NB : X + (long long)(k0 + c) * NB * np + j * NB;
-    const double sgn = below ? 1.0 : -1.0;
+  };
+  fetch_var(0, 0);
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+  for (int k = 0; k < NBO_MAX; ++k) {
+    if (k < nb) {
+      load_block(below ? W + (long long)i * NB * np + (k0 + k) * NB : X + (long long)(k0 + k) * NB * np + j * NB, np, own);
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int c = k; c < NBO_MAX; ++c) {
+        if (c < nb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          C[(long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16] = sgn * acc[m][n][r];
+          for (int u = 0; u < 16; ++u) {
+            const int e = tid + u * INV_THREADS;
+            var[(e >> 6) * LDA + (e & 63)] = rv[u];
+          }
+          __syncthreads();
+          // next pair in the (k, c) walk: (k, c + 1) or (k + 1, k + 1)
+          if (c + 1 < nb) fetch_var(c + 1, k);
+          else if (k + 1 < nb) fetch_var(k + 1, k + 1);
+          if (below) mma_64<true>(As, Bs, wm, wn, lane, acc[c]);
+          else mma_64<false>(As, Bs, wm, wn, lane, acc[c]);
+          __syncthreads();
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NBO_MAX; ++c) {
+    if (c < nb) {
+      gdouble* C = below ? W + (long long)i * NB * np + (k0 + c) * NB : X + (long long)(k0 + c) * NB * np + j * NB;
+      const double sgn = below ? 1.0 : -1.0;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            C[(long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16] = sgn * acc[c][m][n][r];
+    }
   }
 }
 

@@ -17,7 +17,7 @@ for r in rows:
     busy[n] = busy.get(n, 0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 print({k: round(v) for k, v in busy.items()})
 # overlap: time covered by outer_update far kernels (largest grids) vs chain kernels
-for r in rows[-46:]:
+for r in rows[:70]:
     n = r["Kernel_Name"].split("(")[0].replace("curv::", "")
     print(f'{(int(r["Start_Timestamp"]) - t0) / 1e3:9.1f} {(int(r["End_Timestamp"]) - t0) / 1e3:9.1f}  q{r.get("Queue_Id", "?")} grid {r.get("Grid_Size", r.get("Grid_Size_X", "?"))}  {n}')
 PY
