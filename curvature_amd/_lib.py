@@ -85,6 +85,10 @@ class curv_gemm64_desc(ctypes.Structure):
                 ("alpha", ctypes.c_double), ("beta", ctypes.c_double)]
 
 
+class curv_copy_desc(ctypes.Structure):
+    _fields_ = [("dst", ctypes.c_void_p), ("src", ctypes.c_void_p), ("bytes", ctypes.c_ulonglong)]
+
+
 class curv_eigh_desc(ctypes.Structure):
     _fields_ = [("F", ctypes.c_void_p), ("U", ctypes.c_void_p), ("w", ctypes.c_void_p), ("n", ctypes.c_int32),
                 ("reserved", ctypes.c_int32)]
@@ -129,6 +133,7 @@ SIGNATURES = {
     "curv_clamp_min0": (_i, [_vp, _vp, _ll]),
     "curv_sqrt_scale": (_i, [_vp, _vp, _d, _vp, _ll]),
     "curv_mul": (_i, [_vp, _vp, _vp, _vp, _ll]),
+    "curv_copy_batched": (_i, [_vp, ctypes.POINTER(curv_copy_desc), _i]),
 }
 
 

@@ -139,3 +139,75 @@ extern "C" int curv_mul(void* stream, const float* a, const float* b, float* out
   CURV_LAUNCH_CHECK();
   return CURV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Batched device-to-device copy (see curv_copy_batched): descriptors travel in the kernel arguments,
+// one workgroup per 64 KB piece.
+// ------------------------------------------------------------------------------------------------
+namespace curv {
+constexpr int COPY_MAX = 96;                       // buffers per launch: the argument block stays below 4 KB
+constexpr unsigned long long COPY_PIECE = 65536;
+struct CopyArgs {
+  void* dst[COPY_MAX];
+  const void* src[COPY_MAX];
+  unsigned long long bytes[COPY_MAX];
+  int wg_base[COPY_MAX + 1];
+};
+static_assert(sizeof(CopyArgs) <= 3840, "kernel argument block must stay below 4 KB");
+
+__global__ void __launch_bounds__(256) copy_batched_kernel(CopyArgs a, int n) {
+  const int lane = threadIdx.x & 63, bid = (int)blockIdx.x;
+  int t = 0;
+  for (int b0 = 0; b0 < n; b0 += 64) {             // largest t with wg_base[t] <= bid (bases ascend)
+    const int i = b0 + lane;
+    const bool le = i < n && a.wg_base[i] <= bid;
+    t += __popcll(__ballot(le));
+  }
+  t = __builtin_amdgcn_readfirstlane(t - 1);
+  const unsigned long long off = (unsigned long long)(bid - a.wg_base[t]) * COPY_PIECE;
+  const unsigned long long left = a.bytes[t] - off;
+  const unsigned long long len = left < COPY_PIECE ? left : COPY_PIECE;
+  char* d = reinterpret_cast<char*>(a.dst[t]) + off;
+  const char* s = reinterpret_cast<const char*>(a.src[t]) + off;
+  const unsigned long long mis = reinterpret_cast<unsigned long long>(d) | reinterpret_cast<unsigned long long>(s);
+  if ((mis & 15) == 0) {
+    const unsigned long long n16 = len >> 4;
+    for (unsigned long long i = threadIdx.x; i < n16; i += 256)
+      reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+    for (unsigned long long i = (n16 << 4) + threadIdx.x; i < len; i += 256) d[i] = s[i];
+  } else if ((mis & 3) == 0) {
+    const unsigned long long n4 = len >> 2;
+    for (unsigned long long i = threadIdx.x; i < n4; i += 256)
+      reinterpret_cast<unsigned*>(d)[i] = reinterpret_cast<const unsigned*>(s)[i];
+    for (unsigned long long i = (n4 << 2) + threadIdx.x; i < len; i += 256) d[i] = s[i];
+  } else {
+    for (unsigned long long i = threadIdx.x; i < len; i += 256) d[i] = s[i];
+  }
+}
+}  // namespace curv
+
+extern "C" int curv_copy_batched(void* stream, const curv_copy_desc* descs, int n) {
+  using namespace curv;
+  CURV_REQUIRE(n >= 0 && (n == 0 || descs != nullptr), "curv_copy_batched: bad arguments");
+  int i = 0;
+  while (i < n) {
+    CopyArgs a;
+    memset(&a, 0, sizeof(a));
+    int cnt = 0, wgs = 0;
+    while (i < n && cnt < COPY_MAX) {
+      const curv_copy_desc& c = descs[i++];
+      if (c.bytes == 0) continue;
+      CURV_REQUIRE(c.dst != nullptr && c.src != nullptr, "curv_copy_batched: buffer %d: null pointer", i - 1);
+      const unsigned long long pieces = (c.bytes + COPY_PIECE - 1) / COPY_PIECE;
+      CURV_REQUIRE(pieces < (1ull << 24), "curv_copy_batched: buffer %d too large", i - 1);
+      a.dst[cnt] = c.dst; a.src[cnt] = c.src; a.bytes[cnt] = c.bytes; a.wg_base[cnt] = wgs;
+      wgs += (int)pieces;
+      ++cnt;
+    }
+    if (cnt == 0) continue;
+    a.wg_base[cnt] = wgs;
+    hipLaunchKernelGGL(copy_batched_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a, cnt);
+    CURV_LAUNCH_CHECK();
+  }
+  return CURV_OK;
+}

@@ -18,7 +18,7 @@ no CPU fallback: CPU models raise ``RuntimeError``.
 import copy
 import numbers
 from abc import ABC, abstractmethod
-from typing import Any, Dict, List, Optional, Union
+from typing import Any, Dict, List, Optional, Sequence, Union
 
 import torch
 from torch import Tensor
@@ -103,6 +103,31 @@ class Curvature(ABC):
         self.noise_offset += (numel + 3) // 4
         return out
 
+    def _reload_mean(self, skip: Sequence[Tensor] = ()):
+        """``model.load_state_dict(model_state)`` (curvatures.py:119) as one batched copy: a ResNet-50 has
+        ~320 state tensors, i.e. ~320 copy launches (3 ms) through torch.  `skip`: live tensors the
+        caller overwrites completely right afterwards."""
+        live = getattr(self, "_reload_live", None)
+        if live is None:
+            state = self.model.state_dict(keep_vars=True)
+            if list(state.keys()) != list(self.model_state.keys()):
+                raise RuntimeError("model structure changed since the estimator was created")
+            self._reload_live = live = [(k, v) for k, v in state.items()]
+            self._reload_plans = {}
+        if not live or not live[0][1].is_cuda:
+            self.model.load_state_dict(self.model_state)     # CPU models: torch plumbing, nothing to batch
+            return
+        ptrs = tuple(v.data_ptr() for _, v in live)           # parameters may have been re-homed (.to(), ...)
+        key = (ptrs, tuple(sorted(t.data_ptr() for t in skip)))
+        plan = self._reload_plans.get(key)
+        if plan is None:
+            self._reload_plans.clear()
+            skipped = set(key[1])
+            pairs = [(v.data, self.model_state[k]) for k, v in live if v.data_ptr() not in skipped]
+            plan = ops.CopyPlan([d for d, _ in pairs], [s_ for _, s_ in pairs])
+            self._reload_plans[key] = plan
+        plan.run()
+
     @staticmethod
     def _replace(sample: Tensor, weight: Tensor, bias: Tensor = None):
         """weight += sample[:, :-1], bias += sample[:, -1] (curvatures.py:67-82)."""
@@ -127,7 +152,7 @@ class Curvature(ABC):
 
     def sample_and_replace(self):
         """Reset to the mean weights, then add one posterior sample per selected layer (curvatures.py:117-129)."""
-        self.model.load_state_dict(self.model_state)
+        self._reload_mean()
         for _, layer in self._owned():
             _sample = self.sample(layer)
             self._replace(_sample, layer.weight, layer.bias)
@@ -260,24 +285,14 @@ class KFAC(Curvature):
         ops.gemm_batched([ops.Gemm(tmp, first.t(), out, tri=ops.TRI_B_UPPER)])      # L_A^T upper triangular
         return out
 
-    def _reload_mean(self):
-        """``model.load_state_dict(model_state)`` (curvatures.py:119) as ONE multi-tensor copy instead of a
-        few hundred small ones: same tensors, same values."""
-        if not hasattr(self, "_reload_lists"):
-            live = self.model.state_dict(keep_vars=True)
-            if list(live.keys()) != list(self.model_state.keys()):
-                raise RuntimeError("model structure changed since the estimator was created")
-            dst = [live[k].data if hasattr(live[k], "data") else live[k] for k in live]
-            self._reload_lists = (dst, [self.model_state[k] for k in live])
-        torch._foreach_copy_(self._reload_lists[0], self._reload_lists[1])
-
     def sample_and_replace(self, noise: Optional[Dict[Module, Tensor]] = None):
         """Fused form of the base-class loop: two batched GEMM launches for the whole model, the second
         writing ``mean + sample`` straight into the parameters (same result as curvatures.py:117-129)."""
         assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
-        self._reload_mean()
-        stage1, stage2 = [], []
         owned = self._owned()
+        # the second GEMM stage overwrites weight and bias of every owned layer with mean + sample
+        self._reload_mean(skip=[p for _, l in owned for p in (l.weight, l.bias) if p is not None])
+        stage1, stage2 = [], []
         flat, pos = None, 0
         if noise is None and owned:        # one generator launch for the whole model
             dev = self.inv_state[owned[0][1]][0].device

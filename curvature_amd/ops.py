@@ -211,6 +211,34 @@ def mul(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
     return out
 
 
+class CopyPlan:
+    """A fixed list of (dst, src) tensor pairs copied with one or a few launches (curv_copy_batched).
+
+    The descriptor array is built once; `run()` only enqueues.  Every pair must be contiguous, of equal
+    byte size and on the GPU; the tensors are kept alive by the plan."""
+
+    def __init__(self, dsts: Sequence[torch.Tensor], srcs: Sequence[torch.Tensor]):
+        if len(dsts) != len(srcs):
+            raise RuntimeError("CopyPlan: list lengths differ")
+        for t in (*dsts, *srcs):                 # any dtype: this is a byte copy
+            if not t.is_cuda:
+                raise RuntimeError("curvature_amd runs on MI355X only: got a CPU tensor (no CPU fallback)")
+        self._keep = (list(dsts), list(srcs))
+        self.n = len(dsts)
+        self.descs = (_lib.curv_copy_desc * max(self.n, 1))()
+        for i, (d, s) in enumerate(zip(dsts, srcs)):
+            if not (d.is_contiguous() and s.is_contiguous()):
+                raise RuntimeError("CopyPlan: tensors must be contiguous")
+            nb = d.numel() * d.element_size()
+            if nb != s.numel() * s.element_size() or d.dtype != s.dtype:
+                raise RuntimeError("CopyPlan: size / dtype mismatch")
+            self.descs[i].dst, self.descs[i].src, self.descs[i].bytes = d.data_ptr(), s.data_ptr(), nb
+
+    def run(self) -> None:
+        if self.n:
+            _lib.check(_lib.lib().curv_copy_batched(_lib.stream_ptr(), self.descs, self.n), "curv_copy_batched")
+
+
 # ---------------------------------------------------------------------------------------------- EFB / INF helpers
 from ._lib import curv_cholinv_desc, curv_gemm64_desc, curv_select_desc  # noqa: E402
 

@@ -194,6 +194,17 @@ int curv_sqrt_scale(void* stream, const float* v, double s, float* out, long lon
 /* out = a*b */
 int curv_mul(void* stream, const float* a, const float* b, float* out, long long count);
 
+/* Batched device-to-device copy: dst[i][0 .. bytes[i]) = src[i][...] for n buffers in one or a few
+ * launches (Curvature.sample_and_replace reloads the mean weights with `load_state_dict`,
+ * curvatures.py:118: ~320 separate tensors for a ResNet-50, i.e. ~320 copy launches otherwise).
+ * Buffers may have any size and alignment; pairs must not overlap. */
+typedef struct curv_copy_desc {
+  void* dst;
+  const void* src;
+  unsigned long long bytes;
+} curv_copy_desc;
+int curv_copy_batched(void* stream, const curv_copy_desc* descs, int n);
+
 /* ------------------------------------------------------------------------------------------------
  * utils.get_eigenvectors (curvature/utils.py:45-60): symmetric eigendecomposition F = U diag(w) U^T of a
  * batch of fp32 matrices by a two-sided block-Jacobi method in fp64.  U (n x n, fp32) holds the

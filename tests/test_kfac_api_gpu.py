@@ -167,3 +167,59 @@ def test_sharded_ranks_cover_the_unsharded_result(gpu):
     for part in (results[(2, 0)], results[(2, 1)]):
         for li, (LA, LG) in part.items():
             assert torch.equal(LA, full[li][0]) and torch.equal(LG, full[li][1])     # bitwise: same kernels, same inputs
+
+
+@pytest.mark.gpu
+def test_copy_batched_matches_torch(gpu):
+    """curv_copy_batched: any size / alignment / dtype, several launches' worth of buffers."""
+    from curvature_amd import ops
+    torch.manual_seed(3)
+    sizes = [1, 3, 4, 17, 256, 1000, 65536 // 4, 65536 // 4 + 5, 300001] + [7 + i for i in range(120)]
+    srcs, dsts = [], []
+    base = torch.randn(sum(sizes) + len(sizes) + 8, device=gpu)
+    off = 0
+    for i, n in enumerate(sizes):
+        off += (i % 3 == 0)                       # odd element offsets: 4-byte aligned only
+        srcs.append(base[off:off + n])
+        off += n
+        dsts.append(torch.full((n,), float("nan"), device=gpu))
+    srcs.append(torch.arange(5, device=gpu, dtype=torch.int64))          # 8-byte elements
+    dsts.append(torch.zeros(5, device=gpu, dtype=torch.int64))
+    srcs.append(torch.arange(11, device=gpu, dtype=torch.uint8)[1:])     # byte-aligned only
+    dsts.append(torch.zeros(10, device=gpu, dtype=torch.uint8))
+    ops.CopyPlan(dsts, srcs).run()
+    torch.cuda.synchronize()
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d, s)
+
+
+@pytest.mark.gpu
+def test_sample_and_replace_restores_every_state_tensor(gpu):
+    """The batched reload must behave like load_state_dict(model_state) (curvatures.py:119): buffers and
+    unselected parameters are reset too; selected layers end up at mean + sample."""
+    from curvature_amd.curvatures import KFAC
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.BatchNorm2d(4), torch.nn.ReLU(),
+                                torch.nn.Flatten(), torch.nn.Linear(4 * 6 * 6, 5)).to(gpu)
+    kfac = KFAC(model)
+    x = torch.randn(8, 3, 6, 6, device=gpu)
+    out = model(x)
+    loss = torch.nn.functional.cross_entropy(out, torch.randint(0, 5, (8,), device=gpu))
+    loss.backward()
+    kfac.update(batch_size=8)
+    kfac.invert(add=1.0, multiply=10.0)
+    mean = {k: v.clone() for k, v in kfac.model_state.items()}
+    with torch.no_grad():                         # perturb everything, as training / BN statistics would
+        for v in model.state_dict().values():
+            v.add_(1)
+    kfac.sample_and_replace()
+    torch.cuda.synchronize()
+    state = model.state_dict()
+    for k in ("1.weight", "1.bias", "1.running_mean", "1.running_var", "1.num_batches_tracked"):
+        assert torch.equal(state[k], mean[k]), k
+    for k in ("0.weight", "4.weight", "4.bias"):
+        assert not torch.equal(state[k], mean[k]) and torch.isfinite(state[k]).all()
+        assert float((state[k] - mean[k]).abs().max()) < 10.0
+    kfac.sample_and_replace()                     # second call reuses the cached plan
+    torch.cuda.synchronize()
+    assert torch.equal(model.state_dict()["1.running_mean"], mean["1.running_mean"])
