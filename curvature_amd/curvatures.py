@@ -95,11 +95,11 @@ class Curvature(ABC):
             return float(add[index]), float(multiply[index])
         return float(add), float(multiply)
 
-    def _randn(self, *shape, device) -> Tensor:
+    def _randn(self, *shape, device, out: Optional[Tensor] = None) -> Tensor:
         numel = 1
         for s in shape:
             numel *= int(s)
-        out = ops.randn(shape, device, self.noise_seed, self.noise_offset)
+        out = ops.randn(shape, device, self.noise_seed, self.noise_offset, out=out)
         self.noise_offset += (numel + 3) // 4
         return out
 
@@ -268,7 +268,10 @@ class KFAC(Curvature):
                 factors.append(factor)
                 adds.append(n)
                 muls.append(s)
-        chols = ops.chol_inv_lower(factors, adds, muls)      # RuntimeError if not positive definite
+        # outputs of the previous call are overwritten in place (stable addresses keep the cached launch
+        # plan of sample_and_replace valid); RuntimeError if a damped factor is not positive definite
+        prev = [t for layer in self.state.keys() for t in self.inv_state.get(layer, (None, None))]
+        chols = ops.chol_inv_lower(factors, adds, muls, outs=prev)
         for index, layer in enumerate(self.state.keys()):
             self.inv_state[layer] = (chols[2 * index], chols[2 * index + 1])
 
@@ -292,33 +295,44 @@ class KFAC(Curvature):
         owned = self._owned()
         # the second GEMM stage overwrites weight and bias of every owned layer with mean + sample
         self._reload_mean(skip=[p for _, l in owned for p in (l.weight, l.bias) if p is not None])
-        stage1, stage2 = [], []
-        flat, pos = None, 0
-        if noise is None and owned:        # one generator launch for the whole model
-            dev = self.inv_state[owned[0][1]][0].device
-            total = sum(self.inv_state[l][0].size(0) * self.inv_state[l][1].size(0) for _, l in owned)
-            flat = self._randn(total, device=dev)
-        for _, layer in owned:
-            first, second = self.inv_state[layer]
-            n, m = first.size(0), second.size(0)
-            if noise is not None:
-                z = noise[layer]
-            else:
-                z = flat[pos:pos + n * m].view(n, m)
-                pos += n * m
-            tmp = torch.empty(m, n, dtype=torch.float32, device=first.device)
-            stage1.append(ops.Gemm(second, z.t(), tmp, tri=ops.TRI_A_LOWER))
-            n0 = n - int(layer.bias is not None)
-            w = layer.weight.data.view(m, n0)
-            w_mean = self.model_state_of(layer, 'weight').view(m, n0)
-            la_t = first.t()
-            stage2.append(ops.Gemm(tmp, la_t[:, :n0], w, epilogue=ops.EPI_ADD_E, E=w_mean, tri=ops.TRI_B_UPPER))
-            if layer.bias is not None:
-                b = layer.bias.data.view(m, 1)
-                b_mean = self.model_state_of(layer, 'bias').view(m, 1)
-                stage2.append(ops.Gemm(tmp, la_t[:, n0:], b, epilogue=ops.EPI_ADD_E, E=b_mean))
-        ops.gemm_batched(stage1)
-        ops.gemm_batched(stage2)
+        # The two GEMM launches are described once and replayed while the tensors involved stay where they
+        # are (invert() rewrites inv_state in place): per call only the noise is drawn.
+        key = (noise is None, tuple(t.data_ptr() for _, l in owned for t in self.inv_state[l]),
+               tuple(p.data_ptr() for _, l in owned for p in (l.weight, l.bias) if p is not None),
+               tuple(z.data_ptr() for z in noise.values()) if noise is not None else ())
+        plan = getattr(self, "_sample_plan", None)
+        if plan is None or plan[0] != key:
+            stage1, stage2 = [], []
+            flat, pos = None, 0
+            if noise is None and owned:        # one generator launch for the whole model
+                dev = self.inv_state[owned[0][1]][0].device
+                total = sum(self.inv_state[l][0].size(0) * self.inv_state[l][1].size(0) for _, l in owned)
+                flat = torch.empty(total, dtype=torch.float32, device=dev)
+            for _, layer in owned:
+                first, second = self.inv_state[layer]
+                n, m = first.size(0), second.size(0)
+                if noise is not None:
+                    z = noise[layer]
+                else:
+                    z = flat[pos:pos + n * m].view(n, m)
+                    pos += n * m
+                tmp = torch.empty(m, n, dtype=torch.float32, device=first.device)
+                stage1.append(ops.Gemm(second, z.t(), tmp, tri=ops.TRI_A_LOWER))
+                n0 = n - int(layer.bias is not None)
+                w = layer.weight.data.view(m, n0)
+                w_mean = self.model_state_of(layer, 'weight').view(m, n0)
+                la_t = first.t()
+                stage2.append(ops.Gemm(tmp, la_t[:, :n0], w, epilogue=ops.EPI_ADD_E, E=w_mean, tri=ops.TRI_B_UPPER))
+                if layer.bias is not None:
+                    b = layer.bias.data.view(m, 1)
+                    b_mean = self.model_state_of(layer, 'bias').view(m, 1)
+                    stage2.append(ops.Gemm(tmp, la_t[:, n0:], b, epilogue=ops.EPI_ADD_E, E=b_mean))
+            plan = (key, flat, ops.GemmPlan(stage1), ops.GemmPlan(stage2))
+            self._sample_plan = plan
+        if plan[1] is not None:
+            self._randn(plan[1].numel(), device=plan[1].device, out=plan[1])
+        plan[2].run()
+        plan[3].run()
         self._allgather_sampled()
 
     def model_state_of(self, layer: Module, name: str) -> Tensor:

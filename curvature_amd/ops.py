@@ -112,7 +112,7 @@ def sq_accumulate(grad_w: torch.Tensor, grad_b: Optional[torch.Tensor], batch_si
 
 
 def chol_inv_lower(factors: Sequence[torch.Tensor], adds: Sequence[float], multiplies: Sequence[float],
-                   check: bool = True) -> List[torch.Tensor]:
+                   check: bool = True, outs: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
     """[chol_lower((sqrt(s_i) F_i + sqrt(n_i) I)^-1)] for all factors in one batched sweep.
 
     Raises ``RuntimeError`` (like torch's cholesky in the reference, curvatures.py:378-380) when a damped
@@ -121,12 +121,15 @@ def chol_inv_lower(factors: Sequence[torch.Tensor], adds: Sequence[float], multi
     if n == 0:
         return []
     arr = (curv_inv_desc * n)()
+    given = list(outs) if outs is not None else [None] * n
     outs = []
-    for d, F, a, s in zip(arr, factors, adds, multiplies):
+    for d, F, a, s, out in zip(arr, factors, adds, multiplies, given):
         _require_gpu(F)
         if F.dim() != 2 or F.shape[0] != F.shape[1]:
             raise RuntimeError("factor must be a square matrix")
-        out = torch.empty_like(F)
+        if out is None or out.shape != F.shape or out.device != F.device or not out.is_contiguous() \
+                or out.dtype != torch.float32:
+            out = torch.empty_like(F)          # `outs` entries are reused when they fit (stable pointers)
         outs.append(out)
         d.F, d.L, d.n, d.add, d.multiply = F.data_ptr(), out.data_ptr(), F.shape[0], float(a), float(s)
     dev = factors[0].device
@@ -137,10 +140,11 @@ def chol_inv_lower(factors: Sequence[torch.Tensor], adds: Sequence[float], multi
     _lib.check(L.curv_chol_inv_lower(_lib.stream_ptr(), arr, n, info.data_ptr(), ws.data_ptr(), ws.numel()),
                "curv_chol_inv_lower")
     if check:
-        bad = torch.nonzero(info).flatten().tolist()
+        host = info.cpu()                        # the one host synchronisation of invert()
+        bad = torch.nonzero(host).flatten().tolist()
         if bad:
             raise RuntimeError(f"cholesky: damped factor(s) {bad} are not positive-definite "
-                               f"(first failing pivot {int(info[bad[0]]) - 1})")
+                               f"(first failing pivot {int(host[bad[0]]) - 1})")
     return outs
 
 
@@ -162,10 +166,7 @@ def _check_view(t: torch.Tensor):
         raise RuntimeError("GEMM operands must be 2-D float32 GPU tensors (no CPU fallback)")
 
 
-def gemm_batched(jobs: Sequence[Gemm]) -> None:
-    """All products in one launch (one work item per 64x64 output tile)."""
-    if not jobs:
-        return
+def _gemm_descs(jobs: Sequence[Gemm]):
     n = len(jobs)
     arr = (curv_gemm_desc * n)()
     for d, j in zip(arr, jobs):
@@ -187,14 +188,40 @@ def gemm_batched(jobs: Sequence[Gemm]) -> None:
             d.e_rs, d.e_cs = j.E.stride()
         d.M, d.N, d.K = M, N, K
         d.alpha, d.beta, d.epilogue, d.tri = j.alpha, j.beta, j.epilogue, j.tri
-    L = _lib.lib()
-    ws = workspace(L.curv_gemm_workspace_bytes(n), jobs[0].C.device, "gemm")
-    _lib.check(L.curv_gemm_batched(_lib.stream_ptr(), arr, n, ws.data_ptr(), ws.numel()), "curv_gemm_batched")
+    return arr
 
 
-def randn(shape, device, seed: int, offset: int = 0) -> torch.Tensor:
+def gemm_batched(jobs: Sequence[Gemm]) -> None:
+    """All products in one launch (one work item per 64x64 output tile)."""
+    if not jobs:
+        return
+    GemmPlan(jobs).run()
+
+
+class GemmPlan:
+    """A fixed list of products: descriptors are built once, `run()` only enqueues (one launch).  The
+    operand tensors are kept alive by the plan; their contents may change between runs."""
+
+    def __init__(self, jobs: Sequence[Gemm]):
+        self.jobs = list(jobs)
+        self.n = len(self.jobs)
+        self.descs = _gemm_descs(self.jobs) if self.n else None
+
+    def run(self) -> None:
+        if not self.n:
+            return
+        L = _lib.lib()
+        ws = workspace(L.curv_gemm_workspace_bytes(self.n), self.jobs[0].C.device, "gemm")
+        _lib.check(L.curv_gemm_batched(_lib.stream_ptr(), self.descs, self.n, ws.data_ptr(), ws.numel()),
+                   "curv_gemm_batched")
+
+
+def randn(shape, device, seed: int, offset: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Standard normal noise from the library's Philox generator (counter `offset` in units of 4 values)."""
-    out = torch.empty(shape, dtype=torch.float32, device=device)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+    else:
+        _require_gpu(out)
     _lib.check(_lib.lib().curv_randn(_lib.stream_ptr(), out.data_ptr(), out.numel(), int(seed) & (2 ** 64 - 1),
                                      int(offset)), "curv_randn")
     return out
