@@ -224,10 +224,15 @@ inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int ken
 }
 
 // (2o)/(4o) once per outer panel [k0, kend): everything beyond the panel, K = (kend - k0) * 64.
-// The next K block is fetched into registers while the MFMAs of the current one run.
-__global__ void __launch_bounds__(INV_THREADS)
+// K advances in steps of 32 (two 17 KB operand tiles in LDS instead of two 33 KB ones): four workgroups
+// fit a CU, twice as many loads are in flight per CU, and that - not L2 bandwidth - is what this
+// latency-bound streaming kernel was short of.  The next step is fetched into registers while the MFMAs
+// of the current one run.
+constexpr int OKS = 32;                // K step
+constexpr int OPA = OKS + 1;           // LDS pitch of a [64][32] operand (rows K-contiguous)
+__global__ void __launch_bounds__(INV_THREADS, 3)
 outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int row0, int strip, int n_items) {
-  __shared__ double As[NB * LDA], Bs[NB * LDA];
+  __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
   bool trailing;
   int i, j, f, local;
   if (strip) {
@@ -283,30 +288,52 @@ outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int kk_first = trailing ? k0 : (j > k0 ? j : k0);
   const bool same = trailing && i == j;
-  double ra[16], rb[16];
-  auto fetch = [&](int kk) {
-    const gdouble* ga = W + (long long)i * NB * np + kk * NB;
-    const gdouble* gb = trailing ? W + (long long)j * NB * np + kk * NB : X + (long long)kk * NB * np + j * NB;
+  const int r16 = lane & 15, kq = lane >> 4;
+  double ra[8], rb[8];
+  // per-lane byte offsets inside an operand tile (constant); the tile base and the row-group stride are
+  // wave-uniform, so every load is SGPR base + 32-bit VGPR offset: no 64-bit per-lane address registers
+  typedef __attribute__((address_space(1))) char gchar;
+  const unsigned voff_k = (unsigned)(((long long)(tid >> 5) * np + (tid & 31)) * 8);   // [rows][32 k] operands
+  const unsigned voff_n = (unsigned)(((long long)(tid >> 6) * np + (tid & 63)) * 8);   // [32 k][64 cols] operand
+  const long long step_k = 8ll * np * 8, step_n = 4ll * np * 8;                        // 8 / 4 rows per 256 lanes
+  auto fetch = [&](int ke) {                      // ke: first K element of the step
+    const gchar* ga = (const gchar*)(W + (long long)i * NB * np + ke);
+    const gchar* gb = (const gchar*)(trailing ? W + (long long)j * NB * np + ke : X + (long long)ke * np + j * NB);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int e = tid + u * INV_THREADS, rr = e >> 6, cc = e & 63;
-      ra[u] = ga[(long long)rr * np + cc];
-      rb[u] = same ? 0.0 : gb[(long long)rr * np + cc];
+    for (int u = 0; u < 8; ++u) {
+      ra[u] = *(const gdouble*)(ga + u * step_k + voff_k);
+      if (trailing) rb[u] = same ? 0.0 : *(const gdouble*)(gb + u * step_k + voff_k);
+      else rb[u] = *(const gdouble*)(gb + u * step_n + voff_n);
     }
   };
   f64x4 acc[2][2] = {};
-  fetch(kk_first);
-  for (int kk = kk_first; kk < kend; ++kk) {
+  const int ke0 = kk_first * NB, ke1 = kend * NB;
+  fetch(ke0);
+  for (int ke = ke0; ke < ke1; ke += OKS) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int e = tid + u * INV_THREADS, rr = e >> 6, cc = e & 63;
-      As[rr * LDA + cc] = ra[u];
-      if (!same) Bs[rr * LDA + cc] = rb[u];
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + u * INV_THREADS;
+      As[(e >> 5) * OPA + (e & 31)] = ra[u];
+      if (trailing) { if (!same) Bs[(e >> 5) * OPA + (e & 31)] = rb[u]; }
+      else Bs[(e >> 6) * LDA + (e & 63)] = rb[u];
     }
     __syncthreads();
-    if (kk + 1 < kend) fetch(kk + 1);
-    if (trailing) mma_64<true>(As, same ? As : Bs, wm, wn, lane, acc);
-    else mma_64<false>(As, Bs, wm, wn, lane, acc);
+    if (ke + OKS < ke1) fetch(ke + OKS);
+    const double* Bt = same ? As : Bs;
+#pragma unroll 4
+    for (int ks = 0; ks < OKS / 4; ++ks) {
+      const int k = 4 * ks + kq;
+      double a[2], b[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m] = As[(32 * wm + 16 * m + r16) * OPA + k];
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        b[n] = trailing ? Bt[(32 * wn + 16 * n + r16) * OPA + k] : Bs[k * LDA + 32 * wn + 16 * n + r16];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
     __syncthreads();
   }
   if (trailing) store_sub((gdouble*)d.W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);
@@ -674,8 +701,12 @@ static int stream_set(StreamSet** out) {
   CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.aux, hipStreamNonBlocking));
   CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
   CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
+  // the far updates are throughput work: lowest priority, so that the latency-critical chain launches of
+  // the other streams get workgroup slots first
+  int prio_low = 0, prio_high = 0;
+  CURV_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
   for (int g = 0; g < 2; ++g) {
-    CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.side[g].stream, hipStreamNonBlocking));
+    CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.side[g].stream, hipStreamNonBlocking, prio_low));
     for (int i = 0; i < 2; ++i) {
       CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_main[i], hipEventDisableTiming));
       CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_side[i], hipEventDisableTiming));
