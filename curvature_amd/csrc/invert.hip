@@ -88,6 +88,20 @@ inv_prepare_kernel(const InvDev* __restrict__ t, int nf) {
   const float* __restrict__ F = d.F;
   gdouble* W = (gdouble*)d.W;
   if (bi == 0 && bj == 0 && threadIdx.x == 0) *d.info = 0;
+  // The symmetrisation needs F[ri][rj] and its mirror F[rj][ri]: the mirror block is read row-wise (coalesced)
+  // into LDS and consumed transposed, instead of 64 lanes striding through 64 rows of F.
+  __shared__ float Tm[NB][NB + 1];
+  for (int e = threadIdx.x; e < NB * NB; e += INV_THREADS) {
+    const int r = e >> 6, c = e & 63;                       // mirror block: row index from the j range, col from the i range
+    const int j = bj * NB + r, i = bi * NB + c;
+    float v = 0.0f;
+    if (i < n && j < n) {
+      const int ri = d.reverse ? n - 1 - i : i, rj = d.reverse ? n - 1 - j : j;
+      v = F[(long long)rj * n + ri];
+    }
+    Tm[r][c] = v;
+  }
+  __syncthreads();
   for (int e = threadIdx.x; e < NB * NB; e += INV_THREADS) {
     const int i = bi * NB + (e >> 6), j = bj * NB + (e & 63);
     double v;
@@ -95,7 +109,7 @@ inv_prepare_kernel(const InvDev* __restrict__ t, int nf) {
       const int ri = d.reverse ? n - 1 - i : i, rj = d.reverse ? n - 1 - j : j;
       // reg = s**0.5 * F + diag(n**0.5); reg = (reg + reg.t()) / 2   (curvatures.py:368-375), in fp32
       float a = __fmul_rn(ss, F[(long long)ri * n + rj]);
-      float b = __fmul_rn(ss, F[(long long)rj * n + ri]);
+      float b = __fmul_rn(ss, Tm[e & 63][e >> 6]);
       if (i == j) { a = __fadd_rn(a, sn); b = __fadd_rn(b, sn); }
       v = (double)__fmul_rn(__fadd_rn(a, b), 0.5f);
     } else {
