@@ -929,8 +929,40 @@ struct Plan {
   long long slab_floats = 0;
 };
 
+static int build_plan(const curv_factor_desc* descs, int n, Plan& plan);
+
+// The plan depends on the geometry of the factors only (plus the 16-byte alignment of the sources); a
+// training loop asks for the same one every step, twice per step (workspace size, then the launch).  The
+// last plan is kept per thread and re-used with the pointers / scale / first flag patched in (the chunk
+// search costs ~240 us per call for a ResNet-50 otherwise).
 static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
   CURV_REQUIRE(n >= 0 && (n == 0 || descs != nullptr), "curv_kfac: bad descriptor array");
+  static thread_local std::vector<int> cached_key;
+  static thread_local Plan cached_plan;
+  std::vector<int> key;
+  key.reserve((size_t)n * 12 + 1);
+  { const char* ab = getenv("CURV_SYRK_ABLATE"); key.push_back(ab ? atoi(ab) : 0); }
+  for (int i = 0; i < n; ++i) {
+    const curv_factor_desc& s = descs[i];
+    const int vals[12] = {s.N, s.C, s.H, s.W, s.kh, s.kw, s.sh, s.sw, s.ph, s.pw, s.has_bias,
+                          (int)(reinterpret_cast<uintptr_t>(s.src) & 15)};
+    key.insert(key.end(), vals, vals + 12);
+  }
+  if (key == cached_key && (int)cached_plan.f.size() == n) {
+    plan = cached_plan;
+    for (int i = 0; i < n; ++i) {
+      CURV_REQUIRE(descs[i].src != nullptr && descs[i].dst != nullptr, "curv_kfac: factor %d: null pointer", i);
+      plan.f[i].src = descs[i].src; plan.f[i].dst = descs[i].dst;
+      plan.f[i].first = descs[i].first; plan.f[i].scale = descs[i].scale;
+    }
+    return CURV_OK;
+  }
+  const int rc = build_plan(descs, n, plan);
+  if (rc == CURV_OK) { cached_key = key; cached_plan = plan; }
+  return rc;
+}
+
+static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
   plan.f.resize(n);
   std::vector<double> chunk_cost(n);   // MFMA CU-cycles of one (tile, chunk)
   double total_cost = 0.0;
