@@ -126,45 +126,46 @@ def main():
     owned = [i for i, _ in kfac._owned()]
 
     L = _lib.lib()
-    ev = (L.curv_event_create(), L.curv_event_create())
-    kfac._timing_events = ev
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    # one set of events per timed step: they are read after the timed region, so that the steps run back to
+    # back (the only host synchronisation inside a step is invert()'s read-back of its status words)
+    hip_ev = [(L.curv_event_create(), L.curv_event_create()) for _ in range(max(args.steps, 1))]
+    tev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(max(args.steps, 1))]
 
-    def step(timed):
-        if timed:
+    def step(e):
+        if e is not None:
             e[0].record()
         kfac.update(batch_size=args.batch)
-        if timed:
+        if e is not None:
             e[1].record()
         kfac.invert(add=1.0, multiply=1000.0)
-        if timed:
+        if e is not None:
             e[2].record()
         kfac.sample_and_replace()
-        if timed:
+        if e is not None:
             e[3].record()
 
+    kfac._timing_events = hip_ev[0]
     for _ in range(args.warmup):
-        step(False)
+        step(None)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    phase = [0.0, 0.0, 0.0]
-    syrk_ms = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-        # event bookkeeping happens after the step's work is enqueued; reading them waits for that step,
-        # which every step does anyway (invert reads its status words back)
-        torch.cuda.synchronize()
-        for p in range(3):
-            phase[p] += e[p].elapsed_time(e[p + 1])
-        ms = __import__("ctypes").c_float(0.0)
-        _lib.check(L.curv_event_elapsed_ms(ev[0], ev[1], ms), "curv_event_elapsed_ms")
-        syrk_ms += ms.value
+    for k in range(args.steps):
+        kfac._timing_events = hip_ev[k]
+        step(tev[k])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    phase = [0.0, 0.0, 0.0]
+    syrk_ms = 0.0
+    for k in range(args.steps):
+        for p in range(3):
+            phase[p] += tev[k][p].elapsed_time(tev[k][p + 1])
+        ms = __import__("ctypes").c_float(0.0)
+        _lib.check(L.curv_event_elapsed_ms(hip_ev[k][0], hip_ev[k][1], ms), "curv_event_elapsed_ms")
+        syrk_ms += ms.value
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
