@@ -220,39 +220,70 @@ class KFAC(Curvature):
     def _save_output(self, module, grad_output):
         self.record[module][1] = grad_output         # raw; the reference stores grad * N (curvatures.py:310)
 
-    def update(self, batch_size: int = None):
-        """A += X X^T / (N L), G += (N g)(N g)^T / (N L) for every selected layer: one grouped launch."""
+    def update(self, batch_size: int = None, *, inputs: bool = True, grads: bool = True, input_weight: float = 1.0):
+        """A += X X^T / (N L), G += (N g)(N g)^T / (N L) for every selected layer: one grouped launch.
+
+        The keyword-only arguments extend the reference's ``update(batch_size)`` (curvatures.py:312) for
+        Monte-Carlo Fisher loops that run several backward passes per forward pass
+        (``curvature_amd.factors.compute_factors``): the A side depends only on the layer inputs, so it is
+        built once per forward with ``input_weight`` = number of backward passes (``inputs=False`` for the
+        others), instead of adding the same matrix again and again."""
         jobs = []
+        fresh = getattr(self, "_fresh", None)
+        if fresh is None:
+            fresh = self._fresh = set()              # factors allocated here that nothing has written yet
         for _, layer in self._owned():
             forward, backward = self.record[layer]
-            if forward is None or backward is None:
+            if (inputs and forward is None) or (grads and backward is None):
                 raise RuntimeError("KFAC.update: no recorded forward/backward pass for a selected layer")
-            x = forward.detach()
-            g = backward.detach()
-            if x.dtype != torch.float32 or g.dtype != torch.float32:
-                raise RuntimeError("KFAC.update expects float32 activations and gradients")
-            x, g = x.contiguous(), g.contiguous()
             has_bias = layer.bias is not None
+            x = g = None
+            if forward is not None:
+                x = forward.detach()
+                if x.dtype != torch.float32:
+                    raise RuntimeError("KFAC.update expects float32 activations and gradients")
+                x = x.contiguous()
+            if backward is not None:
+                g = backward.detach()
+                if g.dtype != torch.float32:
+                    raise RuntimeError("KFAC.update expects float32 activations and gradients")
+                g = g.contiguous()
             if layer.__class__.__name__ == 'Conv2d':
-                N, C = x.shape[0], x.shape[1]
                 kernel, stride, padding = layer.kernel_size, layer.stride, layer.padding
-                L = g.shape[2] * g.shape[3]
+                C, m = layer.in_channels, layer.out_channels
+                N = (x if x is not None else g).shape[0]
+                if g is not None:
+                    L = g.shape[2] * g.shape[3]
+                else:
+                    L = ((x.shape[2] + 2 * padding[0] - kernel[0]) // stride[0] + 1) * \
+                        ((x.shape[3] + 2 * padding[1] - kernel[1]) // stride[1] + 1)
                 n = C * kernel[0] * kernel[1] + int(has_bias)
             else:
-                if x.dim() != 2:                      # (N, *, in) inputs: flatten the leading dims
+                if x is not None and x.dim() != 2:      # (N, *, in) inputs: flatten the leading dims
                     x = x.reshape(-1, x.shape[-1])
+                if g is not None and g.dim() != 2:
                     g = g.reshape(-1, g.shape[-1])
-                N, C = x.shape
+                N = (x if x is not None else g).shape[0]
+                C, m = layer.in_features, layer.out_features
                 kernel, stride, padding, L = (1, 1), (1, 1), (0, 0), 1
                 n = C + int(has_bias)
-            m = g.shape[1]
-            first = layer not in self.state
-            if first:
-                self.state[layer] = [torch.empty(n, n, dtype=torch.float32, device=x.device),
-                                     torch.empty(m, m, dtype=torch.float32, device=x.device)]
+            dev = (x if x is not None else g).device
+            if layer not in self.state:
+                # a side that is not written by this call must start from zero, not from garbage
+                alloc = torch.empty if (inputs and grads) else torch.zeros
+                self.state[layer] = [alloc(n, n, dtype=torch.float32, device=dev),
+                                     alloc(m, m, dtype=torch.float32, device=dev)]
+                if inputs and grads:
+                    fresh.update(((layer, 0), (layer, 1)))
             A, G = self.state[layer]
-            jobs.append(ops.FactorJob(x, A, kernel, stride, padding, has_bias, 1.0 / (N * L), first))
-            jobs.append(ops.FactorJob(g, G, (1, 1), (1, 1), (0, 0), False, float(N) / L, first))
+            if inputs:
+                first = (layer, 0) in fresh
+                fresh.discard((layer, 0))
+                jobs.append(ops.FactorJob(x, A, kernel, stride, padding, has_bias, float(input_weight) / (N * L), first))
+            if grads:
+                first = (layer, 1) in fresh
+                fresh.discard((layer, 1))
+                jobs.append(ops.FactorJob(g, G, (1, 1), (1, 1), (0, 0), False, float(N) / L, first))
         ops.kfac_accumulate(jobs, events=getattr(self, "_timing_events", None))
 
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):

@@ -306,3 +306,27 @@ def model_kfac_sample(inv_state: dict, model: torch.nn.Module, noise: Optional[d
         z = noise[layer] if noise is not None else torch.randn(L_A.size(0), L_G.size(0), dtype=L_A.dtype)
         out[layer] = kfac_sample(L_A, L_G, z)
     return out
+
+
+def mc_fisher_kfac(model: torch.nn.Module, batches, samples: int, label_fn) -> dict:
+    """The MC-Fisher outer loop of the reference's driver (scripts/factors.py:47-61) with KFAC: per batch one
+    forward, then `samples` times {labels ~ Categorical(logits) (here: label_fn(logits, batch, sample)),
+    backward(retain_graph=True), KFAC.update}.  Literal: the A side is rebuilt for every sample."""
+    state = {}
+    for b, images in enumerate(batches):
+        rec, handles = {}, []
+        for layer in selected_layers(model):
+            def fwd(mod, inp, out):
+                rec[mod] = [inp[0].detach(), None]
+                out.register_hook(lambda g, mod=mod: rec[mod].__setitem__(1, g.detach()))
+            handles.append(layer.register_forward_hook(fwd))
+        logits = model(images)
+        for h in handles:
+            h.remove()
+        for smp in range(samples):
+            labels = label_fn(logits, b, smp)
+            loss = F.cross_entropy(logits, labels)
+            model.zero_grad()
+            loss.backward(retain_graph=True)
+            state = model_kfac_update(state, model, rec)
+    return state

@@ -223,3 +223,32 @@ def test_sample_and_replace_restores_every_state_tensor(gpu):
     kfac.sample_and_replace()                     # second call reuses the cached plan
     torch.cuda.synchronize()
     assert torch.equal(model.state_dict()["1.running_mean"], mean["1.running_mean"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("share_inputs", [True, False])
+def test_mc_fisher_driver_matches_reference_loop(gpu, share_inputs):
+    """compute_factors (scripts/factors.py:33-62 of the reference) on LeNet-5: the accumulated KFAC factors
+    after 2 batches x 3 label draws equal the reference's (golden g12), with and without building the A
+    side once per forward pass."""
+    from curvature_amd import models
+    from curvature_amd.factors import compute_factors
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "g12_mc_fisher_lenet.npz")).items()}
+    g1 = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "g1_kfac_lenet.npz")).items()}
+    model = models.lenet5()
+    layers = [l for l in model.modules() if l.__class__.__name__ in ("Linear", "Conv2d")]
+    with torch.no_grad():
+        for li, layer in enumerate(layers):                   # the bundled MNIST weights the golden run used
+            layer.weight.copy_(g1[f"w_l{li}"])
+            layer.bias.copy_(g1[f"bias_l{li}"])
+    model = model.to(gpu)
+    samples = int(g["samples"])
+    data = [(g[f"b{b}_x"], None) for b in range(2)]
+    est = compute_factors(None, model, data, estimator="kfac", samples=samples, epochs=1, device=gpu,
+                          share_inputs=share_inputs,
+                          label_sampler=lambda logits, b, s: g[f"b{b}_s{s}_labels"].to(gpu))
+    torch.cuda.synchronize()
+    for li, layer in enumerate(layers):
+        A, G = est.state[layer]
+        assert rel_fro(A, g[f"A_l{li}"]) < 1e-5, (li, rel_fro(A, g[f"A_l{li}"]))
+        assert rel_fro(G, g[f"G_l{li}"]) < 1e-5, (li, rel_fro(G, g[f"G_l{li}"]))

@@ -175,3 +175,22 @@ def test_layer_tables_match_models():
         for a, b in zip(rows, ref):
             assert (a["index"], a["name"], a["kind"], a["n"], a["m"], a["L"], a["has_bias"]) == \
                    (b["index"], b["name"], b["kind"], b["n"], b["m"], b["L"], b["has_bias"]), (name, a, b)
+
+
+def test_mc_fisher_loop():
+    """The oracle's restatement of the reference driver loop (scripts/factors.py:47-61) against the factors
+    the reference's own KFAC accumulated in that loop (golden g12)."""
+    from curvature_amd import models
+    g, g1 = load("g12_mc_fisher_lenet.npz"), load("g1_kfac_lenet.npz")
+    model = models.lenet5()
+    layers = [l for l in model.modules() if l.__class__.__name__ in ("Linear", "Conv2d")]
+    with torch.no_grad():
+        for li, layer in enumerate(layers):
+            layer.weight.copy_(g1[f"w_l{li}"])
+            layer.bias.copy_(g1[f"bias_l{li}"])
+    model.train()
+    state = o.mc_fisher_kfac(model, [g[f"b{b}_x"] for b in range(2)], int(g["samples"]),
+                             lambda logits, b, s: g[f"b{b}_s{s}_labels"])
+    for li, layer in enumerate(layers):
+        assert rel_fro(state[layer][0], g[f"A_l{li}"]) < 1e-6
+        assert rel_fro(state[layer][1], g[f"G_l{li}"]) < 1e-6

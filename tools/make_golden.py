@@ -323,6 +323,36 @@ def gen_layer_tables():
         json.dump(tables, fh, indent=0)
 
 
+def gen_mc_fisher():
+    """G12: the MC-Fisher outer loop of scripts/factors.py:47-61 (one forward, `samples` label draws from
+    Categorical(logits), backward(retain_graph=True) + update per draw), driven with the reference's KFAC
+    class.  The script itself imports torchvision (absent here), so its loop is restated; labels are fixed
+    by seeding right before each draw and recorded."""
+    N, samples = 8, 3
+    model = lenet5(pretrained="mnist", device="cpu").train()
+    criterion = torch.nn.CrossEntropyLoss()
+    est = KFAC(model)
+    arrays = {"samples": np.array(samples)}
+    for b in range(2):
+        torch.manual_seed(400 + b)
+        images = torch.rand(N, 1, 28, 28)
+        arrays[f"b{b}_x"] = npf(images)
+        logits = model(images)
+        dist = torch.distributions.Categorical(logits=logits)
+        for smp in range(samples):
+            torch.manual_seed(500 + 10 * b + smp)
+            labels = dist.sample()
+            arrays[f"b{b}_s{smp}_labels"] = npf(labels)
+            loss = criterion(logits, labels)
+            model.zero_grad()
+            loss.backward(retain_graph=True)
+            est.update(images.size(0))
+    for li, layer in enumerate(layers_of(est)):
+        arrays[f"A_l{li}"] = npf(est.state[layer][0])
+        arrays[f"G_l{li}"] = npf(est.state[layer][1])
+    save("g12_mc_fisher_lenet.npz", **arrays)
+
+
 def gen_kron():
     """G10: the reference's only known-answer test (curvature/utils.py:301-309)."""
     a = torch.tensor([[1, 2], [3, 4]])
@@ -334,7 +364,9 @@ def gen_kron():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_kron()
-    gen_conv_shapes()
-    gen_lenet()
-    gen_layer_tables()
+    only = sys.argv[1:]                      # e.g. `python tools/make_golden.py mc_fisher` regenerates one set
+    gens = {"kron": gen_kron, "conv_shapes": gen_conv_shapes, "lenet": gen_lenet, "layer_tables": gen_layer_tables,
+            "mc_fisher": gen_mc_fisher}
+    for name, fn in gens.items():
+        if not only or name in only:
+            fn()
