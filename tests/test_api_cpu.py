@@ -72,3 +72,28 @@ def test_model_state_is_a_deep_copy():
         m[0].weight.add_(1.0)
     assert torch.equal(k.model_state['0.weight'], w0)
     assert k.model_state_of(m[0], 'weight') is k.model_state['0.weight']
+
+
+def test_named_state_round_trip(tmp_path):
+    """curvature_amd.io: estimator state keyed by layer name, loaded into another model instance, and the
+    reference's module-keyed format matched by position."""
+    import torch
+    from curvature_amd import io, models
+    from curvature_amd.curvatures import KFAC
+    m1, m2 = models.lenet5(), models.lenet5()
+    k1, k2 = KFAC(m1), KFAC(m2)
+    layers1 = [l for l in m1.modules() if l.__class__.__name__ in ("Linear", "Conv2d")]
+    layers2 = [l for l in m2.modules() if l.__class__.__name__ in ("Linear", "Conv2d")]
+    torch.manual_seed(0)
+    k1.state = {l: [torch.randn(3, 3), torch.randn(2, 2)] for l in layers1}
+    path = str(tmp_path / "kfac_state.pth")
+    io.save_state(k1, path)
+    io.load_state(k2, path)
+    assert list(k2.state.keys()) == layers2
+    for a, b in zip(layers1, layers2):
+        assert torch.equal(k1.state[a][0], k2.state[b][0]) and torch.equal(k1.state[a][1], k2.state[b][1])
+    names = io.named_state(k1)
+    assert list(names.keys()) == [n for n, mod in m1.named_modules() if mod in layers1]
+    k3 = KFAC(models.lenet5())
+    io.load_state(k3, k1.state)                      # module-keyed dict of ANOTHER instance: by position
+    assert torch.equal(list(k3.state.values())[4][1], k1.state[layers1[4]][1])
