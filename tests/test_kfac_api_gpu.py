@@ -252,3 +252,56 @@ def test_mc_fisher_driver_matches_reference_loop(gpu, share_inputs):
         A, G = est.state[layer]
         assert rel_fro(A, g[f"A_l{li}"]) < 1e-5, (li, rel_fro(A, g[f"A_l{li}"]))
         assert rel_fro(G, g[f"G_l{li}"]) < 1e-5, (li, rel_fro(G, g[f"G_l{li}"]))
+
+
+@pytest.mark.gpu
+def test_eval_bnn_matches_oracle(gpu):
+    """eval_bnn (scripts/evaluate.py:121-152): mean softmax over posterior samples, against the oracle's
+    sampler + a CPU forward with the same factors, hyper-parameters and noise."""
+    import copy
+    import oracle.curvature_oracle as o
+    from curvature_amd import models
+    from curvature_amd.curvatures import KFAC
+    from curvature_amd.evaluate import eval_bnn
+    g1 = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "g1_kfac_lenet.npz")).items()}
+    model = models.lenet5()
+    layers = [l for l in model.modules() if l.__class__.__name__ in ("Linear", "Conv2d")]
+    with torch.no_grad():
+        for li, layer in enumerate(layers):
+            layer.weight.copy_(g1[f"w_l{li}"])
+            layer.bias.copy_(g1[f"bias_l{li}"])
+    cpu_model = copy.deepcopy(model).eval()
+    cpu_layers = [l for l in cpu_model.modules() if l.__class__.__name__ in ("Linear", "Conv2d")]
+    model = model.to(gpu)
+    kfac = KFAC(model)
+    kfac.state = {l: [g1[f"A_after3_l{li}"].to(gpu), g1[f"G_after3_l{li}"].to(gpu)] for li, l in enumerate(layers)}
+    kfac.invert(add=0.5, multiply=1)
+    torch.manual_seed(7)
+    data = [(torch.rand(6, 1, 28, 28), torch.arange(6)) for _ in range(2)]
+    n_samples = 3
+    noises = [{l: torch.randn(g1[f"A_after3_l{li}"].shape[0], g1[f"G_after3_l{li}"].shape[0])
+               for li, l in enumerate(layers)} for _ in range(n_samples)]
+    calls = {"i": 0}
+    plain = kfac.sample_and_replace
+
+    def with_noise():
+        plain(noise={l: z.to(gpu) for l, z in noises[calls["i"]].items()})
+        calls["i"] += 1
+    kfac.sample_and_replace = with_noise
+    mean_pred, labels = eval_bnn(model, data, kfac, samples=n_samples, device=gpu)
+    assert labels.tolist() == list(range(6)) * 2 and mean_pred.shape == (12, 10)
+    # oracle: same factors / hyper-parameters / noise on the CPU
+    state = {cl: [g1[f"A_after3_l{li}"], g1[f"G_after3_l{li}"]] for li, cl in enumerate(cpu_layers)}
+    inv = o.model_kfac_invert(state, 0.5, 1)
+    mean = [(cl.weight.detach().clone(), cl.bias.detach().clone()) for cl in cpu_layers]
+    ref = torch.zeros(12, 10, dtype=torch.float64)
+    for s in range(n_samples):
+        smp = o.model_kfac_sample(inv, cpu_model, {cl: noises[s][l] for cl, l in zip(cpu_layers, layers)})
+        with torch.no_grad():
+            for cl, (w, b) in zip(cpu_layers, mean):
+                w_new, b_new = o.replace(smp[cl], w, b)
+                cl.weight.copy_(w_new)
+                cl.bias.copy_(b_new)
+            ref += torch.cat([torch.softmax(cpu_model(x), dim=1) for x, _ in data]).double()
+    ref /= n_samples
+    assert float(np.abs(mean_pred - ref.numpy()).max()) < 1e-4
