@@ -128,6 +128,15 @@ class Curvature(ABC):
             self._reload_plans[key] = plan
         plan.run()
 
+    def model_state_of(self, layer: Module, name: str) -> Tensor:
+        """The mean (MAP) tensor of `layer.<name>` inside ``model_state``."""
+        if not hasattr(self, "_state_keys"):
+            self._state_keys = {}
+            for prefix, mod in self.model.named_modules():
+                for pname, _ in mod.named_parameters(recurse=False):
+                    self._state_keys[(mod, pname)] = (prefix + "." if prefix else "") + pname
+        return self.model_state[self._state_keys[(layer, name)]]
+
     @staticmethod
     def _replace(sample: Tensor, weight: Tensor, bias: Tensor = None):
         """weight += sample[:, :-1], bias += sample[:, -1] (curvatures.py:67-82)."""
@@ -366,16 +375,6 @@ class KFAC(Curvature):
         plan[3].run()
         self._allgather_sampled()
 
-    def model_state_of(self, layer: Module, name: str) -> Tensor:
-        """The mean (MAP) tensor of `layer.<name>` inside ``model_state``."""
-        if not hasattr(self, "_state_keys"):
-            self._state_keys = {}
-            for prefix, mod in self.model.named_modules():
-                for pname, _ in mod.named_parameters(recurse=False):
-                    self._state_keys[(mod, pname)] = (prefix + "." if prefix else "") + pname
-        return self.model_state[self._state_keys[(layer, name)]]
-
-
 class EFB(Curvature):
     """Eigenvalue-corrected Kronecker factorisation (curvatures.py:395-460).
 
@@ -432,6 +431,36 @@ class EFB(Curvature):
         ops.gemm_batched([ops.Gemm(second, zt, tmp)])
         ops.gemm_batched([ops.Gemm(tmp, first.t(), out)])
         return out
+
+
+    def sample_and_replace(self, noise: Optional[Dict[Module, Tensor]] = None):
+        """Fused form of the base-class loop (same result as curvatures.py:117-129 with EFB.sample): the
+        scaled noise per layer, then two batched GEMM launches for the whole model, the second writing
+        ``mean + sample`` straight into the parameters.  `noise[layer]` (n, m) may be supplied."""
+        assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
+        owned = self._owned()
+        self._reload_mean(skip=[p for _, l in owned for p in (l.weight, l.bias) if p is not None])
+        stage1, stage2 = [], []
+        for _, layer in owned:
+            first, second = self.eigvecs[layer]
+            lambdas = self.inv_state[layer]
+            n, m = first.size(0), second.size(0)
+            z = noise[layer] if noise is not None else self._randn(n, m, device=first.device)
+            zt = ops.mul2d(z.t(), lambdas)                                # (m, n)
+            tmp = torch.empty(m, n, dtype=torch.float32, device=first.device)
+            stage1.append(ops.Gemm(second, zt, tmp))
+            n0 = n - int(layer.bias is not None)
+            w = layer.weight.data.view(m, n0)
+            w_mean = self.model_state_of(layer, 'weight').view(m, n0)
+            ua_t = first.t()
+            stage2.append(ops.Gemm(tmp, ua_t[:, :n0], w, epilogue=ops.EPI_ADD_E, E=w_mean))
+            if layer.bias is not None:
+                b = layer.bias.data.view(m, 1)
+                b_mean = self.model_state_of(layer, 'bias').view(m, 1)
+                stage2.append(ops.Gemm(tmp, ua_t[:, n0:], b, epilogue=ops.EPI_ADD_E, E=b_mean))
+        ops.gemm_batched(stage1)
+        ops.gemm_batched(stage2)
+        self._allgather_sampled()
 
 
 class INF(Curvature):

@@ -90,6 +90,13 @@ def test_efb_chain(gpu):
         assert rel_fro(efb.inv_state[layer], g6[f"inv_l{li}"]) < TOL
         s = efb.sample(layer, z=g6[f"z_l{li}"].to(gpu))
         assert rel_fro(s, g6[f"sample_l{li}"]) < TOL
+    # fused whole-model path with the golden noise: parameters = mean + the reference's sample
+    efb.sample_and_replace(noise={l: g6[f"z_l{li}"].to(gpu) for li, l in enumerate(layers)})
+    for li, layer in enumerate(layers):
+        smp = g6[f"sample_l{li}"].to(gpu)
+        w_ref = g1[f"w_l{li}"].to(gpu) + smp[:, :-1].reshape(layer.weight.shape)
+        b_ref = g1[f"bias_l{li}"].to(gpu) + smp[:, -1]
+        assert rel_fro(layer.weight.data, w_ref) < TOL and rel_fro(layer.bias.data, b_ref) < TOL
     efb.sample_and_replace()
     assert all(torch.isfinite(l.weight).all() for l in layers)
 
