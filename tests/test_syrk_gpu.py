@@ -22,6 +22,11 @@ CONV_CASES = [
     (1, 130, 5, 6, 3, 1, 1, True),      # many tiles (n = 1171), bias, non-square
     (2, 8, 40, 150, 3, 1, 1, False),    # wide rows -> column-split chunks
     (5, 4, 6, 6, (3, 1), (1, 2), (0, 1), True),  # anisotropic kernel/stride/padding
+    (2, 64, 8, 8, 1, 1, 0, False),      # flattened 1x1, 16-byte rows: float4 staging, 64x64 tiles
+    (2, 256, 4, 4, 1, 1, 0, False),     # float4 staging, 128x128 tiles, several samples per chunk
+    (3, 256, 7, 7, 3, 1, 1, False),     # linear staging, odd width (1 float per lane), 16 channels per panel
+    (2, 5, 9, 9, 3, 1, 1, True),        # linear staging, channel count that is neither 8 nor 16
+    (2, 40, 10, 10, 3, 2, 1, False),    # linear staging, stride 2, even width (2 floats per lane)
 ]
 
 
