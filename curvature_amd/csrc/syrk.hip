@@ -133,12 +133,22 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   const int i0 = ti * TMv, j0 = tj * TMv;
 
   // wave roles
-  const int wm = (TMv == 128) ? (wave >> 1) : 0;
-  const int wn = (TMv == 128) ? (wave & 1) : 0;
+  // 128x128 tiles: wave (wm, wn) owns the 64x64 quadrant (wm, wn), i.e. 2x2 MFMA blocks.  On a diagonal
+  // tile the quadrant (1, 0) is redundant and the diagonal quadrants skip their lower-left block, so the
+  // work is 3 + 4 + 0 + 3 blocks: the otherwise idle wave takes the right block column of quadrant (0, 1)
+  // (part 3) and the wave of that quadrant keeps the left one (part 2): 3 + 2 + 2 + 3.
+  //   part 0: all four blocks   1: all but the lower-left   2: left block column   3: right block column
+  int wm_ = (TMv == 128) ? (wave >> 1) : 0;
+  int wn_ = (TMv == 128) ? (wave & 1) : 0;
+  int part_ = 0;
+  if (diag) {
+    if (wm_ == wn_) part_ = 1;
+    else if (TMv == 128) { part_ = (wm_ == 0) ? 2 : 3; wm_ = 0; wn_ = 1; }
+  }
+  const int wm = wm_, wn = wn_, part = part_;
   const int kfirst = (TMv == 128) ? 0 : wave;      // first k pair of this wave within a chunk
   constexpr int KSTRIDE = (TMv == 128) ? 1 : 4;
-  const bool idle = (TMv == 128) && diag && wm == 1 && wn == 0;
-  const bool skip10 = diag && (wm == wn);          // 64x64 block on the diagonal: lower-left redundant
+  constexpr bool idle = false;
 
   // the pointer comes out of the descriptor table, so tell the compiler it is a GLOBAL address:
   // a flat load would also count on lgkmcnt and serialise the prefetch with the LDS operand reads
@@ -567,9 +577,10 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   // SKIP: the wave sits on the diagonal (lower-left 32x32 block redundant); CHECK: some run of the chunk
   // is padded or missing, so validity masks must be honoured.  Both are wave-uniform per chunk and
   // compiled as separate loop bodies: the common body is branch-free between its MFMAs.
-  auto compute_ops = [&](auto rl_tag, auto skip_tag, auto check_tag, Ops& op) {
+  auto compute_ops = [&](auto rl_tag, auto part_tag, auto check_tag, Ops& op) {
     constexpr int RLc = decltype(rl_tag)::value;
-    constexpr bool SKIP = decltype(skip_tag)::value, CHECK = decltype(check_tag)::value;
+    constexpr int PART = decltype(part_tag)::value;
+    constexpr bool CHECK = decltype(check_tag)::value;
     constexpr int FULL = (1 << RLc) - 1;
     if (CHECK) {
       if (__ballot(op.mask != FULL) != 0ull) {   // some lane half has padded or missing elements: zero its A
@@ -583,14 +594,14 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
     }
 #pragma unroll
     for (int j = 0; j < RLc; ++j) {
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a0[j], op.b0[j], acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a0[j], op.b1[j], acc01, 0, 0, 0);
-      if (!SKIP) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1[j], op.b0[j], acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1[j], op.b1[j], acc11, 0, 0, 0);
+      if (PART != 3) acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a0[j], op.b0[j], acc00, 0, 0, 0);
+      if (PART != 2) acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a0[j], op.b1[j], acc01, 0, 0, 0);
+      if (PART == 0 || PART == 2) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1[j], op.b0[j], acc10, 0, 0, 0);
+      if (PART != 2) acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1[j], op.b1[j], acc11, 0, 0, 0);
     }
   };
 
-  auto mfma_runs = [&](auto rl_tag, auto skip_tag, auto check_tag, int niter) {
+  auto mfma_runs = [&](auto rl_tag, auto part_tag, auto check_tag, int niter) {
     Ops A, B;
     const int last = 2 * niter - 1;          // table entries exist up to here
     int it = kfirst;
@@ -603,12 +614,12 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
       const int it1 = it + KSTRIDE;
       const bool n1 = it1 < niter;
       if (n1) { load_ops(rl_tag, B, e); e = ktab[min(2 * (it1 + KSTRIDE) + h, last)]; }
-      compute_ops(rl_tag, skip_tag, check_tag, A);
+      compute_ops(rl_tag, part_tag, check_tag, A);
       if (!n1) break;
       it = it1 + KSTRIDE;
       const bool n2 = it < niter;
       if (n2) { load_ops(rl_tag, A, e); e = ktab[min(2 * (it + KSTRIDE) + h, last)]; }
-      compute_ops(rl_tag, skip_tag, check_tag, B);
+      compute_ops(rl_tag, part_tag, check_tag, B);
       if (!n2) break;
     }
   };
@@ -659,8 +670,13 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
       using F = std::false_type;
       const bool check = (work.wa % RL != 0) || (work.nruns & 1);
       auto go = [&](auto rl_tag) {
-        if (skip10) { if (check) mfma_runs(rl_tag, T{}, T{}, work.niter); else mfma_runs(rl_tag, T{}, F{}, work.niter); }
-        else { if (check) mfma_runs(rl_tag, F{}, T{}, work.niter); else mfma_runs(rl_tag, F{}, F{}, work.niter); }
+        auto with_part = [&](auto part_tag) {
+          if (check) mfma_runs(rl_tag, part_tag, T{}, work.niter); else mfma_runs(rl_tag, part_tag, F{}, work.niter);
+        };
+        if (part == 0) with_part(std::integral_constant<int, 0>{});
+        else if (part == 1) with_part(std::integral_constant<int, 1>{});
+        else if (part == 2) with_part(std::integral_constant<int, 2>{});
+        else with_part(std::integral_constant<int, 3>{});
       };
       if (RL == 2) go(std::integral_constant<int, 2>{});
       else go(std::integral_constant<int, 1>{});
@@ -691,10 +707,10 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      q[row * 128 + r32] = acc00[reg];
-      q[row * 128 + 32 + r32] = acc01[reg];
-      q[(32 + row) * 128 + r32] = acc10[reg];
-      q[(32 + row) * 128 + 32 + r32] = acc11[reg];
+      if (part != 3) q[row * 128 + r32] = acc00[reg];
+      if (part != 2) q[row * 128 + 32 + r32] = acc01[reg];
+      if (part != 3) q[(32 + row) * 128 + r32] = acc10[reg];
+      if (part != 2) q[(32 + row) * 128 + 32 + r32] = acc11[reg];
     }
   }
 }
