@@ -117,12 +117,14 @@ class Curvature(ABC):
         if not live or not live[0][1].is_cuda:
             self.model.load_state_dict(self.model_state)     # CPU models: torch plumbing, nothing to batch
             return
-        ptrs = tuple(v.data_ptr() for _, v in live)           # parameters may have been re-homed (.to(), ...)
-        key = (ptrs, tuple(sorted(t.data_ptr() for t in skip)))
+        # parameters may have been re-homed (.to(), ...) and model_state may have been reassigned
+        ptrs = tuple(v.data_ptr() for _, v in live)
+        means = tuple(self.model_state[k].data_ptr() for k, _ in live)
+        key = (ptrs, means, tuple(sorted(t.data_ptr() for t in skip)))
         plan = self._reload_plans.get(key)
         if plan is None:
             self._reload_plans.clear()
-            skipped = set(key[1])
+            skipped = set(key[2])
             pairs = [(v.data, self.model_state[k]) for k, v in live if v.data_ptr() not in skipped]
             plan = ops.CopyPlan([d for d, _ in pairs], [s_ for _, s_ in pairs])
             self._reload_plans[key] = plan
@@ -339,6 +341,8 @@ class KFAC(Curvature):
         # are (invert() rewrites inv_state in place): per call only the noise is drawn.
         key = (noise is None, tuple(t.data_ptr() for _, l in owned for t in self.inv_state[l]),
                tuple(p.data_ptr() for _, l in owned for p in (l.weight, l.bias) if p is not None),
+               tuple(self.model_state_of(l, nm).data_ptr() for _, l in owned for nm in ('weight', 'bias')
+                     if getattr(l, nm) is not None),
                tuple(z.data_ptr() for z in noise.values()) if noise is not None else ())
         plan = getattr(self, "_sample_plan", None)
         if plan is None or plan[0] != key:
