@@ -435,20 +435,22 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
         const int c_lo = pnl ? c_lo_j : c_lo_i;
         if (vec4) {
           const int voff = (lx < (c.wa >> 2)) ? (prow0 * HW + c.iw_base + 4 * lx) * 4 : OOB;
-          int srow = 0, cb = 0;                          // uniform (sample, first channel) of the slot
-          asm volatile("" : "+s"(srow), "+s"(cb));
+          // slot j holds channel rows j * prow_step + prow0 of the folded (sample, channel) index: the
+          // plane offset advances by a constant per slot, plus the jump to the next sample at a wrap
+          int soff = c_lo * HW * 4, cb = 0, rows = 0;
+          asm volatile("" : "+s"(soff), "+s"(cb));
+          const int step = prow_step * HW * 4, wrap = (C - nch) * HW * 4;
 #pragma unroll
           for (int j = 0; j < STAGE_SLOTS / 4; ++j) {
-            if (j * prow_step < flat_rows) {
-              const int soff = ((srow * C + c_lo + cb) * HW) * 4;
+            if (rows < flat_rows) {
               const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
               st[pnl * STAGE_SLOTS + 4 * j + 0] = v.x;
               st[pnl * STAGE_SLOTS + 4 * j + 1] = v.y;
               st[pnl * STAGE_SLOTS + 4 * j + 2] = v.z;
               st[pnl * STAGE_SLOTS + 4 * j + 3] = v.w;
             }
-            cb += prow_step;
-            if (cb == nch) { cb = 0; ++srow; }
+            rows += prow_step; soff += step; cb += prow_step;
+            if (cb == nch) { cb = 0; soff += wrap; }
           }
         } else if (flat1) {
           const int voff = (lx < c.wa) ? (prow0 * HW + c.iw_base + lx) * 4 : OOB;
@@ -497,20 +499,18 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
         float* lbase = fs + PATCH_OFF + (pnl ? off_j : 0);
         if (vec4) {
           if (lx < (c.wa >> 2)) {
-            float* l0 = lbase + prow0 * PS + 4 * lx;
-            int srow = 0, cb = 0;
-          asm volatile("" : "+s"(srow), "+s"(cb));
+            float* l = lbase + prow0 * PS + 4 * lx;
+            int rows = 0, lstep = prow_step * PS;     // SS = nch * PS: the sample wrap needs no extra step
+            asm volatile("" : "+s"(rows), "+s"(lstep));
 #pragma unroll
             for (int j = 0; j < STAGE_SLOTS / 4; ++j) {
-              if (j * prow_step < flat_rows) {
-                float* l = l0 + srow * SS + cb * PS;
+              if (rows < flat_rows) {
                 l[0] = st[pnl * STAGE_SLOTS + 4 * j + 0];
                 l[1] = st[pnl * STAGE_SLOTS + 4 * j + 1];
                 l[2] = st[pnl * STAGE_SLOTS + 4 * j + 2];
                 l[3] = st[pnl * STAGE_SLOTS + 4 * j + 3];
               }
-              cb += prow_step;
-              if (cb == nch) { cb = 0; ++srow; }
+              rows += prow_step; l += lstep;
             }
           }
         } else if (flat1) {
