@@ -454,16 +454,14 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
           }
         } else if (flat1) {
           const int voff = (lx < c.wa) ? (prow0 * HW + c.iw_base + lx) * 4 : OOB;
-          int srow = 0, cb = 0;
-          asm volatile("" : "+s"(srow), "+s"(cb));
+          int soff = c_lo * HW * 4, cb = 0, rows = 0;
+          asm volatile("" : "+s"(soff), "+s"(cb));
+          const int step = prow_step * HW * 4, wrap = (C - nch) * HW * 4;
 #pragma unroll
           for (int j = 0; j < STAGE_SLOTS; ++j) {
-            if (j * prow_step < flat_rows) {
-              const int soff = ((srow * C + c_lo + cb) * HW) * 4;
-              st[pnl * STAGE_SLOTS + j] = bload(rs, voff, soff);
-            }
-            cb += prow_step;
-            if (cb == nch) { cb = 0; ++srow; }
+            if (rows < flat_rows) st[pnl * STAGE_SLOTS + j] = bload(rs, voff, soff);
+            rows += prow_step; soff += step; cb += prow_step;
+            if (cb == nch) { cb = 0; soff += wrap; }
           }
         } else if (lin) {
           int t = tid;
@@ -515,14 +513,13 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
           }
         } else if (flat1) {
           if (lx < c.wa) {
-            float* l0 = lbase + prow0 * PS + lx;
-            int srow = 0, cb = 0;
-          asm volatile("" : "+s"(srow), "+s"(cb));
+            float* l = lbase + prow0 * PS + lx;
+            int rows = 0, lstep = prow_step * PS;     // SS = nch * PS: the sample wrap needs no extra step
+            asm volatile("" : "+s"(rows), "+s"(lstep));
 #pragma unroll
             for (int j = 0; j < STAGE_SLOTS; ++j) {
-              if (j * prow_step < flat_rows) l0[srow * SS + cb * PS] = st[pnl * STAGE_SLOTS + j];
-              cb += prow_step;
-              if (cb == nch) { cb = 0; ++srow; }
+              if (rows < flat_rows) *l = st[pnl * STAGE_SLOTS + j];
+              rows += prow_step; l += lstep;
             }
           }
         } else if (lin) {
