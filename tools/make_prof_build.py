@@ -27,10 +27,10 @@ def main():
     s = sub(s, "    // ---- MFMA over this wave's share of the chunk's k-runs ----", "    PROF(4)")
     s = sub(s, "      else go(std::integral_constant<int, 1>{});\n    }\n    __syncthreads();\n",
             "      else go(std::integral_constant<int, 1>{});\n"
-            "      nmf += (work.niter - kfirst + KSTRIDE - 1) / KSTRIDE * (skip10 ? 3 : 4) * RL;\n    }\n"
+            "      nmf += (work.niter - kfirst + KSTRIDE - 1) / KSTRIDE * (part == 0 ? 4 : part == 1 ? 3 : 2) * RL;\n    }\n"
             "    PROF(5)\n    __syncthreads();\n    PROF(6)\n")
-    s = sub(s, "      q[(32 + row) * 128 + 32 + r32] = acc11[reg];\n    }\n  }\n}\n",
-            "      q[(32 + row) * 128 + 32 + r32] = acc11[reg];\n    }\n  }\n  PROF(7)\n"
+    s = sub(s, "      if (part != 2) q[(32 + row) * 128 + 32 + r32] = acc11[reg];\n    }\n  }\n}\n",
+            "      if (part != 2) q[(32 + row) * 128 + 32 + r32] = acc11[reg];\n    }\n  }\n  PROF(7)\n"
             "  if (lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&g_prof[k], (unsigned long long)pacc[k]);"
             " atomicAdd(&g_prof[10], (unsigned long long)nmf); atomicAdd(&g_prof[11], 1ull);"
             " atomicAdd(&g_prof[8], (unsigned long long)pacc8); atomicAdd(&g_prof[12], (unsigned long long)nchunk); }\n"
