@@ -15,9 +15,11 @@ import torch.distributed as dist
 
 def layer_cost(n: int, m: int, K: int) -> float:
     """Rough per-layer time model (arbitrary units): factor build + invert + sample at measured rates."""
-    build = (n * (n + 1.0) + m * (m + 1.0)) * K / 60e12        # executed SYRK flops at ~60 TFLOP/s
-    invert = (2.0 / 3.0) * (n ** 3 + m ** 3) / 2e12 + (n + m) / 64 * 3 * 25e-6 / 8   # fp64 sweeps, launch-bound part
-    sample = (2.0 * n * n * m + 2.0 * n * m * m) / 20e12
+    build = (n * (n + 1.0) + m * (m + 1.0)) * K / 80e12        # executed SYRK flops at ~80 TFLOP/s
+    # invert: throughput part at ~20 TFLOP/s (fp64) + the serial chain of 64-column steps (~80 us each; the
+    # chains of a rank's factors run side by side, so only a fraction of it adds up)
+    invert = (2.0 / 3.0) * (n ** 3 + m ** 3) / 20e12 + (n + m) / 64 * 80e-6 * 0.3
+    sample = (n * n * m + n * m * m) / 30e12                    # triangular GEMMs at ~30 TFLOP/s
     return build + invert + sample
 
 
@@ -43,36 +45,64 @@ class Shard:
 
     def allgather_params(self, params_per_layer: List[List[torch.Tensor]]) -> None:
         """params_per_layer[i] = parameter tensors of layer i (same shapes on every rank).  After the call
-        every rank holds the owner's values for every layer.  One all-gather of equal-sized packed shards."""
+        every rank holds the owner's values for every layer.  One all-gather of equal-sized packed shards;
+        on the GPU the packing and unpacking are one batched copy each (curv_copy_batched) and the buffers
+        and copy plans are kept while the parameter tensors stay where they are."""
         if self.world == 1:
             return
-        sizes = [0] * self.world
-        for i, ps in enumerate(params_per_layer):
-            sizes[self.owner[i]] += sum(p.numel() for p in ps)
-        cap = max(max(sizes), 1)
         ref = params_per_layer[0][0]
-        mine = torch.zeros(cap, dtype=ref.dtype, device=ref.device)
-        pos = 0
-        for i, ps in enumerate(params_per_layer):
-            if self.owner[i] == self.rank:
+        key = tuple(p.data_ptr() for ps in params_per_layer for p in ps)
+        cache = getattr(self, "_plan", None)
+        if cache is None or cache["key"] != key:
+            sizes = [0] * self.world
+            for i, ps in enumerate(params_per_layer):
+                sizes[self.owner[i]] += sum(p.numel() for p in ps)
+            cap = max(max(sizes), 1)
+            mine = torch.zeros(cap, dtype=ref.dtype, device=ref.device)
+            gathered = torch.empty(self.world * cap, dtype=ref.dtype, device=ref.device)
+            pack, unpack = [], []
+            cursor = [r * cap for r in range(self.world)]
+            pos = 0
+            for i, ps in enumerate(params_per_layer):
+                r = self.owner[i]
                 for p in ps:
-                    mine[pos:pos + p.numel()].copy_(p.detach().reshape(-1))
-                    pos += p.numel()
-        gathered = torch.empty(self.world * cap, dtype=ref.dtype, device=ref.device)
-        if mine.is_cuda and dist.get_backend(self.group) == "gloo":
+                    if not p.is_contiguous():
+                        raise RuntimeError("sharded parameters must be contiguous")
+                    n = p.numel()
+                    if r == self.rank:
+                        pack.append((mine[pos:pos + n], p.detach().reshape(-1)))
+                        pos += n
+                    else:
+                        unpack.append((p.detach().reshape(-1), gathered[cursor[r]:cursor[r] + n]))
+                    cursor[r] += n
+            cache = {"key": key, "cap": cap, "mine": mine, "gathered": gathered, "pack": pack, "unpack": unpack,
+                     "pack_plan": None, "unpack_plan": None}
+            if ref.is_cuda:
+                from . import ops
+                cache["pack_plan"] = ops.CopyPlan([d for d, _ in pack], [s_ for _, s_ in pack])
+                cache["unpack_plan"] = ops.CopyPlan([d for d, _ in unpack], [s_ for _, s_ in unpack])
+            self._plan = cache
+        mine, gathered = cache["mine"], cache["gathered"]
+        if cache["pack_plan"] is not None:
+            cache["pack_plan"].run()
+        else:
+            for d, s_ in cache["pack"]:
+                d.copy_(s_)
+        backend = dist.get_backend(self.group)
+        if mine.is_cuda and backend == "gloo":
             # test configurations only (several ranks sharing one GPU over gloo): stage through the host
-            host = torch.empty(self.world * cap, dtype=ref.dtype)
+            host = torch.empty(self.world * cache["cap"], dtype=ref.dtype)
             dist.all_gather(list(host.chunk(self.world)), mine.cpu(), group=self.group)
             gathered.copy_(host)
+        elif backend == "nccl":
+            dist.all_gather_into_tensor(gathered, mine, group=self.group)               # the one collective
         else:
-            dist.all_gather(list(gathered.chunk(self.world)), mine, group=self.group)   # the one collective
-        cursor = [r * cap for r in range(self.world)]
-        for i, ps in enumerate(params_per_layer):
-            r = self.owner[i]
-            for p in ps:
-                if r != self.rank:
-                    p.detach().copy_(gathered[cursor[r]:cursor[r] + p.numel()].view_as(p))
-                cursor[r] += p.numel()
+            dist.all_gather(list(gathered.chunk(self.world)), mine, group=self.group)
+        if cache["unpack_plan"] is not None:
+            cache["unpack_plan"].run()
+        else:
+            for d, s_ in cache["unpack"]:
+                d.copy_(s_)
 
 
 def make_shard(costs: Sequence[float], rank: Optional[int] = None, world: Optional[int] = None, group=None) -> Shard:
