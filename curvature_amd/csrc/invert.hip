@@ -712,7 +712,10 @@ static int stream_set(StreamSet** out) {
   CURV_HIP_CHECK(hipGetDevice(&dev));
   for (auto& e : cache) if (e.first == dev) { *out = &e.second; return CURV_OK; }
   StreamSet s;
-  CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.aux, hipStreamNonBlocking));
+  int plo = 0, phi = 0;
+  CURV_HIP_CHECK(hipDeviceGetStreamPriorityRange(&plo, &phi));
+  // the large group's chain of short launches is the critical path of the sweep: highest priority
+  CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.aux, hipStreamNonBlocking, phi));
   CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
   CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
   // the far updates are throughput work: lowest priority, so that the latency-critical chain launches of
@@ -871,9 +874,9 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   if (big.empty() || small.empty()) return chol_sweep_group(stream, &ss->side[0], big.empty() ? small : big, table0);
   CURV_HIP_CHECK(hipEventRecord(ss->ev_fork, stream));
   CURV_HIP_CHECK(hipStreamWaitEvent(ss->aux, ss->ev_fork, 0));
-  int rc = chol_sweep_group(stream, &ss->side[0], big, table0);
+  int rc = chol_sweep_group(ss->aux, &ss->side[0], big, table0);
   if (rc != CURV_OK) return rc;
-  rc = chol_sweep_group(ss->aux, &ss->side[1], small, table1);
+  rc = chol_sweep_group(stream, &ss->side[1], small, table1);
   if (rc != CURV_OK) return rc;
   CURV_HIP_CHECK(hipEventRecord(ss->ev_join, ss->aux));
   CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->ev_join, 0));
