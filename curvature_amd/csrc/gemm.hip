@@ -64,7 +64,11 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, int local, float* ld
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, h = lane >> 5;
-  const int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
+  int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
+  // triangular operands cut K per tile: hand out the long tiles first, so the tail of the launch is made of
+  // the short ones
+  if (d.tri == CURV_TRI_A_LOWER) tm = (d.M + TMv - 1) / TMv - 1 - tm;
+  else if (d.tri == CURV_TRI_B_UPPER) tn = d.tiles_n - 1 - tn;
   const int i0 = tm * TMv, j0 = tn * TMv;
   const int M = d.M, N = d.N;
   int K = d.K;

@@ -371,6 +371,9 @@ class KFAC(Curvature):
                     b = layer.bias.data.view(m, 1)
                     b_mean = self.model_state_of(layer, 'bias').view(m, 1)
                     stage2.append(ops.Gemm(tmp, la_t[:, n0:], b, epilogue=ops.EPI_ADD_E, E=b_mean))
+            # largest products first: the tail of each launch is then made of the short tiles
+            stage1.sort(key=lambda j: -(j.A.shape[0] * j.A.shape[1] * j.B.shape[1]))
+            stage2.sort(key=lambda j: -(j.A.shape[0] * j.A.shape[1] * j.B.shape[1]))
             plan = (key, flat, ops.GemmPlan(stage1), ops.GemmPlan(stage2))
             self._sample_plan = plan
         if plan[1] is not None:
