@@ -13,9 +13,10 @@
 //     lane_base encodes (channel, kh, kw), ktab[k] encodes (sample, out row, out col) of the chunk;
 //     row/plane strides are padded so that 32 consecutive unfolded rows hit 32 distinct banks;
 //   * the bias row of ones and the zero padding rows are two constant LDS words;
-//   * global loads of chunk t+1 are issued into registers before the MFMA loop of chunk t and written
-//     to LDS after it, so HBM/L2 latency hides under the matrix pipe; two workgroups per CU cover each
-//     other's LDS-store phases;
+//   * raw buffer loads of chunk t+1 are issued into registers before the MFMA loop of chunk t and written
+//     to LDS after it, so HBM/L2 latency hides under the matrix pipe; padding lanes carry an out-of-range
+//     offset and get their zeros from the hardware range check; two workgroups per CU cover each other's
+//     staging phases;
 //   * tile 64x64 (four waves split the K range of a chunk, each owning the full tile) for small or
 //     awkward dims, tile 128x128 (2x2 waves of 64x64) for large ones; every wave works on 2x2
 //     v_mfma_f32_32x32x2_f32 blocks and skips the redundant lower-left block on the diagonal;
@@ -114,7 +115,7 @@ struct Chunk {
 template <int TMv>
 __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, float* __restrict__ slabs,
                                           const float* __restrict__ zeros_, int* smem) {
-  const gfloat* zeros = (const gfloat*)zeros_;
+  (void)zeros_;            // (zeroed pad of the workspace: unused since padding comes from the buffer range check)
   float* fs = reinterpret_cast<float*>(smem);
   int* ktab = smem + KTAB_OFF;
 
