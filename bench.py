@@ -122,7 +122,7 @@ def main():
     loss.backward()                       # activations / gradients of every layer now resident in HBM
     dims = layer_dims(layers, kfac.record)
     if world > 1:
-        kfac.shard = sharding.make_shard([sharding.layer_cost(*d) for d in dims], rank, world)
+        kfac.shard = sharding.make_layer_shard(dims, rank, world)
     owned = [i for i, _ in kfac._owned()]
 
     L = _lib.lib()

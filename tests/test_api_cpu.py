@@ -97,3 +97,23 @@ def test_named_state_round_trip(tmp_path):
     k3 = KFAC(models.lenet5())
     io.load_state(k3, k1.state)                      # module-keyed dict of ANOTHER instance: by position
     assert torch.equal(list(k3.state.values())[4][1], k1.state[layers1[4]][1])
+
+
+def test_partition_layers_resnet50():
+    """Layer partition under the non-additive rank cost: every layer owned once, identical on every call, the
+    4608-wide layers alone on their ranks at 8 GPUs (their serial chain is the step time there)."""
+    from curvature_amd import models, sharding
+    rows = models.layer_table(models.resnet50(), (3, 224, 224))
+    dims = [(r["n"], r["m"], 32 * r["L"]) for r in rows]
+    for world in (1, 2, 4, 8):
+        owner = sharding.partition_layers(dims, world)
+        assert owner == sharding.partition_layers(dims, world) and len(owner) == len(dims)
+        assert set(owner) == set(range(world))
+        est = [sharding.rank_cost([d for d, o in zip(dims, owner) if o == r]) for r in range(world)]
+        additive = sharding.lpt_partition([sharding.rank_cost([d]) for d in dims], world)
+        est_add = [sharding.rank_cost([d for d, o in zip(dims, additive) if o == r]) for r in range(world)]
+        assert max(est) <= max(est_add) * 1.001
+    owner8 = sharding.partition_layers(dims, 8)
+    for i, d in enumerate(dims):
+        if d[0] == 4608:
+            assert sum(1 for o in owner8 if o == owner8[i]) == 1
