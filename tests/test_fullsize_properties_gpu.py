@@ -1,0 +1,108 @@
+"""Size-independent properties at the full benchmark configuration (ResNet-50, N = 32, 3x224x224): the oracle
+would take minutes there, so the HIP path is checked through identities that hold at any size.
+
+  factor build   exact symmetry; tr(A) = ||unfold(x)||^2 / (N L) (+1 for the ones row); accumulating the same
+                 batch twice doubles the factors; the grouped launch equals per-layer launches bit for bit
+  invert         L lower triangular and (L L^T)(sqrt(s) F + sqrt(n) I) = I for the largest factors
+  sample         sample(layer, z) = (L_A z L_G^T)^T against a torch fp64 product, layer order = modules() order
+"""
+import pytest
+import torch
+
+from conftest import rel_fro
+
+
+@pytest.fixture(scope="module")
+def resnet50_kfac(gpu):
+    from curvature_amd import models
+    from curvature_amd.curvatures import KFAC
+    torch.manual_seed(0)
+    model = models.resnet50().to(gpu).train()
+    kfac = KFAC(model)
+    x = torch.randn(32, 3, 224, 224, device=gpu)
+    logits = model(x)
+    labels = torch.distributions.Categorical(logits=logits).sample()
+    torch.nn.functional.cross_entropy(logits, labels).backward()
+    kfac.update(batch_size=32)
+    torch.cuda.synchronize()
+    return model, kfac
+
+
+@pytest.mark.gpu
+def test_factor_build_properties(gpu, resnet50_kfac):
+    from curvature_amd import ops
+    model, kfac = resnet50_kfac
+    layers = kfac._layers()
+    assert len(layers) == 54 and list(kfac.state.keys()) == layers          # modules() order, bit-exact indexing
+    for layer in layers:
+        A, G = kfac.state[layer]
+        assert torch.equal(A, A.t()) and torch.equal(G, G.t())              # exactly symmetric
+        assert torch.isfinite(A).all() and torch.isfinite(G).all()
+        x, g = kfac.record[layer]
+        N = x.shape[0]
+        L = g.shape[2] * g.shape[3] if g.dim() == 4 else 1
+        # tr(G) = (N / L) ||g||^2   (the hook's factor N of the reference folded into the scale)
+        tr_g = float(g.double().pow(2).sum()) * N / L
+        assert abs(float(torch.trace(G.double())) - tr_g) <= 1e-5 * abs(tr_g)
+        if layer.__class__.__name__ == "Conv2d" and layer.kernel_size == (1, 1) and layer.stride == (1, 1):
+            tr_a = float(x.double().pow(2).sum()) / (N * L)                  # unfold of a 1x1 conv is x itself
+            assert abs(float(torch.trace(A.double())) - tr_a) <= 1e-5 * abs(tr_a)
+        elif layer.__class__.__name__ == "Conv2d":
+            unf = torch.nn.functional.unfold(x[:4].double(), layer.kernel_size, padding=layer.padding, stride=layer.stride)
+            # diagonal of A restricted to 4 samples is a lower bound of the full diagonal (sum of squares)
+            d4 = unf.pow(2).sum(dim=(0, 2)) / (N * L)
+            assert (torch.diagonal(A.double())[:d4.numel()] + 1e-9 >= d4 * (1 - 1e-6)).all()
+    # linearity: the same batch once more doubles every factor
+    before = {l: [kfac.state[l][0].clone(), kfac.state[l][1].clone()] for l in layers}
+    kfac.update(batch_size=32)
+    torch.cuda.synchronize()
+    for l in layers:
+        assert rel_fro(kfac.state[l][0], 2 * before[l][0]) < 1e-6 and rel_fro(kfac.state[l][1], 2 * before[l][1]) < 1e-6
+    # the grouped launch is deterministic and independent of what else is in the launch: three layers alone
+    for l in (layers[0], layers[20], layers[53]):
+        x, g = kfac.record[l]
+        N = x.shape[0]
+        if l.__class__.__name__ == "Conv2d":
+            Lp = g.shape[2] * g.shape[3]
+            A1 = torch.empty_like(before[l][0])
+            ops.kfac_accumulate([ops.FactorJob(x.detach().contiguous(), A1, l.kernel_size, l.stride, l.padding,
+                                               l.bias is not None, 1.0 / (N * Lp), True)])
+        else:
+            A1 = torch.empty_like(before[l][0])
+            ops.kfac_accumulate([ops.FactorJob(x.detach().contiguous(), A1, (1, 1), (1, 1), (0, 0), l.bias is not None,
+                                               1.0 / N, True)])
+        torch.cuda.synchronize()
+        assert rel_fro(A1, before[l][0]) < 1e-6
+    for l in layers:                                   # restore single-batch factors for the tests below
+        kfac.state[l][0].copy_(before[l][0])
+        kfac.state[l][1].copy_(before[l][1])
+
+
+@pytest.mark.gpu
+def test_invert_and_sample_properties(gpu, resnet50_kfac):
+    model, kfac = resnet50_kfac
+    kfac.invert(add=1.0, multiply=1000.0)
+    layers = kfac._layers()
+    big = sorted(layers, key=lambda l: -kfac.state[l][0].shape[0])[:2] + [layers[0], layers[53]]
+    for layer in big:
+        for F, Lf in zip(kfac.state[layer], kfac.inv_state[layer]):
+            n = F.shape[0]
+            assert torch.equal(Lf, torch.tril(Lf))
+            M = (1000.0 ** 0.5) * F.double() + torch.eye(n, device=gpu, dtype=torch.float64)
+            M = (M + M.t()) / 2
+            R = (Lf.double() @ Lf.double().t()) @ M - torch.eye(n, device=gpu, dtype=torch.float64)
+            assert float(torch.linalg.norm(R)) / n ** 0.5 < 1e-4, (n, float(torch.linalg.norm(R)) / n ** 0.5)
+    layer = big[0]
+    LA, LG = kfac.inv_state[layer]
+    torch.manual_seed(3)
+    z = torch.randn(LA.shape[0], LG.shape[0], device=gpu)
+    s = kfac.sample(layer, z=z)
+    ref = (LA.double() @ z.double() @ LG.double().t()).t()
+    assert rel_fro(s, ref) < 1e-5
+    mean = {k: v.clone() for k, v in kfac.model_state.items()}
+    kfac.sample_and_replace()
+    torch.cuda.synchronize()
+    state = model.state_dict()
+    changed = sum(int(not torch.equal(state[k], mean[k])) for k in state)
+    assert all(torch.isfinite(v).all() for v in state.values())
+    assert changed == 54 + 1                      # 54 weights and the one bias (fc); BatchNorm tensors restored
