@@ -703,8 +703,11 @@ struct SideStream {
 };
 struct StreamSet {
   SideStream side[2];
-  hipStream_t aux = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t aux = nullptr;             // the large group's chain: high priority, all CUs
+  hipStream_t masked = nullptr;          // the small group's sweep (an internal stream of its own: measured 3 %
+                                         // faster than running it on the caller's stream; confining it to a
+                                         // CU subset with hipExtStreamCreateWithCUMask did not help)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
 };
 static int stream_set(StreamSet** out) {
   static thread_local std::vector<std::pair<int, StreamSet>> cache;
@@ -722,6 +725,8 @@ static int stream_set(StreamSet** out) {
   // the other streams get workgroup slots first
   int prio_low = 0, prio_high = 0;
   CURV_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+  CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_join2, hipEventDisableTiming));
+  CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.masked, hipStreamNonBlocking));
   for (int g = 0; g < 2; ++g) {
     CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.side[g].stream, hipStreamNonBlocking, prio_low));
     for (int i = 0; i < 2; ++i) {
@@ -874,12 +879,15 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   if (big.empty() || small.empty()) return chol_sweep_group(stream, &ss->side[0], big.empty() ? small : big, table0);
   CURV_HIP_CHECK(hipEventRecord(ss->ev_fork, stream));
   CURV_HIP_CHECK(hipStreamWaitEvent(ss->aux, ss->ev_fork, 0));
+  CURV_HIP_CHECK(hipStreamWaitEvent(ss->masked, ss->ev_fork, 0));
   int rc = chol_sweep_group(ss->aux, &ss->side[0], big, table0);
   if (rc != CURV_OK) return rc;
-  rc = chol_sweep_group(stream, &ss->side[1], small, table1);
+  rc = chol_sweep_group(ss->masked, &ss->side[1], small, table1);
   if (rc != CURV_OK) return rc;
   CURV_HIP_CHECK(hipEventRecord(ss->ev_join, ss->aux));
   CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->ev_join, 0));
+  CURV_HIP_CHECK(hipEventRecord(ss->ev_join2, ss->masked));
+  CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->ev_join2, 0));
   return CURV_OK;
 }
 
