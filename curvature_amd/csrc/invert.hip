@@ -62,8 +62,8 @@ __device__ __forceinline__ bool locate(const InvDev* __restrict__ t, int nf, int
     if (bid < base + total) {
       const unsigned long long m = __ballot(bid < base + incl);
       const int l = __ffsll((long long)m) - 1;
-      f = f0 + l;
-      local = bid - (base + __shfl(incl - c, l, 64));
+      f = __builtin_amdgcn_readfirstlane(f0 + l);               // wave-uniform by construction: let the
+      local = __builtin_amdgcn_readfirstlane(bid - (base + __shfl(incl - c, l, 64)));   // compiler know it
       return true;
     }
     base += total;

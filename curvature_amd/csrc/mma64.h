@@ -36,12 +36,21 @@ __device__ __forceinline__ void mma_64(const double* __restrict__ As, const doub
   }
 }
 
-// 64x64 block copy global (pitch ld) -> LDS (pitch LDA)
+// 64x64 block copy global (pitch ld) -> LDS (pitch LDA).  The block base is wave-uniform and every lane's
+// offset inside the block is a constant: all 16 loads are issued before the first LDS store, as SGPR base +
+// 32-bit VGPR offset, without per-element 64-bit index arithmetic (these copies sit on the serial chain of
+// the blocked Cholesky, where their issue time is latency).
+typedef __attribute__((address_space(1))) char gbyte;
 __device__ __forceinline__ void load_block(const gdouble* __restrict__ g, int ld, double* __restrict__ s) {
-  for (int e = threadIdx.x; e < NB * NB; e += MMA_THREADS) {
-    const int r = e >> 6, c = e & 63;
-    s[r * LDA + c] = g[(long long)r * ld + c];
-  }
+  const int tid = threadIdx.x, r0 = tid >> 6, c = tid & 63;
+  const unsigned voff = (unsigned)(((long long)r0 * ld + c) * 8);
+  const long long step = 4ll * ld * 8;                       // four rows per 256 lanes
+  const gbyte* base = (const gbyte*)g;
+  double v[NB * NB / MMA_THREADS];
+#pragma unroll
+  for (int u = 0; u < NB * NB / MMA_THREADS; ++u) v[u] = *(const gdouble*)(base + u * step + voff);
+#pragma unroll
+  for (int u = 0; u < NB * NB / MMA_THREADS; ++u) s[(r0 + 4 * u) * LDA + c] = v[u];
 }
 
 // wave quadrant accumulators -> LDS tile [row][col]
