@@ -155,17 +155,7 @@ __device__ __host__ __forceinline__ long long strip_tiles(int P, int kend, int r
 
 __device__ __forceinline__ void store_sub(gdouble* C, int np, const f64x4 (&acc)[2][2], int wm, int wn, int lane,
                                           int mode) {   // mode 0: C -= acc, 1: C = acc, 2: C += acc
-  const int c16 = lane & 15, rq = lane >> 4;
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const long long idx = (long long)(32 * wm + 16 * m + rq + 4 * q) * np + 32 * wn + 16 * n + c16;
-        const double v = acc[m][n][q];
-        C[idx] = mode == 0 ? C[idx] - v : (mode == 1 ? v : C[idx] + v);
-      }
+  store_acc(C, np, acc, wm, wn, lane, mode);
 }
 
 __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base);
@@ -216,11 +206,7 @@ inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int ken
       }
       __syncthreads();
       factor_invert_64(As, Bs, &bad, j * NB);
-      gdouble* Xg = X + (long long)j * NB * np + j * NB;
-      for (int e = threadIdx.x; e < NB * NB; e += INV_THREADS) {
-        const int r = e >> 6, q = e & 63;
-        Xg[(long long)r * np + q] = Bs[r * LDA + q];
-      }
+      store_block(X + (long long)j * NB * np + j * NB, np, Bs);
       if (threadIdx.x == 0 && bad != 0) atomicCAS(d.info, 0, bad);
     } else {
       store_sub(W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);
@@ -495,11 +481,7 @@ chol_diag_kernel(const InvDev* __restrict__ t, int nf, int k) {
   load_block(W + (long long)k * NB * np + k * NB, np, Ds);
   __syncthreads();
   factor_invert_64(Ds, Is, &bad, k * NB);
-  gdouble* Xg = (gdouble*)d.X + (long long)k * NB * np + k * NB;
-  for (int e = tid; e < NB * NB; e += INV_THREADS) {
-    const int r = e >> 6, q = e & 63;
-    Xg[(long long)r * np + q] = Is[r * LDA + q];
-  }
+  store_block((gdouble*)d.X + (long long)k * NB * np + k * NB, np, Is);
   if (tid == 0 && bad != 0) atomicCAS(d.info, 0, bad);
 }
 
@@ -528,28 +510,14 @@ chol_panel_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int kend)
     load_block(X + (long long)k * NB * np + k * NB, np, Bs);            // X_kk rows are the K-contiguous operand
     __syncthreads();
     mma_64<true>(As, Bs, wm, wn, lane, acc);
-    gdouble* C = W + (long long)i * NB * np + k * NB;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          C[(long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16] = acc[m][n][r];
+    store_acc(W + (long long)i * NB * np + k * NB, np, acc, wm, wn, lane, 1);
   } else {
     const int j = k0 + local - n_solve;
     load_block(X + (long long)k * NB * np + k * NB, np, As);            // X_kk as [row][kk]
     load_block(X + (long long)k * NB * np + j * NB, np, Bs);            // S_kj as [kk][col]
     __syncthreads();
     mma_64<false>(As, Bs, wm, wn, lane, acc);
-    gdouble* C = X + (long long)k * NB * np + j * NB;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          C[(long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16] = -acc[m][n][r];
+    store_acc(X + (long long)k * NB * np + j * NB, np, acc, wm, wn, lane, 3);
   }
 }
 
@@ -587,13 +555,12 @@ panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
   double* own = below ? As : Bs;                    // A_ik as [row][kk]  /  S_kj as [kk][col]
   double* var = below ? Bs : As;                    // X_sq[c][k] as [col][kk]  /  as [row][kk]
   double rv[16];
+  const unsigned voff_blk = (unsigned)(((long long)(tid >> 6) * np + (tid & 63)) * 8);
+  const long long step_blk = 4ll * np * 8;
   auto fetch_var = [&](int c, int k) {
-    const gdouble* g = X + (long long)(k0 + c) * NB * np + (k0 + k) * NB;
+    const gbyte* g = (const gbyte*)(X + (long long)(k0 + c) * NB * np + (k0 + k) * NB);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int e = tid + u * INV_THREADS;
-      rv[u] = g[(long long)(e >> 6) * np + (e & 63)];
-    }
+    for (int u = 0; u < 16; ++u) rv[u] = *(const gdouble*)(g + u * step_blk + voff_blk);
   };
   fetch_var(0, 0);
 #pragma unroll
@@ -604,10 +571,7 @@ panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
       for (int c = k; c < NBO_MAX; ++c) {
         if (c < nb) {
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            const int e = tid + u * INV_THREADS;
-            var[(e >> 6) * LDA + (e & 63)] = rv[u];
-          }
+          for (int u = 0; u < 16; ++u) var[((tid >> 6) + 4 * u) * LDA + (tid & 63)] = rv[u];
           __syncthreads();
           // next pair in the (k, c) walk: (k, c + 1) or (k + 1, k + 1)
           if (c + 1 < nb) fetch_var(c + 1, k);
@@ -623,14 +587,7 @@ panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
   for (int c = 0; c < NBO_MAX; ++c) {
     if (c < nb) {
       gdouble* C = below ? W + (long long)i * NB * np + (k0 + c) * NB : X + (long long)(k0 + c) * NB * np + j * NB;
-      const double sgn = below ? 1.0 : -1.0;
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            C[(long long)(32 * wm + 16 * m + rq + 4 * r) * np + 32 * wn + 16 * n + c16] = sgn * acc[c][m][n][r];
+      store_acc(C, np, acc[c], wm, wn, lane, below ? 1 : 3);
     }
   }
 }

@@ -53,6 +53,46 @@ __device__ __forceinline__ void load_block(const gdouble* __restrict__ g, int ld
   for (int u = 0; u < NB * NB / MMA_THREADS; ++u) s[(r0 + 4 * u) * LDA + c] = v[u];
 }
 
+// 64x64 block copy LDS (pitch LDA) -> global (pitch ld), same addressing as load_block
+__device__ __forceinline__ void store_block(gdouble* __restrict__ g, int ld, const double* __restrict__ s) {
+  const int tid = threadIdx.x, r0 = tid >> 6, c = tid & 63;
+  const unsigned voff = (unsigned)(((long long)r0 * ld + c) * 8);
+  const long long step = 4ll * ld * 8;
+  gbyte* base = (gbyte*)g;
+#pragma unroll
+  for (int u = 0; u < NB * NB / MMA_THREADS; ++u) *(gdouble*)(base + u * step + voff) = s[(r0 + 4 * u) * LDA + c];
+}
+
+// wave quadrant accumulators (2x2 MFMA tiles of the 32x32 quadrant (wm, wn)) <-> a 64x64 global tile of pitch
+// ld: element (m, n, q) of a lane sits at a wave-uniform offset from the lane's first element.
+//   mode 0: C -= acc   1: C = acc   2: C += acc   3: C = -acc
+__device__ __forceinline__ void store_acc(gdouble* __restrict__ C, int ld, const f64x4 (&acc)[2][2], int wm, int wn,
+                                          int lane, int mode) {
+  const int c16 = lane & 15, rq = lane >> 4;
+  const unsigned voff = (unsigned)(((long long)(32 * wm + rq) * ld + 32 * wn + c16) * 8);
+  gbyte* base = (gbyte*)C;
+  double old[2][2][4];
+  if (mode == 0 || mode == 2) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          old[m][n][q] = *(const gdouble*)(base + ((long long)(16 * m + 4 * q) * ld + 16 * n) * 8 + voff);
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double v = acc[m][n][q];
+        const double out = mode == 0 ? old[m][n][q] - v : mode == 1 ? v : mode == 2 ? old[m][n][q] + v : -v;
+        *(gdouble*)(base + ((long long)(16 * m + 4 * q) * ld + 16 * n) * 8 + voff) = out;
+      }
+}
+
 // wave quadrant accumulators -> LDS tile [row][col]
 __device__ __forceinline__ void acc_to_lds(const f64x4 (&acc)[2][2], int wm, int wn, int lane, double* s) {
   const int c16 = lane & 15, rq = lane >> 4;
