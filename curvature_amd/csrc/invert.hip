@@ -58,7 +58,7 @@ __device__ __forceinline__ bool locate(const InvDev* __restrict__ t, int nf, int
       const int v = __shfl_up(incl, o, 64);
       if (lane >= o) incl += v;
     }
-    const int total = __shfl(incl, 63, 64);
+    const int total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));   // uniform: keeps the callers' control flow scalar
     if (bid < base + total) {
       const unsigned long long m = __ballot(bid < base + incl);
       const int l = __ffsll((long long)m) - 1;
