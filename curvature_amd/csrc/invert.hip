@@ -143,13 +143,13 @@ __device__ __host__ __forceinline__ long long outer_tiles(int P, int kend, int r
   const long long nsb = (r + SB - 1) / SB, ncb = (kend + SB - 1) / SB;
   return (nsb * (nsb + 1) / 2 + nsb * ncb) * (SB * SB);
 }
-// near part ("strip"): what the next panel's chain of diagonal steps needs first: trailing tiles of the
-// block columns [kend, row0) and S tiles of the block rows [kend, row0)
-__device__ __host__ __forceinline__ long long strip_tiles(int P, int kend, int row0) {
-  const int re = row0 < P ? row0 : P;
+// a "strip" of an outer update: trailing tiles of the block columns [lo, hi) and S tiles of the block rows
+// [lo, hi) (S columns < kend).  [kend, kend + 4) is what the next panel's chain touches ("near").
+__device__ __host__ __forceinline__ long long strip_tiles(int P, int kend, int lo, int hi) {
+  const int re = hi < P ? hi : P;
   long long n = 0;
-  for (int j = kend; j < re; ++j) n += P - j;
-  if (re > kend) n += (long long)(re - kend) * kend;
+  for (int j = lo; j < re; ++j) n += P - j;
+  if (re > lo) n += (long long)(re - lo) * kend;
   return n;
 }
 
@@ -230,18 +230,81 @@ inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int ken
 // of the current one run.
 constexpr int OKS = 32;                // K step
 constexpr int OPA = OKS + 1;           // LDS pitch of a [64][32] operand (rows K-contiguous)
+// One 64x64 output tile, K advancing in steps of 32 through two 17 KB LDS operand tiles, the next step
+// fetched into registers while the MFMAs of the current one run; loads are SGPR base + 32-bit lane offset.
+// Shared by the outer updates and the panel products: every kernel built on it has the same footprint
+// (116 VGPRs, 33.8 KB LDS), so a workgroup of one fits exactly the slot a retiring workgroup of another frees.
+struct TileJob {                        // everything wave-uniform
+  const gbyte* a0;                      // A: rows K-contiguous, element (r, ke) at a0 + (r * np + ke) * 8
+  const gbyte* b0;                      // B: bt ? rows K-contiguous like A : element (ke, c) at b0 + (ke * np + c) * 8
+  gdouble* C;                           // output tile, pitch np
+  int np, ke0, ke1, mode;               // K range in elements; mode of store_acc
+  bool bt, same;                        // same: B is A (diagonal tile of a symmetric update)
+};
+__device__ __forceinline__ void tile_product_k32(const TileJob& o, double* __restrict__ As, double* __restrict__ Bs) {
+  const int np = o.np;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const bool trailing = o.bt, same = o.same;
+  const int r16 = lane & 15, kq = lane >> 4;
+  double ra[8], rb[8];
+  const unsigned voff_k = (unsigned)(((long long)(tid >> 5) * np + (tid & 31)) * 8);   // [rows][32 k] operands
+  const unsigned voff_n = (unsigned)(((long long)(tid >> 6) * np + (tid & 63)) * 8);   // [32 k][64 cols] operand
+  const long long step_k = 8ll * np * 8, step_n = 4ll * np * 8;                        // 8 / 4 rows per 256 lanes
+  auto fetch = [&](int ke) __attribute__((always_inline)) {                            // ke: first K element of the step
+    const gbyte* ga = o.a0 + (long long)ke * 8;
+    const gbyte* gb = trailing ? o.b0 + (long long)ke * 8 : o.b0 + (long long)ke * np * 8;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      ra[u] = *(const gdouble*)(ga + u * step_k + voff_k);
+      if (trailing) rb[u] = same ? 0.0 : *(const gdouble*)(gb + u * step_k + voff_k);
+      else rb[u] = *(const gdouble*)(gb + u * step_n + voff_n);
+    }
+  };
+  f64x4 acc[2][2] = {};
+  const int ke0 = o.ke0, ke1 = o.ke1;
+  fetch(ke0);
+  for (int ke = ke0; ke < ke1; ke += OKS) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + u * INV_THREADS;
+      As[(e >> 5) * OPA + (e & 31)] = ra[u];
+      if (trailing) { if (!same) Bs[(e >> 5) * OPA + (e & 31)] = rb[u]; }
+      else Bs[(e >> 6) * LDA + (e & 63)] = rb[u];
+    }
+    __syncthreads();
+    if (ke + OKS < ke1) fetch(ke + OKS);
+    const double* Bt = same ? As : Bs;
+#pragma unroll 4
+    for (int ks = 0; ks < OKS / 4; ++ks) {
+      const int k = 4 * ks + kq;
+      double a[2], b[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m] = As[(32 * wm + 16 * m + r16) * OPA + k];
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        b[n] = trailing ? Bt[(32 * wn + 16 * n + r16) * OPA + k] : Bs[k * LDA + 32 * wn + 16 * n + r16];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  store_acc(o.C, np, acc, wm, wn, lane, o.mode);
+}
+
 __global__ void __launch_bounds__(INV_THREADS, 3)
-outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int row0, int strip, int n_items) {
+outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int lo, int hi, int strip, int n_items) {
   __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
   bool trailing;
   int i, j, f, local;
   if (strip) {
-    // near part: block columns / rows [kend, row0)
-    if (!locate(t, nf, blockIdx.x, [kend, row0](const InvDev& d) { return (int)strip_tiles(d.P, kend, row0); }, f, local))
+    // strip: block columns / rows [lo, hi)
+    if (!locate(t, nf, blockIdx.x, [kend, lo, hi](const InvDev& d) { return (int)strip_tiles(d.P, kend, lo, hi); }, f, local))
       return;
-    const int P = t[f].P, re = row0 < P ? row0 : P;
+    const int P = t[f].P, re = hi < P ? hi : P;
     trailing = false;
-    j = kend;
+    j = lo;
     for (; j < re; ++j) {
       if (local < P - j) { trailing = true; break; }
       local -= P - j;
@@ -250,10 +313,11 @@ outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int 
       i = j + local;
     } else {
       const int a = local / kend;
-      i = kend + a; j = local - a * kend;
+      i = lo + a; j = local - a * kend;
     }
   } else {
-    // far part.  XCD grouping: workgroups with equal blockIdx % 8 share an XCD; give each XCD whole super-blocks
+    const int row0 = lo;
+    // far part: everything from block row / column lo on.  XCD grouping: workgroups with equal blockIdx % 8 share an XCD; give each XCD whole super-blocks
     int item;
     {
       const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3;
@@ -285,59 +349,17 @@ outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int 
   const int np = d.np;
   const gdouble* W = (const gdouble*)d.W;
   gdouble* X = (gdouble*)d.X;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int kk_first = trailing ? k0 : (j > k0 ? j : k0);
-  const bool same = trailing && i == j;
-  const int r16 = lane & 15, kq = lane >> 4;
-  double ra[8], rb[8];
-  // per-lane byte offsets inside an operand tile (constant); the tile base and the row-group stride are
-  // wave-uniform, so every load is SGPR base + 32-bit VGPR offset: no 64-bit per-lane address registers
-  typedef __attribute__((address_space(1))) char gchar;
-  const unsigned voff_k = (unsigned)(((long long)(tid >> 5) * np + (tid & 31)) * 8);   // [rows][32 k] operands
-  const unsigned voff_n = (unsigned)(((long long)(tid >> 6) * np + (tid & 63)) * 8);   // [32 k][64 cols] operand
-  const long long step_k = 8ll * np * 8, step_n = 4ll * np * 8;                        // 8 / 4 rows per 256 lanes
-  auto fetch = [&](int ke) {                      // ke: first K element of the step
-    const gchar* ga = (const gchar*)(W + (long long)i * NB * np + ke);
-    const gchar* gb = (const gchar*)(trailing ? W + (long long)j * NB * np + ke : X + (long long)ke * np + j * NB);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      ra[u] = *(const gdouble*)(ga + u * step_k + voff_k);
-      if (trailing) rb[u] = same ? 0.0 : *(const gdouble*)(gb + u * step_k + voff_k);
-      else rb[u] = *(const gdouble*)(gb + u * step_n + voff_n);
-    }
-  };
-  f64x4 acc[2][2] = {};
-  const int ke0 = kk_first * NB, ke1 = kend * NB;
-  fetch(ke0);
-  for (int ke = ke0; ke < ke1; ke += OKS) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = tid + u * INV_THREADS;
-      As[(e >> 5) * OPA + (e & 31)] = ra[u];
-      if (trailing) { if (!same) Bs[(e >> 5) * OPA + (e & 31)] = rb[u]; }
-      else Bs[(e >> 6) * LDA + (e & 63)] = rb[u];
-    }
-    __syncthreads();
-    if (ke + OKS < ke1) fetch(ke + OKS);
-    const double* Bt = same ? As : Bs;
-#pragma unroll 4
-    for (int ks = 0; ks < OKS / 4; ++ks) {
-      const int k = 4 * ks + kq;
-      double a[2], b[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) a[m] = As[(32 * wm + 16 * m + r16) * OPA + k];
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-        b[n] = trailing ? Bt[(32 * wn + 16 * n + r16) * OPA + k] : Bs[k * LDA + 32 * wn + 16 * n + r16];
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  if (trailing) store_sub((gdouble*)d.W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);
-  else store_sub(X + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, j >= k0 ? 1 : 2);
+  TileJob o;
+  o.np = np;
+  o.bt = trailing;
+  o.same = trailing && i == j;
+  o.a0 = (const gbyte*)(W + (long long)i * NB * np);
+  o.b0 = trailing ? (const gbyte*)(W + (long long)j * NB * np) : (const gbyte*)(X + j * NB);
+  o.ke0 = (trailing ? k0 : (j > k0 ? j : k0)) * NB;
+  o.ke1 = kend * NB;
+  o.C = trailing ? (gdouble*)d.W + (long long)i * NB * np + j * NB : X + (long long)i * NB * np + j * NB;
+  o.mode = trailing ? 0 : (j >= k0 ? 1 : 2);
+  tile_product_k32(o, As, Bs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -531,9 +553,9 @@ chol_panel_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int kend)
 // doing these rows step by step (nb panel solves + nb (nb - 1) / 2 rank-64 updates, each a read-modify-
 // write of 64x64 tiles) the row panel is read and written once.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(INV_THREADS)
+__global__ void __launch_bounds__(INV_THREADS, 3)
 panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
-  __shared__ double As[NB * LDA], Bs[NB * LDA];
+  __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
   int f, local;
   if (!locate(t, nf, blockIdx.x,
               [k0, kend](const InvDev& d) { return d.P > k0 ? (d.P > kend ? d.P - kend : 0) + k0 : 0; }, f, local))
@@ -543,52 +565,21 @@ panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
   const int n_below = d.P > kend ? d.P - kend : 0;
   gdouble* W = (gdouble*)d.W;
   gdouble* X = (gdouble*)d.X;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int c16 = lane & 15, rq = lane >> 4;
   const bool below = local < n_below;
   const int i = kend + local, j = local - n_below;
-  // Loop order: input block k outermost, so the workgroup's own tile (A_ik / S_kj) is loaded once per k;
-  // all nb outputs accumulate in registers and are written after the last read (hence in place).  The
-  // X_sq tile of the next (k, c) pair is fetched into registers while the MFMAs of the current one run.
-  constexpr int NBO_MAX = 4;
-  f64x4 acc[NBO_MAX][2][2] = {};
-  double* own = below ? As : Bs;                    // A_ik as [row][kk]  /  S_kj as [kk][col]
-  double* var = below ? Bs : As;                    // X_sq[c][k] as [col][kk]  /  as [row][kk]
-  double rv[16];
-  const unsigned voff_blk = (unsigned)(((long long)(tid >> 6) * np + (tid & 63)) * 8);
-  const long long step_blk = 4ll * np * 8;
-  auto fetch_var = [&](int c, int k) {
-    const gbyte* g = (const gbyte*)(X + (long long)(k0 + c) * NB * np + (k0 + k) * NB);
-#pragma unroll
-    for (int u = 0; u < 16; ++u) rv[u] = *(const gdouble*)(g + u * step_blk + voff_blk);
-  };
-  fetch_var(0, 0);
-#pragma unroll
-  for (int k = 0; k < NBO_MAX; ++k) {
-    if (k < nb) {
-      load_block(below ? W + (long long)i * NB * np + (k0 + k) * NB : X + (long long)(k0 + k) * NB * np + j * NB, np, own);
-#pragma unroll
-      for (int c = k; c < NBO_MAX; ++c) {
-        if (c < nb) {
-#pragma unroll
-          for (int u = 0; u < 16; ++u) var[((tid >> 6) + 4 * u) * LDA + (tid & 63)] = rv[u];
-          __syncthreads();
-          // next pair in the (k, c) walk: (k, c + 1) or (k + 1, k + 1)
-          if (c + 1 < nb) fetch_var(c + 1, k);
-          else if (k + 1 < nb) fetch_var(k + 1, k + 1);
-          if (below) mma_64<true>(As, Bs, wm, wn, lane, acc[c]);
-          else mma_64<false>(As, Bs, wm, wn, lane, acc[c]);
-          __syncthreads();
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < NBO_MAX; ++c) {
-    if (c < nb) {
-      gdouble* C = below ? W + (long long)i * NB * np + (k0 + c) * NB : X + (long long)(k0 + c) * NB * np + j * NB;
-      store_acc(C, np, acc[c], wm, wn, lane, below ? 1 : 3);
-    }
+  TileJob o;
+  o.np = np;
+  o.bt = below;
+  o.same = false;
+  o.ke0 = 0;
+  o.mode = below ? 1 : 3;
+  for (int c = nb - 1; c >= 0; --c) {      // descending: output c reads only inputs k <= c
+    const gdouble* xsq = X + (long long)(k0 + c) * NB * np + k0 * NB;              // block row c of X_sq
+    o.a0 = below ? (const gbyte*)(W + (long long)i * NB * np + k0 * NB) : (const gbyte*)xsq;
+    o.b0 = below ? (const gbyte*)xsq : (const gbyte*)(X + (long long)k0 * NB * np + j * NB);
+    o.C = below ? W + (long long)i * NB * np + (k0 + c) * NB : X + (long long)(k0 + c) * NB * np + j * NB;
+    o.ke1 = (c + 1) * NB;
+    tile_product_k32(o, As, Bs);
   }
 }
 
@@ -685,7 +676,26 @@ static int stream_set(StreamSet** out) {
   CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_join2, hipEventDisableTiming));
   CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.masked, hipStreamNonBlocking));
   for (int g = 0; g < 2; ++g) {
-    CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.side[g].stream, hipStreamNonBlocking, prio_low));
+    {
+      // The far updates fill every workgroup slot they can get (4 per CU), and a retiring far workgroup frees
+      // half the LDS a chain kernel's workgroup needs: the slot is refilled before a second one retires, and
+      // stream priorities do not reserve anything - traced: a 9-workgroup chol_panel launch waited 200-260 us
+      // for the far update beside it to drain.  So the side streams may not use the last CURV_FREE_CUS CUs
+      // (mask bits are dealt round-robin over the XCDs: 2 CUs of every XCD), which the chain then finds free.
+      static const int free_cus = getenv("CURV_FREE_CUS") ? atoi(getenv("CURV_FREE_CUS")) : 32;
+      hipDeviceProp_t prop;
+      int dev_id = 0;
+      CURV_HIP_CHECK(hipGetDevice(&dev_id));
+      CURV_HIP_CHECK(hipGetDeviceProperties(&prop, dev_id));
+      const int n_cu = prop.multiProcessorCount;
+      if (free_cus > 0 && free_cus < n_cu) {
+        std::vector<uint32_t> mask((size_t)cdiv(n_cu, 32), 0u);
+        for (int c = 0; c < n_cu - free_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
+        CURV_HIP_CHECK(hipExtStreamCreateWithCUMask(&s.side[g].stream, (uint32_t)mask.size(), mask.data()));
+      } else {
+        CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.side[g].stream, hipStreamNonBlocking, prio_low));
+      }
+    }
     for (int i = 0; i < 2; ++i) {
       CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_main[i], hipEventDisableTiming));
       CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_side[i], hipEventDisableTiming));
@@ -734,9 +744,8 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
   CURV_LAUNCH_CHECK();
   constexpr int NBO = 4;                       // outer panel: 4 block columns = 256
   // Per panel: the chain of diagonal steps (small, latency-bound launches) runs on the caller's stream,
-  // then the near part of the outer update (the block columns / rows the NEXT chain touches).  The far
-  // part goes to a second stream and overlaps the next chain; the two only meet again at the next near
-  // part, which updates tiles the far part has written.
+  // then the near part of the outer update (the block columns / rows the NEXT chain touches); the rest of
+  // the outer update goes to a second stream and overlaps the following chains (see below).
   bool far_pending = false;
   int panel = 0;
   for (int k0 = 0; k0 < Pmax; k0 += NBO, ++panel) {
@@ -767,29 +776,33 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
       hipLaunchKernelGGL(panel_product_kernel, dim3((unsigned)prod_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend);
       CURV_LAUNCH_CHECK();
     }
+    // Outer update of this panel in two parts: near = the strip the next chain touches (this stream, on the
+    // critical path), far = everything beyond, on the side stream beside the next panel's chain.  The two
+    // meet again at the next near part, which rewrites tiles the far part has written.  (Splitting off a
+    // "mid" strip so that a far update has two chain periods before anything waits for it was measured
+    // 2-4 % slower: the far updates are throughput-bound, not waited for.)
     long long near_tiles = 0, far_tiles = 0;
     for (const InvDev& d : tab) {
-      near_tiles += strip_tiles(d.P, kend, row0);
+      near_tiles += strip_tiles(d.P, kend, kend, row0);
       far_tiles += outer_tiles(d.P, kend, row0);
     }
-    if (far_tiles > 0) {
-      // fork: the far part needs this panel's chain, and follows the previous far part in stream order
+    if (far_tiles > 0) {                         // fork: the far part needs this panel's chain
       CURV_HIP_CHECK(hipEventRecord(side->ev_main[panel & 1], stream));
       CURV_HIP_CHECK(hipStreamWaitEvent(side->stream, side->ev_main[panel & 1], 0));
     }
     if (near_tiles > 0) {
-      if (far_pending) {                       // join: the previous far part wrote the tiles updated here
+      if (far_pending) {                         // join: the previous far part wrote the tiles updated here
         CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_side[(panel + 1) & 1], 0));
         far_pending = false;
       }
       hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)near_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0,
-                         kend, row0, 1, (int)near_tiles);
+                         kend, kend, row0, 1, (int)near_tiles);
       CURV_LAUNCH_CHECK();
     }
     if (far_tiles > 0) {
       const long long grid = cdivll(far_tiles, 8 * SB * SB) * 8 * SB * SB;
       hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, side->stream, table, n_factors, k0,
-                         kend, row0, 0, (int)far_tiles);
+                         kend, row0, 0, 0, (int)far_tiles);
       CURV_LAUNCH_CHECK();
       CURV_HIP_CHECK(hipEventRecord(side->ev_side[panel & 1], side->stream));
       far_pending = true;
@@ -833,7 +846,18 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   { const int rc = stream_set(&ss); if (rc != CURV_OK) return rc; }
   InvDev* table0 = reinterpret_cast<InvDev*>(workspace);
   InvDev* table1 = reinterpret_cast<InvDev*>(reinterpret_cast<char*>(workspace) + inv_table_bytes(n_factors));
-  if (big.empty() || small.empty()) return chol_sweep_group(stream, &ss->side[0], big.empty() ? small : big, table0);
+  if (big.empty() || small.empty()) {
+    // one group: still swept on an internal stream.  The CU-masked side streams are created by an API that
+    // has no "non-blocking" flag, so they synchronise implicitly with the legacy default stream - which the
+    // caller's stream may be.
+    CURV_HIP_CHECK(hipEventRecord(ss->ev_fork, stream));
+    CURV_HIP_CHECK(hipStreamWaitEvent(ss->aux, ss->ev_fork, 0));
+    const int rc1 = chol_sweep_group(ss->aux, &ss->side[0], big.empty() ? small : big, table0);
+    if (rc1 != CURV_OK) return rc1;
+    CURV_HIP_CHECK(hipEventRecord(ss->ev_join, ss->aux));
+    CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->ev_join, 0));
+    return CURV_OK;
+  }
   CURV_HIP_CHECK(hipEventRecord(ss->ev_fork, stream));
   CURV_HIP_CHECK(hipStreamWaitEvent(ss->aux, ss->ev_fork, 0));
   CURV_HIP_CHECK(hipStreamWaitEvent(ss->masked, ss->ev_fork, 0));

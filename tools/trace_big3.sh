@@ -1,0 +1,34 @@
+# kernel timeline of one mid-sweep panel while three 4608^2 factors are inverted
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cat > /tmp/big3.py <<'PY'
+import sys, torch
+sys.path.insert(0, '.')
+from curvature_amd import ops
+dev = torch.device('cuda:0')
+Fs = []
+for i in range(3):
+    torch.manual_seed(i)
+    X = torch.randn(4608, 4096, device=dev)
+    Fs.append((X @ X.t() / 4096).contiguous())
+for _ in range(3):
+    ops.chol_inv_lower(Fs, [1.0] * 3, [1000.0] * 3, check=False)
+torch.cuda.synchronize()
+PY
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tr3 -- python /tmp/big3.py > gpurun_out/tr3.log 2>&1
+python - <<'PY'
+import csv, glob
+f = glob.glob("gpurun_out/tr3/*/*kernel_trace.csv")[0]
+rows = [r for r in csv.DictReader(open(f)) if "curv::" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+rows = rows[len(rows) * 2 // 3:]
+t0 = int(rows[0]["Start_Timestamp"])
+print("span us", (max(int(r["End_Timestamp"]) for r in rows) - t0) / 1e3, "kernels", len(rows))
+cnt = 0
+for r in rows:
+    n = r["Kernel_Name"].split("(")[0].replace("curv::", "")
+    if n == "chol_diag_kernel":
+        cnt += 1
+    if cnt in (6, 7, 8):
+        st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        print(f'{(st - t0) / 1e3:9.1f} -> {(en - t0) / 1e3:9.1f} dur {(en - st) / 1e3:7.1f}  q{r.get("Queue_Id", "?")} wgs {int(r["Grid_Size_X"]) // 256:6d}  {n}')
+PY
