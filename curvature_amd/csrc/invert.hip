@@ -24,6 +24,8 @@
 #include "mma64.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <mutex>
 #include <vector>
 
 namespace curv {
@@ -657,6 +659,22 @@ struct StreamSet {
                                          // CU subset with hipExtStreamCreateWithCUMask did not help)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
 };
+// CU-masked streams are destroyed explicitly when the process exits: left to the runtime's own teardown they
+// crashed inside __cxa_finalize when a profiler (rocprofv3) was attached.  The handler is registered after the
+// HIP runtime initialised, so it runs before the runtime's exit handlers.
+static std::mutex g_masked_mutex;
+static std::vector<std::pair<int, hipStream_t>> g_masked_streams;
+static void destroy_masked_streams() {
+  std::lock_guard<std::mutex> lock(g_masked_mutex);
+  for (auto& e : g_masked_streams) {
+    if (hipSetDevice(e.first) == hipSuccess) {
+      (void)hipStreamSynchronize(e.second);
+      (void)hipStreamDestroy(e.second);
+    }
+  }
+  g_masked_streams.clear();
+}
+
 static int stream_set(StreamSet** out) {
   static thread_local std::vector<std::pair<int, StreamSet>> cache;
   int dev = 0;
@@ -692,6 +710,9 @@ static int stream_set(StreamSet** out) {
         std::vector<uint32_t> mask((size_t)cdiv(n_cu, 32), 0u);
         for (int c = 0; c < n_cu - free_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
         CURV_HIP_CHECK(hipExtStreamCreateWithCUMask(&s.side[g].stream, (uint32_t)mask.size(), mask.data()));
+        std::lock_guard<std::mutex> lock(g_masked_mutex);
+        if (g_masked_streams.empty()) atexit(destroy_masked_streams);
+        g_masked_streams.emplace_back(dev_id, s.side[g].stream);
       } else {
         CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.side[g].stream, hipStreamNonBlocking, prio_low));
       }

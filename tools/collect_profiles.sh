@@ -6,12 +6,14 @@ R=${1:-r01}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/sq.log 2>&1
+# warm MIOpen's per-user find database first: on a fresh box the first run benchmarks every conv solver
+python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/warm.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/sq.log 2>&1
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_bench_kernel_stats.csv
-tail -1 $OUT/bench_trace.log > gpurun_out/${R}_bench_under_profiler.json
+grep '^{"metric"' $OUT/bench_trace.log | tail -1 > gpurun_out/${R}_bench_under_profiler.json
 python tools/parse_pmc.py $OUT > gpurun_out/${R}_syrk_pmc.json
 cat gpurun_out/${R}_syrk_pmc.json
 head -8 gpurun_out/${R}_bench_kernel_stats.csv | cut -c1-140
