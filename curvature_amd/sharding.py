@@ -37,15 +37,15 @@ def lpt_partition(costs: Sequence[float], world: int) -> List[int]:
 def rank_cost(dims: Sequence[Sequence[int]]) -> float:
     """Estimated step time (s) of a rank that owns the layers `dims` = [(n, m, K), ...].  Not additive: the
     factors of a rank are inverted in one batched sweep, so the serial chains of 64-column steps overlap and
-    only the longest one counts (calibrated on MI355X: single 4608^2 factor 5.9 ms, 1024^2 1.06 ms, all 108
-    ResNet-50 factors 12.8 ms)."""
+    only the longest one counts (calibrated on MI355X: single 4608^2 factor 4.3 ms = 72 steps x 60 us, three of
+    them 6.6 ms, all 108 ResNet-50 factors 9.6 ms; build 85 TFLOP/s executed, sampling GEMMs 95 TFLOP/s)."""
     if not dims:
         return 0.0
-    build = sum((n * (n + 1.0) + m * (m + 1.0)) * K for n, m, K in dims) / 80e12
-    sample = sum(n * n * m + n * m * m for n, m, _ in dims) / 45e12
-    chain = max(max(n, m) for n, m, _ in dims) / 64.0 * 80e-6
-    invert = 0.85 * chain + sum((2.0 / 3.0) * (n ** 3 + m ** 3) for n, m, _ in dims) / 40e12
-    return build + invert + sample + 0.4e-3
+    build = sum((n * (n + 1.0) + m * (m + 1.0)) * K for n, m, K in dims) / 85e12
+    sample = sum(2.0 * (n * n * m + n * m * m) for n, m, _ in dims) / 95e12
+    chain = max(max(n, m) for n, m, _ in dims) / 64.0 * 60e-6
+    invert = 0.7 * chain + sum((2.0 / 3.0) * (n ** 3 + m ** 3) for n, m, _ in dims) / 42e12
+    return build + invert + sample + 1.0e-3
 
 
 def partition_layers(dims: Sequence[Sequence[int]], world: int) -> List[int]:
