@@ -8,17 +8,33 @@ from torch.nn import Module
 from . import ops
 
 
+# The reference decomposes the same factors twice - once in the EFB constructor, once in the INF constructor
+# (curvatures.py:403, 473) - which is 7.5 s of eigensolver per call on ResNet-18.  The last result is kept and
+# handed out again while every factor tensor is still the same memory at the same version.
+_last = {"key": None, "vecs": None}
+
+
+def _factor_key(mats):
+    return tuple((m.data_ptr(), m._version, tuple(m.shape), str(m.device)) for m in mats)
+
+
 def get_eigenvectors(factors: Dict[Module, Tensor]) -> Dict[Module, Tensor]:
     """Eigenvectors (columns, eigenvalues ascending) of both Kronecker factors of every layer.
 
     The reference decomposes F + F^T (utils.py:55-58); F is exactly symmetric here, so F itself has the
-    same eigenvectors.  Computed by the library's batched block-Jacobi eigensolver (curv_syevd)."""
+    same eigenvectors.  Computed by the library's batched block-Jacobi eigensolver (curv_syevd).  A second
+    call on unchanged factors returns clones of the first call's result."""
     layers = list(factors.keys())
     mats = []
     for layer in layers:
         xxt, ggt = factors[layer]
         mats.extend([xxt, ggt])
-    vecs = ops.eigh(mats)
+    key = _factor_key(mats)
+    if _last["key"] == key:
+        vecs = [v.clone() for v in _last["vecs"]]
+    else:
+        vecs = ops.eigh(mats)
+        _last["key"], _last["vecs"] = key, [v.clone() for v in vecs]
     return {layer: (vecs[2 * i], vecs[2 * i + 1]) for i, layer in enumerate(layers)}
 
 

@@ -106,3 +106,64 @@ def test_invert_and_sample_properties(gpu, resnet50_kfac):
     changed = sum(int(not torch.equal(state[k], mean[k])) for k in state)
     assert all(torch.isfinite(v).all() for v in state.values())
     assert changed == 54 + 1                      # 54 weights and the one bias (fc); BatchNorm tensors restored
+
+
+@pytest.mark.gpu
+def test_resnet18_full_estimator_chain(gpu):
+    """SURVEY 8(d) config 3 at full size: Diagonal -> KFAC -> EFB -> INF(rank = 100) -> invert -> sample on an
+    ImageNet ResNet-18 (random init, N = 8).  No oracle at this size; checked through what must hold anyway."""
+    from curvature_amd import models
+    from curvature_amd.curvatures import Diagonal, KFAC, EFB, INF
+    torch.manual_seed(0)
+    N, rank = 8, 100
+    model = models.resnet18().to(gpu).train()
+    diag, kfac = Diagonal(model), KFAC(model)
+    x = torch.randn(N, 3, 224, 224, device=gpu)
+    logits = model(x)
+    labels = torch.distributions.Categorical(logits=logits).sample()
+    torch.nn.functional.cross_entropy(logits, labels).backward()
+    diag.update(N)
+    kfac.update(N)
+    layers = kfac._layers()
+    assert len(layers) == 21 and list(diag.state.keys()) == layers
+    efb = EFB(model, kfac.state)
+    efb.update(N)
+    inf = INF(model, diag.state, kfac.state, efb.state)      # second decomposition of unchanged factors: cached
+    for layer in layers:
+        for u_efb, u_inf in zip(efb.eigvecs[layer], inf.eigvecs[layer]):
+            assert torch.equal(u_efb, u_inf) and u_efb.data_ptr() != u_inf.data_ptr()
+    # eigenvectors of the largest factor: orthonormal, and they diagonalise it
+    big = max(layers, key=lambda l: kfac.state[l][0].shape[0])
+    A = kfac.state[big][0].double()
+    U = efb.eigvecs[big][0].double()
+    n = A.shape[0]
+    assert n == 4608
+    assert (U.t() @ U - torch.eye(n, dtype=torch.float64, device=gpu)).abs().max().item() < 1e-5
+    D = U.t() @ A @ U
+    off = D - torch.diag(torch.diagonal(D))
+    assert off.norm().item() <= 1e-5 * A.norm().item()
+    w = torch.diagonal(D)
+    assert (w[1:] >= w[:-1] - 1e-6 * w.abs().max()).all()     # ascending, like symeig
+    for layer in layers:
+        assert (efb.state[layer] >= 0).all()                  # Lambda accumulates squares
+    inf.update(rank=rank)
+    for layer in layers:
+        ua, ug, lam, corr = inf.state[layer]
+        n_l, m_l = kfac.state[layer][0].shape[0], kfac.state[layer][1].shape[0]
+        a, b = ua.shape[1], ug.shape[1]
+        assert ua.shape[0] == n_l and ug.shape[0] == m_l and 1 <= a <= min(rank, n_l) and 1 <= b <= min(rank, m_l)
+        assert a * b >= min(rank, n_l * m_l) and lam.numel() == a * b and corr.numel() == n_l * m_l
+        # the selected columns are columns of the full eigenvector matrices, in ascending index order
+        UA = inf.eigvecs[layer][0]
+        idx = [int((UA == ua[:, k:k + 1]).all(dim=0).nonzero()[0]) for k in (0, a - 1)]
+        assert idx[0] <= idx[1]
+    for est in (diag, kfac, efb, inf):
+        est.invert(1.0, 1000.0)
+        est.sample_and_replace()
+        changed = 0
+        for k, v in model.state_dict().items():             # mean = the state captured at construction (:41)
+            assert torch.isfinite(v).all(), k
+            changed += int(not torch.equal(v, est.model_state[k]))
+        assert changed == 22                                   # 21 weights + the fc bias; BatchNorm restored
+    L_A = kfac.inv_state[big][0]
+    assert torch.equal(L_A, torch.tril(L_A))
