@@ -526,7 +526,6 @@ chol_panel_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int kend)
   gdouble* W = (gdouble*)d.W;
   gdouble* X = (gdouble*)d.X;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-  const int c16 = lane & 15, rq = lane >> 4;
   f64x4 acc[2][2] = {};
   if (local < n_solve) {
     const int i = k + 1 + local;

@@ -151,9 +151,6 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   constexpr int KSTRIDE = (TMv == 128) ? 1 : 4;
   constexpr bool idle = false;
 
-  // the pointer comes out of the descriptor table, so tell the compiler it is a GLOBAL address:
-  // a flat load would also count on lgkmcnt and serialise the prefetch with the LDS operand reads
-  const gfloat* __restrict__ src = (const gfloat*)d.src;
   const int N = d.N, C = d.C, H = d.H, W = d.W;
   const int kh = d.kh, kw = d.kw, sh = d.sh, sw = d.sw, ph = d.ph, pw = d.pw;
   const int Ho = d.Ho, Wo = d.Wo, khkw = d.khkw, rows = d.rows, has_bias = d.has_bias;
@@ -164,7 +161,6 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   const int HW = H * W;
 
   const int c_lo_i = i0 / khkw, c_lo_j = j0 / khkw;
-  const int nch_i = min(nch, C - c_lo_i), nch_j = min(nch, C - c_lo_j);
   const int off_j = diag ? 0 : PANEL_WORDS;
   const int n_panels = diag ? 1 : 2;
 
