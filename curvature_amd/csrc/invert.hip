@@ -85,33 +85,41 @@ inv_prepare_kernel(const InvDev* __restrict__ t, int nf) {
   int bi = 0;
   while (tile > bi) { tile -= bi + 1; ++bi; }       // lower-triangular enumeration: row bi has bi+1 blocks
   const int bj = tile;
-  const int n = d.n, np = d.np;
+  const int n = d.n, np = d.np, rev = d.reverse;
   const float ss = d.sqrt_s, sn = d.sqrt_n;
-  const float* __restrict__ F = d.F;
+  typedef __attribute__((address_space(1))) float gfloat;
+  const gfloat* F = (const gfloat*)d.F;
   gdouble* W = (gdouble*)d.W;
   if (bi == 0 && bj == 0 && threadIdx.x == 0) *d.info = 0;
   // The symmetrisation needs F[ri][rj] and its mirror F[rj][ri]: the mirror block is read row-wise (coalesced)
-  // into LDS and consumed transposed, instead of 64 lanes striding through 64 rows of F.
+  // into LDS and consumed transposed, instead of 64 lanes striding through 64 rows of F.  A wave owns the rows
+  // w, w + 4, ... of the block, so every row base is wave-uniform; all 32 loads of a lane are issued before
+  // the first use (HBM-bound kernel: 12 B per element of the lower triangle).
   __shared__ float Tm[NB][NB + 1];
-  for (int e = threadIdx.x; e < NB * NB; e += INV_THREADS) {
-    const int r = e >> 6, c = e & 63;                       // mirror block: row index from the j range, col from the i range
-    const int j = bj * NB + r, i = bi * NB + c;
-    float v = 0.0f;
-    if (i < n && j < n) {
-      const int ri = d.reverse ? n - 1 - i : i, rj = d.reverse ? n - 1 - j : j;
-      v = F[(long long)rj * n + ri];
-    }
-    Tm[r][c] = v;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = threadIdx.x & 63;
+  const int j = bj * NB + c, rj = rev ? n - 1 - j : j;           // direct block: column of this lane
+  const int mi = bi * NB + c, rmi = rev ? n - 1 - mi : mi;       // mirror block: column of this lane (i range)
+  float fd[16], fm[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int r = w + 4 * u;
+    const int i = bi * NB + r, ri = rev ? n - 1 - i : i;         // direct row
+    const int mj = bj * NB + r, rmj = rev ? n - 1 - mj : mj;     // mirror row (j range)
+    fd[u] = (i < n && j < n) ? F[(long long)ri * n + rj] : 0.0f;
+    fm[u] = (mi < n && mj < n) ? F[(long long)rmj * n + rmi] : 0.0f;
   }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) Tm[w + 4 * u][c] = fm[u];
   __syncthreads();
-  for (int e = threadIdx.x; e < NB * NB; e += INV_THREADS) {
-    const int i = bi * NB + (e >> 6), j = bj * NB + (e & 63);
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int r = w + 4 * u;
+    const int i = bi * NB + r;
     double v;
     if (i < n && j < n) {
-      const int ri = d.reverse ? n - 1 - i : i, rj = d.reverse ? n - 1 - j : j;
       // reg = s**0.5 * F + diag(n**0.5); reg = (reg + reg.t()) / 2   (curvatures.py:368-375), in fp32
-      float a = __fmul_rn(ss, F[(long long)ri * n + rj]);
-      float b = __fmul_rn(ss, Tm[e & 63][e >> 6]);
+      float a = __fmul_rn(ss, fd[u]);
+      float b = __fmul_rn(ss, Tm[c][r]);
       if (i == j) { a = __fadd_rn(a, sn); b = __fadd_rn(b, sn); }
       v = (double)__fmul_rn(__fadd_rn(a, b), 0.5f);
     } else {
@@ -585,46 +593,53 @@ panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// (5) L[i][j] = (float) X[n-1-j][n-1-i] for j <= i, 0 above the diagonal (32x32 tiles via LDS)
+// (5) L[i][j] = (float) X[n-1-j][n-1-i] for j <= i, 0 above the diagonal (64x64 tiles via LDS)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(INV_THREADS)
 inv_finalize_kernel(const InvDev* __restrict__ t, int nf) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[NB][NB + 1];
   int f, local;
-  if (!locate(t, nf, blockIdx.x, [](const InvDev& d) { const int q = (d.n + 31) / 32; return q * q; }, f, local)) return;
+  if (!locate(t, nf, blockIdx.x, [](const InvDev& d) { return d.P * d.P; }, f, local)) return;
   const InvDev& d = t[f];
-  const int n = d.n, np = d.np, q = (n + 31) / 32;
-  const int ti = local / q, tj = local - ti * q;       // output tile (rows ti*32.., cols tj*32..)
+  const int n = d.n, np = d.np, q = d.P;
+  const int ti = local / q, tj = local - ti * q;       // output tile (rows ti*64.., cols tj*64..)
   const gdouble* X = (const gdouble*)d.X;
-  float* __restrict__ L = d.L;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  typedef __attribute__((address_space(1))) float gfloat;
+  gfloat* L = (gfloat*)d.L;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = threadIdx.x & 63;   // a wave owns rows w, w + 4, ...
   if (!d.reverse) {                                          // plain copy of the lower triangle, fp64
     gdouble* Xo = (gdouble*)d.Xout;
-    for (int r = ty; r < 32; r += 8) {
-      const int i = ti * 32 + r, j = tj * 32 + tx;
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+      const int i = ti * NB + w + 4 * u, j = tj * NB + c;
       if (i < n && j < n) Xo[(long long)i * n + j] = (j <= i) ? X[(long long)i * np + j] : 0.0;
     }
     return;
   }
   if (tj > ti) {
-    for (int r = ty; r < 32; r += 8) {
-      const int i = ti * 32 + r, j = tj * 32 + tx;
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+      const int i = ti * NB + w + 4 * u, j = tj * NB + c;
       if (i < n && j < n) L[(long long)i * n + j] = 0.0f;
     }
     return;
   }
-  // source element for output (i, j) is X[n-1-j][n-1-i]: read rows of X coalesced along its columns
-  for (int r = ty; r < 32; r += 8) {
-    const int j = tj * 32 + r;          // output column -> source row n-1-j
-    const int i = ti * 32 + tx;         // output row    -> source col n-1-i
-    float v = 0.0f;
-    if (i < n && j < n && j <= i) v = (float)X[(long long)(n - 1 - j) * np + (n - 1 - i)];
-    tile[r][tx] = v;
+  // source element for output (i, j) is X[n-1-j][n-1-i]: rows of X are read coalesced along its columns
+  // (all 16 loads of a lane in flight), transposed through LDS, and L is written row-wise
+  double xv[16];
+  const int i_l = ti * NB + c;                               // output row   -> source col n-1-i
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int j = tj * NB + w + 4 * u;                       // output column -> source row n-1-j
+    xv[u] = (i_l < n && j < n && j <= i_l) ? X[(long long)(n - 1 - j) * np + (n - 1 - i_l)] : 0.0;
   }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) tile[w + 4 * u][c] = (float)xv[u];
   __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int i = ti * 32 + r, j = tj * 32 + tx;
-    if (i < n && j < n) L[(long long)i * n + j] = tile[tx][r];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int i = ti * NB + w + 4 * u, j = tj * NB + c;
+    if (i < n && j < n) L[(long long)i * n + j] = tile[c][w + 4 * u];
   }
 }
 
@@ -749,8 +764,7 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
   for (const InvDev& d : tab) {
     Pmax = std::max(Pmax, d.P);
     prep_tiles += (long long)d.P * (d.P + 1) / 2;
-    const long long q = cdiv(d.n, 32);
-    fin_tiles += q * q;
+    fin_tiles += (long long)d.P * d.P;
   }
   for (int b = 0; b < n_factors; b += INV_UPLOAD_CHUNK) {
     InvChunk chunk;
