@@ -197,25 +197,29 @@ jacobi_rows_kernel(const EighDev* __restrict__ t, int nf, int step) {
   rr_pair(d.Nb, step, tp, p, q);
   gdouble* A = (gdouble*)d.A;
   const gdouble* Qg = (const gdouble*)d.Q + (long long)tp * NB * NB;
-  for (int e = tid; e < NB * NB; e += EIG_THREADS) {
-    const int x = e >> 6, y = e & 63;
-    As[y * LDA + x] = Qg[e];                                            // As[row][k] = Q[k][row]  (Q^T)
-    Bs[x * LDA + y] = A[(long long)gidx(p, q, x) * np + ct * NB + y];   // T as [k][col]
+  // a wave owns the rows w, w + 4, ... of both operand tiles: every row base is wave-uniform (SGPR base +
+  // constant lane offset), and all 32 loads of a lane are in flight before the first LDS store
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), c = tid & 63;
+  double qv[16], tv[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int x = w + 4 * u;
+    qv[u] = Qg[x * NB + c];
+    tv[u] = A[(long long)gidx(p, q, x) * np + ct * NB + c];
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int x = w + 4 * u;
+    As[c * LDA + x] = qv[u];                                            // As[row][k] = Q[k][row]  (Q^T)
+    Bs[x * LDA + c] = tv[u];                                            // T as [k][col]
   }
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int lane = tid & 63, wm = w >> 1, wn = w & 1;
   f64x4 acc[2][2] = {};
   mma_64<false>(As, Bs, wm, wn, lane, acc);
-  const int c16 = lane & 15, rq = lane >> 4;
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int x = 32 * wm + 16 * m + rq + 4 * r, y = 32 * wn + 16 * n + c16;
-        A[(long long)gidx(p, q, x) * np + ct * NB + y] = acc[m][n][r];
-      }
+  // output rows 32 wm .. are the rows of block (wm ? q : p): one base per wave, store_acc's tile addressing
+  gdouble* C = A + ((long long)(wm ? q : p) * JB - 32 * wm) * np + ct * NB;
+  store_acc(C, np, acc, wm, wn, lane, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -235,25 +239,28 @@ jacobi_cols_kernel(const EighDev* __restrict__ t, int nf, int step) {
   rr_pair(d.Nb, step, tp, p, q);
   gdouble* Mx = which ? (gdouble*)d.V : (gdouble*)d.A;
   const gdouble* Qg = (const gdouble*)d.Q + (long long)tp * NB * NB;
-  for (int e = tid; e < NB * NB; e += EIG_THREADS) {
-    const int x = e >> 6, y = e & 63;
-    As[x * LDA + y] = Mx[(long long)(rt * NB + x) * np + gidx(p, q, y)];   // T as [row][k]
-    Bs[x * LDA + y] = Qg[e];                                               // Q as [k][col]
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), c = tid & 63;
+  const int gc = gidx(p, q, c);                                      // this lane's column of the matrix
+  double qv[16], tv[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int x = w + 4 * u;
+    tv[u] = Mx[(long long)(rt * NB + x) * np + gc];
+    qv[u] = Qg[x * NB + c];
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int x = w + 4 * u;
+    As[x * LDA + c] = tv[u];                                              // T as [row][k]
+    Bs[x * LDA + c] = qv[u];                                              // Q as [k][col]
   }
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int lane = tid & 63, wm = w >> 1, wn = w & 1;
   f64x4 acc[2][2] = {};
   mma_64<false>(As, Bs, wm, wn, lane, acc);
-  const int c16 = lane & 15, rq = lane >> 4;
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int x = 32 * wm + 16 * m + rq + 4 * r, y = 32 * wn + 16 * n + c16;
-        Mx[(long long)(rt * NB + x) * np + gidx(p, q, y)] = acc[m][n][r];
-      }
+  // output columns 32 wn .. are the columns of block (wn ? q : p)
+  gdouble* C = Mx + (long long)rt * NB * np + ((wn ? q : p) * JB - 32 * wn);
+  store_acc(C, np, acc, wm, wn, lane, 1);
 }
 
 // off-diagonal / diagonal squared norms of A (convergence test)
