@@ -251,32 +251,40 @@ struct TileJob {                        // everything wave-uniform
   int np, ke0, ke1, mode;               // K range in elements; mode of store_acc
   bool bt, same;                        // same: B is A (diagonal tile of a symmetric update)
 };
+// WV x WV waves per workgroup.  WV = 2 (256 threads, a 32x32 quadrant per wave) is the throughput form: <= 128 VGPRs,
+// four workgroups per CU hide each other's latencies.  When a launch has fewer workgroups than the GPU has CUs -
+// the near update and the panel product of a single large factor, both on the chain's critical path - nobody
+// hides anything and a lone workgroup is bound by its own serial issue (LDS operand read -> 4 dependent MFMAs
+// of 64 cycles, 8 times per K step: 45 us for a K = 256 tile; keeping four K steps of loads in flight did not
+// change that).  WV = 4 (1024 threads, one 16x16 MFMA tile per wave) divides that serial part by four.
+template <int WV>
 __device__ __forceinline__ void tile_product_k32(const TileJob& o, double* __restrict__ As, double* __restrict__ Bs) {
+  constexpr int THREADS = 64 * WV * WV, T = 4 / WV, LPT = NB * OKS / THREADS;   // MFMA tiles per wave edge, loads per thread
   const int np = o.np;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WV, wn = wave % WV;
   const bool trailing = o.bt, same = o.same;
   const int r16 = lane & 15, kq = lane >> 4;
-  double ra[8], rb[8];
+  double ra[LPT], rb[LPT];
   const unsigned voff_k = (unsigned)(((long long)(tid >> 5) * np + (tid & 31)) * 8);   // [rows][32 k] operands
   const unsigned voff_n = (unsigned)(((long long)(tid >> 6) * np + (tid & 63)) * 8);   // [32 k][64 cols] operand
-  const long long step_k = 8ll * np * 8, step_n = 4ll * np * 8;                        // 8 / 4 rows per 256 lanes
+  const long long step_k = (long long)(THREADS / 32) * np * 8, step_n = (long long)(THREADS / 64) * np * 8;
   auto fetch = [&](int ke) __attribute__((always_inline)) {                            // ke: first K element of the step
     const gbyte* ga = o.a0 + (long long)ke * 8;
     const gbyte* gb = trailing ? o.b0 + (long long)ke * 8 : o.b0 + (long long)ke * np * 8;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < LPT; ++u) {
       ra[u] = *(const gdouble*)(ga + u * step_k + voff_k);
       if (trailing) rb[u] = same ? 0.0 : *(const gdouble*)(gb + u * step_k + voff_k);
       else rb[u] = *(const gdouble*)(gb + u * step_n + voff_n);
     }
   };
-  f64x4 acc[2][2] = {};
+  f64x4 acc[T][T] = {};
   const int ke0 = o.ke0, ke1 = o.ke1;
   fetch(ke0);
   for (int ke = ke0; ke < ke1; ke += OKS) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = tid + u * INV_THREADS;
+    for (int u = 0; u < LPT; ++u) {
+      const int e = tid + u * THREADS;
       As[(e >> 5) * OPA + (e & 31)] = ra[u];
       if (trailing) { if (!same) Bs[(e >> 5) * OPA + (e & 31)] = rb[u]; }
       else Bs[(e >> 6) * LDA + (e & 63)] = rb[u];
@@ -287,25 +295,43 @@ __device__ __forceinline__ void tile_product_k32(const TileJob& o, double* __res
 #pragma unroll 4
     for (int ks = 0; ks < OKS / 4; ++ks) {
       const int k = 4 * ks + kq;
-      double a[2], b[2];
+      double a[T], b[T];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) a[m] = As[(32 * wm + 16 * m + r16) * OPA + k];
+      for (int m = 0; m < T; ++m) a[m] = As[(16 * T * wm + 16 * m + r16) * OPA + k];
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-        b[n] = trailing ? Bt[(32 * wn + 16 * n + r16) * OPA + k] : Bs[k * LDA + 32 * wn + 16 * n + r16];
+      for (int n = 0; n < T; ++n)
+        b[n] = trailing ? Bt[(16 * T * wn + 16 * n + r16) * OPA + k] : Bs[k * LDA + 16 * T * wn + 16 * n + r16];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < T; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < T; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
     }
     __syncthreads();
   }
-  store_acc(o.C, np, acc, wm, wn, lane, o.mode);
+  if constexpr (WV == 2) {
+    store_acc(o.C, np, acc, wm, wn, lane, o.mode);
+  } else {
+    // one 16x16 tile per wave: rows 16 wm + rq + 4 q, column 16 wn + c16
+    const int c16 = lane & 15, rq = lane >> 4;
+    gbyte* base = (gbyte*)o.C;
+    const unsigned voff = (unsigned)(((long long)(16 * wm + rq) * np + 16 * wn + c16) * 8);
+    double old[4];
+    if (o.mode == 0 || o.mode == 2) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) old[q] = *(const gdouble*)(base + (long long)(4 * q) * np * 8 + voff);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double v = acc[0][0][q];
+      const double out = o.mode == 0 ? old[q] - v : o.mode == 1 ? v : o.mode == 2 ? old[q] + v : -v;
+      *(gdouble*)(base + (long long)(4 * q) * np * 8 + voff) = out;
+    }
+  }
 }
 
-__global__ void __launch_bounds__(INV_THREADS, 3)
-outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int lo, int hi, int strip, int n_items) {
-  __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
+template <int WV>
+__device__ __forceinline__ void outer_update_body(const InvDev* __restrict__ t, int nf, int k0, int kend, int lo, int hi,
+                                                  int strip, int n_items, double* __restrict__ As, double* __restrict__ Bs) {
   bool trailing;
   int i, j, f, local;
   if (strip) {
@@ -369,7 +395,17 @@ outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int 
   o.ke1 = kend * NB;
   o.C = trailing ? (gdouble*)d.W + (long long)i * NB * np + j * NB : X + (long long)i * NB * np + j * NB;
   o.mode = trailing ? 0 : (j >= k0 ? 1 : 2);
-  tile_product_k32(o, As, Bs);
+  tile_product_k32<WV>(o, As, Bs);
+}
+__global__ void __launch_bounds__(INV_THREADS, 3)
+outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int lo, int hi, int strip, int n_items) {
+  __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
+  outer_update_body<2>(t, nf, k0, kend, lo, hi, strip, n_items, As, Bs);
+}
+__global__ void __launch_bounds__(1024)
+outer_update_wide_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int lo, int hi, int strip, int n_items) {
+  __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
+  outer_update_body<4>(t, nf, k0, kend, lo, hi, strip, n_items, As, Bs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -562,9 +598,9 @@ chol_panel_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int kend)
 // doing these rows step by step (nb panel solves + nb (nb - 1) / 2 rank-64 updates, each a read-modify-
 // write of 64x64 tiles) the row panel is read and written once.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(INV_THREADS, 3)
-panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
-  __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
+template <int WV>
+__device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t, int nf, int k0, int kend,
+                                                   double* __restrict__ As, double* __restrict__ Bs) {
   int f, local;
   if (!locate(t, nf, blockIdx.x,
               [k0, kend](const InvDev& d) { return d.P > k0 ? (d.P > kend ? d.P - kend : 0) + k0 : 0; }, f, local))
@@ -588,8 +624,18 @@ panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
     o.b0 = below ? (const gbyte*)xsq : (const gbyte*)(X + (long long)k0 * NB * np + j * NB);
     o.C = below ? W + (long long)i * NB * np + (k0 + c) * NB : X + (long long)(k0 + c) * NB * np + j * NB;
     o.ke1 = (c + 1) * NB;
-    tile_product_k32(o, As, Bs);
+    tile_product_k32<WV>(o, As, Bs);
   }
+}
+__global__ void __launch_bounds__(INV_THREADS, 3)
+panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
+  __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
+  panel_product_body<2>(t, nf, k0, kend, As, Bs);
+}
+__global__ void __launch_bounds__(1024)
+panel_product_wide_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
+  __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
+  panel_product_body<4>(t, nf, k0, kend, As, Bs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -780,6 +826,9 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
   // Per panel: the chain of diagonal steps (small, latency-bound launches) runs on the caller's stream,
   // then the near part of the outer update (the block columns / rows the NEXT chain touches); the rest of
   // the outer update goes to a second stream and overlaps the following chains (see below).
+  // launches narrower than the GPU take the 1024-thread form of the tile kernels (see tile_product_k32)
+  static const long long wide_near = getenv("CURV_WIDE_NEAR") ? atoll(getenv("CURV_WIDE_NEAR")) : 512;
+  static const long long wide_prod = getenv("CURV_WIDE_PROD") ? atoll(getenv("CURV_WIDE_PROD")) : 256;
   bool far_pending = false;
   int panel = 0;
   for (int k0 = 0; k0 < Pmax; k0 += NBO, ++panel) {
@@ -807,7 +856,10 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
     for (const InvDev& d : tab)
       if (d.P > k0) prod_tiles += std::max(0, d.P - kend) + k0;
     if (prod_tiles > 0) {   // rows below / columns left of the square: one triangular product each
-      hipLaunchKernelGGL(panel_product_kernel, dim3((unsigned)prod_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend);
+      if (prod_tiles <= wide_prod)
+        hipLaunchKernelGGL(panel_product_wide_kernel, dim3((unsigned)prod_tiles), dim3(1024), 0, stream, table, n_factors, k0, kend);
+      else
+        hipLaunchKernelGGL(panel_product_kernel, dim3((unsigned)prod_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend);
       CURV_LAUNCH_CHECK();
     }
     // Outer update of this panel in two parts: near = the strip the next chain touches (this stream, on the
@@ -829,8 +881,12 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
         CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_side[(panel + 1) & 1], 0));
         far_pending = false;
       }
-      hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)near_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0,
-                         kend, kend, row0, 1, (int)near_tiles);
+      if (near_tiles <= wide_near)
+        hipLaunchKernelGGL(outer_update_wide_kernel, dim3((unsigned)near_tiles), dim3(1024), 0, stream, table, n_factors,
+                           k0, kend, kend, row0, 1, (int)near_tiles);
+      else
+        hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)near_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0,
+                           kend, kend, row0, 1, (int)near_tiles);
       CURV_LAUNCH_CHECK();
     }
     if (far_tiles > 0) {
