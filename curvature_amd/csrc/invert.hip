@@ -766,16 +766,20 @@ static int stream_set(StreamSet** out) {
       CURV_HIP_CHECK(hipGetDevice(&dev_id));
       CURV_HIP_CHECK(hipGetDeviceProperties(&prop, dev_id));
       const int n_cu = prop.multiProcessorCount;
-      if (free_cus > 0 && free_cus < n_cu) {
+      bool masked_ok = false;
+      if (free_cus > 0 && 2 * free_cus <= n_cu) {
         std::vector<uint32_t> mask((size_t)cdiv(n_cu, 32), 0u);
         for (int c = 0; c < n_cu - free_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
-        CURV_HIP_CHECK(hipExtStreamCreateWithCUMask(&s.side[g].stream, (uint32_t)mask.size(), mask.data()));
-        std::lock_guard<std::mutex> lock(g_masked_mutex);
-        if (g_masked_streams.empty()) atexit(destroy_masked_streams);
-        g_masked_streams.emplace_back(dev_id, s.side[g].stream);
-      } else {
-        CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.side[g].stream, hipStreamNonBlocking, prio_low));
+        if (hipExtStreamCreateWithCUMask(&s.side[g].stream, (uint32_t)mask.size(), mask.data()) == hipSuccess) {
+          masked_ok = true;
+          std::lock_guard<std::mutex> lock(g_masked_mutex);
+          if (g_masked_streams.empty()) atexit(destroy_masked_streams);
+          g_masked_streams.emplace_back(dev_id, s.side[g].stream);
+        } else {
+          (void)hipGetLastError();            // a runtime without CU masks: plain low-priority stream below
+        }
       }
+      if (!masked_ok) CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.side[g].stream, hipStreamNonBlocking, prio_low));
     }
     for (int i = 0; i < 2; ++i) {
       CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_main[i], hipEventDisableTiming));
