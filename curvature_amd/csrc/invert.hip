@@ -234,16 +234,16 @@ inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int ken
 }
 
 // (2o)/(4o) once per outer panel [k0, kend): everything beyond the panel, K = (kend - k0) * 64.
-// K advances in steps of 32 (two 17 KB operand tiles in LDS instead of two 33 KB ones): four workgroups
-// fit a CU, twice as many loads are in flight per CU, and that - not L2 bandwidth - is what this
-// latency-bound streaming kernel was short of.  The next step is fetched into registers while the MFMAs
-// of the current one run.
-constexpr int OKS = 32;                // K step
-constexpr int OPA = OKS + 1;           // LDS pitch of a [64][32] operand (rows K-contiguous)
-// One 64x64 output tile, K advancing in steps of 32 through two 17 KB LDS operand tiles, the next step
-// fetched into registers while the MFMAs of the current one run; loads are SGPR base + 32-bit lane offset.
-// Shared by the outer updates and the panel products: every kernel built on it has the same footprint
-// (116 VGPRs, 33.8 KB LDS), so a workgroup of one fits exactly the slot a retiring workgroup of another frees.
+// K advances in short steps through two small LDS operand tiles; the next step is fetched into registers while
+// the MFMAs of the current one run.  What this latency-bound streaming kernel is short of is workgroups per CU
+// (loads in flight, somebody else's MFMAs to run while one workgroup waits), not L2 bandwidth or tile size:
+// K step 64 (two 33 KB tiles, 2 per CU) -> 32 (17 KB, 4 per CU): 14.8 -> 12.8 ms for the ResNet-50 factors at
+// the time; 32 -> 16 (8.7 KB tiles, 96 VGPRs, 5 per CU): 9.6 -> 9.25 ms.
+constexpr int OKS = 16;                // K step (elements); with 1024 threads a step is one load per thread
+constexpr int OPA = OKS + 1;           // LDS pitch of a [64][OKS] operand (rows K-contiguous)
+// One 64x64 output tile; loads are SGPR base + 32-bit lane offset.  Shared by the outer updates and the panel
+// products: every kernel built on it has the same footprint (96 VGPRs, 17.4 KB LDS), so a workgroup of one fits
+// exactly the slot a retiring workgroup of another frees.
 struct TileJob {                        // everything wave-uniform
   const gbyte* a0;                      // A: rows K-contiguous, element (r, ke) at a0 + (r * np + ke) * 8
   const gbyte* b0;                      // B: bt ? rows K-contiguous like A : element (ke, c) at b0 + (ke * np + c) * 8
@@ -255,7 +255,7 @@ struct TileJob {                        // everything wave-uniform
 // four workgroups per CU hide each other's latencies.  When a launch has fewer workgroups than the GPU has CUs -
 // the near update and the panel product of a single large factor, both on the chain's critical path - nobody
 // hides anything and a lone workgroup is bound by its own serial issue (LDS operand read -> 4 dependent MFMAs
-// of 64 cycles, 8 times per K step: 45 us for a K = 256 tile; keeping four K steps of loads in flight did not
+// of 64 cycles per group of four K elements: 45 us for a K = 256 tile; keeping four K steps of loads in flight did not
 // change that).  WV = 4 (1024 threads, one 16x16 MFMA tile per wave) divides that serial part by four.
 template <int WV>
 __device__ __forceinline__ void tile_product_k32(const TileJob& o, double* __restrict__ As, double* __restrict__ Bs) {
@@ -265,9 +265,9 @@ __device__ __forceinline__ void tile_product_k32(const TileJob& o, double* __res
   const bool trailing = o.bt, same = o.same;
   const int r16 = lane & 15, kq = lane >> 4;
   double ra[LPT], rb[LPT];
-  const unsigned voff_k = (unsigned)(((long long)(tid >> 5) * np + (tid & 31)) * 8);   // [rows][32 k] operands
-  const unsigned voff_n = (unsigned)(((long long)(tid >> 6) * np + (tid & 63)) * 8);   // [32 k][64 cols] operand
-  const long long step_k = (long long)(THREADS / 32) * np * 8, step_n = (long long)(THREADS / 64) * np * 8;
+  const unsigned voff_k = (unsigned)(((long long)(tid / OKS) * np + (tid % OKS)) * 8);   // [rows][OKS k] operands
+  const unsigned voff_n = (unsigned)(((long long)(tid >> 6) * np + (tid & 63)) * 8);   // [OKS k][64 cols] operand
+  const long long step_k = (long long)(THREADS / OKS) * np * 8, step_n = (long long)(THREADS / 64) * np * 8;
   auto fetch = [&](int ke) __attribute__((always_inline)) {                            // ke: first K element of the step
     const gbyte* ga = o.a0 + (long long)ke * 8;
     const gbyte* gb = trailing ? o.b0 + (long long)ke * 8 : o.b0 + (long long)ke * np * 8;
@@ -285,8 +285,8 @@ __device__ __forceinline__ void tile_product_k32(const TileJob& o, double* __res
 #pragma unroll
     for (int u = 0; u < LPT; ++u) {
       const int e = tid + u * THREADS;
-      As[(e >> 5) * OPA + (e & 31)] = ra[u];
-      if (trailing) { if (!same) Bs[(e >> 5) * OPA + (e & 31)] = rb[u]; }
+      As[(e / OKS) * OPA + (e % OKS)] = ra[u];
+      if (trailing) { if (!same) Bs[(e / OKS) * OPA + (e % OKS)] = rb[u]; }
       else Bs[(e >> 6) * LDA + (e & 63)] = rb[u];
     }
     __syncthreads();
