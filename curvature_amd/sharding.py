@@ -37,13 +37,13 @@ def lpt_partition(costs: Sequence[float], world: int) -> List[int]:
 def rank_cost(dims: Sequence[Sequence[int]]) -> float:
     """Estimated step time (s) of a rank that owns the layers `dims` = [(n, m, K), ...].  Not additive: the
     factors of a rank are inverted in one batched sweep, so the serial chains of 64-column steps overlap and
-    only the longest one counts (calibrated on MI355X: single 4608^2 factor 4.0 ms = 72 steps x 56 us, three of
+    only the longest one counts (calibrated on MI355X: single 4608^2 factor 3.9 ms = 72 steps x 54 us, three of
     them 6.6 ms, all 108 ResNet-50 factors 9.6 ms; build 85 TFLOP/s executed, sampling GEMMs 95 TFLOP/s)."""
     if not dims:
         return 0.0
     build = sum((n * (n + 1.0) + m * (m + 1.0)) * K for n, m, K in dims) / 85e12
     sample = sum(2.0 * (n * n * m + n * m * m) for n, m, _ in dims) / 95e12
-    chain = max(max(n, m) for n, m, _ in dims) / 64.0 * 56e-6
+    chain = max(max(n, m) for n, m, _ in dims) / 64.0 * 54e-6
     invert = 0.7 * chain + sum((2.0 / 3.0) * (n ** 3 + m ** 3) for n, m, _ in dims) / 42e12
     return build + invert + sample + 1.0e-3
 
