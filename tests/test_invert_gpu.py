@@ -114,3 +114,42 @@ def test_many_large_factors_no_race(gpu):
     for idx in (0, 5, 6, 15, 16, 55):
         exact = o.chol_of_inverse(damp32_then_64(Fs[idx].cpu(), 1.0, 1000.0))
         assert rel_fro(outs[idx], exact) < 1e-6
+
+
+def test_same_result_without_cu_masks(gpu, tmp_path):
+    """The sweep's stream layout (CU-masked side streams, or plain low-priority ones when CURV_FREE_CUS=0 / the
+    runtime has no CU masks) must not change a single bit: every tile is written by exactly one workgroup and
+    the accumulation order inside a tile is fixed.  The setting is read once per process, hence a subprocess."""
+    import subprocess
+    import sys
+    from curvature_amd import ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sizes = [1100, 300, 64, 2304]
+
+    def factors():
+        out = []
+        for i, n in enumerate(sizes):
+            g = torch.Generator().manual_seed(100 + i)
+            X = torch.randn(n, n + 8, generator=g)
+            out.append((X @ X.t() / (n + 8)).contiguous())
+        return out
+
+    here = [L.cpu() for L in ops.chol_inv_lower([F.to(gpu) for F in factors()], [1.0] * 4, [1000.0] * 4)]
+    script = tmp_path / "inv.py"
+    script.write_text(
+        "import sys, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from curvature_amd import ops\n"
+        f"sizes = {sizes!r}\n"
+        "Fs = []\n"
+        "for i, n in enumerate(sizes):\n"
+        "    g = torch.Generator().manual_seed(100 + i)\n"
+        "    X = torch.randn(n, n + 8, generator=g)\n"
+        "    Fs.append((X @ X.t() / (n + 8)).contiguous().cuda())\n"
+        "Ls = ops.chol_inv_lower(Fs, [1.0] * 4, [1000.0] * 4)\n"
+        f"torch.save([L.cpu() for L in Ls], {str(tmp_path / 'out.pt')!r})\n")
+    env = dict(os.environ, CURV_FREE_CUS="0")
+    subprocess.run([sys.executable, str(script)], check=True, env=env, timeout=300)
+    there = torch.load(tmp_path / "out.pt")
+    for a, b in zip(here, there):
+        assert torch.equal(a, b)
