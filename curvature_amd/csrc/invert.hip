@@ -807,7 +807,8 @@ extern "C" size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int 
 
 // One batched sweep over the factors of `tab` (work matrices already assigned), everything enqueued on
 // `stream` except the far outer updates, which go to side->stream.
-static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vector<InvDev>& tab, InvDev* table) {
+static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vector<InvDev>& tab, InvDev* table,
+                            hipEvent_t progress_event = nullptr, int progress_panel = -1) {
   const int n_factors = (int)tab.size();
   int Pmax = 0;
   long long prep_tiles = 0, fin_tiles = 0;
@@ -837,6 +838,7 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
   int panel = 0;
   for (int k0 = 0; k0 < Pmax; k0 += NBO, ++panel) {
     const int kend = k0 + NBO, row0 = kend + NBO;
+    if (progress_event != nullptr && panel == progress_panel) CURV_HIP_CHECK(hipEventRecord(progress_event, stream));
     long long prod_tiles = 0;
     for (int k = k0; k < std::min(kend, Pmax); ++k) {
       long long diag_tiles = 0, panel_tiles = 0, upd_tiles = 0;
@@ -955,8 +957,20 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   CURV_HIP_CHECK(hipEventRecord(ss->ev_fork, stream));
   CURV_HIP_CHECK(hipStreamWaitEvent(ss->aux, ss->ev_fork, 0));
   CURV_HIP_CHECK(hipStreamWaitEvent(ss->masked, ss->ev_fork, 0));
-  int rc = chol_sweep_group(ss->aux, &ss->side[0], big, table0);
+  // The large group is bound by its far updates in its first panels and by its chain in its last ones (the far
+  // work shrinks with (P^2 - k^2), the chain does not): the small group starts when the large one has done
+  // `start_panel` panels, so that its throughput work fills the large group's chain-bound tail.
+  static const int start_frac = getenv("CURV_SMALL_START") ? atoi(getenv("CURV_SMALL_START")) : 30;  // percent of the panels
+  // (ResNet-50: 0 -> 9.25 ms, 20 -> 9.2, 30 -> 9.0, 40 -> 9.2, 50 -> 9.5)
+  const int n_panels = cdiv(Pmax, 4);
+  long long far0 = 0;                          // far tiles of the large group's first panel
+  for (const InvDev& d : big) far0 += outer_tiles(d.P, 4, 8);
+  // only a far-bound large group has such a tail to fill (a chain step is ~54 us, a far tile ~0.04 us of the
+  // whole GPU): with [2048 | 1024, 512, 256] the delay costs 8 %
+  const int start_panel = far0 >= 5000 ? std::min(n_panels - 1, n_panels * start_frac / 100) : 0;
+  int rc = chol_sweep_group(ss->aux, &ss->side[0], big, table0, start_panel > 0 ? ss->ev_join2 : nullptr, start_panel);
   if (rc != CURV_OK) return rc;
+  if (start_panel > 0) CURV_HIP_CHECK(hipStreamWaitEvent(ss->masked, ss->ev_join2, 0));
   rc = chol_sweep_group(ss->masked, &ss->side[1], small, table1);
   if (rc != CURV_OK) return rc;
   CURV_HIP_CHECK(hipEventRecord(ss->ev_join, ss->aux));
