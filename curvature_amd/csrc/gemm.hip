@@ -80,20 +80,40 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, int local, float* ld
   // staging map: lanes run along the unit-stride dimension of the operand so that global reads coalesce
   const bool a_kfast = (a_cs == 1), b_kfast = (b_rs == 1);
   int ar[PER_T], ak[PER_T], bc[PER_T], bk[PER_T];
+  // Per-thread element offsets inside the tile's operand panels are computed once (32-bit: the host checks
+  // that a tile spans less than 2^31 elements); a stage adds only the wave-uniform k0 * stride to the panel
+  // base, so every load is SGPR base + 32-bit lane offset.  (Per-element 64-bit i * rs + k * cs index
+  // arithmetic was ~1300 VALU cycles per stage and wave, next to 2048 MFMA cycles.)
+  int oa[PER_T], ob[PER_T];
+  unsigned va = 0, vb = 0;                        // row / column inside the matrix?
 #pragma unroll
   for (int u = 0; u < PER_T; ++u) {
     const int e = tid + u * GEMM_THREADS;
     if (a_kfast) { ak[u] = e & 15; ar[u] = e >> 4; } else { ar[u] = e % TMv; ak[u] = e / TMv; }
     if (b_kfast) { bk[u] = e & 15; bc[u] = e >> 4; } else { bc[u] = e % TMv; bk[u] = e / TMv; }
+    oa[u] = (int)(ar[u] * a_rs + ak[u] * a_cs);
+    ob[u] = (int)(bk[u] * b_rs + bc[u] * b_cs);
+    if (i0 + ar[u] < M) va |= 1u << u;
+    if (j0 + bc[u] < N) vb |= 1u << u;
   }
+  const gfl* At = A + (long long)i0 * a_rs;
+  const gfl* Bt = B + (long long)j0 * b_cs;
   float ra[PER_T], rb[PER_T];
-  auto fetch = [&](int k0) {
+  auto fetch = [&](int k0) __attribute__((always_inline)) {
+    const gfl* Ak = At + (long long)k0 * a_cs;
+    const gfl* Bk = Bt + (long long)k0 * b_rs;
+    if (k0 + GK <= K) {                           // whole stage inside K (wave-uniform)
 #pragma unroll
-    for (int u = 0; u < PER_T; ++u) {
-      const int i = i0 + ar[u], k = k0 + ak[u];
-      ra[u] = (i < M && k < K) ? A[i * a_rs + k * a_cs] : 0.0f;
-      const int j = j0 + bc[u], kk = k0 + bk[u];
-      rb[u] = (j < N && kk < K) ? B[kk * b_rs + j * b_cs] : 0.0f;
+      for (int u = 0; u < PER_T; ++u) {
+        ra[u] = ((va >> u) & 1) ? Ak[oa[u]] : 0.0f;
+        rb[u] = ((vb >> u) & 1) ? Bk[ob[u]] : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < PER_T; ++u) {
+        ra[u] = (((va >> u) & 1) && k0 + ak[u] < K) ? Ak[oa[u]] : 0.0f;
+        rb[u] = (((vb >> u) & 1) && k0 + bk[u] < K) ? Bk[ob[u]] : 0.0f;
+      }
     }
   };
   auto stash = [&](int buf) {
@@ -344,6 +364,12 @@ extern "C" int curv_gemm_batched(void* stream_, const curv_gemm_desc* descs, int
     CURV_REQUIRE(s.tri >= 0 && s.tri <= CURV_TRI_B_UPPER, "curv_gemm_batched: desc %d: bad tri flag", i);
     d.tri = s.tri;
     d.tm = (s.M >= 96 && s.N >= 96) ? 128 : 64;
+    {   // the kernel addresses a tile's operand panels with 32-bit element offsets (non-negative strides)
+      const long long lim = (1LL << 31) - 1;
+      CURV_REQUIRE(s.a_rs >= 0 && s.a_cs >= 0 && s.b_rs >= 0 && s.b_cs >= 0, "curv_gemm_batched: desc %d: negative stride", i);
+      CURV_REQUIRE((long long)d.tm * s.a_rs + 16 * s.a_cs < lim && (long long)d.tm * s.b_cs + 16 * s.b_rs < lim,
+                   "curv_gemm_batched: desc %d: operand stride too large", i);
+    }
     d.tiles_n = cdiv(s.N, d.tm);
     d.tile_base = (int)tiles;
     tiles += (long long)cdiv(s.M, d.tm) * d.tiles_n;
