@@ -186,81 +186,99 @@ jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sw
 // ------------------------------------------------------------------------------------------------
 // (2) rows {p,q} of A <- Q^T rows, one 64-column tile per workgroup
 // ------------------------------------------------------------------------------------------------
+// Both update kernels walk eig_etw() consecutive 64-wide tiles of their block pair per workgroup: the pair's Q is staged
+// once, and the next tile is in flight (registers) while the MFMAs of the current one run.
+// (four for matrices of 2048 and more, fewer below: small matrices need the workgroups more than the reuse)
+__device__ __host__ __forceinline__ int eig_etw(int tiles) { return tiles >= 32 ? 4 : tiles >= 16 ? 2 : 1; }
+__device__ __host__ __forceinline__ int eig_groups(int tiles) { const int e = eig_etw(tiles); return (tiles + e - 1) / e; }
+
 __global__ void __launch_bounds__(EIG_THREADS)
 jacobi_rows_kernel(const EighDev* __restrict__ t, int nf, int step) {
   __shared__ double As[NB * LDA], Bs[NB * LDA];
   int f, local;
-  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return (d.Nb / 2) * (d.np / NB); }, f, local)) return;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return (d.Nb / 2) * eig_groups(d.np / NB); }, f, local)) return;
   const EighDev& d = t[f];
-  const int nct = d.np / NB, tp = local / nct, ct = local - tp * nct, np = d.np, tid = threadIdx.x;
+  const int nct = d.np / NB, ng = eig_groups(nct), etw = eig_etw(nct), tp = local / ng, ct0 = (local - tp * ng) * etw, np = d.np, tid = threadIdx.x;
+  const int ct1 = ct0 + etw < nct ? ct0 + etw : nct;
   int p, q;
   rr_pair(d.Nb, step, tp, p, q);
   gdouble* A = (gdouble*)d.A;
   const gdouble* Qg = (const gdouble*)d.Q + (long long)tp * NB * NB;
   // a wave owns the rows w, w + 4, ... of both operand tiles: every row base is wave-uniform (SGPR base +
-  // constant lane offset), and all 32 loads of a lane are in flight before the first LDS store
+  // constant lane offset), and all loads of a lane are in flight before the first LDS store
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), c = tid & 63;
+  const int lane = tid & 63, wm = w >> 1, wn = w & 1;
   double qv[16], tv[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     const int x = w + 4 * u;
     qv[u] = Qg[x * NB + c];
-    tv[u] = A[(long long)gidx(p, q, x) * np + ct * NB + c];
+    tv[u] = A[(long long)gidx(p, q, x) * np + ct0 * NB + c];
   }
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int x = w + 4 * u;
-    As[c * LDA + x] = qv[u];                                            // As[row][k] = Q[k][row]  (Q^T)
-    Bs[x * LDA + c] = tv[u];                                            // T as [k][col]
+  for (int u = 0; u < 16; ++u) As[c * LDA + w + 4 * u] = qv[u];           // As[row][k] = Q[k][row]  (Q^T)
+  for (int ct = ct0; ct < ct1; ++ct) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) Bs[(w + 4 * u) * LDA + c] = tv[u];        // T as [k][col]
+    __syncthreads();
+    if (ct + 1 < ct1) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) tv[u] = A[(long long)gidx(p, q, w + 4 * u) * np + (ct + 1) * NB + c];
+    }
+    f64x4 acc[2][2] = {};
+    mma_64<false>(As, Bs, wm, wn, lane, acc);
+    // output rows 32 wm .. are the rows of block (wm ? q : p): one base per wave, store_acc's tile addressing
+    gdouble* C = A + ((long long)(wm ? q : p) * JB - 32 * wm) * np + ct * NB;
+    store_acc(C, np, acc, wm, wn, lane, 1);
+    __syncthreads();
   }
-  __syncthreads();
-  const int lane = tid & 63, wm = w >> 1, wn = w & 1;
-  f64x4 acc[2][2] = {};
-  mma_64<false>(As, Bs, wm, wn, lane, acc);
-  // output rows 32 wm .. are the rows of block (wm ? q : p): one base per wave, store_acc's tile addressing
-  gdouble* C = A + ((long long)(wm ? q : p) * JB - 32 * wm) * np + ct * NB;
-  store_acc(C, np, acc, wm, wn, lane, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
-// (3) cols {p,q} of A and of V <- cols * Q, one 64-row tile per workgroup
+// (3) cols {p,q} of A and of V <- cols * Q, eig_etw() 64-row tiles per workgroup
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(EIG_THREADS)
 jacobi_cols_kernel(const EighDev* __restrict__ t, int nf, int step) {
   __shared__ double As[NB * LDA], Bs[NB * LDA];
   int f, local;
-  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return (d.Nb / 2) * (d.np / NB) * 2; }, f, local)) return;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return (d.Nb / 2) * eig_groups(d.np / NB) * 2; }, f, local)) return;
   const EighDev& d = t[f];
-  const int nrt = d.np / NB, np = d.np, tid = threadIdx.x;
-  const int which = local / ((d.Nb / 2) * nrt);                     // 0: A, 1: V
-  const int l2 = local - which * (d.Nb / 2) * nrt;
-  const int tp = l2 / nrt, rt = l2 - tp * nrt;
+  const int nrt = d.np / NB, ng = eig_groups(nrt), np = d.np, tid = threadIdx.x;
+  const int which = local / ((d.Nb / 2) * ng);                      // 0: A, 1: V
+  const int l2 = local - which * (d.Nb / 2) * ng;
+  const int etw = eig_etw(nrt), tp = l2 / ng, rt0 = (l2 - tp * ng) * etw;
+  const int rt1 = rt0 + etw < nrt ? rt0 + etw : nrt;
   int p, q;
   rr_pair(d.Nb, step, tp, p, q);
   gdouble* Mx = which ? (gdouble*)d.V : (gdouble*)d.A;
   const gdouble* Qg = (const gdouble*)d.Q + (long long)tp * NB * NB;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), c = tid & 63;
+  const int lane = tid & 63, wm = w >> 1, wn = w & 1;
   const int gc = gidx(p, q, c);                                      // this lane's column of the matrix
   double qv[16], tv[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     const int x = w + 4 * u;
-    tv[u] = Mx[(long long)(rt * NB + x) * np + gc];
+    tv[u] = Mx[(long long)(rt0 * NB + x) * np + gc];
     qv[u] = Qg[x * NB + c];
   }
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int x = w + 4 * u;
-    As[x * LDA + c] = tv[u];                                              // T as [row][k]
-    Bs[x * LDA + c] = qv[u];                                              // Q as [k][col]
+  for (int u = 0; u < 16; ++u) Bs[(w + 4 * u) * LDA + c] = qv[u];          // Q as [k][col]
+  for (int rt = rt0; rt < rt1; ++rt) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) As[(w + 4 * u) * LDA + c] = tv[u];        // T as [row][k]
+    __syncthreads();
+    if (rt + 1 < rt1) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) tv[u] = Mx[(long long)((rt + 1) * NB + w + 4 * u) * np + gc];
+    }
+    f64x4 acc[2][2] = {};
+    mma_64<false>(As, Bs, wm, wn, lane, acc);
+    // output columns 32 wn .. are the columns of block (wn ? q : p)
+    gdouble* C = Mx + (long long)rt * NB * np + ((wn ? q : p) * JB - 32 * wn);
+    store_acc(C, np, acc, wm, wn, lane, 1);
+    __syncthreads();
   }
-  __syncthreads();
-  const int lane = tid & 63, wm = w >> 1, wn = w & 1;
-  f64x4 acc[2][2] = {};
-  mma_64<false>(As, Bs, wm, wn, lane, acc);
-  // output columns 32 wn .. are the columns of block (wn ? q : p)
-  gdouble* C = Mx + (long long)rt * NB * np + ((wn ? q : p) * JB - 32 * wn);
-  store_acc(C, np, acc, wm, wn, lane, 1);
 }
 
 // off-diagonal / diagonal squared norms of A (convergence test)
@@ -421,7 +439,7 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
     const long long P = d.np / NB;
     prep_tiles += P * P;
     pair_wgs += d.Nb / 2;
-    row_tiles += (long long)(d.Nb / 2) * P;
+    row_tiles += (long long)(d.Nb / 2) * eig_groups(P);
     const long long Pg = cdiv(s.n, NB);
     gather_tiles += Pg * Pg;
   }
