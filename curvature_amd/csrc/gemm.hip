@@ -226,18 +226,38 @@ gemm_f64_kernel(Gemm64Dev d0, Gemm64Dev d1, Gemm64Dev d2, Gemm64Dev d3, int n_de
   const gdbl* B = (const gdbl*)d.B;
   const bool a_kfast = (d.a_cs == 1), b_kfast = (d.b_rs == 1);
   f64x4 acc[2][2] = {};
+  // staging map (lanes along the unit-stride dimension) and element offsets, computed once; the next K stage is
+  // fetched into registers while the MFMAs of the current one run (these products sit on INF.invert's serial
+  // path with a handful of tiles each: without the prefetch every stage paid a full load round trip)
+  int ar[4], ak[4], bc[4], bk[4];
+  long long oa[4], ob[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + u * GEMM_THREADS;
+    if (a_kfast) { ak[u] = e & 15; ar[u] = e >> 4; } else { ar[u] = e & 63; ak[u] = e >> 6; }
+    if (b_kfast) { bk[u] = e & 15; bc[u] = e >> 4; } else { bc[u] = e & 63; bk[u] = e >> 6; }
+    oa[u] = (long long)(i0 + ar[u]) * d.a_rs + (long long)ak[u] * d.a_cs;
+    ob[u] = (long long)bk[u] * d.b_rs + (long long)(j0 + bc[u]) * d.b_cs;
+  }
+  double ra[4], rb[4];
+  auto fetch = [&](int k0) __attribute__((always_inline)) {
+    const gdbl* Ak = A + (long long)k0 * d.a_cs;
+    const gdbl* Bk = B + (long long)k0 * d.b_rs;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ra[u] = (i0 + ar[u] < M && k0 + ak[u] < K) ? Ak[oa[u]] : 0.0;
+      rb[u] = (j0 + bc[u] < N && k0 + bk[u] < K) ? Bk[ob[u]] : 0.0;
+    }
+  };
+  if (K > 0) fetch(0);
   for (int k0 = 0; k0 < K; k0 += GK) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int e = tid + u * GEMM_THREADS;
-      int ar, ak, bc, bk;
-      if (a_kfast) { ak = e & 15; ar = e >> 4; } else { ar = e & 63; ak = e >> 6; }
-      if (b_kfast) { bk = e & 15; bc = e >> 4; } else { bc = e & 63; bk = e >> 6; }
-      const int i = i0 + ar, k = k0 + ak, j = j0 + bc, kk = k0 + bk;
-      As[ak * GP + ar] = (i < M && k < K) ? A[i * d.a_rs + k * d.a_cs] : 0.0;
-      Bs[bk * GP + bc] = (j < N && kk < K) ? B[kk * d.b_rs + j * d.b_cs] : 0.0;
+      As[ak[u] * GP + ar[u]] = ra[u];
+      Bs[bk[u] * GP + bc[u]] = rb[u];
     }
     __syncthreads();
+    if (k0 + GK < K) fetch(k0 + GK);
 #pragma unroll
     for (int ks = 0; ks < GK / 4; ++ks) {
       const int k = 4 * ks + kq;
