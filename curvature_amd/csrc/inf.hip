@@ -25,13 +25,17 @@ struct SelDev {
   int n, m, rank, pad;
 };
 
+constexpr int SEL_BATCH = 32;          // layers per launch (one workgroup each), descriptors by value
+struct SelBatch { SelDev d[SEL_BATCH]; };
+static_assert(sizeof(SelBatch) <= 3584, "kernel argument block must stay below 4 KB");
+
 __global__ void __launch_bounds__(SEL_THREADS)
-inf_select_kernel(SelDev d0, SelDev d1, SelDev d2, SelDev d3, int n_desc) {
+inf_select_kernel(SelBatch batch, int n_desc) {
   __shared__ unsigned hist[256];
   __shared__ unsigned s_prefix, s_remaining;
   __shared__ unsigned char rowflag[8192], colflag[8192];
   __shared__ int s_scan[SEL_THREADS];
-  const SelDev d = blockIdx.x == 0 ? d0 : blockIdx.x == 1 ? d1 : blockIdx.x == 2 ? d2 : d3;
+  const SelDev& d = batch.d[blockIdx.x];
   const int tid = threadIdx.x;
   const long long total = (long long)d.n * d.m;
   const gflt* lam = (const gflt*)d.lam;
@@ -178,10 +182,11 @@ using namespace curv;
 
 extern "C" int curv_inf_select(void* stream, const curv_select_desc* descs, int n_desc) {
   CURV_REQUIRE(n_desc >= 0 && (n_desc == 0 || descs), "curv_inf_select: bad arguments");
-  for (int base = 0; base < n_desc; base += 4) {
-    SelDev d[4];
-    memset(d, 0, sizeof(d));
-    const int cnt = n_desc - base < 4 ? n_desc - base : 4;
+  for (int base = 0; base < n_desc; base += SEL_BATCH) {
+    SelBatch batch;
+    SelDev* d = batch.d;
+    memset(&batch, 0, sizeof(batch));
+    const int cnt = n_desc - base < SEL_BATCH ? n_desc - base : SEL_BATCH;
     for (int i = 0; i < cnt; ++i) {
       const curv_select_desc& s = descs[base + i];
       CURV_REQUIRE(s.lambda_vec && s.I && s.J && s.counts, "curv_inf_select: desc %d: null pointer", base + i);
@@ -190,8 +195,7 @@ extern "C" int curv_inf_select(void* stream, const curv_select_desc* descs, int 
       d[i].lam = s.lambda_vec; d[i].I = (long long*)s.I; d[i].J = (long long*)s.J; d[i].counts = s.counts;
       d[i].n = s.n; d[i].m = s.m; d[i].rank = s.rank;
     }
-    hipLaunchKernelGGL(inf_select_kernel, dim3(cnt), dim3(SEL_THREADS), 0, (hipStream_t)stream, d[0], d[1], d[2],
-                       d[3], cnt);
+    hipLaunchKernelGGL(inf_select_kernel, dim3(cnt), dim3(SEL_THREADS), 0, (hipStream_t)stream, batch, cnt);
     CURV_LAUNCH_CHECK();
   }
   return CURV_OK;

@@ -490,16 +490,24 @@ class INF(Curvature):
         self.diags = diags
 
     def update(self, rank: int = 100):
-        for layer in list(self.diags.keys()):
+        layers = list(self.diags.keys())
+        # the index sets of all layers in one launch and one read-back (a launch + host sync per layer was a
+        # quarter of update() on ResNet-18)
+        vecs = {layer: self.lambdas[layer].t().contiguous().view(-1) for layer in layers}   # index i*m + j
+        need = [layer for layer in layers if rank < vecs[layer].shape[0]]
+        picked = dict(zip(need, ops.inf_select_many(
+            [vecs[layer] for layer in need],
+            [(self.eigvecs[layer][0].shape[0], self.eigvecs[layer][1].shape[0]) for layer in need], rank)))
+        for layer in layers:
             xxt_eigvecs, ggt_eigvecs = self.eigvecs[layer]
-            lambdas, diags = self.lambdas[layer], self.diags[layer]
+            diags = self.diags[layer]
             n, m = xxt_eigvecs.shape[0], ggt_eigvecs.shape[0]
-            lambda_vec = lambdas.t().contiguous().view(-1)             # index i*m + j
+            lambda_vec = vecs[layer]
             diag_vec = diags.t().contiguous().view(-1)
-            if rank >= lambda_vec.shape[0]:
+            if layer not in picked:
                 ua, ug, lam = xxt_eigvecs, ggt_eigvecs, lambda_vec
             else:
-                I, J = ops.inf_select(lambda_vec, n, m, rank)
+                I, J = picked[layer]
                 ua = xxt_eigvecs.index_select(1, I).contiguous()
                 ug = ggt_eigvecs.index_select(1, J).contiguous()
                 lam = lambda_vec.view(n, m).index_select(0, I).index_select(1, J).contiguous().view(-1)

@@ -296,19 +296,32 @@ def sqrt_scale(v: torch.Tensor, s: float) -> torch.Tensor:
     return out
 
 
+def inf_select_many(lambda_vecs, dims, rank: int):
+    """[(I, J), ...] int64 index tensors of INF._dim_reduction (exact integers, ascending) for several layers:
+    one launch (a workgroup per layer) and ONE host read-back of all low-rank sizes."""
+    if not lambda_vecs:
+        return []
+    dev = lambda_vecs[0].device
+    k = len(lambda_vecs)
+    counts = torch.zeros(k, 2, dtype=torch.int32, device=dev)
+    d = (curv_select_desc * k)()
+    Is, Js = [], []
+    for i, (vec, (n, m)) in enumerate(zip(lambda_vecs, dims)):
+        _require_gpu(vec)
+        I = torch.empty(n, dtype=torch.int64, device=dev)
+        J = torch.empty(m, dtype=torch.int64, device=dev)
+        Is.append(I)
+        Js.append(J)
+        d[i].lambda_vec, d[i].I, d[i].J, d[i].counts = vec.data_ptr(), I.data_ptr(), J.data_ptr(), counts[i].data_ptr()
+        d[i].n, d[i].m, d[i].rank = n, m, int(rank)
+    _lib.check(_lib.lib().curv_inf_select(_lib.stream_ptr(), d, k), "curv_inf_select")
+    sizes = counts.tolist()                    # host read-back: sizes of the low-rank factors
+    return [(I[:a], J[:b]) for I, J, (a, b) in zip(Is, Js, sizes)]
+
+
 def inf_select(lambda_vec: torch.Tensor, n: int, m: int, rank: int):
-    """(I, J) int64 index tensors of INF._dim_reduction (exact integers, ascending)."""
-    _require_gpu(lambda_vec)
-    dev = lambda_vec.device
-    I = torch.empty(n, dtype=torch.int64, device=dev)
-    J = torch.empty(m, dtype=torch.int64, device=dev)
-    counts = torch.zeros(2, dtype=torch.int32, device=dev)
-    d = (curv_select_desc * 1)()
-    d[0].lambda_vec, d[0].I, d[0].J, d[0].counts = lambda_vec.data_ptr(), I.data_ptr(), J.data_ptr(), counts.data_ptr()
-    d[0].n, d[0].m, d[0].rank = n, m, int(rank)
-    _lib.check(_lib.lib().curv_inf_select(_lib.stream_ptr(), d, 1), "curv_inf_select")
-    a, b = counts.tolist()                     # host read-back: sizes of the low-rank factors
-    return I[:a], J[:b]
+    """(I, J) of one layer (see inf_select_many)."""
+    return inf_select_many([lambda_vec], [(n, m)], rank)[0]
 
 
 def colpairs(U: torch.Tensor) -> torch.Tensor:
