@@ -522,14 +522,52 @@ class INF(Curvature):
 
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
         assert self.state, "State dict is empty. Did you call 'update' prior to this?"
-        for index, (layer, value) in enumerate(self.state.items()):
+        # All layers advance together through the stages of pre_sampler (:538-572): one batched launch per GEMM
+        # stage, ONE batched fp64 factorisation sweep for the 2 x layers matrices vtv and vtv + I (and one
+        # status read-back) instead of a sweep and a host synchronisation per layer.
+        layers, regs = list(self.state.keys()), []
+        for index, layer in enumerate(layers):
             n, s = self._hyper(add, multiply, index, len(self.state))
-            lr_frst_eigvecs, lr_scnd_eigvecs, lr_lambda, correction = value
+            lr_frst_eigvecs, lr_scnd_eigvecs, lr_lambda, correction = self.state[layer]
             ops.clamp_min0_(correction)                                  # in place on `state`, like :523
             reg_lr_lambda = ops.sqrt_scale(lr_lambda, s)
             reg_inv_correction = ops.rsqrt_affine(correction, n, s)
-            pre_sample = self.pre_sampler(lr_frst_eigvecs, lr_scnd_eigvecs, reg_lr_lambda, reg_inv_correction)
-            self.inv_state[layer] = (lr_frst_eigvecs, lr_scnd_eigvecs, reg_inv_correction, pre_sample)
+            regs.append((lr_frst_eigvecs, lr_scnd_eigvecs, reg_lr_lambda, reg_inv_correction))
+        pre_samples = self.pre_sampler_many(regs)
+        for layer, (ua, ug, _, r), pre_sample in zip(layers, regs, pre_samples):
+            self.inv_state[layer] = (ua, ug, r, pre_sample)
+
+    @staticmethod
+    def pre_sampler_many(regs) -> List[Tensor]:
+        """`pre_sampler` for a list of (U_A_lr, U_G_lr, sigma, r) tuples, stage by stage."""
+        if not regs:
+            return []
+        dev = regs[0][0].device
+        stage1, stage2, parts = [], [], []
+        for ua, ug, sigma, r in regs:
+            (n, a), (m, b) = ua.shape, ug.shape
+            PA, PG = ops.colpairs(ua), ops.colpairs(ug)                  # (n, a*a), (m, b*b)
+            r2 = ops.mul(r, r).view(n, m)
+            M = torch.empty(a * a, m, dtype=torch.float32, device=dev)
+            V4 = torch.empty(a * a, b * b, dtype=torch.float32, device=dev)
+            stage1.append(ops.Gemm(PA.t(), r2, M))
+            stage2.append(ops.Gemm(M, PG, V4))
+            parts.append((V4, sigma, a, b))
+        ops.gemm_batched(stage1)
+        ops.gemm_batched(stage2)
+        vtvs = [ops.inf_vtv_assemble(V4, sigma, a, b) for V4, sigma, a, b in parts]
+        mats, adds = [], []
+        for v in vtvs:
+            mats += [v, v]
+            adds += [0.0, 1.0]
+        inv = ops.chol_factor_inverse(mats, adds)                        # float64, lower triangular
+        out = []
+        for i, (_, _, sigma, _) in enumerate(regs):
+            A_inv, B_inv = inv[2 * i], inv[2 * i + 1]
+            T = ops.gemm_f64(B_inv, A_inv, alpha=-1.0, beta=1.0, C=A_inv.clone())      # (I - B^-1) A^-1
+            L_c = ops.gemm_f64(A_inv.t(), T)
+            out.append(ops.diag_scale(L_c, sigma, sigma))
+        return out
 
     @staticmethod
     def vtv(frst_eigvecs: Tensor, scnd_eigvecs: Tensor, reg_lambda: Tensor, reg_inv_correction: Tensor) -> Tensor:
