@@ -595,6 +595,37 @@ class INF(Curvature):
         a, b, c, d = self.inv_state[layer]
         return self.sampler(a, b, c, d, X=X, randn=self._randn).t()
 
+    def sample_and_replace(self, noise: Optional[Dict[Module, Tensor]] = None):
+        """The base-class loop (curvatures.py:117-129) with INF.sample, all layers advancing together through the
+        five products of `sampler` (one batched launch each).  `noise[layer]`: the (n*m,) vector X of :578."""
+        assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
+        owned = self._owned()
+        self._reload_mean()
+        st1, st2, st3, st4, st5, outs = [], [], [], [], [], []
+        for _, layer in owned:
+            ua, ug, r, P = self.inv_state[layer]
+            (n, a), (m, b) = ua.shape, ug.shape
+            dev = ua.device
+            X = noise[layer].reshape(-1) if noise is not None else self._randn(n * m, device=dev)
+            Y_l = ops.mul(r, X)                                                    # (n*m,)
+            t1 = torch.empty(b, n, dtype=torch.float32, device=dev)
+            xq_t = torch.empty(a, b, dtype=torch.float32, device=dev)
+            qx = torch.empty(a * b, 1, dtype=torch.float32, device=dev)
+            t2 = torch.empty(m, a, dtype=torch.float32, device=dev)
+            out = Y_l.clone().view(n, m)                                           # becomes Y_l - Y_r
+            r2 = ops.mul(r, r).view(n, m)
+            st1.append(ops.Gemm(ug.t(), Y_l.view(m, n), t1))                       # U_G^T unvec(Y_l): (b, n)
+            st2.append(ops.Gemm(t1, ua, xq_t.t()))                                 # flat order of Xq^T: k*b + l
+            st3.append(ops.Gemm(P, xq_t.view(a * b, 1), qx))
+            st4.append(ops.Gemm(ug, qx.view(b, a), t2))                            # U_G unvec(Qx): (m, a)
+            st5.append(ops.Gemm(ua, t2.t(), out, alpha=-1.0, beta=1.0, epilogue=ops.EPI_MUL_E, E=r2))
+            outs.append(out)
+        for stage in (st1, st2, st3, st4, st5):
+            ops.gemm_batched(stage)
+        for (_, layer), out in zip(owned, outs):
+            self._replace(out.t(), layer.weight, layer.bias)
+        self._allgather_sampled()
+
     @staticmethod
     def sampler(frst_eigvecs: Tensor, scnd_eigvecs: Tensor, reg_inv_correction: Tensor, pre_sample: Tensor,
                 X: Optional[Tensor] = None, randn=None) -> Tensor:

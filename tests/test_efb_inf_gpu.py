@@ -171,5 +171,15 @@ def test_inf_invert_and_sample(gpu):
         s = inf.sample(layer, X=g9[f"X_l{li}"].to(gpu))
         assert s.shape == g9[f"sample_l{li}"].shape
         assert rel_fro(s, g9[f"sample_l{li}"]) < TOL, (li, rel_fro(s, g9[f"sample_l{li}"]))
+    # the batched sample_and_replace with the reference's noise: mean + reference sample, through _replace
+    inf.sample_and_replace(noise={l: g9[f"X_l{li}"].to(gpu) for li, l in enumerate(layers)})
+    for li, layer in enumerate(layers):
+        ref = g9[f"sample_l{li}"].to(gpu)                                      # (m, n), bias = last column
+        w_mean = inf.model_state_of(layer, 'weight')
+        want_w = w_mean + ref[:, :-1].reshape(w_mean.shape) if layer.bias is not None else w_mean + ref.reshape(w_mean.shape)
+        assert rel_fro(layer.weight.data - w_mean, want_w - w_mean) < TOL
+        if layer.bias is not None:
+            b_mean = inf.model_state_of(layer, 'bias')
+            assert rel_fro(layer.bias.data - b_mean, ref[:, -1]) < TOL
     inf.sample_and_replace()
     assert all(torch.isfinite(l.weight).all() for l in layers)
