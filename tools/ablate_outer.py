@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Ablation builds of outer_update_kernel (diagnostics): `build` writes tools/micro/libcurv_abl{0,1,2,3}.so
-(0 = as shipped, 1 = no MFMA, 2 = no global loads in the K loop, 3 = neither), `run <v>` inverts three
+(0 = as shipped, 1 = no MFMA, 2 = no global loads in the K loop, 3 = neither; the patch goes into the shared
+tile core, so the panel products are ablated too), `run <v>` inverts three
 4608^2 factors with variant v (to be timed under rocprofv3 --kernel-trace, see tools/ablate_outer.sh)."""
 import os
 import subprocess
@@ -20,8 +21,8 @@ def build():
     for v in range(4):
         s = base
         if v & 1:
-            s = sub(s, "        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);\n    }\n    __syncthreads();\n  }\n  if (trailing) store_sub",
-                    "        for (int n = 0; n < 2; ++n) acc[m][n][0] += a[m] * b[n];\n    }\n    __syncthreads();\n  }\n  if (trailing) store_sub")
+            s = sub(s, "        for (int n = 0; n < T; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);\n",
+                    "        for (int n = 0; n < T; ++n) acc[m][n][0] += a[m] * b[n];\n")
         if v & 2:
             s = sub(s, "    if (ke + OKS < ke1) fetch(ke + OKS);\n", "")
         src = f"/tmp/invert_abl{v}.hip"

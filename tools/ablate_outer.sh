@@ -13,9 +13,9 @@ for v in range(4):
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     rows = rows[len(rows) * 2 // 3:]
     span = (max(int(r["End_Timestamp"]) for r in rows) - int(rows[0]["Start_Timestamp"])) / 1e3
-    far = [r for r in rows if "outer_update" in r["Kernel_Name"] and int(r["Grid_Size"]) > 256 * 1200]
-    near = [r for r in rows if "outer_update" in r["Kernel_Name"] and int(r["Grid_Size"]) <= 256 * 1200]
+    far = [r for r in rows if "outer_update" in r["Kernel_Name"] and int(r["Grid_Size_X"]) > 256 * 1200]
+    near = [r for r in rows if "outer_update" in r["Kernel_Name"] and int(r["Grid_Size_X"]) <= 256 * 1200]
     d = lambda rs: sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs) / 1e3
-    big = max(far, key=lambda r: int(r["Grid_Size"]))
-    print(f"variant {v}: call span {span:.0f} us, far {len(far)} launches {d(far):.0f} us, other outer {len(near)} launches {d(near):.0f} us; largest far grid {int(big['Grid_Size']) // 256} wgs {(int(big['End_Timestamp']) - int(big['Start_Timestamp'])) / 1e3:.0f} us")
+    big = max(far, key=lambda r: int(r["Grid_Size_X"]))
+    print(f"variant {v}: call span {span:.0f} us, far {len(far)} launches {d(far):.0f} us, other outer {len(near)} launches {d(near):.0f} us; largest far grid {int(big['Grid_Size_X']) // 256} wgs {(int(big['End_Timestamp']) - int(big['Start_Timestamp'])) / 1e3:.0f} us")
 PY

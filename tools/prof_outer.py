@@ -20,22 +20,27 @@ def sub(s, a, b):
 
 def build():
     s = open(os.path.join(CSRC, "invert.hip")).read()
-    s = sub(s, "constexpr int OKS = 32;", "__device__ unsigned long long g_ot[8 * %d];\n__device__ int g_probe_k0 = 32;\nconstexpr int OKS = 32;" % NREC)
-    s = sub(s, "  __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];\n  bool trailing;",
-            "  __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];\n"
-            "  const unsigned long long w0 = wall_clock64(); unsigned long long w1 = 0;\n  bool trailing;")
-    s = sub(s, "    __syncthreads();\n    if (ke + OKS < ke1) fetch(ke + OKS);", "    __syncthreads();\n    if (ke == ke0) w1 = wall_clock64();\n    if (ke + OKS < ke1) fetch(ke + OKS);")
-    s = sub(s, "  if (trailing) store_sub((gdouble*)d.W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);\n"
-               "  else store_sub(X + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, j >= k0 ? 1 : 2);\n",
-            "  const unsigned long long w2 = wall_clock64();\n"
-            "  if (trailing) store_sub((gdouble*)d.W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);\n"
-            "  else store_sub(X + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, j >= k0 ? 1 : 2);\n"
-            "  if (!strip && k0 == g_probe_k0 && tid == 0 && blockIdx.x < %d) {\n"
-            "    unsigned long long* o = g_ot + 8 * blockIdx.x;\n"
-            "    o[0] = w0; o[1] = w1; o[2] = w2; o[3] = wall_clock64();\n"
-            "    o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
-            "    o[6] = ((unsigned long long)(trailing ? 1 : 0) << 40) | ((unsigned long long)i << 20) | (unsigned)j; o[7] = (ke1 - ke0) / OKS;\n"
-            "  }\n" % NREC)
+    s = sub(s, "constexpr int OKS = 16;", "__device__ unsigned long long g_ot[8 * %d];\n__device__ int g_probe_k0 = 32;\n"
+            "__device__ unsigned long long g_t_first, g_t_loop;   // scratch of the probing workgroup's thread 0\n"
+            "constexpr int OKS = 16;" % NREC)
+    # inside the tile core: time of the first barrier (first operands in LDS) and of the end of the K loop,
+    # kept in registers of thread 0 and handed back through two by-reference arguments
+    s = sub(s, "__device__ __forceinline__ void tile_product_k32(const TileJob& o, double* __restrict__ As, double* __restrict__ Bs) {",
+            "__device__ __forceinline__ void tile_product_k32(const TileJob& o, double* __restrict__ As, double* __restrict__ Bs,\n"
+            "                                                 unsigned long long* t_first = nullptr, unsigned long long* t_loop = nullptr) {")
+    s = sub(s, "    __syncthreads();\n    if (ke + OKS < ke1) fetch(ke + OKS);", "    __syncthreads();\n    if (t_first && ke == ke0) *t_first = wall_clock64();\n    if (ke + OKS < ke1) fetch(ke + OKS);")
+    s = sub(s, "  if constexpr (WV == 2) {\n    store_acc(o.C, np, acc, wm, wn, lane, o.mode);", "  if (t_loop) *t_loop = wall_clock64();\n  if constexpr (WV == 2) {\n    store_acc(o.C, np, acc, wm, wn, lane, o.mode);")
+    s = sub(s, "                                                  int strip, int n_items, double* __restrict__ As, double* __restrict__ Bs) {\n",
+            "                                                  int strip, int n_items, double* __restrict__ As, double* __restrict__ Bs) {\n"
+            "  const unsigned long long w0 = wall_clock64();\n  unsigned long long w1 = 0, w2 = 0;\n")
+    s = sub(s, "  tile_product_k32<WV>(o, As, Bs);\n}\n__global__ void __launch_bounds__(INV_THREADS, 3)\nouter_update_kernel(",
+            "  tile_product_k32<WV>(o, As, Bs, &w1, &w2);\n"
+            "  if (!strip && k0 == g_probe_k0 && threadIdx.x == 0 && blockIdx.x < %d) {\n"
+            "    unsigned long long* q = g_ot + 8 * blockIdx.x;\n"
+            "    q[0] = w0; q[1] = w1; q[2] = w2; q[3] = wall_clock64();\n"
+            "    q[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4); q[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
+            "    q[6] = ((unsigned long long)(trailing ? 1 : 0) << 40) | ((unsigned long long)i << 20) | (unsigned)j; q[7] = (o.ke1 - o.ke0) / OKS;\n"
+            "  }\n}\n__global__ void __launch_bounds__(INV_THREADS, 3)\nouter_update_kernel(" % NREC)
     s += '''
 extern "C" int curv_debug_outer_times(unsigned long long* out, int k0) {
   if (out == nullptr) return (int)hipMemcpyToSymbol(HIP_SYMBOL(curv::g_probe_k0), &k0, sizeof(int));

@@ -30,5 +30,5 @@ for r in rows:
         cnt += 1
     if cnt in (9, 10):
         st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-        print(f'{(st - t0) / 1e3:9.1f} dur {(en - st) / 1e3:7.1f}  q{r.get("Queue_Id", "?")} wgs {int(r.get("Grid_Size", 0)) // max(int(r.get("Workgroup_Size", 256)), 1):6d}  {n}')
+        print(f'{(st - t0) / 1e3:9.1f} dur {(en - st) / 1e3:7.1f}  q{r.get("Queue_Id", "?")} wgs {int(r.get("Grid_Size_X", 0)) // max(int(r.get("Workgroup_Size_X", 256)), 1):6d}  {n}')
 PY
