@@ -257,12 +257,17 @@ struct TileJob {                        // everything wave-uniform
 // hides anything and a lone workgroup is bound by its own serial issue (LDS operand read -> 4 dependent MFMAs
 // of 64 cycles per group of four K elements: 45 us for a K = 256 tile; keeping four K steps of loads in flight did not
 // change that).  WV = 4 (1024 threads, one 16x16 MFMA tile per wave) divides that serial part by four.
-template <int WV>
-__device__ __forceinline__ void tile_product_k32(const TileJob& o, double* __restrict__ As, double* __restrict__ Bs) {
+// MODE 0: B rows K-contiguous (trailing update / rows-below product), 1: the same with B = A (diagonal tile),
+// 2: B as [k][col] (S accumulation / columns-left product).  The K loop is compiled once per mode: with the
+// flags tested inside it, every step carried ~13 scalar branches, 9 v_cndmask and 16 v_mov next to its 16 MFMAs,
+// and VALU instructions do not overlap with another wave's MFMAs on this chip (tools/micro/f64_mfma_overlap.hip:
+// a wave issuing MFMAs back to back starves the VALU work of the other wave of its SIMD completely).
+template <int WV, int MODE>
+__device__ __forceinline__ void tile_product_impl(const TileJob& o, double* __restrict__ As, double* __restrict__ Bs) {
   constexpr int THREADS = 64 * WV * WV, T = 4 / WV, LPT = NB * OKS / THREADS;   // MFMA tiles per wave edge, loads per thread
   const int np = o.np;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WV, wn = wave % WV;
-  const bool trailing = o.bt, same = o.same;
+  constexpr bool trailing = MODE != 2, same = MODE == 1;
   const int r16 = lane & 15, kq = lane >> 4;
   double ra[LPT], rb[LPT];
   const unsigned voff_k = (unsigned)(((long long)(tid / OKS) * np + (tid % OKS)) * 8);   // [rows][OKS k] operands
@@ -327,6 +332,13 @@ __device__ __forceinline__ void tile_product_k32(const TileJob& o, double* __res
       *(gdouble*)(base + (long long)(4 * q) * np * 8 + voff) = out;
     }
   }
+}
+
+template <int WV>
+__device__ __forceinline__ void tile_product_k32(const TileJob& o, double* __restrict__ As, double* __restrict__ Bs) {
+  if (!o.bt) tile_product_impl<WV, 2>(o, As, Bs);
+  else if (o.same) tile_product_impl<WV, 1>(o, As, Bs);
+  else tile_product_impl<WV, 0>(o, As, Bs);
 }
 
 template <int WV>
