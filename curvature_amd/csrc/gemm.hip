@@ -96,13 +96,22 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, int local, float* ld
     if (i0 + ar[u] < M) va |= 1u << u;
     if (j0 + bc[u] < N) vb |= 1u << u;
   }
+  const bool interior = (i0 + TMv <= M) && (j0 + TMv <= N);
   const gfl* At = A + (long long)i0 * a_rs;
   const gfl* Bt = B + (long long)j0 * b_cs;
   float ra[PER_T], rb[PER_T];
   auto fetch = [&](int k0) __attribute__((always_inline)) {
     const gfl* Ak = At + (long long)k0 * a_cs;
     const gfl* Bk = Bt + (long long)k0 * b_rs;
-    if (k0 + GK <= K) {                           // whole stage inside K (wave-uniform)
+    if (interior && k0 + GK <= K) {               // tile and stage inside the matrices (wave-uniform): plain loads.
+      // (A predicated load costs an exec-mask save / branch / restore and a v_mov around it: ~100 extra
+      // instructions per stage of 32 MFMAs, and vector instructions do not hide behind MFMAs)
+#pragma unroll
+      for (int u = 0; u < PER_T; ++u) {
+        ra[u] = Ak[oa[u]];
+        rb[u] = Bk[ob[u]];
+      }
+    } else if (k0 + GK <= K) {                    // whole stage inside K
 #pragma unroll
       for (int u = 0; u < PER_T; ++u) {
         ra[u] = ((va >> u) & 1) ? Ak[oa[u]] : 0.0f;
