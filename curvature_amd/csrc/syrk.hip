@@ -445,6 +445,12 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
               st[pnl * STAGE_SLOTS + 4 * j + 1] = v.y;
               st[pnl * STAGE_SLOTS + 4 * j + 2] = v.z;
               st[pnl * STAGE_SLOTS + 4 * j + 3] = v.w;
+            } else {
+              // the slot is not stored either: tell the compiler its registers hold nothing worth keeping, or it
+              // copies the previous chunk's values around the skipped load (4 v_mov per load, in the middle of an
+              // issue phase whose vector instructions wait for the other wave's MFMAs)
+              asm volatile("" : "=v"(st[pnl * STAGE_SLOTS + 4 * j + 0]), "=v"(st[pnl * STAGE_SLOTS + 4 * j + 1]),
+                                "=v"(st[pnl * STAGE_SLOTS + 4 * j + 2]), "=v"(st[pnl * STAGE_SLOTS + 4 * j + 3]));
             }
             rows += prow_step; soff += step; cb += prow_step;
             if (cb == nch) { cb = 0; soff += wrap; }
@@ -457,6 +463,7 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
 #pragma unroll
           for (int j = 0; j < STAGE_SLOTS; ++j) {
             if (rows < flat_rows) st[pnl * STAGE_SLOTS + j] = bload(rs, voff, soff);
+            else asm volatile("" : "=v"(st[pnl * STAGE_SLOTS + j]));      // see the float4 path
             rows += prow_step; soff += step; cb += prow_step;
             if (cb == nch) { cb = 0; soff += wrap; }
           }
