@@ -435,7 +435,7 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
           // slot j holds channel rows j * prow_step + prow0 of the folded (sample, channel) index: the
           // plane offset advances by a constant per slot, plus the jump to the next sample at a wrap
           int soff = c_lo * HW * 4, cb = 0, rows = 0;
-          asm volatile("" : "+s"(soff), "+s"(cb));
+          asm volatile("" : "+s"(soff), "+s"(cb), "+s"(rows));   // keeps the slot conditions out of the loop-invariant (spilled) set
           const int step = prow_step * HW * 4, wrap = (C - nch) * HW * 4;
 #pragma unroll
           for (int j = 0; j < STAGE_SLOTS / 4; ++j) {
@@ -458,7 +458,7 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
         } else if (flat1) {
           const int voff = (lx < c.wa) ? (prow0 * HW + c.iw_base + lx) * 4 : OOB;
           int soff = c_lo * HW * 4, cb = 0, rows = 0;
-          asm volatile("" : "+s"(soff), "+s"(cb));
+          asm volatile("" : "+s"(soff), "+s"(cb), "+s"(rows));   // keeps the slot conditions out of the loop-invariant (spilled) set
           const int step = prow_step * HW * 4, wrap = (C - nch) * HW * 4;
 #pragma unroll
           for (int j = 0; j < STAGE_SLOTS; ++j) {
