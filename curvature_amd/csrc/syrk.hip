@@ -420,17 +420,27 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   // the first channel of a slot are wave-uniform.
   const int flat_rows = NS * nch;
 
+  // staging path of this factor as one scalar: 0 float4 flat, 1 scalar flat, 2-4 linear V = 2 (16 / 8 / other
+  // channels), 5-6 linear V = 1 (16 / other), 7-9 general (16 / 8 / other channel groups)
+  const int path_id = __builtin_amdgcn_readfirstlane(
+      vec4 ? 0 : flat1 ? 1 : lin == 2 ? (nch == 16 ? 2 : nch == 8 ? 3 : 4) : lin ? (nch == 16 ? 5 : 6)
+      : n_cgs == 16 ? 7 : n_cgs == 8 ? 8 : 9);
   auto issue_loads = [&](const Chunk& c) {
     // lane geometry made opaque per call: otherwise per-slot values are hoisted out of the chunk loop
     // and pinned in registers, which spills
     int lx = lx_, prow0 = prow0_;
     asm volatile("" : "+v"(lx), "+v"(prow0));
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(c);
+    // one scalar code for the staging path, re-read per chunk: the individual tests (vec4, flat1, lin == 2,
+    // nch == 16, ...) are loop invariants the compiler turns into a dozen 64-bit lane masks, spills, and
+    // reloads with v_readlane in every chunk - vector instructions that wait for the other wave's MFMAs
+    int path = path_id;
+    asm volatile("" : "+s"(path));
 #pragma unroll
     for (int pnl = 0; pnl < 2; ++pnl) {
       if (pnl < n_panels) {
         const int c_lo = pnl ? c_lo_j : c_lo_i;
-        if (vec4) {
+        if (path == 0) {
           const int voff = (lx < (c.wa >> 2)) ? (prow0 * HW + c.iw_base + 4 * lx) * 4 : OOB;
           // slot j holds channel rows j * prow_step + prow0 of the folded (sample, channel) index: the
           // plane offset advances by a constant per slot, plus the jump to the next sample at a wrap
@@ -455,7 +465,7 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
             rows += prow_step; soff += step; cb += prow_step;
             if (cb == nch) { cb = 0; soff += wrap; }
           }
-        } else if (flat1) {
+        } else if (path == 1) {
           const int voff = (lx < c.wa) ? (prow0 * HW + c.iw_base + lx) * 4 : OOB;
           int soff = c_lo * HW * 4, cb = 0, rows = 0;
           asm volatile("" : "+s"(soff), "+s"(cb), "+s"(rows));   // keeps the slot conditions out of the loop-invariant (spilled) set
@@ -467,22 +477,19 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
             rows += prow_step; soff += step; cb += prow_step;
             if (cb == nch) { cb = 0; soff += wrap; }
           }
-        } else if (lin) {
+        } else if (path <= 6) {
           int t = tid;
           asm volatile("" : "+v"(t));
           using I2 = std::integral_constant<int, 2>;
           using I1 = std::integral_constant<int, 1>;
-          if (lin == 2) {
-            if (nch == 16) issue_lin(std::integral_constant<int, 16>{}, I2{}, c, rs, pnl, c_lo, t);
-            else if (nch == 8) issue_lin(std::integral_constant<int, 8>{}, I2{}, c, rs, pnl, c_lo, t);
-            else issue_lin(std::integral_constant<int, 0>{}, I2{}, c, rs, pnl, c_lo, t);
-          } else {
-            if (nch == 16) issue_lin(std::integral_constant<int, 16>{}, I1{}, c, rs, pnl, c_lo, t);
-            else issue_lin(std::integral_constant<int, 0>{}, I1{}, c, rs, pnl, c_lo, t);
-          }
-        } else if (n_cgs == 16) {
+          if (path == 2) issue_lin(std::integral_constant<int, 16>{}, I2{}, c, rs, pnl, c_lo, t);
+          else if (path == 3) issue_lin(std::integral_constant<int, 8>{}, I2{}, c, rs, pnl, c_lo, t);
+          else if (path == 4) issue_lin(std::integral_constant<int, 0>{}, I2{}, c, rs, pnl, c_lo, t);
+          else if (path == 5) issue_lin(std::integral_constant<int, 16>{}, I1{}, c, rs, pnl, c_lo, t);
+          else issue_lin(std::integral_constant<int, 0>{}, I1{}, c, rs, pnl, c_lo, t);
+        } else if (path == 7) {
           issue_general(std::integral_constant<int, 16>{}, c, rs, pnl, c_lo, lx, prow0);
-        } else if (n_cgs == 8) {
+        } else if (path == 8) {
           issue_general(std::integral_constant<int, 8>{}, c, rs, pnl, c_lo, lx, prow0);
         } else {
           issue_general(std::integral_constant<int, 0>{}, c, rs, pnl, c_lo, lx, prow0);
@@ -495,11 +502,13 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   auto store_stage = [&](const Chunk& c) {
     int lx = lx_, prow0 = prow0_;
     asm volatile("" : "+v"(lx), "+v"(prow0));
+    int path = path_id;                                   // see issue_loads
+    asm volatile("" : "+s"(path));
 #pragma unroll
     for (int pnl = 0; pnl < 2; ++pnl) {
       if (pnl < n_panels) {
         float* lbase = fs + PATCH_OFF + (pnl ? off_j : 0);
-        if (vec4) {
+        if (path == 0) {
           if (lx < (c.wa >> 2)) {
             float* l = lbase + prow0 * PS + 4 * lx;
             int rows = 0, lstep = prow_step * PS;     // SS = nch * PS: the sample wrap needs no extra step
@@ -515,7 +524,7 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
               rows += prow_step; l += lstep;
             }
           }
-        } else if (flat1) {
+        } else if (path == 1) {
           if (lx < c.wa) {
             float* l = lbase + prow0 * PS + lx;
             int rows = 0, lstep = prow_step * PS;     // SS = nch * PS: the sample wrap needs no extra step
@@ -526,22 +535,19 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
               rows += prow_step; l += lstep;
             }
           }
-        } else if (lin) {
+        } else if (path <= 6) {
           int t = tid;
           asm volatile("" : "+v"(t));
           using I2 = std::integral_constant<int, 2>;
           using I1 = std::integral_constant<int, 1>;
-          if (lin == 2) {
-            if (nch == 16) store_lin(std::integral_constant<int, 16>{}, I2{}, c, lbase, pnl, t);
-            else if (nch == 8) store_lin(std::integral_constant<int, 8>{}, I2{}, c, lbase, pnl, t);
-            else store_lin(std::integral_constant<int, 0>{}, I2{}, c, lbase, pnl, t);
-          } else {
-            if (nch == 16) store_lin(std::integral_constant<int, 16>{}, I1{}, c, lbase, pnl, t);
-            else store_lin(std::integral_constant<int, 0>{}, I1{}, c, lbase, pnl, t);
-          }
-        } else if (n_cgs == 16) {
+          if (path == 2) store_lin(std::integral_constant<int, 16>{}, I2{}, c, lbase, pnl, t);
+          else if (path == 3) store_lin(std::integral_constant<int, 8>{}, I2{}, c, lbase, pnl, t);
+          else if (path == 4) store_lin(std::integral_constant<int, 0>{}, I2{}, c, lbase, pnl, t);
+          else if (path == 5) store_lin(std::integral_constant<int, 16>{}, I1{}, c, lbase, pnl, t);
+          else store_lin(std::integral_constant<int, 0>{}, I1{}, c, lbase, pnl, t);
+        } else if (path == 7) {
           store_general(std::integral_constant<int, 16>{}, c, lbase, pnl, lx, prow0);
-        } else if (n_cgs == 8) {
+        } else if (path == 8) {
           store_general(std::integral_constant<int, 8>{}, c, lbase, pnl, lx, prow0);
         } else {
           store_general(std::integral_constant<int, 0>{}, c, lbase, pnl, lx, prow0);
