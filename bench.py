@@ -44,39 +44,93 @@ def layer_dims(layers, record):
     return dims
 
 
-def cpu_baseline(batch_full, seed):
-    """The oracle (torch-CPU restatement of the reference path) timed on this box's host cores, on a
-    bounded sample of the same workload: ResNet-50 at N = 4 for update (scaled to N = 32), full invert
-    and sample_and_replace of all 54 layers."""
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(batch_full, seed, budget_s=75.0):
+    """The oracle (torch-CPU restatement of the reference path, validated against the imported reference) timed
+    on this box's host cores on the SAME workload: ResNet-50, N = `batch_full`, update + invert(1, 1000) +
+    sample_and_replace of all 54 layers (os.cpu_count() threads, CPU model stated, 2 warm-ups, median
+    of 5).  The leg is bounded by `budget_s` seconds of CPU work: if the spec's 7 passes of a phase do not fit,
+    fewer passes are run and the line says how many (nothing is scaled)."""
+    import statistics
     import oracle.curvature_oracle as o
     from curvature_amd import models
-    # a bounded thread count: torch/MKL with hundreds of threads on these matrix sizes runs slower than
-    # with 16, and the sample has to stay within tens of seconds
-    cores = min(os.cpu_count() or 1, 16)
+    cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     torch.manual_seed(seed)
     model = models.resnet50().train()
-    n_small = 4
-    x = torch.randn(n_small, 3, 224, 224)
+    x = torch.randn(batch_full, 3, 224, 224)
     rec, _, _ = o.capture(model, x, seed=seed)
-    t0 = time.perf_counter()
-    state = o.model_kfac_update({}, model, rec)
-    t_update = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    inv = o.model_kfac_invert(state, 1.0, 1000.0)
-    t_invert = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    samples = o.model_kfac_sample(inv, model)
-    for layer, s in samples.items():
-        o.replace(s, layer.weight.data, layer.bias.data if layer.bias is not None else None)
-    t_sample = time.perf_counter() - t0
-    step = t_update * (batch_full / n_small) + t_invert + t_sample
+
+    def timed(fn, share):
+        """(median seconds, warm-ups, timed passes, last result) within `share` of the budget."""
+        t0 = time.perf_counter()
+        out = fn()
+        first = time.perf_counter() - t0
+        allowed = share * budget_s
+        if first * 7 <= allowed:
+            warm, reps = 2, 5
+        elif first * 3 <= allowed:
+            warm, reps = 1, 2
+        else:
+            return first, 0, 1, out                    # the single pass is the measurement
+        for _ in range(warm - 1):
+            out = fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), warm, reps, out
+
+    t_update, wu, ru, state = timed(lambda: o.model_kfac_update({}, model, rec), 0.6)
+    t_invert, wi, ri, inv = timed(lambda: o.model_kfac_invert(state, 1.0, 1000.0), 0.3)
+
+    def sample_pass():
+        samples = o.model_kfac_sample(inv, model)
+        for layer, s in samples.items():
+            o.replace(s, layer.weight.data, layer.bias.data if layer.bias is not None else None)
+    t_sample, ws, rs_, _ = timed(sample_pass, 0.1)
+    step = t_update + t_invert + t_sample
     n_layers = len(state)
     return {"value": n_layers / step, "unit": "layers/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/curvature_oracle.py on ResNet-50: update at N={n_small} ({t_update:.2f} s, scaled x"
-                      f"{batch_full // n_small}), invert ({t_invert:.2f} s) and sample ({t_sample:.2f} s) of all "
-                      f"{n_layers} layers, torch {torch.get_num_threads()} threads",
-            "update_s": t_update, "invert_s": t_invert, "sample_s": t_sample}
+            "cpu_model": _cpu_model(),
+            "sample": f"oracle/curvature_oracle.py on the same workload (ResNet-50, N={batch_full}, all {n_layers} layers), "
+                      f"torch {torch.get_num_threads()} threads on '{_cpu_model()}': update {t_update:.2f} s "
+                      f"(median of {ru} after {wu} warm-ups), invert(1, 1000) {t_invert:.2f} s (median of {ri} after {wi}), "
+                      f"sample_and_replace {t_sample:.2f} s (median of {rs_} after {ws}); KFAC leg only, no EFB/INF leg",
+            "update_s": t_update, "invert_s": t_invert, "sample_s": t_sample,
+            "invert_plus_sample_s": t_invert + t_sample}
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh rank processes (one per GPU) with
+    torch.distributed.run and return its exit code.  Called before this process has made any HIP call (torch is
+    imported, the GPU is not initialised), and it starts CHILD processes - it never replaces this one."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()          # does not initialise the GPU on this image
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -88,8 +142,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -180,13 +238,16 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they are
     # collected by tools/collect_profiles.sh (rocprofv3, separate FETCH_SIZE / WRITE_SIZE passes, gfx950
     # correction of MI355X_MICROARCH.md) on this same workload and committed under profiles/
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_syrk_pmc.json")
-    if world == 1 and args.batch == 32 and os.path.exists(pmc_path):
-        try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic, traffic_source = None, None
+    for name in ("r02_syrk_pmc.json", "r01_syrk_pmc.json"):
+        pmc_path = os.path.join(ROOT, "profiles", name)
+        if world == 1 and args.batch == 32 and os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                traffic_source = f"profiles/{name}: rocprofv3 PMC passes of this workload, NOT measured in this run"
+                break
+            except Exception:
+                traffic = None
 
     if rank == 0:
         n_layers = len(layers)
@@ -209,7 +270,7 @@ def main():
                        "parallelism": f"layer-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "curv::syrk_patch_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_F32_MFMA / 1e12),
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "flops_counted": "executed symmetric: sum (n(n+1)+m(m+1)) K over the rank's layers",
                          "dense_equivalent_tflops": dense_flops / syrk_s / 1e12,
                          "kernel_ms": syrk_s * 1e3},

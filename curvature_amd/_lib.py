@@ -70,7 +70,8 @@ class curv_gemm_desc(ctypes.Structure):
                [(k, ctypes.c_longlong) for k in ("a_rs", "a_cs", "b_rs", "b_cs", "c_rs", "c_cs", "e_rs", "e_cs")] + \
                [("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("epilogue", ctypes.c_int32),
                 ("alpha", ctypes.c_float), ("beta", ctypes.c_float), ("tri", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("reserved", ctypes.c_int32), ("F", ctypes.c_void_p), ("f_rs", ctypes.c_longlong),
+                ("f_cs", ctypes.c_longlong)]
 
 
 class curv_cholinv_desc(ctypes.Structure):
@@ -124,6 +125,8 @@ SIGNATURES = {
     "curv_colpairs": (_i, [_vp, _vp, _i, _i, _ll, _vp]),
     "curv_inf_vtv_assemble": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "curv_diag_scale": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i]),
+    "curv_gather2d": (_i, [_vp, _vp, _ll, _ll, _vp, _vp, _vp, _i, _i]),
+    "curv_kron": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
     "curv_mul2d": (_i, [_vp, _vp, _ll, _ll, _vp, _ll, _ll, _vp, _i, _i]),
     "curv_gemm_workspace_bytes": (_sz, [_i]),
     "curv_gemm_batched": (_i, [_vp, ctypes.POINTER(curv_gemm_desc), _i, _vp, _sz]),
@@ -135,6 +138,10 @@ SIGNATURES = {
     "curv_mul": (_i, [_vp, _vp, _vp, _vp, _ll]),
     "curv_copy_batched": (_i, [_vp, ctypes.POINTER(curv_copy_desc), _i]),
 }
+
+
+ABI_VERSION = 2                     # CURV_ABI_VERSION of include/curv_hip.h
+ERR_NOT_PD, ERR_INVALID, ERR_WORKSPACE, ERR_HIP, ERR_NOT_CONVERGED = 1, 2, 3, 4, 5     # CURV_ERR_* of the header
 
 
 def lib() -> ctypes.CDLL:
@@ -155,7 +162,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)   # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.curv_version() != 1:
+        if handle.curv_version() != ABI_VERSION:
             raise RuntimeError("libcurv_hip.so ABI version mismatch")
         _lib = handle
     return _lib

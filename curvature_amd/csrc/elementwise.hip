@@ -88,9 +88,34 @@ mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __re
     out[j] = a[j] * b[j];
 }
 
+// out[(i*br + k)][(j*bc + l)] = a[i][j] * b[k][l]   (utils.kron)
+__global__ void __launch_bounds__(256)
+kron_kernel(const float* __restrict__ a, int ar, int ac, const float* __restrict__ b, int br, int bc,
+            float* __restrict__ out) {
+  const long long cols = (long long)ac * bc, count = (long long)ar * br * cols;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) {
+    const long long row = e / cols, col = e - row * cols;
+    const int i = (int)(row / br), k = (int)(row - (long long)i * br);
+    const int j = (int)(col / bc), l = (int)(col - (long long)j * bc);
+    out[e] = a[(long long)i * ac + j] * b[(long long)k * bc + l];
+  }
+}
+
 }  // namespace curv
 
 using namespace curv;
+
+extern "C" int curv_kron(void* stream, const float* a, int ar, int ac, const float* b, int br, int bc,
+                         float* out) {
+  CURV_REQUIRE(ar >= 0 && ac >= 0 && br >= 0 && bc >= 0, "curv_kron: negative shape");
+  const long long count = (long long)ar * br * ac * bc;
+  if (count == 0) return CURV_OK;
+  CURV_REQUIRE(a && b && out, "curv_kron: null pointer");
+  hipLaunchKernelGGL(kron_kernel, sweep_grid(count, 1), dim3(256), 0, (hipStream_t)stream, a, ar, ac, b, br, bc, out);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}
 
 extern "C" int curv_rsqrt_affine(void* stream, const float* v, double s, double n, float* out,
                                  long long count) {

@@ -27,10 +27,12 @@ struct GemmDev {
   const float* B;
   float* C;
   const float* E;         // optional elementwise operand of the epilogue
+  const float* F;         // optional second (additive) operand: CURV_EPI_MUL_E_ADD_F
   long long a_rs, a_cs;   // op(A) is M x K: element (i, k) at A[i*a_rs + k*a_cs]
   long long b_rs, b_cs;   // op(B) is K x N: element (k, j) at B[k*b_rs + j*b_cs]
   long long c_rs, c_cs;
   long long e_rs, e_cs;
+  long long f_rs, f_cs;
   int M, N, K;
   int epilogue;
   float alpha, beta;
@@ -166,6 +168,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, int local, float* ld
   // epilogue; C/D map of the 32x32 block: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   gfl* C = (gfl*)d.C;
   const gfl* E = (const gfl*)d.E;
+  const gfl* F = (const gfl*)d.F;
   const float alpha = d.alpha, beta = d.beta;
   const int ep = d.epilogue;
 #pragma unroll
@@ -182,6 +185,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, int local, float* ld
           if (ep == CURV_EPI_SQUARE) v = alpha * acc[m][n][reg] * acc[m][n][reg];
           else if (ep == CURV_EPI_MUL_E) v *= E[i * d.e_rs + j * d.e_cs];
           else if (ep == CURV_EPI_ADD_E) v += E[i * d.e_rs + j * d.e_cs];
+          else if (ep == CURV_EPI_MUL_E_ADD_F) v = v * E[i * d.e_rs + j * d.e_cs] + F[i * d.f_rs + j * d.f_cs];
           if (beta != 0.0f) v += beta * C[ci];
           C[ci] = v;
         }
@@ -299,7 +303,7 @@ gemm_f64_kernel(Gemm64Dev d0, Gemm64Dev d1, Gemm64Dev d2, Gemm64Dev d3, int n_de
       }
 }
 
-constexpr int GEMM_UPLOAD_CHUNK = 24;
+constexpr int GEMM_UPLOAD_CHUNK = 20;
 struct GemmChunk { GemmDev f[GEMM_UPLOAD_CHUNK]; };
 static_assert(sizeof(GemmChunk) <= 3840, "kernel argument block must stay below 4 KB");
 
@@ -380,12 +384,13 @@ extern "C" int curv_gemm_batched(void* stream_, const curv_gemm_desc* descs, int
     if (s.M == 0 || s.N == 0) continue;
     CURV_REQUIRE(s.C != nullptr && (s.K == 0 || (s.A != nullptr && s.B != nullptr)),
                  "curv_gemm_batched: desc %d: null pointer", i);
-    CURV_REQUIRE(s.epilogue >= 0 && s.epilogue <= CURV_EPI_ADD_E, "curv_gemm_batched: desc %d: bad epilogue", i);
-    CURV_REQUIRE((s.epilogue != CURV_EPI_MUL_E && s.epilogue != CURV_EPI_ADD_E) || s.E != nullptr,
-                 "curv_gemm_batched: desc %d: epilogue needs E", i);
+    CURV_REQUIRE(s.epilogue >= 0 && s.epilogue <= CURV_EPI_MUL_E_ADD_F, "curv_gemm_batched: desc %d: bad epilogue", i);
+    CURV_REQUIRE(s.epilogue < CURV_EPI_MUL_E || s.E != nullptr, "curv_gemm_batched: desc %d: epilogue needs E", i);
+    CURV_REQUIRE(s.epilogue != CURV_EPI_MUL_E_ADD_F || s.F != nullptr, "curv_gemm_batched: desc %d: epilogue needs F", i);
     GemmDev d;
     memset(&d, 0, sizeof(d));
-    d.A = s.A; d.B = s.B; d.C = s.C; d.E = s.E;
+    d.A = s.A; d.B = s.B; d.C = s.C; d.E = s.E; d.F = s.F;
+    d.f_rs = s.f_rs; d.f_cs = s.f_cs;
     d.a_rs = s.a_rs; d.a_cs = s.a_cs; d.b_rs = s.b_rs; d.b_cs = s.b_cs;
     d.c_rs = s.c_rs; d.c_cs = s.c_cs; d.e_rs = s.e_rs; d.e_cs = s.e_cs;
     d.M = s.M; d.N = s.N; d.K = s.K;

@@ -169,6 +169,20 @@ mul2d_kernel(const float* __restrict__ A, long long a_rs, long long a_cs, const 
   }
 }
 
+// out[r][c] = src[(ri ? ri[r] : r) * rs + (ci ? ci[c] : c) * cs]: transposes (strides), torch.index_select on
+// either axis (int64 index lists, as inf_select_kernel writes them) or both, as one contiguous write
+__global__ void __launch_bounds__(256)
+gather2d_kernel(const float* __restrict__ src, long long rs, long long cs, const long long* __restrict__ ri,
+                const long long* __restrict__ ci, float* __restrict__ out, int rows, int cols) {
+  const long long total = (long long)rows * cols;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int r = (int)(e / cols), c = (int)(e - (long long)r * cols);
+    const long long sr = ri ? ri[r] : r, sc = ci ? ci[c] : c;
+    out[e] = src[sr * rs + sc * cs];
+  }
+}
+
 static inline dim3 grid_for(long long count) {
   long long blocks = cdivll(count, 256);
   if (blocks > 2048) blocks = 2048;
@@ -229,6 +243,16 @@ extern "C" int curv_inf_vtv_assemble(void* stream, const float* V4, const float*
   CURV_REQUIRE(V4 && sigma && vtv, "curv_inf_vtv_assemble: null pointer");
   hipLaunchKernelGGL(vtv_assemble_kernel, grid_for((long long)a * b * a * b), dim3(256), 0, (hipStream_t)stream, V4,
                      sigma, a, b, vtv);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}
+
+extern "C" int curv_gather2d(void* stream, const float* src, long long src_rs, long long src_cs,
+                             const int64_t* row_index, const int64_t* col_index, float* out, int rows, int cols) {
+  if (rows <= 0 || cols <= 0) return CURV_OK;
+  CURV_REQUIRE(src && out, "curv_gather2d: null pointer");
+  hipLaunchKernelGGL(gather2d_kernel, grid_for((long long)rows * cols), dim3(256), 0, (hipStream_t)stream, src, src_rs,
+                     src_cs, (const long long*)row_index, (const long long*)col_index, out, rows, cols);
   CURV_LAUNCH_CHECK();
   return CURV_OK;
 }

@@ -659,20 +659,32 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
         ktab[q] = v;
       }
     }
+#ifdef CURV_DIAG
     if (!(d.pad0 & 10) || ch == ch_begin) store_stage(cur);
+#else
+    store_stage(cur);
+#endif
     __syncthreads();
 
     const Chunk work = cur;
     if (ch + 1 < ch_end) {
       cur = decode_chunk(ch + 1);
-      if (!(d.pad0 & 6)) issue_loads(cur);                  // in flight during the MFMA loop below
+#ifdef CURV_DIAG
+      if (!(d.pad0 & 6)) issue_loads(cur);
+#else
+      issue_loads(cur);                                     // in flight during the MFMA loop below
+#endif
     }
 
     // ---- MFMA over this wave's share of the chunk's k-runs ----
     // Per iteration each lane half owns one run of RL LDS-adjacent k values: one table lookup and one
     // address per operand row feed RL MFMA groups.  Two register sets alternate so that the operand
     // reads of iteration t+1 are in flight while the 4*RL MFMAs of iteration t issue.
+#ifdef CURV_DIAG
     if (!idle && kfirst < work.niter && !(d.pad0 & 1)) {
+#else
+    if (!idle && kfirst < work.niter) {
+#endif
       using T = std::true_type;
       using F = std::false_type;
       const bool check = (work.wa % RL != 0) || (work.nruns & 1);
@@ -964,7 +976,9 @@ static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
   static thread_local Plan cached_plan;
   std::vector<int> key;
   key.reserve((size_t)n * 12 + 1);
+#ifdef CURV_DIAG
   { const char* ab = getenv("CURV_SYRK_ABLATE"); key.push_back(ab ? atoi(ab) : 0); }
+#endif
   for (int i = 0; i < n; ++i) {
     const curv_factor_desc& s = descs[i];
     const int vals[12] = {s.N, s.C, s.H, s.W, s.kh, s.kw, s.sh, s.sw, s.ph, s.pw, s.has_bias,
@@ -1017,7 +1031,9 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     f.dim = f.rows + f.has_bias;
     f.first = s.first;
     f.scale = s.scale;
-    { const char* ab = getenv("CURV_SYRK_ABLATE"); f.pad0 = ab ? atoi(ab) : 0; }   // diagnostics only
+#ifdef CURV_DIAG   // diagnostic builds only (tools/make_prof_build.py): ablation switches for the phase profile
+    { const char* ab = getenv("CURV_SYRK_ABLATE"); f.pad0 = ab ? atoi(ab) : 0; }
+#endif
     CURV_REQUIRE((long long)f.N * f.C * f.H * f.W < (1LL << 31), "curv_kfac: factor %d: source too large", i);
 
     // tile edge: 128 where the padding it adds is small, 64 otherwise

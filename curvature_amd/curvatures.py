@@ -40,7 +40,12 @@ class Curvature(ABC):
     Mirrors curvature/curvatures.py:17-129.  Layers are selected by class NAME in ``model.modules()``
     order; that order is the layer index used by per-layer ``add`` / ``multiply`` lists."""
 
-    def __init__(self, model: Union[Module, Sequential], layer_types: Union[List[str], str] = None):
+    # estimators whose reference implementation handles nn.MultiheadAttention (Diagonal only here; the
+    # reference's KFAC / EFB raise NotImplementedError for it, curvatures.py:303-304, 435-436)
+    _supports_mha = False
+
+    def __init__(self, model: Union[Module, Sequential], layer_types: Union[List[str], str] = None, *,
+                 shard=None):
         self.model = model
         self.model_state = copy.deepcopy(model.state_dict())
         self.layer_types = list()
@@ -56,10 +61,15 @@ class Curvature(ABC):
             assert _type in SUPPORTED_LAYERS
         self.state = dict()
         self.inv_state = dict()
-        # optional layer sharding across ranks (curvature_amd.sharding.Shard); None = own every layer
-        self.shard = None
-        # device-side noise generator of the samplers (Philox): advance `noise_offset` per draw
-        self.noise_seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+        # optional layer sharding across ranks (curvature_amd.sharding.Shard); None = own every layer.
+        # Keyword-only extension of the reference signature; may also be assigned after construction for
+        # estimators whose constructor does no per-layer work (Diagonal, KFAC).
+        self.shard = shard
+        # device-side noise generator of the samplers (Philox4x32): `noise_offset` advances per draw.  The
+        # seed is drawn from torch's default generator at the FIRST draw of this instance (the reference
+        # draws its noise from that generator, so successive estimators and samples are independent and
+        # torch.manual_seed() before sampling is honoured); assign `noise_seed` to pin it.
+        self.noise_seed = None
         self.noise_offset = 0
 
     # ------------------------------------------------------------------ helpers
@@ -71,9 +81,15 @@ class Curvature(ABC):
             if name in self.layer_types:
                 if name in ('Linear', 'Conv2d'):
                     out.append(layer)
-                elif name == 'MultiheadAttention':
+                elif name == 'MultiheadAttention' and not self._supports_mha:
                     raise NotImplementedError
         return out
+
+    def _attention(self) -> List[Module]:
+        """Selected MultiheadAttention modules in ``model.modules()`` order (Diagonal only)."""
+        if 'MultiheadAttention' not in self.layer_types:
+            return []
+        return [l for l in self.model.modules() if l.__class__.__name__ == 'MultiheadAttention']
 
     def _owned(self):
         """[(global layer index, layer)] of the layers this rank owns (all of them without a shard)."""
@@ -81,6 +97,23 @@ class Curvature(ABC):
         if self.shard is None:
             return list(enumerate(layers))
         return [(i, l) for i, l in enumerate(layers) if self.shard.owns(i)]
+
+    def _global_index(self) -> Dict[Any, int]:
+        """state key -> position in the reference's ``enumerate(self.state)`` order of an UNSHARDED run:
+        first-seen order over ``model.modules()`` of the selected Linear / Conv2d layers (and, for Diagonal,
+        the 'attn_in' / 'attn_out' keys).  This is the index of per-layer ``add`` / ``multiply`` lists
+        (curvatures.py:184, 360, 444, 515); a rank that holds only its own layers in `state` still looks its
+        hyper-parameters up by this global position."""
+        order = []
+        for layer in self.model.modules():
+            name = layer.__class__.__name__
+            if name not in self.layer_types:
+                continue
+            if name in ('Linear', 'Conv2d'):
+                order.append(layer)
+            elif name == 'MultiheadAttention' and self._supports_mha:
+                order.extend(k for k in ('attn_in', 'attn_out') if k not in order)
+        return {k: i for i, k in enumerate(order)}
 
     def _allgather_sampled(self):
         """Multi-GPU: the single collective of the path, reassembling every layer's sampled parameters."""
@@ -95,11 +128,19 @@ class Curvature(ABC):
             return float(add[index]), float(multiply[index])
         return float(add), float(multiply)
 
+    def _seed(self) -> int:
+        if self.noise_seed is None:
+            drawn = int(torch.empty((), dtype=torch.int64).random_().item())      # torch's default CPU generator
+            rank = self.shard.rank if self.shard is not None else 0
+            # ranks of a sharded run replay the same torch seeds (replicated forward/backward): decorrelate them
+            self.noise_seed = (drawn + 0x9E3779B97F4A7C15 * rank) & (2 ** 63 - 1)
+        return self.noise_seed
+
     def _randn(self, *shape, device, out: Optional[Tensor] = None) -> Tensor:
         numel = 1
         for s in shape:
             numel *= int(s)
-        out = ops.randn(shape, device, self.noise_seed, self.noise_offset, out=out)
+        out = ops.randn(shape, device, self._seed(), self.noise_offset, out=out)
         self.noise_offset += (numel + 3) // 4
         return out
 
@@ -171,20 +212,42 @@ class Curvature(ABC):
 
 
 class Diagonal(Curvature):
-    """Diagonal Fisher: state += grad**2 * batch_size (curvatures.py:132-193)."""
+    """Diagonal Fisher: state += grad**2 * batch_size (curvatures.py:132-193).
+
+    ``nn.MultiheadAttention`` modules are handled as in the reference (:159-174, 125-129): their input and
+    output projections accumulate under the string keys ``'attn_in'`` / ``'attn_out'`` (ONE pair of keys for
+    the whole model, as in the reference).  With a layer shard every rank owns a disjoint set of the
+    Linear / Conv2d layers; the attention entries are small and kept on every rank."""
+
+    _supports_mha = True
 
     def update(self, batch_size: int):
-        for layer in self._layers():
+        for _, layer in self._owned():
             bias_grad = layer.bias.grad if layer.bias is not None else None
             self.state[layer] = ops.sq_accumulate(layer.weight.grad.contiguous(), bias_grad, batch_size,
                                                   self.state.get(layer))
+        for layer in self._attention():
+            for key, weight, bias in (('attn_in', layer.in_proj_weight, layer.in_proj_bias),
+                                      ('attn_out', layer.out_proj.weight, layer.out_proj.bias)):
+                self.state[key] = ops.sq_accumulate(weight.grad.contiguous(), bias.grad, batch_size,
+                                                    self.state.get(key))
 
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
         assert self.state, "State dict is empty. Did you call 'update' prior to this?"
-        for index, (layer, value) in enumerate(self.state.items()):
-            # Diagonal uses lists when both are list/tuple (curvatures.py:183); same outcome as _hyper
-            n, s = self._hyper(add, multiply, index, len(self.state))
-            self.inv_state[layer] = ops.rsqrt_affine(value, n, s)
+        gindex = self._global_index()
+        for position, (layer, value) in enumerate(self.state.items()):
+            # Diagonal uses lists when both are list/tuple (curvatures.py:183); same outcome as _hyper.
+            # Keys that are not layers of this model (a foreign state dict) fall back to their position.
+            n, s = self._hyper(add, multiply, gindex.get(layer, position), max(len(gindex), len(self.state)))
+            self.inv_state[layer] = ops.rsqrt_affine(value, n, s, out=self._reuse(self.inv_state.get(layer), value))
+
+    @staticmethod
+    def _reuse(prev: Optional[Tensor], like: Tensor) -> Optional[Tensor]:
+        """The previous inverse-state tensor if it can be overwritten in place (stable addresses keep cached
+        launch plans valid)."""
+        if prev is not None and prev.shape == like.shape and prev.device == like.device and prev.is_contiguous():
+            return prev
+        return None
 
     def sample(self, layer: Union[Module, str], z: Optional[Tensor] = None) -> Tensor:
         assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
@@ -192,6 +255,17 @@ class Diagonal(Curvature):
         if z is None:
             z = self._randn(*inv.shape, device=inv.device)
         return ops.mul(z, inv)
+
+    def sample_and_replace(self):
+        """curvatures.py:117-129 including the MultiheadAttention branch."""
+        self._reload_mean()
+        for _, layer in self._owned():
+            self._replace(self.sample(layer), layer.weight, layer.bias)
+        for layer in self._attention():
+            for weight, bias, key in ((layer.in_proj_weight, layer.in_proj_bias, 'attn_in'),
+                                      (layer.out_proj.weight, layer.out_proj.bias, 'attn_out')):
+                self._replace(self.sample(key), weight, bias)
+        self._allgather_sampled()
 
 
 class KFAC(Curvature):
@@ -202,8 +276,8 @@ class KFAC(Curvature):
     reference the recorded grad_output is NOT pre-multiplied by the batch size (curvatures.py:310); the
     factor N is folded into the scale of the G-side SYRK, which saves one pass over every gradient."""
 
-    def __init__(self, model: Union[Module, Sequential], layer_types: Union[List[str], str] = None):
-        super().__init__(model, layer_types)
+    def __init__(self, model: Union[Module, Sequential], layer_types: Union[List[str], str] = None, *, shard=None):
+        super().__init__(model, layer_types, shard=shard)
         self.hooks = list()
         self.record = dict()
         for layer in model.modules():
@@ -300,12 +374,11 @@ class KFAC(Curvature):
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
         assert self.state, "State dict is empty. Did you call 'update' prior to this?"
         factors, adds, muls = [], [], []
-        all_layers = self._layers()
-        gindex = {l: i for i, l in enumerate(all_layers)}
-        for layer, value in self.state.items():
+        gindex = self._global_index()
+        for position, (layer, value) in enumerate(self.state.items()):
             # layer index = position among the selected layers in modules() order (== enumerate(state)
             # of the reference, curvatures.py:360, when every layer is owned)
-            n, s = self._hyper(add, multiply, gindex.get(layer, 0), len(all_layers))
+            n, s = self._hyper(add, multiply, gindex.get(layer, position), max(len(gindex), len(self.state)))
             for factor in value:
                 factors.append(factor)
                 adds.append(n)
@@ -382,47 +455,118 @@ class KFAC(Curvature):
         plan[3].run()
         self._allgather_sampled()
 
+def _arena(shapes: Sequence[Sequence[int]], device, zero: bool = False):
+    """One flat fp32 buffer and one view per shape, laid out back to back: whole-model elementwise steps
+    (noise scaling, scalar-hyper-parameter inverts) then take ONE launch over the flat buffer instead of one
+    per layer."""
+    sizes = []
+    for shape in shapes:
+        count = 1
+        for d in shape:
+            count *= int(d)
+        sizes.append(count)
+    flat = (torch.zeros if zero else torch.empty)(max(sum(sizes), 1), dtype=torch.float32, device=device)
+    views, pos = [], 0
+    for shape, count in zip(shapes, sizes):
+        views.append(flat[pos:pos + count].view(*shape))
+        pos += count
+    return flat, views
+
+
+def _is_arena(flat: Optional[Tensor], tensors: Sequence[Tensor]) -> bool:
+    """True if `tensors` are exactly the consecutive contiguous views `_arena` handed out for `flat`."""
+    if flat is None:
+        return False
+    pos = flat.data_ptr()
+    for t in tensors:
+        if not t.is_contiguous() or t.dtype != torch.float32 or t.data_ptr() != pos:
+            return False
+        pos += 4 * t.numel()
+    return pos <= flat.data_ptr() + 4 * flat.numel()
+
+
 class EFB(Curvature):
     """Eigenvalue-corrected Kronecker factorisation (curvatures.py:395-460).
 
     ``state[layer]`` = Lambda (m, n) accumulating (U_G^T grad U_A)**2, ``diags[layer]`` the diagonal Fisher
-    grad**2 * batch_size, ``eigvecs[layer] = (U_A, U_G)``, ``inv_state[layer] = (s Lambda + n)^-1/2``."""
+    grad**2 * batch_size, ``eigvecs[layer] = (U_A, U_G)``, ``inv_state[layer] = (s Lambda + n)^-1/2``.
+
+    Keyword-only extensions of the reference constructor: `shard` (this rank decomposes, updates, inverts and
+    samples only the layers it owns; with a layer-sharded KFAC `factors` already holds just those) and
+    `eigvecs` (a precomputed ``{layer: (U_A, U_G)}``, e.g. another estimator's, instead of decomposing)."""
 
     def __init__(self, model: Union[Module, Sequential], factors: Dict[Module, Tensor],
-                 layer_types: Union[List[str], str] = None):
-        super().__init__(model, layer_types)
-        from .utils import get_eigenvectors
-        self.eigvecs = get_eigenvectors(factors)
+                 layer_types: Union[List[str], str] = None, *, shard=None, eigvecs=None):
+        super().__init__(model, layer_types, shard=shard)
+        if eigvecs is None:
+            from .utils import get_eigenvectors
+            if shard is not None:
+                mine = {l for _, l in self._owned()}
+                factors = {l: f for l, f in factors.items() if l in mine}
+            eigvecs = get_eigenvectors(factors)
+        self.eigvecs = eigvecs
         self.diags = dict()
 
+    def _mine(self) -> List[Module]:
+        """Owned layers that have eigenvectors, in ``modules()`` order."""
+        return [l for _, l in self._owned() if l in self.eigvecs]
+
     def update(self, batch_size: int):
-        stage1, stage2 = [], []
-        for layer in self._layers():
-            gw = layer.weight.grad.contiguous()
-            m = gw.shape[0]
-            gw2 = gw.view(m, -1)
-            n0 = gw2.shape[1]
-            gb = layer.bias.grad if layer.bias is not None else None
-            n = n0 + int(gb is not None)
-            U_A, U_G = self.eigvecs[layer]
-            tmp = torch.empty(m, n, dtype=torch.float32, device=gw.device)
-            stage1.append(ops.Gemm(U_G.t(), gw2, tmp[:, :n0]))                      # U_G^T [W.grad | b.grad]
-            if gb is not None:
-                stage1.append(ops.Gemm(U_G.t(), gb.view(m, 1), tmp[:, n0:]))
-            first = layer not in self.state
-            if first:
-                self.state[layer] = torch.empty(m, n, dtype=torch.float32, device=gw.device)
-            stage2.append(ops.Gemm(tmp, U_A, self.state[layer], beta=0.0 if first else 1.0,
-                                   epilogue=ops.EPI_SQUARE))                        # Lambda (+)= (. U_A)**2
+        layers = self._mine()
+        if not layers:
+            return
+        grads = []
+        for layer in layers:
+            gw = layer.weight.grad
+            if gw is None:
+                raise RuntimeError("EFB.update: a selected layer has no gradient (call backward() first)")
+            grads.append((gw.contiguous(), layer.bias.grad if layer.bias is not None else None))
+        dev = grads[0][0].device
+        missing = [k for k, layer in enumerate(layers) if layer not in self.state]
+        if missing:
+            # Lambda of all (new) layers in one zeroed arena: every update is then the same accumulate launch pair
+            _, views = _arena([(grads[k][0].shape[0], grads[k][0].numel() // grads[k][0].shape[0] +
+                                int(grads[k][1] is not None)) for k in missing], dev, zero=True)
+            for k, v in zip(missing, views):
+                self.state[layers[k]] = v
+        key = tuple(t.data_ptr() for gw, gb in grads for t in (gw, gb) if t is not None) + \
+            tuple(self.state[l].data_ptr() for l in layers) + tuple(t.data_ptr() for l in layers for t in self.eigvecs[l])
+        plan = getattr(self, "_update_plan", None)
+        if plan is None or plan[0] != key:
+            stage1, stage2 = [], []
+            _, tmps = _arena([tuple(self.state[l].shape) for l in layers], dev)
+            for layer, (gw, gb), tmp in zip(layers, grads, tmps):
+                m = gw.shape[0]
+                gw2 = gw.view(m, -1)
+                n0 = gw2.shape[1]
+                U_A, U_G = self.eigvecs[layer]
+                stage1.append(ops.Gemm(U_G.t(), gw2, tmp[:, :n0]))                  # U_G^T [W.grad | b.grad]
+                if gb is not None:
+                    stage1.append(ops.Gemm(U_G.t(), gb.view(m, 1), tmp[:, n0:]))
+                stage2.append(ops.Gemm(tmp, U_A, self.state[layer], beta=1.0, epilogue=ops.EPI_SQUARE))   # Lambda += (. U_A)**2
+            plan = (key, ops.GemmPlan(stage1), ops.GemmPlan(stage2))
+            self._update_plan = plan
+        plan[1].run()
+        plan[2].run()
+        for layer, (gw, gb) in zip(layers, grads):
             self.diags[layer] = ops.sq_accumulate(gw, gb, batch_size, self.diags.get(layer))
-        ops.gemm_batched(stage1)
-        ops.gemm_batched(stage2)
 
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
         assert self.state, "State dict is empty. Did you call 'update' prior to this?"
-        for index, (layer, value) in enumerate(self.state.items()):
-            n, s = self._hyper(add, multiply, index, len(self.state))
-            self.inv_state[layer] = ops.rsqrt_affine(value, n, s)
+        gindex = self._global_index()
+        layers = list(self.state.keys())
+        values = [self.state[l] for l in layers]
+        prev = [self.inv_state.get(l) for l in layers]
+        if not (all(p is not None and p.shape == v.shape for p, v in zip(prev, values))
+                and _is_arena(getattr(self, "_inv_flat", None), prev)):
+            # inverse state of all layers in one arena, overwritten in place by later calls (stable addresses
+            # keep the sampler's launch plan valid; the noise scaling is one launch over the flat buffer)
+            self._inv_flat, views = _arena([tuple(v.shape) for v in values], values[0].device)
+            for layer, v in zip(layers, views):
+                self.inv_state[layer] = v
+        for position, (layer, value) in enumerate(zip(layers, values)):
+            n, s = self._hyper(add, multiply, gindex.get(layer, position), max(len(gindex), len(layers)))
+            ops.rsqrt_affine(value, n, s, out=self.inv_state[layer])
 
     def sample(self, layer: Module, z: Optional[Tensor] = None) -> Tensor:
         """(U_A (z * inv^T) U_G^T)^T = U_G (z^T * inv) U_A^T -> (m, n) (curvatures.py:453-460)."""
@@ -439,34 +583,62 @@ class EFB(Curvature):
         ops.gemm_batched([ops.Gemm(tmp, first.t(), out)])
         return out
 
-
     def sample_and_replace(self, noise: Optional[Dict[Module, Tensor]] = None):
         """Fused form of the base-class loop (same result as curvatures.py:117-129 with EFB.sample): the
-        scaled noise per layer, then two batched GEMM launches for the whole model, the second writing
-        ``mean + sample`` straight into the parameters.  `noise[layer]` (n, m) may be supplied."""
+        scaled noise, then two batched GEMM launches for the whole model, the second writing
+        ``mean + sample`` straight into the parameters.  `noise[layer]` (n, m) may be supplied.  The launches
+        are described once and replayed while the tensors involved stay where they are."""
         assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
-        owned = self._owned()
-        self._reload_mean(skip=[p for _, l in owned for p in (l.weight, l.bias) if p is not None])
-        stage1, stage2 = [], []
-        for _, layer in owned:
-            first, second = self.eigvecs[layer]
-            lambdas = self.inv_state[layer]
-            n, m = first.size(0), second.size(0)
-            z = noise[layer] if noise is not None else self._randn(n, m, device=first.device)
-            zt = ops.mul2d(z.t(), lambdas)                                # (m, n)
-            tmp = torch.empty(m, n, dtype=torch.float32, device=first.device)
-            stage1.append(ops.Gemm(second, zt, tmp))
-            n0 = n - int(layer.bias is not None)
-            w = layer.weight.data.view(m, n0)
-            w_mean = self.model_state_of(layer, 'weight').view(m, n0)
-            ua_t = first.t()
-            stage2.append(ops.Gemm(tmp, ua_t[:, :n0], w, epilogue=ops.EPI_ADD_E, E=w_mean))
-            if layer.bias is not None:
-                b = layer.bias.data.view(m, 1)
-                b_mean = self.model_state_of(layer, 'bias').view(m, 1)
-                stage2.append(ops.Gemm(tmp, ua_t[:, n0:], b, epilogue=ops.EPI_ADD_E, E=b_mean))
-        ops.gemm_batched(stage1)
-        ops.gemm_batched(stage2)
+        layers = self._mine()
+        self._reload_mean(skip=[p for l in layers for p in (l.weight, l.bias) if p is not None])
+        if not layers:
+            self._allgather_sampled()
+            return
+        key = (noise is None, tuple(t.data_ptr() for l in layers for t in (*self.eigvecs[l], self.inv_state[l])),
+               tuple(p.data_ptr() for l in layers for p in (l.weight, l.bias) if p is not None),
+               tuple(self.model_state_of(l, nm).data_ptr() for l in layers for nm in ('weight', 'bias')
+                     if getattr(l, nm) is not None))
+        plan = getattr(self, "_sample_plan", None)
+        if plan is None or plan[0] != key:
+            dev = self.inv_state[layers[0]].device
+            shapes = [tuple(self.inv_state[l].shape) for l in layers]               # (m, n)
+            zflat, zts = _arena(shapes, dev)
+            _, tmps = _arena(shapes, dev)
+            stage1, stage2 = [], []
+            for layer, zt, tmp in zip(layers, zts, tmps):
+                first, second = self.eigvecs[layer]
+                n, m = first.size(0), second.size(0)
+                stage1.append(ops.Gemm(second, zt, tmp))
+                n0 = n - int(layer.bias is not None)
+                w = layer.weight.data.view(m, n0)
+                w_mean = self.model_state_of(layer, 'weight').view(m, n0)
+                ua_t = first.t()
+                stage2.append(ops.Gemm(tmp, ua_t[:, :n0], w, epilogue=ops.EPI_ADD_E, E=w_mean))
+                if layer.bias is not None:
+                    b = layer.bias.data.view(m, 1)
+                    b_mean = self.model_state_of(layer, 'bias').view(m, 1)
+                    stage2.append(ops.Gemm(tmp, ua_t[:, n0:], b, epilogue=ops.EPI_ADD_E, E=b_mean))
+            stage1.sort(key=lambda j: -(j.A.shape[0] * j.A.shape[1] * j.B.shape[1]))
+            stage2.sort(key=lambda j: -(j.A.shape[0] * j.A.shape[1] * j.B.shape[1]))
+            inv_flat = getattr(self, "_inv_flat", None)
+            whole = _is_arena(inv_flat, [self.inv_state[l] for l in layers]) and \
+                sum(self.inv_state[l].numel() for l in layers) == zflat.numel()
+            plan = (key, zflat, zts, ops.GemmPlan(stage1), ops.GemmPlan(stage2), inv_flat if whole else None)
+            self._sample_plan = plan
+        _, zflat, zts, plan1, plan2, inv_flat = plan
+        if noise is None:
+            # z^T of the reference drawn directly in (m, n) layout: the transpose of iid noise is iid noise
+            self._randn(zflat.numel(), device=zflat.device, out=zflat)
+            if inv_flat is not None:
+                ops.mul(zflat, inv_flat[:zflat.numel()], out=zflat)                 # one launch for the model
+            else:
+                for layer, zt in zip(layers, zts):
+                    ops.mul(zt, self.inv_state[layer], out=zt)
+        else:
+            for layer, zt in zip(layers, zts):
+                ops.mul2d(noise[layer].t(), self.inv_state[layer], out=zt)          # (m, n)
+        plan1.run()
+        plan2.run()
         self._allgather_sampled()
 
 
@@ -477,48 +649,62 @@ class INF(Curvature):
     The (n m) x (a b) Kronecker matrix V_s of the reference's pre_sampler is never formed: V_s^T V_s is
     computed in closed form from Khatri-Rao squares, and the dense chain after it,
     L_c = (C^-1 + vtv)^-1 with C = A^-T (B - I) A^-1, A = chol(vtv), B = chol(vtv + I), is evaluated as the
-    algebraically identical A^-T (I - B^-1) A^-1 in fp64 (no symmetry is assumed; P_c stays non-symmetric)."""
+    algebraically identical A^-T (I - B^-1) A^-1 in fp64 (no symmetry is assumed; P_c stays non-symmetric).
+
+    Keyword-only extensions of the reference constructor: `shard` (only this rank's layers are decomposed,
+    reduced, inverted and sampled; dicts coming from sharded estimators already hold just those) and `eigvecs`
+    (reuse e.g. ``efb.eigvecs`` instead of decomposing the same factors again, curvatures.py:403 vs :473)."""
 
     def __init__(self, model: Union[Module, Sequential], diags: Dict[Module, Tensor],
                  factors: Dict[Module, Tensor], lambdas: Dict[Module, Tensor],
-                 layer_types: Union[List[str], str] = None):
-        super().__init__(model, layer_types)
+                 layer_types: Union[List[str], str] = None, *, shard=None, eigvecs=None):
+        super().__init__(model, layer_types, shard=shard)
         assert diags.keys() == factors.keys() == lambdas.keys()
-        from .utils import get_eigenvectors
-        self.eigvecs = get_eigenvectors(factors)
+        if shard is not None:
+            mine = {l for _, l in self._owned()}
+            diags = {l: v for l, v in diags.items() if l in mine}
+            factors = {l: v for l, v in factors.items() if l in mine}
+            lambdas = {l: v for l, v in lambdas.items() if l in mine}
+        if eigvecs is None:
+            from .utils import get_eigenvectors
+            eigvecs = get_eigenvectors(factors)
+        self.eigvecs = eigvecs
         self.lambdas = lambdas
         self.diags = diags
 
     def update(self, rank: int = 100):
         layers = list(self.diags.keys())
-        # the index sets of all layers in one launch and one read-back (a launch + host sync per layer was a
-        # quarter of update() on ResNet-18)
-        vecs = {layer: self.lambdas[layer].t().contiguous().view(-1) for layer in layers}   # index i*m + j
+        # lambda^T.flatten() (index i*m + j) of every layer, then the index sets of all layers in one launch and
+        # one read-back (a launch + host sync per layer was a quarter of update() on ResNet-18)
+        vecs = {layer: ops.gather2d(self.lambdas[layer].t()).view(-1) for layer in layers}
         need = [layer for layer in layers if rank < vecs[layer].shape[0]]
         picked = dict(zip(need, ops.inf_select_many(
             [vecs[layer] for layer in need],
             [(self.eigvecs[layer][0].shape[0], self.eigvecs[layer][1].shape[0]) for layer in need], rank)))
+        stage1, stage2 = [], []
         for layer in layers:
             xxt_eigvecs, ggt_eigvecs = self.eigvecs[layer]
-            diags = self.diags[layer]
             n, m = xxt_eigvecs.shape[0], ggt_eigvecs.shape[0]
             lambda_vec = vecs[layer]
-            diag_vec = diags.t().contiguous().view(-1)
+            diag_vec = ops.gather2d(self.diags[layer].t())                          # (n, m): index i*m + j
             if layer not in picked:
                 ua, ug, lam = xxt_eigvecs, ggt_eigvecs, lambda_vec
             else:
                 I, J = picked[layer]
-                ua = xxt_eigvecs.index_select(1, I).contiguous()
-                ug = ggt_eigvecs.index_select(1, J).contiguous()
-                lam = lambda_vec.view(n, m).index_select(0, I).index_select(1, J).contiguous().view(-1)
+                ua = ops.gather2d(xxt_eigvecs, cols=I)
+                ug = ops.gather2d(ggt_eigvecs, cols=J)
+                lam = ops.gather2d(lambda_vec.view(n, m), rows=I, cols=J).view(-1)
             a, b = ua.shape[1], ug.shape[1]
             # D = diag_vec - ((U_A**2) Lambda_lr (U_G**2)^T).flatten()
             ua2, ug2 = ops.mul(ua, ua), ops.mul(ug, ug)
             tmp = torch.empty(n, b, dtype=torch.float32, device=ua.device)
             corr = torch.empty(n, m, dtype=torch.float32, device=ua.device)
-            ops.gemm_batched([ops.Gemm(ua2, lam.view(a, b), tmp)])
-            ops.gemm_batched([ops.Gemm(tmp, ug2.t(), corr, alpha=-1.0, epilogue=ops.EPI_ADD_E, E=diag_vec.view(n, m))])
+            stage1.append(ops.Gemm(ua2, lam.view(a, b), tmp))
+            stage2.append(ops.Gemm(tmp, ug2.t(), corr, alpha=-1.0, epilogue=ops.EPI_ADD_E, E=diag_vec))
             self.state[layer] = (ua, ug, lam, corr.view(-1))
+        ops.gemm_batched(stage1)
+        ops.gemm_batched(stage2)
+        self._sample_plan = None
 
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
         assert self.state, "State dict is empty. Did you call 'update' prior to this?"
@@ -526,20 +712,28 @@ class INF(Curvature):
         # stage, ONE batched fp64 factorisation sweep for the 2 x layers matrices vtv and vtv + I (and one
         # status read-back) instead of a sweep and a host synchronisation per layer.
         layers, regs = list(self.state.keys()), []
-        for index, layer in enumerate(layers):
-            n, s = self._hyper(add, multiply, index, len(self.state))
+        gindex = self._global_index()
+        # r of all layers in one arena, overwritten in place by later calls (stable addresses for the sampler's plan)
+        rs = [self.inv_state[l][2] for l in layers] if len(self.inv_state) == len(layers) else []
+        if not rs or not _is_arena(getattr(self, "_r_flat", None), rs) or \
+                any(r.numel() != self.state[l][3].numel() for r, l in zip(rs, layers)):
+            self._r_flat, rs = _arena([(self.state[l][3].numel(),) for l in layers], self.state[layers[0]][3].device)
+        for position, (layer, r) in enumerate(zip(layers, rs)):
+            n, s = self._hyper(add, multiply, gindex.get(layer, position), max(len(gindex), len(layers)))
             lr_frst_eigvecs, lr_scnd_eigvecs, lr_lambda, correction = self.state[layer]
             ops.clamp_min0_(correction)                                  # in place on `state`, like :523
             reg_lr_lambda = ops.sqrt_scale(lr_lambda, s)
-            reg_inv_correction = ops.rsqrt_affine(correction, n, s)
-            regs.append((lr_frst_eigvecs, lr_scnd_eigvecs, reg_lr_lambda, reg_inv_correction))
-        pre_samples = self.pre_sampler_many(regs)
+            ops.rsqrt_affine(correction, n, s, out=r)
+            regs.append((lr_frst_eigvecs, lr_scnd_eigvecs, reg_lr_lambda, r))
+        prev = [self.inv_state[l][3] if l in self.inv_state else None for l in layers]
+        pre_samples = self.pre_sampler_many(regs, outs=prev)
         for layer, (ua, ug, _, r), pre_sample in zip(layers, regs, pre_samples):
             self.inv_state[layer] = (ua, ug, r, pre_sample)
 
     @staticmethod
-    def pre_sampler_many(regs) -> List[Tensor]:
-        """`pre_sampler` for a list of (U_A_lr, U_G_lr, sigma, r) tuples, stage by stage."""
+    def pre_sampler_many(regs, outs: Optional[Sequence[Optional[Tensor]]] = None) -> List[Tensor]:
+        """`pre_sampler` for a list of (U_A_lr, U_G_lr, sigma, r) tuples, stage by stage.  `outs`: previous
+        P_c tensors, overwritten in place where the shape still fits."""
         if not regs:
             return []
         dev = regs[0][0].device
@@ -561,12 +755,15 @@ class INF(Curvature):
             mats += [v, v]
             adds += [0.0, 1.0]
         inv = ops.chol_factor_inverse(mats, adds)                        # float64, lower triangular
+        # T = (I - B^-1) A^-1 = A^-1 - B^-1 A^-1 (accumulated onto a copy of A^-1); L_c = A^-T T
+        Ts = [torch.empty_like(inv[2 * i]) for i in range(len(regs))]
+        ops.CopyPlan(Ts, [inv[2 * i] for i in range(len(regs))]).run()
+        ops.gemm_f64_batched([ops.Gemm64(inv[2 * i + 1], inv[2 * i], T, alpha=-1.0, beta=1.0) for i, T in enumerate(Ts)])
+        L_cs = ops.gemm_f64_batched([ops.Gemm64(inv[2 * i].t(), T) for i, T in enumerate(Ts)])
         out = []
         for i, (_, _, sigma, _) in enumerate(regs):
-            A_inv, B_inv = inv[2 * i], inv[2 * i + 1]
-            T = ops.gemm_f64(B_inv, A_inv, alpha=-1.0, beta=1.0, C=A_inv.clone())      # (I - B^-1) A^-1
-            L_c = ops.gemm_f64(A_inv.t(), T)
-            out.append(ops.diag_scale(L_c, sigma, sigma))
+            prev = outs[i] if outs is not None else None
+            out.append(ops.diag_scale(L_cs[i], sigma, sigma, out=prev))
         return out
 
     @staticmethod
@@ -584,11 +781,8 @@ class INF(Curvature):
     @staticmethod
     def pre_sampler(frst_eigvecs: Tensor, scnd_eigvecs: Tensor, reg_lambda: Tensor,
                     reg_inv_correction: Tensor) -> Tensor:
-        vtv = INF.vtv(frst_eigvecs, scnd_eigvecs, reg_lambda, reg_inv_correction)
-        A_inv, B_inv = ops.chol_factor_inverse([vtv, vtv], [0.0, 1.0])        # float64, lower triangular
-        T = ops.gemm_f64(B_inv, A_inv, alpha=-1.0, beta=1.0, C=A_inv.clone())      # (I - B^-1) A^-1
-        L_c = ops.gemm_f64(A_inv.t(), T)
-        return ops.diag_scale(L_c, reg_lambda, reg_lambda)
+        """P_c of one layer (curvatures.py:538-572)."""
+        return INF.pre_sampler_many([(frst_eigvecs, scnd_eigvecs, reg_lambda, reg_inv_correction)])[0]
 
     def sample(self, layer: Module, X: Optional[Tensor] = None) -> Tensor:
         assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
@@ -597,33 +791,67 @@ class INF(Curvature):
 
     def sample_and_replace(self, noise: Optional[Dict[Module, Tensor]] = None):
         """The base-class loop (curvatures.py:117-129) with INF.sample, all layers advancing together through the
-        five products of `sampler` (one batched launch each).  `noise[layer]`: the (n*m,) vector X of :578."""
+        five products of `sampler` (one batched launch each); the last one writes
+        ``mean + (Y_l - Y_r)^T`` straight into the parameters through its output strides.  `noise[layer]`: the
+        (n*m,) vector X of :578.  Launches are described once and replayed while the tensors stay in place."""
         assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
-        owned = self._owned()
-        self._reload_mean()
-        st1, st2, st3, st4, st5, outs = [], [], [], [], [], []
-        for _, layer in owned:
-            ua, ug, r, P = self.inv_state[layer]
-            (n, a), (m, b) = ua.shape, ug.shape
-            dev = ua.device
-            X = noise[layer].reshape(-1) if noise is not None else self._randn(n * m, device=dev)
-            Y_l = ops.mul(r, X)                                                    # (n*m,)
-            t1 = torch.empty(b, n, dtype=torch.float32, device=dev)
-            xq_t = torch.empty(a, b, dtype=torch.float32, device=dev)
-            qx = torch.empty(a * b, 1, dtype=torch.float32, device=dev)
-            t2 = torch.empty(m, a, dtype=torch.float32, device=dev)
-            out = Y_l.clone().view(n, m)                                           # becomes Y_l - Y_r
-            r2 = ops.mul(r, r).view(n, m)
-            st1.append(ops.Gemm(ug.t(), Y_l.view(m, n), t1))                       # U_G^T unvec(Y_l): (b, n)
-            st2.append(ops.Gemm(t1, ua, xq_t.t()))                                 # flat order of Xq^T: k*b + l
-            st3.append(ops.Gemm(P, xq_t.view(a * b, 1), qx))
-            st4.append(ops.Gemm(ug, qx.view(b, a), t2))                            # U_G unvec(Qx): (m, a)
-            st5.append(ops.Gemm(ua, t2.t(), out, alpha=-1.0, beta=1.0, epilogue=ops.EPI_MUL_E, E=r2))
-            outs.append(out)
-        for stage in (st1, st2, st3, st4, st5):
-            ops.gemm_batched(stage)
-        for (_, layer), out in zip(owned, outs):
-            self._replace(out.t(), layer.weight, layer.bias)
+        layers = [l for _, l in self._owned() if l in self.inv_state]
+        self._reload_mean()                                   # the last product accumulates onto the mean
+        if not layers:
+            self._allgather_sampled()
+            return
+        key = (tuple(t.data_ptr() for l in layers for t in self.inv_state[l]),
+               tuple(p.data_ptr() for l in layers for p in (l.weight, l.bias) if p is not None))
+        plan = getattr(self, "_sample_plan", None)
+        if plan is None or plan[0] != key:
+            dev = self.inv_state[layers[0]][0].device
+            dims = [(self.inv_state[l][0].shape, self.inv_state[l][1].shape) for l in layers]
+            xflat, Xs = _arena([(n * m,) for (n, _), (m, _) in dims], dev)
+            yflat, Ys = _arena([(n * m,) for (n, _), (m, _) in dims], dev)
+            r2flat, r2s = _arena([(n, m) for (n, _), (m, _) in dims], dev)
+            small = []
+            for (n, a), (m, b) in dims:
+                small += [(b, n), (a, b), (a * b, 1), (m, a)]
+            _, sm = _arena(small, dev)
+            stages = [[], [], [], [], []]
+            for k, (layer, ((n, a), (m, b)), Y_l, r2) in enumerate(zip(layers, dims, Ys, r2s)):
+                ua, ug, r, P = self.inv_state[layer]
+                t1, xq_t, qx, t2 = sm[4 * k:4 * k + 4]
+                stages[0].append(ops.Gemm(ug.t(), Y_l.view(m, n), t1))               # U_G^T unvec(Y_l): (b, n)
+                stages[1].append(ops.Gemm(t1, ua, xq_t.t()))                         # flat order of Xq^T: k*b + l
+                stages[2].append(ops.Gemm(P, xq_t.view(a * b, 1), qx))
+                stages[3].append(ops.Gemm(ug, qx.view(b, a), t2))                    # U_G unvec(Qx): (m, a)
+                # (Y_l - r^2 * (U_A t2^T)) as an (n, m) matrix is the transposed sample: rows < n0 go to the
+                # weight seen through transposed strides, the last row to the bias (curvatures.py:67-82, 536)
+                n0 = n - int(layer.bias is not None)
+                Yv = Y_l.view(n, m)
+                w_t = layer.weight.data.view(m, n0).t()
+                stages[4].append(ops.Gemm(ua[:n0], t2.t(), w_t, alpha=-1.0, beta=1.0, epilogue=ops.EPI_MUL_E_ADD_F,
+                                          E=r2[:n0], F=Yv[:n0]))
+                if layer.bias is not None:
+                    stages[4].append(ops.Gemm(ua[n0:], t2.t(), layer.bias.data.view(1, m), alpha=-1.0, beta=1.0,
+                                              epilogue=ops.EPI_MUL_E_ADD_F, E=r2[n0:], F=Yv[n0:]))
+            r_whole = _is_arena(getattr(self, "_r_flat", None), [self.inv_state[l][2] for l in layers]) and \
+                sum(self.inv_state[l][2].numel() for l in layers) == xflat.numel()
+            plan = (key, xflat, Xs, yflat, Ys, r2flat, r2s, [ops.GemmPlan(st) for st in stages],
+                    self._r_flat if r_whole else None)
+            self._sample_plan = plan
+        _, xflat, Xs, yflat, Ys, r2flat, r2s, gemms, r_flat = plan
+        if noise is None:
+            self._randn(xflat.numel(), device=xflat.device, out=xflat)
+        else:
+            ops.CopyPlan(Xs, [noise[l].reshape(-1).contiguous() for l in layers]).run()
+        if r_flat is not None:                                  # Y_l = r * X and r^2 for the whole model
+            rf = r_flat[:xflat.numel()]
+            ops.mul(rf, xflat, out=yflat)
+            ops.mul(rf, rf, out=r2flat)
+        else:
+            for layer, X, Y_l, r2 in zip(layers, Xs, Ys, r2s):
+                r = self.inv_state[layer][2]
+                ops.mul(r, X, out=Y_l)
+                ops.mul(r, r, out=r2.view(-1))
+        for g in gemms:
+            g.run()
         self._allgather_sampled()
 
     @staticmethod
@@ -644,8 +872,9 @@ class INF(Curvature):
         ops.gemm_batched([ops.Gemm(pre_sample, xq_t.view(a * b, 1), qx)])
         t2 = torch.empty(m, a, dtype=torch.float32, device=dev)
         ops.gemm_batched([ops.Gemm(scnd_eigvecs, qx.view(b, a), t2)])           # U_G unvec(Qx): (m, a)
-        out = Y_l.clone().view(n, m)                                           # becomes Y_l - Y_r
+        out = torch.empty(n, m, dtype=torch.float32, device=dev)
         r2 = ops.mul(reg_inv_correction, reg_inv_correction).view(n, m)
         # X_p_s = t2 U_A^T (m, n); Y_r[i*m + q] = r^2[i*m + q] X_p_s[q, i]: write X_p_s^T through the strides
-        ops.gemm_batched([ops.Gemm(frst_eigvecs, t2.t(), out, alpha=-1.0, beta=1.0, epilogue=ops.EPI_MUL_E, E=r2)])
+        ops.gemm_batched([ops.Gemm(frst_eigvecs, t2.t(), out, alpha=-1.0, epilogue=ops.EPI_MUL_E_ADD_F, E=r2,
+                                   F=Y_l.view(n, m))])
         return out

@@ -43,7 +43,8 @@ def named_state(est, attr: str = "state") -> Dict[str, Any]:
     """``getattr(est, attr)`` (a module-keyed dict) re-keyed by qualified layer name, tensors on the CPU."""
     names = _selected(est)
     src = getattr(est, attr)
-    return {names[layer]: _to_cpu(value) for layer, value in src.items()}
+    # string keys (Diagonal's 'attn_in' / 'attn_out' of MultiheadAttention modules) are names already
+    return {(layer if isinstance(layer, str) else names[layer]): _to_cpu(value) for layer, value in src.items()}
 
 
 def save_state(est, path: str, attrs=("state",)) -> None:
@@ -67,12 +68,13 @@ def load_state(est, source: Union[str, Dict], attr: str = "state", device=None):
         device = next(est.model.parameters()).device
     out = {}
     if all(isinstance(k, str) for k in source.keys()):
-        missing = [n for n in source if n not in set(names.values())]
+        attn = ('attn_in', 'attn_out')
+        missing = [n for n in source if n not in set(names.values()) and n not in attn]
         if missing:
             raise KeyError(f"state holds layers the model does not have: {missing[:3]}")
-        for layer, name in names.items():
-            if name in source:
-                out[layer] = _to_device(source[name], device)
+        by_name = {name: layer for layer, name in names.items()}
+        for name, value in source.items():          # stored order = modules() order of the writer
+            out[name if name in attn and name not in by_name else by_name[name]] = _to_device(value, device)
     else:
         layers = list(names.keys())
         if len(source) != len(layers):

@@ -5,6 +5,7 @@ Every wrapper requires CUDA(=HIP) fp32 contiguous tensors and raises ``RuntimeEr
 there is no CPU fallback.
 """
 import ctypes
+import threading
 from typing import List, Optional, Sequence
 
 import torch
@@ -13,6 +14,7 @@ from . import _lib
 from ._lib import curv_factor_desc, curv_gemm_desc, curv_inv_desc
 
 _workspaces = {}
+_workspace_lock = threading.Lock()
 
 
 def _require_gpu(*tensors: torch.Tensor) -> None:
@@ -28,13 +30,27 @@ def _require_gpu(*tensors: torch.Tensor) -> None:
 
 
 def workspace(nbytes: int, device: torch.device, tag: str = "default") -> torch.Tensor:
-    """A cached scratch buffer owned by torch (the library never allocates device memory)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
-    buf = _workspaces.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
-        _workspaces[key] = buf
+    """A cached scratch buffer owned by torch (the library never allocates device memory).
+
+    One buffer per (device, tag, current stream): launches on one stream are ordered, so they may share
+    scratch; two estimators driven from different streams (or threads, each with its own current stream) get
+    different buffers and cannot overwrite each other's slabs or descriptor tables mid-kernel.  The buffer is
+    allocated on the stream it is keyed by, so the caching allocator's stream ownership matches its use, and
+    a regrown buffer's predecessor is only recycled for later work of that same stream."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, tag, int(torch.cuda.current_stream(index).cuda_stream))
+    with _workspace_lock:
+        buf = _workspaces.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+            _workspaces[key] = buf
     return buf
+
+
+def release_workspaces() -> None:
+    """Drop every cached scratch buffer (they are re-created on demand)."""
+    with _workspace_lock:
+        _workspaces.clear()
 
 
 class FactorJob:
@@ -148,16 +164,16 @@ def chol_inv_lower(factors: Sequence[torch.Tensor], adds: Sequence[float], multi
     return outs
 
 
-EPI_NONE, EPI_SQUARE, EPI_MUL_E, EPI_ADD_E = 0, 1, 2, 3
+EPI_NONE, EPI_SQUARE, EPI_MUL_E, EPI_ADD_E, EPI_MUL_E_ADD_F = 0, 1, 2, 3, 4
 TRI_NONE, TRI_A_LOWER, TRI_B_UPPER = 0, 1, 2
 
 
 class Gemm:
     """C = epilogue(alpha * A @ B) [+ beta * C] on 2-D views (any strides: .t() and slices are free)."""
-    __slots__ = ("A", "B", "C", "E", "alpha", "beta", "epilogue", "tri")
+    __slots__ = ("A", "B", "C", "E", "F", "alpha", "beta", "epilogue", "tri")
 
-    def __init__(self, A, B, C, alpha=1.0, beta=0.0, epilogue=EPI_NONE, E=None, tri=0):
-        self.A, self.B, self.C, self.E = A, B, C, E
+    def __init__(self, A, B, C, alpha=1.0, beta=0.0, epilogue=EPI_NONE, E=None, tri=0, F=None):
+        self.A, self.B, self.C, self.E, self.F = A, B, C, E, F
         self.alpha, self.beta, self.epilogue, self.tri = float(alpha), float(beta), int(epilogue), int(tri)
 
 
@@ -186,6 +202,12 @@ def _gemm_descs(jobs: Sequence[Gemm]):
                 raise RuntimeError("GEMM epilogue operand must match the output shape")
             d.E = j.E.data_ptr()
             d.e_rs, d.e_cs = j.E.stride()
+        if j.F is not None:
+            _check_view(j.F)
+            if tuple(j.F.shape) != (M, N):
+                raise RuntimeError("GEMM epilogue operand must match the output shape")
+            d.F = j.F.data_ptr()
+            d.f_rs, d.f_cs = j.F.stride()
         d.M, d.N, d.K = M, N, K
         d.alpha, d.beta, d.epilogue, d.tri = j.alpha, j.beta, j.epilogue, j.tri
     return arr
@@ -270,15 +292,44 @@ class CopyPlan:
 from ._lib import curv_cholinv_desc, curv_gemm64_desc, curv_select_desc  # noqa: E402
 
 
-def mul2d(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+def mul2d(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Contiguous a * b for two strided 2-D float32 views of equal shape."""
     _check_view(a)
     _check_view(b)
     if a.shape != b.shape:
         raise RuntimeError("mul2d: shape mismatch")
-    out = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    else:
+        _require_gpu(out)
+        if out.shape != a.shape:
+            raise RuntimeError("mul2d: output shape mismatch")
     _lib.check(_lib.lib().curv_mul2d(_lib.stream_ptr(), a.data_ptr(), a.stride(0), a.stride(1), b.data_ptr(),
                                      b.stride(0), b.stride(1), out.data_ptr(), a.shape[0], a.shape[1]), "curv_mul2d")
+    return out
+
+
+def gather2d(src: torch.Tensor, rows: Optional[torch.Tensor] = None, cols: Optional[torch.Tensor] = None,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Contiguous copy of the strided 2-D view `src`, optionally restricted to the int64 index lists `rows` /
+    `cols` (``src.index_select(0, rows).index_select(1, cols).contiguous()`` in one launch; a transposed view
+    as `src` gives ``src.t().contiguous()``)."""
+    _check_view(src)
+    for idx in (rows, cols):
+        if idx is not None and (not idx.is_cuda or idx.dtype != torch.int64 or not idx.is_contiguous()):
+            raise RuntimeError("gather2d: index lists must be contiguous int64 GPU tensors")
+    R = src.shape[0] if rows is None else rows.numel()
+    C = src.shape[1] if cols is None else cols.numel()
+    if out is None:
+        out = torch.empty(R, C, dtype=torch.float32, device=src.device)
+    else:
+        _require_gpu(out)
+        if out.numel() != R * C:
+            raise RuntimeError("gather2d: output size mismatch")
+    _lib.check(_lib.lib().curv_gather2d(_lib.stream_ptr(), src.data_ptr(), src.stride(0), src.stride(1),
+                                        rows.data_ptr() if rows is not None else None,
+                                        cols.data_ptr() if cols is not None else None, out.data_ptr(), R, C),
+               "curv_gather2d")
     return out
 
 
@@ -342,12 +393,15 @@ def inf_vtv_assemble(V4: torch.Tensor, sigma: torch.Tensor, a: int, b: int) -> t
     return out
 
 
-def diag_scale(src: torch.Tensor, dl: torch.Tensor, dr: torch.Tensor) -> torch.Tensor:
-    """float32 out[i,j] = src[i,j] dl[i] dr[j]; src float32 or float64, contiguous."""
+def diag_scale(src: torch.Tensor, dl: torch.Tensor, dr: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """float32 out[i,j] = src[i,j] dl[i] dr[j]; src float32 or float64, contiguous.  `out` is reused when it is a
+    contiguous float32 tensor of the right shape on the right device."""
     if not src.is_cuda or not src.is_contiguous() or src.dtype not in (torch.float32, torch.float64):
         raise RuntimeError("diag_scale: bad source")
     _require_gpu(dl, dr)
-    out = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    if out is None or out.shape != src.shape or out.dtype != torch.float32 or out.device != src.device \
+            or not out.is_contiguous():
+        out = torch.empty(src.shape, dtype=torch.float32, device=src.device)
     _lib.check(_lib.lib().curv_diag_scale(_lib.stream_ptr(), src.data_ptr(), int(src.dtype == torch.float64),
                                           out.data_ptr(), dl.data_ptr(), dr.data_ptr(), src.shape[0], src.shape[1]),
                "curv_diag_scale")
@@ -376,8 +430,13 @@ def chol_factor_inverse(mats: Sequence[torch.Tensor], diag_adds: Sequence[float]
     return outs
 
 
-def eigh(mats: Sequence[torch.Tensor], with_values: bool = False, max_sweeps: int = 0, tol: float = 0.0):
-    """Eigenvectors (columns, ascending eigenvalues) of symmetric float32 matrices, batched block-Jacobi."""
+def eigh(mats: Sequence[torch.Tensor], with_values: bool = False, max_sweeps: int = 0, tol: float = 0.0,
+         allow_unconverged: bool = False):
+    """Eigenvectors (columns, ascending eigenvalues) of symmetric float32 matrices, batched block-Jacobi.
+
+    Raises ``RuntimeError`` when the iteration has not converged to `tol` within `max_sweeps` sweeps (defaults
+    1e-8 / 60; the loop ends at convergence, Kronecker factors of ResNets need 19-23) unless
+    `allow_unconverged` is set, in which case the last iterate is returned and ``eigh.converged`` is False."""
     from ._lib import curv_eigh_desc
     n = len(mats)
     if n == 0:
@@ -399,29 +458,82 @@ def eigh(mats: Sequence[torch.Tensor], with_values: bool = False, max_sweeps: in
         raise RuntimeError("eigh: matrix size out of range")
     ws = workspace(need, mats[0].device, "eigh")
     sweeps = ctypes.c_int(0)
-    _lib.check(L.curv_syevd(_lib.stream_ptr(), arr, n, ws.data_ptr(), ws.numel(), int(max_sweeps), float(tol),
-                            ctypes.byref(sweeps)), "curv_syevd")
+    rc = L.curv_syevd(_lib.stream_ptr(), arr, n, ws.data_ptr(), ws.numel(), int(max_sweeps), float(tol),
+                      ctypes.byref(sweeps))
     eigh.last_sweeps = sweeps.value
+    eigh.converged = rc == 0
+    if not (rc == _lib.ERR_NOT_CONVERGED and allow_unconverged):
+        _lib.check(rc, "curv_syevd")
     return (vecs, vals) if with_values else vecs
+
+
+def kron(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Kronecker product, reference index convention (utils.py:288-310): (ar*br) x (ac*bc)."""
+    a, b = a.contiguous(), b.contiguous()
+    _require_gpu(a, b)
+    if a.dim() != 2 or b.dim() != 2:
+        raise RuntimeError("kron: 2-D operands expected")
+    out = torch.empty(a.shape[0] * b.shape[0], a.shape[1] * b.shape[1], dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().curv_kron(_lib.stream_ptr(), a.data_ptr(), a.shape[0], a.shape[1], b.data_ptr(),
+                                    b.shape[0], b.shape[1], out.data_ptr()), "curv_kron")
+    return out
+
+
+def concat(parts: Sequence[torch.Tensor]) -> torch.Tensor:
+    """1-D concatenation of contiguous float32 GPU tensors: one batched copy launch."""
+    for t in parts:
+        _require_gpu(t)
+    total = sum(t.numel() for t in parts)
+    out = torch.empty(total, dtype=torch.float32, device=parts[0].device)
+    pos, dsts = 0, []
+    for t in parts:
+        dsts.append(out[pos:pos + t.numel()])
+        pos += t.numel()
+    CopyPlan(dsts, [t.reshape(-1) for t in parts]).run()
+    return out
+
+
+class Gemm64:
+    """float64 C = alpha * A @ B [+ beta * C] on strided 2-D GPU views; C = None allocates the output."""
+    __slots__ = ("A", "B", "C", "alpha", "beta")
+
+    def __init__(self, A, B, C=None, alpha=1.0, beta=0.0):
+        self.A, self.B, self.C, self.alpha, self.beta = A, B, C, float(alpha), float(beta)
+
+
+def gemm_f64_batched(jobs: Sequence[Gemm64]) -> List[torch.Tensor]:
+    """All products through one call of curv_gemm_f64_batched (it launches four descriptors at a time)."""
+    n = len(jobs)
+    if n == 0:
+        return []
+    d = (curv_gemm64_desc * n)()
+    outs = []
+    for k, j in enumerate(jobs):
+        for t in (j.A, j.B):
+            if not t.is_cuda or t.dtype != torch.float64 or t.dim() != 2:
+                raise RuntimeError("gemm_f64 operands must be 2-D float64 GPU tensors")
+        M, K = j.A.shape
+        K2, N = j.B.shape
+        if K != K2:
+            raise RuntimeError("gemm_f64: shape mismatch")
+        C = j.C
+        if C is None:
+            if j.beta != 0.0:
+                raise RuntimeError("gemm_f64: beta needs an existing C")
+            C = torch.empty(M, N, dtype=torch.float64, device=j.A.device)
+        elif not C.is_cuda or C.dtype != torch.float64 or tuple(C.shape) != (M, N):
+            raise RuntimeError("gemm_f64: bad output tensor")
+        outs.append(C)
+        d[k].A, d[k].B, d[k].C = j.A.data_ptr(), j.B.data_ptr(), C.data_ptr()
+        d[k].a_rs, d[k].a_cs = j.A.stride()
+        d[k].b_rs, d[k].b_cs = j.B.stride()
+        d[k].c_rs, d[k].c_cs = C.stride()
+        d[k].M, d[k].N, d[k].K, d[k].alpha, d[k].beta = M, N, K, j.alpha, j.beta
+    _lib.check(_lib.lib().curv_gemm_f64_batched(_lib.stream_ptr(), d, n), "curv_gemm_f64_batched")
+    return outs
 
 
 def gemm_f64(A: torch.Tensor, B: torch.Tensor, alpha: float = 1.0, beta: float = 0.0,
              C: Optional[torch.Tensor] = None) -> torch.Tensor:
     """float64 C = alpha * A @ B [+ beta * C] on strided 2-D GPU views."""
-    for t in (A, B):
-        if not t.is_cuda or t.dtype != torch.float64 or t.dim() != 2:
-            raise RuntimeError("gemm_f64 operands must be 2-D float64 GPU tensors")
-    M, K = A.shape
-    K2, N = B.shape
-    if K != K2:
-        raise RuntimeError("gemm_f64: shape mismatch")
-    if C is None:
-        C = torch.empty(M, N, dtype=torch.float64, device=A.device)
-    d = (curv_gemm64_desc * 1)()
-    d[0].A, d[0].B, d[0].C = A.data_ptr(), B.data_ptr(), C.data_ptr()
-    d[0].a_rs, d[0].a_cs = A.stride()
-    d[0].b_rs, d[0].b_cs = B.stride()
-    d[0].c_rs, d[0].c_cs = C.stride()
-    d[0].M, d[0].N, d[0].K, d[0].alpha, d[0].beta = M, N, K, float(alpha), float(beta)
-    _lib.check(_lib.lib().curv_gemm_f64_batched(_lib.stream_ptr(), d, 1), "curv_gemm_f64_batched")
-    return C
+    return gemm_f64_batched([Gemm64(A, B, C, alpha, beta)])[0]

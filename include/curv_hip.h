@@ -25,13 +25,14 @@
 extern "C" {
 #endif
 
-#define CURV_ABI_VERSION 1
+#define CURV_ABI_VERSION 2
 
 #define CURV_OK 0
 #define CURV_ERR_NOT_PD 1
 #define CURV_ERR_INVALID 2
 #define CURV_ERR_WORKSPACE 3
 #define CURV_ERR_HIP 4
+#define CURV_ERR_NOT_CONVERGED 5
 
 int curv_version(void);
 const char* curv_last_error(void);
@@ -140,6 +141,7 @@ int curv_chol_factor_inverse(void* stream, const curv_cholinv_desc* descs, int n
 #define CURV_EPI_SQUARE 1
 #define CURV_EPI_MUL_E 2
 #define CURV_EPI_ADD_E 3
+#define CURV_EPI_MUL_E_ADD_F 4   /* alpha*acc*E + F: INF.sampler's Y_l - r^2 * X_p_s written onto the mean (:596-599) */
 /* triangular-operand hints: the K range of every output tile is cut where the operand is known to be 0 */
 #define CURV_TRI_NONE 0
 #define CURV_TRI_A_LOWER 1   /* op(A)(i,k) = 0 for k > i  (e.g. A = L_G) */
@@ -156,6 +158,8 @@ typedef struct curv_gemm_desc {
   float alpha, beta;
   int32_t tri;
   int32_t reserved;
+  const float* F;          /* second elementwise operand (CURV_EPI_MUL_E_ADD_F), else NULL */
+  long long f_rs, f_cs;
 } curv_gemm_desc;
 
 size_t curv_gemm_workspace_bytes(int n_desc);
@@ -212,7 +216,10 @@ int curv_copy_batched(void* stream, const curv_copy_desc* descs, int n);
  * optional) the eigenvalues of F (the reference decomposes F + F^T: same vectors, doubled values, and it
  * discards the values).  Signs / bases of degenerate clusters are arbitrary, as with LAPACK.
  * The call synchronises the stream once per sweep to test convergence (off(A) <= tol * ||A||_F);
- * max_sweeps <= 0 and tol <= 0 select the defaults (30, 1e-8).  n <= 8192.
+ * max_sweeps <= 0 and tol <= 0 select the defaults (60, 1e-8).  n <= 8192.  If the iteration has not
+ * converged after max_sweeps sweeps the outputs hold the last iterate and the call returns
+ * CURV_ERR_NOT_CONVERGED (curv_last_error() carries the final off-norm ratio); *sweeps_done is the
+ * number of sweeps executed either way.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct curv_eigh_desc {
   const float* F;
@@ -249,6 +256,15 @@ int curv_inf_vtv_assemble(void* stream, const float* V4, const float* sigma, int
 /* dst[i][j] = src[i][j] * dl[i] * dr[j] (src fp32 or fp64, dst fp32): P_c = diag(s) L_c diag(s) (:570) */
 int curv_diag_scale(void* stream, const void* src, int src_is_f64, float* dst, const float* dl, const float* dr,
                     int rows, int cols);
+/* out[r][c] = src[(row_index ? row_index[r] : r) * src_rs + (col_index ? col_index[c] : c) * src_cs], out dense
+ * (rows x cols): the `.t().flatten()` views of _dim_reduction (:617-618) and its `[:, I]` / `[I x J]` selections
+ * (:636-645) with the int64 index lists curv_inf_select produced, without leaving the device. */
+int curv_gather2d(void* stream, const float* src, long long src_rs, long long src_cs, const int64_t* row_index,
+                  const int64_t* col_index, float* out, int rows, int cols);
+/* Kronecker product with the reference's index convention (curvature/utils.py:288-310):
+ * out[(i*br + k)][(j*bc + l)] = a[i][j] * b[k][l]; a is ar x ac, b is br x bc, out (ar*br) x (ac*bc), dense
+ * row-major.  The estimators never form it (pre_sampler's closed form); exported for `utils.kron`. */
+int curv_kron(void* stream, const float* a, int ar, int ac, const float* b, int br, int bc, float* out);
 /* out[i][j] = A(i,j) * B(i,j) for strided 2-D views (EFB.sample's z * inv^T, :458) */
 int curv_mul2d(void* stream, const float* A, long long a_rs, long long a_cs, const float* B, long long b_rs,
                long long b_cs, float* out, int rows, int cols);

@@ -16,7 +16,7 @@ def declared_functions():
 def test_library_builds_and_loads():
     _lib.build()
     assert os.path.exists(_lib.LIB_PATH)
-    assert _lib.lib().curv_version() == 1
+    assert _lib.lib().curv_version() == _lib.ABI_VERSION
 
 
 def test_every_declared_symbol_is_exported_and_bound():

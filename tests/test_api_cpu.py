@@ -117,3 +117,48 @@ def test_partition_layers_resnet50():
     for i, d in enumerate(dims):
         if d[0] == 4608:
             assert sum(1 for o in owner8 if o == owner8[i]) == 1
+
+
+def test_global_layer_index_and_shard_kwargs():
+    """Per-layer hyper-parameter lists are indexed by the position among ALL selected layers in modules() order,
+    also on a rank that owns only some of them; estimators accept `shard=` at construction."""
+    from curvature_amd import sharding
+    from curvature_amd.curvatures import EFB, INF
+    m = models.lenet5()
+    layers = [l for l in m.modules() if l.__class__.__name__ in ('Linear', 'Conv2d')]
+    shard = sharding.Shard([0, 1, 0, 1, 1], rank=1, world=2)
+    d = Diagonal(m, shard=shard)
+    assert d._global_index() == {l: i for i, l in enumerate(layers)}
+    assert [i for i, _ in d._owned()] == [1, 3, 4]
+    k = KFAC(m, 'Linear', shard=sharding.Shard([0, 1, 1], rank=1, world=2))
+    assert [i for i, _ in k._owned()] == [1, 2] and list(k._global_index().values()) == [0, 1, 2]
+    # EFB / INF with given eigenvectors do no device work at construction
+    eig = {l: (torch.eye(2), torch.eye(2)) for l in layers}
+    e = EFB(m, {}, shard=shard, eigvecs=eig)
+    assert e.eigvecs is eig and [layers.index(l) for l in e._mine()] == [1, 3, 4]
+    facs = {l: [torch.eye(2), torch.eye(2)] for l in layers}
+    i = INF(m, {l: torch.ones(2, 2) for l in layers}, facs, {l: torch.ones(2, 2) for l in layers}, shard=shard, eigvecs=eig)
+    assert [layers.index(l) for l in i.diags.keys()] == [1, 3, 4] and list(i.lambdas.keys()) == list(i.diags.keys())
+    with pytest.raises(AssertionError):
+        INF(m, {}, facs, {l: torch.ones(2, 2) for l in layers}, eigvecs=eig)
+
+
+def test_diagonal_state_order_with_attention():
+    m = torch.nn.Sequential(torch.nn.Linear(4, 4))
+    m.add_module("attn", torch.nn.MultiheadAttention(4, 2))
+    m.add_module("attn2", torch.nn.MultiheadAttention(4, 2))
+    m.add_module("out", torch.nn.Linear(4, 2))
+    d = Diagonal(m)
+    assert list(d._global_index().keys()) == [m[0], 'attn_in', 'attn_out', m.out]
+    assert len(d._attention()) == 2 and len(d._layers()) == 2        # out_proj is not a selected 'Linear'
+
+
+def test_noise_seed_is_lazy_and_per_instance():
+    m = models.lenet5()
+    a, b = KFAC(m), KFAC(m)
+    assert a.noise_seed is None and b.noise_seed is None            # nothing drawn at construction
+    torch.manual_seed(5)
+    sa, sb = a._seed(), b._seed()
+    assert sa != sb and a._seed() == sa                              # two draws from torch's generator; then pinned
+    torch.manual_seed(5)
+    assert KFAC(m)._seed() == sa

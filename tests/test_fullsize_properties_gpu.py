@@ -111,11 +111,12 @@ def test_invert_and_sample_properties(gpu, resnet50_kfac):
 @pytest.mark.gpu
 def test_resnet18_full_estimator_chain(gpu):
     """SURVEY 8(d) config 3 at full size: Diagonal -> KFAC -> EFB -> INF(rank = 100) -> invert -> sample on an
-    ImageNet ResNet-18 (random init, N = 8).  No oracle at this size; checked through what must hold anyway."""
+    ImageNet ResNet-18 (random init, N = 32 as SURVEY 8(d) prescribes).  No oracle at this size; checked through
+    what must hold anyway."""
     from curvature_amd import models
     from curvature_amd.curvatures import Diagonal, KFAC, EFB, INF
     torch.manual_seed(0)
-    N, rank = 8, 100
+    N, rank = 32, 100
     model = models.resnet18().to(gpu).train()
     diag, kfac = Diagonal(model), KFAC(model)
     x = torch.randn(N, 3, 224, 224, device=gpu)
@@ -128,10 +129,7 @@ def test_resnet18_full_estimator_chain(gpu):
     assert len(layers) == 21 and list(diag.state.keys()) == layers
     efb = EFB(model, kfac.state)
     efb.update(N)
-    inf = INF(model, diag.state, kfac.state, efb.state)      # second decomposition of unchanged factors: cached
-    for layer in layers:
-        for u_efb, u_inf in zip(efb.eigvecs[layer], inf.eigvecs[layer]):
-            assert torch.equal(u_efb, u_inf) and u_efb.data_ptr() != u_inf.data_ptr()
+    inf = INF(model, diag.state, kfac.state, efb.state, eigvecs=efb.eigvecs)   # reuse, do not decompose again
     # eigenvectors of the largest factor: orthonormal, and they diagonalise it
     big = max(layers, key=lambda l: kfac.state[l][0].shape[0])
     A = kfac.state[big][0].double()
@@ -167,3 +165,82 @@ def test_resnet18_full_estimator_chain(gpu):
         assert changed == 22                                   # 21 weights + the fc bias; BatchNorm restored
     L_A = kfac.inv_state[big][0]
     assert torch.equal(L_A, torch.tril(L_A))
+
+
+@pytest.mark.gpu
+def test_config5_resnet50_inf_chain(gpu, resnet50_kfac):
+    """SURVEY 8(d) config 5 on one GPU: ResNet-50 (N = 32) through Diagonal -> KFAC -> EFB -> INF(rank = 100) ->
+    invert at (1, 1000) and at the README's INF values (145307, 60; README.rst:263) -> sample_and_replace, with
+    the size-independent properties of the ResNet-18 chain plus a per-layer comparison with the oracle
+    (oracle.inf_invert / inf_sampler, fp64) on the layers small enough for its explicit Kronecker matrix."""
+    import oracle.curvature_oracle as o
+    from curvature_amd.curvatures import Diagonal, EFB, INF
+    model, kfac = resnet50_kfac
+    N, rank = 32, 100
+    layers = kfac._layers()
+    diag = Diagonal(model)
+    diag.update(N)                                             # gradients of the fixture's backward pass
+    efb = EFB(model, kfac.state)
+    efb.update(N)
+    assert list(diag.state.keys()) == layers and list(efb.state.keys()) == layers
+    # eigenvectors of a large and a small factor: orthonormal, diagonalising, ascending
+    for layer in (max(layers, key=lambda l: kfac.state[l][0].shape[0]), layers[1]):
+        for F, U in zip(kfac.state[layer], efb.eigvecs[layer]):
+            Fd, Ud = F.double(), U.double()
+            n = Fd.shape[0]
+            assert (Ud.t() @ Ud - torch.eye(n, dtype=torch.float64, device=gpu)).abs().max().item() < 1e-5
+            D = Ud.t() @ Fd @ Ud
+            assert (D - torch.diag(torch.diagonal(D))).norm().item() <= 1e-5 * Fd.norm().item()
+            w = torch.diagonal(D)
+            assert (w[1:] >= w[:-1] - 1e-6 * w.abs().max()).all()
+    for layer in layers:
+        assert (efb.state[layer] >= 0).all() and torch.isfinite(efb.state[layer]).all()
+    inf = INF(model, diag.state, kfac.state, efb.state, eigvecs=efb.eigvecs)
+    inf.update(rank=rank)
+    small = []
+    for layer in layers:
+        ua, ug, lam, corr = inf.state[layer]
+        n_l, m_l = kfac.state[layer][0].shape[0], kfac.state[layer][1].shape[0]
+        a, b = ua.shape[1], ug.shape[1]
+        assert ua.shape[0] == n_l and ug.shape[0] == m_l and 1 <= a <= min(rank, n_l) and 1 <= b <= min(rank, m_l)
+        assert a * b >= min(rank, n_l * m_l) and lam.numel() == a * b and corr.numel() == n_l * m_l
+        small.append((n_l * m_l * a * b, layer))
+    # bit-exact index sets against the oracle's selection on the same Lambda, for three layers
+    for _, layer in sorted(small, key=lambda t: t[0])[:3]:
+        U_A, U_G = efb.eigvecs[layer]
+        ref = o.inf_update(U_A.cpu(), U_G.cpu(), efb.state[layer].cpu(), diag.state[layer].cpu(), rank)
+        ua, ug, lam, corr = inf.state[layer]
+        assert torch.equal(ua.cpu(), ref[0]) and torch.equal(ug.cpu(), ref[1]) and torch.equal(lam.cpu(), ref[2])
+        scale = float(torch.linalg.norm(diag.state[layer].double()))
+        assert float(torch.linalg.norm(corr.double().cpu() - ref[3].double())) / scale < 1e-5
+    for add, mul in ((1.0, 1000.0), (145307.0, 60.0)):
+        pre = {l: tuple(t.clone() for t in inf.state[l]) for _, l in sorted(small, key=lambda t: t[0])[:3]}
+        inf.invert(add, mul)
+        for layer in layers:
+            ua, ug, r, Pc = inf.inv_state[layer]
+            assert torch.isfinite(r).all() and torch.isfinite(Pc).all() and Pc.shape == (ua.shape[1] * ug.shape[1],) * 2
+        # oracle in fp64 on the three smallest layers: r, P_c and a sample for the same noise
+        for layer, st in pre.items():
+            ua, ug, lam, corr = (t.double().cpu() for t in st)
+            _, sigma, r64, vtv64, Pc64 = o.inf_invert(ua, ug, lam, corr, add, mul)
+            _, _, r, Pc = inf.inv_state[layer]
+            assert rel_fro(r, r64) < 1e-6
+            e_pc = rel_fro(Pc, Pc64)
+            X = torch.randn(r.numel(), generator=torch.Generator().manual_seed(5))
+            s = inf.sample(layer, X=X.to(gpu))
+            e_s = rel_fro(s, o.inf_sampler(ua, ug, r64, Pc64, X.double()))
+            print(f"config 5, ({add}, {mul}), n*m={r.numel()}, ab={Pc.shape[0]}: P_c err {e_pc:.2e}, sample err {e_s:.2e}")
+            assert e_s < 1e-4, (add, mul, e_s)
+            assert e_pc < 1e-3, (add, mul, e_pc)
+        inf.sample_and_replace()
+        changed = 0
+        for k, v in model.state_dict().items():
+            assert torch.isfinite(v).all(), k
+            changed += int(not torch.equal(v, inf.model_state[k]))
+        assert changed == 54 + 1
+    for est in (diag, efb):
+        est.invert(1.0, 1000.0)
+        est.sample_and_replace()
+        changed = sum(int(not torch.equal(v, est.model_state[k])) for k, v in model.state_dict().items())
+        assert changed == 54 + 1
+    kfac.model.load_state_dict(kfac.model_state)

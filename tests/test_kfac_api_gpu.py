@@ -169,6 +169,55 @@ def test_sharded_ranks_cover_the_unsharded_result(gpu):
             assert torch.equal(LA, full[li][0]) and torch.equal(LG, full[li][1])     # bitwise: same kernels, same inputs
 
 
+def test_sharded_efb_inf_diagonal_cover_the_unsharded_result(gpu):
+    """The same for Diagonal / EFB / INF: with a Shard every rank decomposes, updates,
+    inverts and samples only its own layers, per-layer hyper-parameter LISTS are still indexed by the global
+    layer position, and the union over the ranks is bit-identical to the unsharded run."""
+    from curvature_amd import sharding
+    from curvature_amd.curvatures import KFAC, Diagonal, EFB, INF
+    g1 = load("g1_kfac_lenet.npz")
+    adds, muls = [0.5, 1.0, 2.0, 0.25, 3.0], [1.0, 10.0, 100.0, 5.0, 50.0]
+    costs = [sharding.layer_cost(n, m, K) for n, m, K in [(26, 6, 6272), (151, 16, 800), (401, 120, 8), (121, 84, 8), (85, 10, 8)]]
+    results = {}
+    for world, rank in [(1, 0), (2, 0), (2, 1)]:
+        model, layers = lenet_with_golden_weights(gpu, g1)
+        shard = None
+        if world > 1:
+            shard = sharding.Shard(sharding.lpt_partition(costs, world), rank, 1)     # world=1 inside: no collective
+        kfac, diag = KFAC(model, shard=shard), Diagonal(model, shard=shard)
+        list(run_batches(model, [kfac, diag], g1, gpu, nb=2))
+        efb = EFB(model, kfac.state, shard=shard)
+        list(run_batches(model, [efb], g1, gpu, nb=1))
+        inf = INF(model, diag.state, kfac.state, efb.state, shard=shard, eigvecs=efb.eigvecs)
+        inf.update(rank=10)
+        owned = [li for li, l in enumerate(layers) if shard is None or shard.owns(li)]
+        for est in (diag, efb, inf):
+            assert [layers.index(l) for l in est.state.keys()] == owned
+            est.invert(add=adds, multiply=muls)
+        noise = {l: torch.randn(kfac.state[l][0].shape[0] * kfac.state[l][1].shape[0],
+                                generator=torch.Generator().manual_seed(li)).to(gpu)
+                 for li, l in enumerate(layers) if li in owned}
+        out = {}
+        inf.sample_and_replace(noise=noise)
+        for li in owned:
+            out[li] = dict(diag=diag.inv_state[layers[li]].clone(), efb=efb.inv_state[layers[li]].clone(),
+                           lam=efb.state[layers[li]].clone(), r=inf.inv_state[layers[li]][2].clone(),
+                           Pc=inf.inv_state[layers[li]][3].clone(), w=layers[li].weight.detach().clone(),
+                           b=layers[li].bias.detach().clone())
+        # layers of other ranks stay at the mean (their values arrive through the all-gather in a real run)
+        for li, l in enumerate(layers):
+            if li not in owned:
+                assert torch.equal(l.weight.data, inf.model_state_of(l, 'weight'))
+        results[(world, rank)] = out
+    full = results[(1, 0)]
+    o0, o1 = set(results[(2, 0)]), set(results[(2, 1)])
+    assert o0 and o1 and o0.isdisjoint(o1) and o0 | o1 == set(range(5))
+    for part in (results[(2, 0)], results[(2, 1)]):
+        for li, vals in part.items():
+            for k, v in vals.items():
+                assert torch.equal(v, full[li][k]), (li, k)
+
+
 @pytest.mark.gpu
 def test_copy_batched_matches_torch(gpu):
     """curv_copy_batched: any size / alignment / dtype, several launches' worth of buffers."""

@@ -229,6 +229,7 @@ def gen_lenet():
     inf10.invert(add=add, multiply=mul)
     for li, layer in enumerate(layers_of(kfac)):
         g8[f"Pc64_l{li}"] = npf(inf10.inv_state[layer][3]).astype(np.float32)
+    inv64 = dict(inf10.inv_state)
     inf10.state = {l: tuple(t.clone() for t in v) for l, v in st32.items()}
     inf10.inv_state = {}
     inf10.invert(add=add, multiply=mul)
@@ -255,6 +256,20 @@ def gen_lenet():
     torch.manual_seed(99)
     for li, layer in enumerate(layers_of(kfac)):
         g9[f"sample_l{li}"] = npf(inf10.sample(layer))
+    # fp64 twin: the reference's own sampler on its float64 inverse state with the SAME noise.  The sampler
+    # draws X itself (torch.randn(..., dtype=eigvecs.dtype), curvatures.py:590), and a float64 draw is a
+    # different stream, so torch.randn is pinned to the recorded X for the duration of each call.
+    inv32 = inf10.inv_state
+    inf10.inv_state = inv64
+    real_randn = torch.randn
+    try:
+        for li, layer in enumerate(layers_of(kfac)):
+            X64 = torch.from_numpy(g9[f"X_l{li}"]).double()
+            torch.randn = lambda *a, _x=X64, **k: _x.clone()
+            g9[f"sample64_l{li}"] = npf(inf10.sample(layer)).astype(np.float32)
+    finally:
+        torch.randn = real_randn
+        inf10.inv_state = inv32
     save("g9_inf_sample.npz", **g9)
 
 
