@@ -75,7 +75,7 @@ class curv_gemm_desc(ctypes.Structure):
 
 
 class curv_cholinv_desc(ctypes.Structure):
-    _fields_ = [("M", ctypes.c_void_p), ("X", ctypes.c_void_p), ("n", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    _fields_ = [("M", ctypes.c_void_p), ("X", ctypes.c_void_p), ("n", ctypes.c_int32), ("m_is_f64", ctypes.c_int32),
                 ("diag_add", ctypes.c_double)]
 
 
@@ -124,6 +124,9 @@ SIGNATURES = {
     "curv_inf_select": (_i, [_vp, ctypes.POINTER(curv_select_desc), _i]),
     "curv_colpairs": (_i, [_vp, _vp, _i, _i, _ll, _vp]),
     "curv_inf_vtv_assemble": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "curv_inf_vtv_assemble_f64": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "curv_colpairs_f64": (_i, [_vp, _vp, _i, _i, _ll, _vp]),
+    "curv_square_f64": (_i, [_vp, _vp, _vp, _ll]),
     "curv_diag_scale": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i]),
     "curv_gather2d": (_i, [_vp, _vp, _ll, _ll, _vp, _vp, _vp, _i, _i]),
     "curv_kron": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),

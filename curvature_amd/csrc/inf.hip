@@ -112,16 +112,28 @@ inf_select_kernel(SelBatch batch, int n_desc) {
   }
 }
 
-// out[p][i*a + k] = U[p][i] * U[p][k]   (rows of the Khatri-Rao square used by the closed-form vtv)
+// out[p][i*a + k] = U[p][i] * U[p][k]   (rows of the Khatri-Rao square used by the closed-form vtv);
+// T = double: the product of two fp32 values is exact
+template <typename T>
 __global__ void __launch_bounds__(256)
-colpairs_kernel(const float* __restrict__ U, int n, int a, long long u_rs, float* __restrict__ out) {
+colpairs_kernel(const float* __restrict__ U, int n, int a, long long u_rs, T* __restrict__ out) {
   const long long total = (long long)n * a * a;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
     const int p = (int)(e / ((long long)a * a));
     const int rem = (int)(e - (long long)p * a * a);
     const int i = rem / a, k = rem - i * a;
-    out[e] = U[p * u_rs + i] * U[p * u_rs + k];
+    out[e] = (T)U[p * u_rs + i] * (T)U[p * u_rs + k];
+  }
+}
+
+// out[i] = (double) v[i]^2
+__global__ void __launch_bounds__(256)
+square_f64_kernel(const float* __restrict__ v, double* __restrict__ out, long long count) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) {
+    const double x = (double)v[e];
+    out[e] = x * x;
   }
 }
 
@@ -140,9 +152,10 @@ diag_scale_kernel(const T* __restrict__ src, float* __restrict__ dst, const floa
 
 // V4[(i,k),(j,l)] (a*a x b*b) -> vtv[(i,j),(k,l)] (ab x ab) scaled by sigma, then symmetrised:
 //   vtv[x][y] = (w(x,y) + w(y,x)) / 2,  w((i,j),(k,l)) = sigma[i*b+j] sigma[k*b+l] V4[(i*a+k)][(j*b+l)]
+template <typename T>
 __global__ void __launch_bounds__(256)
-vtv_assemble_kernel(const float* __restrict__ V4, const float* __restrict__ sigma, int a, int b,
-                    float* __restrict__ vtv) {
+vtv_assemble_kernel(const T* __restrict__ V4, const float* __restrict__ sigma, int a, int b,
+                    T* __restrict__ vtv) {
   const int ab = a * b;
   const long long total = (long long)ab * ab;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -150,10 +163,10 @@ vtv_assemble_kernel(const float* __restrict__ V4, const float* __restrict__ sigm
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
     const int x = (int)(e / ab), y = (int)(e - (long long)x * ab);
     const int i = x / b, j = x - i * b, k = y / b, l = y - k * b;
-    const float sxy = sigma[x] * sigma[y];
-    const float w1 = sxy * V4[(long long)(i * a + k) * ld4 + (j * b + l)];
-    const float w2 = sxy * V4[(long long)(k * a + i) * ld4 + (l * b + j)];
-    vtv[e] = (w1 + w2) * 0.5f;
+    const T sxy = (T)sigma[x] * (T)sigma[y];
+    const T w1 = sxy * V4[(long long)(i * a + k) * ld4 + (j * b + l)];
+    const T w2 = sxy * V4[(long long)(k * a + i) * ld4 + (l * b + j)];
+    vtv[e] = (w1 + w2) * (T)0.5;
   }
 }
 
@@ -218,8 +231,25 @@ extern "C" int curv_inf_select(void* stream, const curv_select_desc* descs, int 
 extern "C" int curv_colpairs(void* stream, const float* U, int n, int a, long long u_row_stride, float* out) {
   if (n <= 0 || a <= 0) return CURV_OK;
   CURV_REQUIRE(U && out, "curv_colpairs: null pointer");
-  hipLaunchKernelGGL(colpairs_kernel, grid_for((long long)n * a * a), dim3(256), 0, (hipStream_t)stream, U, n, a,
+  hipLaunchKernelGGL(colpairs_kernel<float>, grid_for((long long)n * a * a), dim3(256), 0, (hipStream_t)stream, U, n, a,
                      u_row_stride, out);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}
+
+extern "C" int curv_colpairs_f64(void* stream, const float* U, int n, int a, long long u_row_stride, double* out) {
+  if (n <= 0 || a <= 0) return CURV_OK;
+  CURV_REQUIRE(U && out, "curv_colpairs_f64: null pointer");
+  hipLaunchKernelGGL(colpairs_kernel<double>, grid_for((long long)n * a * a), dim3(256), 0, (hipStream_t)stream, U, n, a,
+                     u_row_stride, out);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}
+
+extern "C" int curv_square_f64(void* stream, const float* v, double* out, long long count) {
+  if (count <= 0) return CURV_OK;
+  CURV_REQUIRE(v && out, "curv_square_f64: null pointer");
+  hipLaunchKernelGGL(square_f64_kernel, grid_for(count), dim3(256), 0, (hipStream_t)stream, v, out, count);
   CURV_LAUNCH_CHECK();
   return CURV_OK;
 }
@@ -241,7 +271,16 @@ extern "C" int curv_diag_scale(void* stream, const void* src, int src_is_f64, fl
 extern "C" int curv_inf_vtv_assemble(void* stream, const float* V4, const float* sigma, int a, int b, float* vtv) {
   if (a <= 0 || b <= 0) return CURV_OK;
   CURV_REQUIRE(V4 && sigma && vtv, "curv_inf_vtv_assemble: null pointer");
-  hipLaunchKernelGGL(vtv_assemble_kernel, grid_for((long long)a * b * a * b), dim3(256), 0, (hipStream_t)stream, V4,
+  hipLaunchKernelGGL(vtv_assemble_kernel<float>, grid_for((long long)a * b * a * b), dim3(256), 0, (hipStream_t)stream, V4,
+                     sigma, a, b, vtv);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}
+
+extern "C" int curv_inf_vtv_assemble_f64(void* stream, const double* V4, const float* sigma, int a, int b, double* vtv) {
+  if (a <= 0 || b <= 0) return CURV_OK;
+  CURV_REQUIRE(V4 && sigma && vtv, "curv_inf_vtv_assemble_f64: null pointer");
+  hipLaunchKernelGGL(vtv_assemble_kernel<double>, grid_for((long long)a * b * a * b), dim3(256), 0, (hipStream_t)stream, V4,
                      sigma, a, b, vtv);
   CURV_LAUNCH_CHECK();
   return CURV_OK;

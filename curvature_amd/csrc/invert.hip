@@ -41,7 +41,7 @@ struct InvDev {
   int n, np, P;
   float sqrt_s, sqrt_n;
   int reverse;          // 1: factor J M J and emit L = J X^T J (KFAC.invert); 0: plain M, emit X = chol(M)^-1
-  int pad;
+  int f64_in;           // reverse == 0 only: F points to an fp64 matrix (INF's V_s^T V_s), damping added in fp64
   double* Xout;         // reverse == 0: (n x n) fp64 output, lower triangular
 };
 
@@ -91,6 +91,25 @@ inv_prepare_kernel(const InvDev* __restrict__ t, int nf) {
   const gfloat* F = (const gfloat*)d.F;
   gdouble* W = (gdouble*)d.W;
   if (bi == 0 && bj == 0 && threadIdx.x == 0) *d.info = 0;
+  if (d.f64_in) {
+    // fp64 input (already symmetric by construction; symmetrised again at no cost): W = (M + M^T) / 2 + add * I
+    const gdouble* M = (const gdouble*)d.F;
+    const int w0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c0 = threadIdx.x & 63;
+    const int jj = bj * NB + c0;
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+      const int i = bi * NB + w0 + 4 * u;
+      double v;
+      if (i < n && jj < n) {
+        v = 0.5 * (M[(long long)i * n + jj] + M[(long long)jj * n + i]);
+        if (i == jj) v += (double)sn;
+      } else {
+        v = (i == jj) ? 1.0 : 0.0;
+      }
+      W[(long long)i * np + jj] = v;
+    }
+    return;
+  }
   // The symmetrisation needs F[ri][rj] and its mirror F[rj][ri]: the mirror block is read row-wise (coalesced)
   // into LDS and consumed transposed, instead of 64 lanes striding through 64 rows of F.  A wave owns the rows
   // w, w + 4, ... of the block, so every row base is wave-uniform; all 32 loads of a lane are issued before
@@ -1034,7 +1053,8 @@ extern "C" int curv_chol_factor_inverse(void* stream_, const curv_cholinv_desc* 
     CURV_REQUIRE(s.n > 0 && s.M != nullptr && s.X != nullptr, "curv_chol_factor_inverse: matrix %d invalid", i);
     InvDev& d = tab[i];
     memset(&d, 0, sizeof(d));
-    d.F = s.M; d.Xout = s.X; d.n = s.n;
+    d.F = reinterpret_cast<const float*>(s.M); d.Xout = s.X; d.n = s.n;
+    d.f64_in = s.m_is_f64 ? 1 : 0;
     d.P = cdiv(s.n, NB); d.np = d.P * NB;
     d.info = info + i;
     d.sqrt_s = 1.0f;

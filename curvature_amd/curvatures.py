@@ -222,15 +222,23 @@ class Diagonal(Curvature):
     _supports_mha = True
 
     def update(self, batch_size: int):
-        for _, layer in self._owned():
-            bias_grad = layer.bias.grad if layer.bias is not None else None
-            self.state[layer] = ops.sq_accumulate(layer.weight.grad.contiguous(), bias_grad, batch_size,
-                                                  self.state.get(layer))
-        for layer in self._attention():
-            for key, weight, bias in (('attn_in', layer.in_proj_weight, layer.in_proj_bias),
-                                      ('attn_out', layer.out_proj.weight, layer.out_proj.bias)):
-                self.state[key] = ops.sq_accumulate(weight.grad.contiguous(), bias.grad, batch_size,
-                                                    self.state.get(key))
+        # one pass over modules() so that `state` gets the reference's insertion order (curvatures.py:149-174),
+        # which is the order per-layer hyper-parameter lists are indexed by
+        owned = {l for _, l in self._owned()}
+        for layer in self.model.modules():
+            name = layer.__class__.__name__
+            if name not in self.layer_types:
+                continue
+            if name in ('Linear', 'Conv2d'):
+                if layer in owned:
+                    bias_grad = layer.bias.grad if layer.bias is not None else None
+                    self.state[layer] = ops.sq_accumulate(layer.weight.grad.contiguous(), bias_grad, batch_size,
+                                                          self.state.get(layer))
+            elif name == 'MultiheadAttention':
+                for key, weight, bias in (('attn_in', layer.in_proj_weight, layer.in_proj_bias),
+                                          ('attn_out', layer.out_proj.weight, layer.out_proj.bias)):
+                    self.state[key] = ops.sq_accumulate(weight.grad.contiguous(), bias.grad, batch_size,
+                                                        self.state.get(key))
 
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
         assert self.state, "State dict is empty. Did you call 'update' prior to this?"
@@ -736,20 +744,41 @@ class INF(Curvature):
         P_c tensors, overwritten in place where the shape still fits."""
         if not regs:
             return []
-        dev = regs[0][0].device
-        stage1, stage2, parts = [], [], []
+        # bound the float64 scratch of a batch (PA, M, V4, vtv, the two inverses, T, L_c per layer): layers are
+        # processed in groups of at most ~24 GB, far below the 288 GB of the device
+        def scratch(reg):
+            (n, a), (m, b) = reg[0].shape, reg[1].shape
+            return 8.0 * (n * a * a + m * b * b + n * m + a * a * m + 6.0 * (a * b) ** 2)
+        if len(regs) > 1:
+            groups, cur, size = [], [], 0.0
+            for k, reg in enumerate(regs):
+                if cur and size + scratch(reg) > 24e9:
+                    groups.append(cur)
+                    cur, size = [], 0.0
+                cur.append(k)
+                size += scratch(reg)
+            groups.append(cur)
+            if len(groups) > 1:
+                res: List[Optional[Tensor]] = [None] * len(regs)
+                for g in groups:
+                    part = INF.pre_sampler_many([regs[k] for k in g], [outs[k] for k in g] if outs is not None else None)
+                    for k, t in zip(g, part):
+                        res[k] = t
+                return res
+        # V_s^T V_s in closed form, fp64 end to end: with strongly varying r (e.g. invert(1, 1000) on a ResNet) it is a
+        # badly conditioned weighted Gram matrix, and an fp32 evaluation caps P_c - and the samples - at ~1e-3
+        # (measured on ResNet-50's stem: 1.7e-3; with fp64: at the level of the fp32 inputs)
+        first, parts = [], []
         for ua, ug, sigma, r in regs:
             (n, a), (m, b) = ua.shape, ug.shape
-            PA, PG = ops.colpairs(ua), ops.colpairs(ug)                  # (n, a*a), (m, b*b)
-            r2 = ops.mul(r, r).view(n, m)
-            M = torch.empty(a * a, m, dtype=torch.float32, device=dev)
-            V4 = torch.empty(a * a, b * b, dtype=torch.float32, device=dev)
-            stage1.append(ops.Gemm(PA.t(), r2, M))
-            stage2.append(ops.Gemm(M, PG, V4))
-            parts.append((V4, sigma, a, b))
-        ops.gemm_batched(stage1)
-        ops.gemm_batched(stage2)
-        vtvs = [ops.inf_vtv_assemble(V4, sigma, a, b) for V4, sigma, a, b in parts]
+            PA, PG = ops.colpairs(ua, f64=True), ops.colpairs(ug, f64=True)      # (n, a*a), (m, b*b)
+            r2 = ops.square_f64(r).view(n, m)
+            first.append(ops.Gemm64(PA.t(), r2))
+            parts.append((PG, sigma, a, b))
+        Ms = ops.gemm_f64_batched(first)
+        V4s = ops.gemm_f64_batched([ops.Gemm64(M, PG) for M, (PG, _, _, _) in zip(Ms, parts)])
+        vtvs = [ops.inf_vtv_assemble(V4.contiguous(), sigma, a, b) for V4, (_, sigma, a, b) in zip(V4s, parts)]
+        del first, Ms, V4s, parts
         mats, adds = [], []
         for v in vtvs:
             mats += [v, v]
@@ -768,14 +797,12 @@ class INF(Curvature):
 
     @staticmethod
     def vtv(frst_eigvecs: Tensor, scnd_eigvecs: Tensor, reg_lambda: Tensor, reg_inv_correction: Tensor) -> Tensor:
-        """V_s^T V_s, symmetrised, in closed form (no Kronecker matrix)."""
+        """V_s^T V_s, symmetrised, in closed form (no Kronecker matrix), evaluated in float64."""
         (n, a), (m, b) = frst_eigvecs.shape, scnd_eigvecs.shape
-        PA, PG = ops.colpairs(frst_eigvecs), ops.colpairs(scnd_eigvecs)      # (n, a*a), (m, b*b)
-        r2 = ops.mul(reg_inv_correction, reg_inv_correction).view(n, m)
-        M = torch.empty(a * a, m, dtype=torch.float32, device=PA.device)
-        V4 = torch.empty(a * a, b * b, dtype=torch.float32, device=PA.device)
-        ops.gemm_batched([ops.Gemm(PA.t(), r2, M)])
-        ops.gemm_batched([ops.Gemm(M, PG, V4)])
+        PA, PG = ops.colpairs(frst_eigvecs, f64=True), ops.colpairs(scnd_eigvecs, f64=True)
+        r2 = ops.square_f64(reg_inv_correction).view(n, m)
+        M = ops.gemm_f64(PA.t(), r2)
+        V4 = ops.gemm_f64(M, PG)
         return ops.inf_vtv_assemble(V4, reg_lambda, a, b)
 
     @staticmethod

@@ -375,21 +375,32 @@ def inf_select(lambda_vec: torch.Tensor, n: int, m: int, rank: int):
     return inf_select_many([lambda_vec], [(n, m)], rank)[0]
 
 
-def colpairs(U: torch.Tensor) -> torch.Tensor:
-    """(n, a) -> (n, a*a) with out[p, i*a+k] = U[p,i] U[p,k]."""
+def colpairs(U: torch.Tensor, f64: bool = False) -> torch.Tensor:
+    """(n, a) -> (n, a*a) with out[p, i*a+k] = U[p,i] U[p,k]; `f64`: exact products in float64."""
     _require_gpu(U)
     n, a = U.shape
-    out = torch.empty(n, a * a, dtype=torch.float32, device=U.device)
-    _lib.check(_lib.lib().curv_colpairs(_lib.stream_ptr(), U.data_ptr(), n, a, U.stride(0), out.data_ptr()),
-               "curv_colpairs")
+    out = torch.empty(n, a * a, dtype=torch.float64 if f64 else torch.float32, device=U.device)
+    fn = _lib.lib().curv_colpairs_f64 if f64 else _lib.lib().curv_colpairs
+    _lib.check(fn(_lib.stream_ptr(), U.data_ptr(), n, a, U.stride(0), out.data_ptr()), "curv_colpairs")
+    return out
+
+
+def square_f64(v: torch.Tensor) -> torch.Tensor:
+    """float64 v**2 of a float32 tensor (same shape)."""
+    _require_gpu(v)
+    out = torch.empty(v.shape, dtype=torch.float64, device=v.device)
+    _lib.check(_lib.lib().curv_square_f64(_lib.stream_ptr(), v.data_ptr(), out.data_ptr(), v.numel()), "curv_square_f64")
     return out
 
 
 def inf_vtv_assemble(V4: torch.Tensor, sigma: torch.Tensor, a: int, b: int) -> torch.Tensor:
-    _require_gpu(V4, sigma)
-    out = torch.empty(a * b, a * b, dtype=torch.float32, device=V4.device)
-    _lib.check(_lib.lib().curv_inf_vtv_assemble(_lib.stream_ptr(), V4.data_ptr(), sigma.data_ptr(), a, b,
-                                                out.data_ptr()), "curv_inf_vtv_assemble")
+    """vtv (ab x ab) from V4 (a*a x b*b), in V4's precision (float32 or float64)."""
+    _require_gpu(sigma)
+    if not V4.is_cuda or not V4.is_contiguous() or V4.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("inf_vtv_assemble: bad V4")
+    out = torch.empty(a * b, a * b, dtype=V4.dtype, device=V4.device)
+    fn = _lib.lib().curv_inf_vtv_assemble_f64 if V4.dtype == torch.float64 else _lib.lib().curv_inf_vtv_assemble
+    _lib.check(fn(_lib.stream_ptr(), V4.data_ptr(), sigma.data_ptr(), a, b, out.data_ptr()), "curv_inf_vtv_assemble")
     return out
 
 
@@ -409,15 +420,17 @@ def diag_scale(src: torch.Tensor, dl: torch.Tensor, dr: torch.Tensor, out: Optio
 
 
 def chol_factor_inverse(mats: Sequence[torch.Tensor], diag_adds: Sequence[float]) -> List[torch.Tensor]:
-    """[chol_lower(M + d I)^-1] in float64 for symmetric float32 matrices (batched)."""
+    """[chol_lower(M + d I)^-1] in float64 for symmetric float32 or float64 matrices (batched)."""
     n = len(mats)
     arr = (curv_cholinv_desc * n)()
     outs = []
     for d, M, da in zip(arr, mats, diag_adds):
-        _require_gpu(M)
+        if not M.is_cuda or not M.is_contiguous() or M.dtype not in (torch.float32, torch.float64) or M.dim() != 2:
+            raise RuntimeError("chol_factor_inverse: contiguous float32 / float64 GPU matrices expected")
         X = torch.empty(M.shape, dtype=torch.float64, device=M.device)
         outs.append(X)
         d.M, d.X, d.n, d.diag_add = M.data_ptr(), X.data_ptr(), M.shape[0], float(da)
+        d.m_is_f64 = int(M.dtype == torch.float64)
     dev = mats[0].device
     info = torch.empty(n, dtype=torch.int32, device=dev)
     L = _lib.lib()

@@ -114,13 +114,13 @@ int curv_chol_inv_lower(void* stream, const curv_inv_desc* descs, int n_factors,
                         size_t workspace_bytes);
 
 /* X = chol_lower(M + diag_add * I)^-1 in fp64 for a batch of symmetric fp32 matrices (same blocked sweep,
- * no index reversal): the A_c^-1 and B_c^-1 of INF.pre_sampler (curvatures.py:566-567).  X is (n x n)
+ * no index reversal; M may also be given in fp64): the A_c^-1 and B_c^-1 of INF.pre_sampler (curvatures.py:566-567).  X is (n x n)
  * fp64, lower triangular with zeros above.  info as for curv_chol_inv_lower. */
 typedef struct curv_cholinv_desc {
-  const float* M;
+  const void* M;     /* fp32 matrix, or fp64 when m_is_f64 != 0 (diag_add is then added in fp64) */
   double* X;
   int32_t n;
-  int32_t reserved;
+  int32_t m_is_f64;
   double diag_add;
 } curv_cholinv_desc;
 
@@ -251,8 +251,14 @@ int curv_inf_select(void* stream, const curv_select_desc* descs, int n_desc);
 /* out[p][i*a + k] = U[p][i] * U[p][k]: rows of the Khatri-Rao square in the closed form of V_s^T V_s
  * (pre_sampler :556-564 without the (n m) x (a b) Kronecker matrix). U is n x a with row stride u_rs. */
 int curv_colpairs(void* stream, const float* U, int n, int a, long long u_row_stride, float* out);
+/* the same in fp64 (exact products of fp32 values), and out = (double) v^2: the closed form of V_s^T V_s is evaluated
+ * in fp64 end to end (curv_gemm_f64_batched), because V_s^T V_s is ill-conditioned for strongly varying r (e.g.
+ * invert(1, 1000)) and an fp32 evaluation limits P_c to ~1e-3 there */
+int curv_colpairs_f64(void* stream, const float* U, int n, int a, long long u_row_stride, double* out);
+int curv_square_f64(void* stream, const float* v, double* out, long long count);
 /* vtv[(i,j),(k,l)] = (w + w^T)/2, w = sigma_ij sigma_kl V4[(i,k),(j,l)]   (:564-565) */
 int curv_inf_vtv_assemble(void* stream, const float* V4, const float* sigma, int a, int b, float* vtv);
+int curv_inf_vtv_assemble_f64(void* stream, const double* V4, const float* sigma, int a, int b, double* vtv);
 /* dst[i][j] = src[i][j] * dl[i] * dr[j] (src fp32 or fp64, dst fp32): P_c = diag(s) L_c diag(s) (:570) */
 int curv_diag_scale(void* stream, const void* src, int src_is_f64, float* dst, const float* dl, const float* dr,
                     int rows, int cols);

@@ -169,6 +169,22 @@ def test_sharded_ranks_cover_the_unsharded_result(gpu):
             assert torch.equal(LA, full[li][0]) and torch.equal(LG, full[li][1])     # bitwise: same kernels, same inputs
 
 
+def replay_batch(model_layers, ests, g1, b, gpu):
+    """Feed batch `b` of golden g1 to the estimators WITHOUT running backward: the recorded layer inputs / raw
+    grad_outputs go into KFAC.record, the recorded parameter gradients into .grad.  (MIOpen's weight-gradient
+    kernels accumulate with atomics, so two backward passes of the same batch differ in the last bits; bitwise
+    comparisons between separately built estimators need bit-identical inputs.)"""
+    from curvature_amd.curvatures import KFAC
+    for li, layer in enumerate(model_layers):
+        layer.weight.grad = g1[f"b{b}_l{li}_gw"].to(gpu)
+        layer.bias.grad = g1[f"b{b}_l{li}_gb"].to(gpu)
+    for est in ests:
+        if isinstance(est, KFAC):
+            for li, layer in enumerate(model_layers):
+                est.record[layer] = [g1[f"b{b}_l{li}_x"].to(gpu), g1[f"b{b}_l{li}_g"].to(gpu)]
+        est.update(batch_size=8)
+
+
 def test_sharded_efb_inf_diagonal_cover_the_unsharded_result(gpu):
     """The same for Diagonal / EFB / INF: with a Shard every rank decomposes, updates,
     inverts and samples only its own layers, per-layer hyper-parameter LISTS are still indexed by the global
@@ -185,9 +201,10 @@ def test_sharded_efb_inf_diagonal_cover_the_unsharded_result(gpu):
         if world > 1:
             shard = sharding.Shard(sharding.lpt_partition(costs, world), rank, 1)     # world=1 inside: no collective
         kfac, diag = KFAC(model, shard=shard), Diagonal(model, shard=shard)
-        list(run_batches(model, [kfac, diag], g1, gpu, nb=2))
+        for b in range(2):
+            replay_batch(layers, [kfac, diag], g1, b, gpu)
         efb = EFB(model, kfac.state, shard=shard)
-        list(run_batches(model, [efb], g1, gpu, nb=1))
+        replay_batch(layers, [efb], g1, 0, gpu)
         inf = INF(model, diag.state, kfac.state, efb.state, shard=shard, eigvecs=efb.eigvecs)
         inf.update(rank=10)
         owned = [li for li, l in enumerate(layers) if shard is None or shard.owns(li)]

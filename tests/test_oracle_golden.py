@@ -194,3 +194,32 @@ def test_mc_fisher_loop():
     for li, layer in enumerate(layers):
         assert rel_fro(state[layer][0], g[f"A_l{li}"]) < 1e-6
         assert rel_fro(state[layer][1], g[f"G_l{li}"]) < 1e-6
+
+
+def _rel(a, b):
+    return float(torch.linalg.norm(a.double() - b.double()) / torch.linalg.norm(b.double()))
+
+
+def test_inf_sampler_gauge_dependence_of_the_reference():
+    """The measurement behind the gauge remark in tests/test_round2_gpu.py::test_inf_end_to_end_own_chain, on the CPU oracle (a restatement of the reference's sampler,
+    pinned against g9): same state, eigenvector columns negated -> a different sample."""
+    import oracle.curvature_oracle as o
+    g1, g5, g6, g8, g9 = (load(n) for n in ("g1_kfac_lenet.npz", "g5_eigvecs_lenet.npz", "g6_efb_lenet.npz",
+                                            "g8_inf_invert.npz", "g9_inf_sample.npz"))
+    add, mul = float(g8["add"]), float(g8["mul"])
+    moved = []
+    for li in range(2):
+        out = []
+        for flip in (False, True):
+            UA, UG = g5[f"UA_l{li}"].double(), g5[f"UG_l{li}"].double()
+            if flip:
+                UA, UG = UA.clone(), UG.clone()
+                UA[:, ::2] *= -1
+                UG[:, 1::3] *= -1
+            lam = sum(o.efb_update(UA, UG, g1[f"b{b}_l{li}_gw"].double(), g1[f"b{b}_l{li}_gb"].double()) for b in range(2))
+            ua, ug, l, D, _, _ = o.inf_update(UA, UG, lam, g6[f"diags_l{li}"].double(), 10)
+            _, _, r, _, Pc = o.inf_invert(ua, ug, l, D, add, mul)
+            out.append(o.inf_sampler(ua, ug, r, Pc, g9[f"X_l{li}"].double()))
+        assert _rel(out[0], g9[f"sample_l{li}"]) < 1e-6          # unflipped: the reference's sample
+        moved.append(_rel(out[1], out[0]))
+    assert moved[0] > 5e-3 and moved[1] > 2e-2, moved                # 1.7e-2 and 8.2e-2 measured
