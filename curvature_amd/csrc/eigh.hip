@@ -31,9 +31,15 @@ struct EighDev {
   double* A;            // (np x np) work matrix
   double* V;            // (np x np) accumulated rotations
   double* Q;            // (Nb/2) x 64 x 64 rotation blocks of the current step
-  double* norms;        // {off^2, diag^2}
-  int n, np, Nb, pad;
+  double* norms;        // per 64x64 tile {off^2, diag^2} partial sums (P*P pairs), summed in a fixed order
+  int* flags;           // {state, own sweeps}: state 0 = iterating, 1 = converged, 2 = max_sweeps reached
+  int n, np, Nb, spf;   // spf: steps per own sweep (Nb - 1): the matrix is tested - and frozen - after each of ITS sweeps
 };
+// Every matrix follows its own schedule: round r of its tournament is step % (Nb - 1), its convergence test runs
+// after each of its own sweeps, and a converged matrix is frozen (its tile counts drop to zero).  The result for a
+// matrix therefore does not depend on what else is in the batch - a rank that decomposes only its own layers gets
+// bit-identical eigenvectors to a run over all layers.
+__device__ __forceinline__ bool eig_active(const EighDev& d) { return d.flags[0] == 0; }
 
 template <typename CountFn>
 __device__ __forceinline__ bool eig_locate(const EighDev* __restrict__ t, int nf, int bid, CountFn cnt, int& f,
@@ -103,7 +109,7 @@ jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sw
   __shared__ int pairs[2 * 32];
   __shared__ double red[EIG_THREADS];
   int f, tp;
-  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return d.Nb / 2; }, f, tp)) return;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return eig_active(d) ? d.Nb / 2 : 0; }, f, tp)) return;
   const EighDev& d = t[f];
   int p, q;
   rr_pair(d.Nb, step, tp, p, q);
@@ -197,7 +203,7 @@ __global__ void __launch_bounds__(EIG_THREADS)
 jacobi_rows_kernel(const EighDev* __restrict__ t, int nf, int step) {
   __shared__ double As[NB * LDA], Bs[NB * LDA];
   int f, local;
-  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return (d.Nb / 2) * eig_groups(d.np / NB); }, f, local)) return;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return eig_active(d) ? (d.Nb / 2) * eig_groups(d.np / NB) : 0; }, f, local)) return;
   const EighDev& d = t[f];
   const int nct = d.np / NB, ng = eig_groups(nct), etw = eig_etw(nct), tp = local / ng, ct0 = (local - tp * ng) * etw, np = d.np, tid = threadIdx.x;
   const int ct1 = ct0 + etw < nct ? ct0 + etw : nct;
@@ -242,7 +248,7 @@ __global__ void __launch_bounds__(EIG_THREADS)
 jacobi_cols_kernel(const EighDev* __restrict__ t, int nf, int step) {
   __shared__ double As[NB * LDA], Bs[NB * LDA];
   int f, local;
-  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return (d.Nb / 2) * eig_groups(d.np / NB) * 2; }, f, local)) return;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return eig_active(d) ? (d.Nb / 2) * eig_groups(d.np / NB) * 2 : 0; }, f, local)) return;
   const EighDev& d = t[f];
   const int nrt = d.np / NB, ng = eig_groups(nrt), np = d.np, tid = threadIdx.x;
   const int which = local / ((d.Nb / 2) * ng);                      // 0: A, 1: V
@@ -282,12 +288,15 @@ jacobi_cols_kernel(const EighDev* __restrict__ t, int nf, int step) {
   }
 }
 
-// off-diagonal / diagonal squared norms of A (convergence test)
+// off-diagonal / diagonal squared norms of A (convergence test) of the matrices that finished one of their own
+// sweeps with step `step1 - 1`: per-tile partial sums, no atomics (the decision below must be reproducible)
 __global__ void __launch_bounds__(EIG_THREADS)
-eigh_norms_kernel(const EighDev* __restrict__ t, int nf) {
+eigh_norms_kernel(const EighDev* __restrict__ t, int nf, int step1) {
   __shared__ double r0[EIG_THREADS], r1[EIG_THREADS];
   int f, tile;
-  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { const int P = d.np / NB; return P * P; }, f, tile)) return;
+  if (!eig_locate(t, nf, blockIdx.x,
+                  [step1](const EighDev& d) { const int P = d.np / NB; return (eig_active(d) && step1 % d.spf == 0) ? P * P : 0; },
+                  f, tile)) return;
   const EighDev& d = t[f];
   const int P = d.np / NB, bi = tile / P, bj = tile - bi * P, np = d.np, tid = threadIdx.x;
   const gdouble* A = (const gdouble*)d.A;
@@ -303,7 +312,32 @@ eigh_norms_kernel(const EighDev* __restrict__ t, int nf) {
     if (tid < o) { r0[tid] += r0[tid + o]; r1[tid] += r1[tid + o]; }
     __syncthreads();
   }
-  if (tid == 0) { atomicAdd(d.norms, r0[0]); atomicAdd(d.norms + 1, r1[0]); }
+  if (tid == 0) { d.norms[2 * tile] = r0[0]; d.norms[2 * tile + 1] = r1[0]; }
+}
+
+// one workgroup per matrix: sum the tile partials in a fixed order, count the sweep, freeze the matrix when
+// off(A) <= tol ||A||_F (state 1) or when it has used up its sweeps (state 2)
+__global__ void __launch_bounds__(256)
+eigh_check_kernel(const EighDev* __restrict__ t, int nf, int step1, double tol2, int max_sweeps) {
+  __shared__ double r0[256], r1[256];
+  const EighDev& d = t[blockIdx.x];
+  if (d.flags[0] != 0 || step1 % d.spf != 0) return;
+  const int P = d.np / NB, tid = threadIdx.x;
+  double off = 0.0, dg = 0.0;
+  for (int e = tid; e < P * P; e += 256) { off += d.norms[2 * e]; dg += d.norms[2 * e + 1]; }
+  r0[tid] = off; r1[tid] = dg;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { r0[tid] += r0[tid + o]; r1[tid] += r1[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int sweeps = d.flags[1] + 1;
+    d.flags[1] = sweeps;
+    const double off2 = r0[0], all2 = r0[0] + r1[0];
+    if (off2 <= tol2 * all2) d.flags[0] = 1;
+    else if (sweeps >= max_sweeps || !(all2 == all2)) d.flags[0] = 2;
+  }
 }
 
 // eigenvalues ascending (bitonic sort of (value, index) in LDS) and the permuted eigenvectors, fp32
@@ -370,19 +404,29 @@ __global__ void __launch_bounds__(256) eigh_upload_kernel(EighDev* __restrict__ 
 }
 
 struct EighLayout {
-  size_t table, norms, perm, total;
+  size_t table, norms, flags, perm, total;
+  std::vector<size_t> norm_off;
   std::vector<size_t> a_off, v_off, q_off;
   int perm_stride;
 };
 
 static bool eigh_layout(const curv_eigh_desc* descs, int n, EighLayout& L) {
   L.table = align_up((size_t)std::max(n, 1) * sizeof(EighDev), 256);
-  L.norms = align_up((size_t)std::max(n, 1) * 2 * sizeof(double), 256);
   int nmax = 1;
-  for (int i = 0; i < n; ++i) { if (descs[i].n <= 0 || descs[i].n > SORT_MAX) return false; nmax = std::max(nmax, descs[i].n); }
+  size_t norm_doubles = 0;
+  L.norm_off.resize(n);
+  for (int i = 0; i < n; ++i) {
+    if (descs[i].n <= 0 || descs[i].n > SORT_MAX) return false;
+    nmax = std::max(nmax, descs[i].n);
+    const size_t P = (size_t)cdiv(descs[i].n, NB);
+    L.norm_off[i] = norm_doubles;
+    norm_doubles += 2 * P * P;
+  }
+  L.norms = align_up(std::max<size_t>(norm_doubles, 2) * sizeof(double), 256);
+  L.flags = align_up((size_t)std::max(n, 1) * 2 * sizeof(int), 256);
   L.perm_stride = nmax;
   L.perm = align_up((size_t)std::max(n, 1) * nmax * sizeof(int), 256);
-  size_t off = L.table + L.norms + L.perm;
+  size_t off = L.table + L.norms + L.flags + L.perm;
   L.a_off.resize(n); L.v_off.resize(n); L.q_off.resize(n);
   for (int i = 0; i < n; ++i) {
     const size_t np = (size_t)cdiv(descs[i].n, NB) * NB;
@@ -420,7 +464,8 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
   char* base = reinterpret_cast<char*>(workspace);
   EighDev* table = reinterpret_cast<EighDev*>(base);
   double* norms = reinterpret_cast<double*>(base + L.table);
-  int* perm = reinterpret_cast<int*>(base + L.table + L.norms);
+  int* flags = reinterpret_cast<int*>(base + L.table + L.norms);
+  int* perm = reinterpret_cast<int*>(base + L.table + L.norms + L.flags);
   std::vector<EighDev> tab(n_mats);
   long long prep_tiles = 0, pair_wgs = 0, row_tiles = 0, gather_tiles = 0;
   int maxNb = 2;
@@ -435,7 +480,9 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
     d.A = reinterpret_cast<double*>(base + L.a_off[i]);
     d.V = reinterpret_cast<double*>(base + L.v_off[i]);
     d.Q = reinterpret_cast<double*>(base + L.q_off[i]);
-    d.norms = norms + 2 * i;
+    d.norms = norms + L.norm_off[i];
+    d.flags = flags + 2 * i;
+    d.spf = std::max(1, d.Nb - 1);
     maxNb = std::max(maxNb, d.Nb);
     const long long P = d.np / NB;
     prep_tiles += P * P;
@@ -454,40 +501,52 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
   }
   hipLaunchKernelGGL(eigh_prepare_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats);
   CURV_LAUNCH_CHECK();
-  std::vector<double> host_norms(2 * n_mats);
-  int step = 0, sweeps = 0;
-  bool converged = false;
-  double worst_ratio = 0.0;
+  CURV_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)n_mats * 2 * sizeof(int), stream));
+  std::vector<int> host_flags(2 * n_mats);
   // One cyclic sweep over the 64x64 sub-problem per visit.  Diagonalising it to 1e-13 (up to ten inner sweeps)
   // cost 82 % of the solver's time and bought nothing: the outer iteration needs the same number of sweeps
   // either way (ResNet factors: 19-23, linear until the off-norm drops below the small eigenvalue gaps).
   const int inner_sweeps = 1;
   const double inner_tol2 = 1e-26;
   const int steps_per_sweep = std::max(1, maxNb - 1);
-  for (; sweeps < max_sweeps; ++sweeps) {
-    for (int s = 0; s < steps_per_sweep; ++s, ++step) {
-      hipLaunchKernelGGL(jacobi_pair_kernel, dim3((unsigned)pair_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, step, inner_sweeps, inner_tol2);
-      CURV_LAUNCH_CHECK();
-      hipLaunchKernelGGL(jacobi_rows_kernel, dim3((unsigned)row_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, step);
-      CURV_LAUNCH_CHECK();
-      hipLaunchKernelGGL(jacobi_cols_kernel, dim3((unsigned)(2 * row_tiles)), dim3(EIG_THREADS), 0, stream, table, n_mats, step);
-      CURV_LAUNCH_CHECK();
-    }
-    // convergence test (one host round trip per sweep)
-    CURV_HIP_CHECK(hipMemsetAsync(norms, 0, (size_t)n_mats * 2 * sizeof(double), stream));
-    hipLaunchKernelGGL(eigh_norms_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats);
+  const long long max_steps = (long long)max_sweeps * steps_per_sweep;
+  // the host looks at the per-matrix states once per sweep of the largest matrix (the only synchronisation);
+  // freezing itself happens on the device, after each matrix's own sweep
+  const int poll = steps_per_sweep;
+  bool all_done = false;
+  int sweeps = 0;
+  for (long long step = 0; step < max_steps && !all_done; ++step) {
+    hipLaunchKernelGGL(jacobi_pair_kernel, dim3((unsigned)pair_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step, inner_sweeps, inner_tol2);
     CURV_LAUNCH_CHECK();
-    CURV_HIP_CHECK(hipMemcpyAsync(host_norms.data(), norms, (size_t)n_mats * 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
-    CURV_HIP_CHECK(hipStreamSynchronize(stream));
-    bool done = true;
-    worst_ratio = 0.0;
-    for (int i = 0; i < n_mats; ++i) {
-      const double off2 = host_norms[2 * i], dg2 = host_norms[2 * i + 1];
-      if (!(off2 <= tol * tol * (off2 + dg2))) done = false;
-      const double ratio = (off2 + dg2) > 0.0 ? std::sqrt(off2 / (off2 + dg2)) : 0.0;
-      if (!(ratio <= worst_ratio)) worst_ratio = ratio;          // NaN-propagating maximum
+    hipLaunchKernelGGL(jacobi_rows_kernel, dim3((unsigned)row_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step);
+    CURV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(jacobi_cols_kernel, dim3((unsigned)(2 * row_tiles)), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step);
+    CURV_LAUNCH_CHECK();
+    const int step1 = (int)(step + 1);
+    bool any = false;
+    for (int i = 0; i < n_mats && !any; ++i) any = (step1 % tab[i].spf == 0);
+    if (any) {
+      hipLaunchKernelGGL(eigh_norms_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, step1);
+      CURV_LAUNCH_CHECK();
+      hipLaunchKernelGGL(eigh_check_kernel, dim3((unsigned)n_mats), dim3(256), 0, stream, table, n_mats, step1, tol * tol, max_sweeps);
+      CURV_LAUNCH_CHECK();
     }
-    if (done) { ++sweeps; converged = true; break; }
+    if (step1 % poll == 0 || step1 == max_steps) {
+      CURV_HIP_CHECK(hipMemcpyAsync(host_flags.data(), flags, (size_t)n_mats * 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+      CURV_HIP_CHECK(hipStreamSynchronize(stream));
+      all_done = true;
+      for (int i = 0; i < n_mats; ++i) all_done = all_done && host_flags[2 * i] != 0;
+    }
+  }
+  if (!all_done) {
+    CURV_HIP_CHECK(hipMemcpyAsync(host_flags.data(), flags, (size_t)n_mats * 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    CURV_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  bool converged = true;
+  int n_bad = 0, first_bad = -1;
+  for (int i = 0; i < n_mats; ++i) {
+    sweeps = std::max(sweeps, host_flags[2 * i + 1]);
+    if (host_flags[2 * i] != 1) { converged = false; ++n_bad; if (first_bad < 0) first_bad = i; }
   }
   if (sweeps_done) *sweeps_done = sweeps;
   hipLaunchKernelGGL(eigh_sort_kernel, dim3(n_mats), dim3(1024), 0, stream, table, perm, L.perm_stride);
@@ -496,7 +555,8 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
   CURV_LAUNCH_CHECK();
   if (!converged) {
     // the outputs hold the last iterate (sorted, gathered); the caller decides whether that is usable
-    set_error("curv_syevd: not converged after %d sweeps: off(A)/||A||_F = %.3e > tol %.3e", sweeps, worst_ratio, tol);
+    set_error("curv_syevd: not converged: %d of %d matrices (first: %d) still have off(A) > %.1e ||A||_F after %d sweeps",
+              n_bad, n_mats, first_bad, tol, max_sweeps);
     return CURV_ERR_NOT_CONVERGED;
   }
   return CURV_OK;

@@ -9,8 +9,10 @@
 //   * a workgroup stages the RAW activation patch of the channels its two row panels touch in LDS
 //     (never the unfolded matrix: a 3x3 conv reads each input pixel once per chunk instead of nine
 //     times) and MFMA operands are gathered from the patch with per-lane addresses
-//       addr(i, k) = lane_base(i) + ktab[k],
-//     lane_base encodes (channel, kh, kw), ktab[k] encodes (sample, out row, out col) of the chunk;
+//       addr(i, k) = lane_base(i) + koff(k),
+//     lane_base encodes (channel, kh, kw), koff (a scalar) encodes (sample, out row, out col) of the chunk;
+//     along an output row koff advances by a constant, so one address serves several MFMA steps through the
+//     immediate offsets of the LDS reads;
 //     row/plane strides are padded so that 32 consecutive unfolded rows hit 32 distinct banks;
 //   * the bias row of ones and the zero padding rows are two constant LDS words;
 //   * raw buffer loads of chunk t+1 are issued into registers before the MFMA loop of chunk t and written
@@ -33,17 +35,15 @@ namespace curv {
 
 constexpr int SYRK_THREADS = 256;
 constexpr int XCD_GROUP = 32;          // consecutive items that share an XCD
-constexpr int MAX_RL = 2;              // longest k-run (register budget: two operand sets of 4 * RL)
-constexpr int KTAB_MAX = 1024;         // k runs per chunk
+constexpr int GU = 2;                  // k steps (MFMA groups) per operand fetch: one address per operand row serves GU steps
 constexpr int PANEL_WORDS = 8704;      // LDS words per panel patch
 constexpr int PATCH_WORDS = 2 * PANEL_WORDS;   // >= 4 x (64x64) cross-wave reduce scratch
 constexpr int STAGE_SLOTS = 32;        // staging registers per panel per lane (floats)
 constexpr int PANEL_SLOT_ELEMS = STAGE_SLOTS * SYRK_THREADS;   // padded patch elements per panel
 // LDS word offsets
-constexpr int ZERO_OFF = 0;            // 16 zero words (padding rows read run elements 0..RL-1 from here)
+constexpr int ZERO_OFF = 0;            // 16 zero words (padding rows read their GU step elements from here)
 constexpr int ONE_OFF = 16;            // 16 one words (the bias row of ones)
-constexpr int KTAB_OFF = 32;
-constexpr int PATCH_OFF = KTAB_OFF + KTAB_MAX;
+constexpr int PATCH_OFF = 32;
 constexpr int SMEM_WORDS = PATCH_OFF + PATCH_WORDS;   // 18464 words = 73856 B -> 2 workgroups per CU
 static_assert(PATCH_WORDS >= 4 * 64 * 64, "reduce scratch must fit the patch region");
 static_assert(2 * SMEM_WORDS * 4 <= 160 * 1024, "two workgroups per CU");
@@ -64,7 +64,7 @@ struct FactorDev {
   int n_chunks;
   int RS, PS, SS, nch;     // LDS strides in words, channels per panel
   int cshift;              // log2 of the padded patch row length (lanes along x)
-  int RL;                  // k-run length: 1, 2 or 4 LDS-adjacent k values per operand address
+  int RL;                  // (reserved; the k loop no longer works with table-driven runs)
   int P, n_tiles;
   int cpi, n_slices;       // chunks per item, k-slices
   int item_base, n_items;
@@ -109,7 +109,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Position and extent of one K chunk.
 struct Chunk {
-  int s0, ns, oh0, ra, ow0, wa, nruns, niter, rows_in, cols_in, ih_base, iw_base;
+  int s0, ns, oh0, ra, ow0, wa, rows_in, cols_in, ih_base, iw_base;
 };
 
 template <int TMv>
@@ -117,7 +117,6 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
                                           const float* __restrict__ zeros_, int* smem) {
   (void)zeros_;            // (zeroed pad of the workspace: unused since padding comes from the buffer range check)
   float* fs = reinterpret_cast<float*>(smem);
-  int* ktab = smem + KTAB_OFF;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -157,7 +156,7 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   const int compact = d.compact, vec4 = d.vec4;
   const bool flat1 = d.flat && !vec4;                // flattened per-pixel factor staged with scalar loads
   const int NS = d.NS, R = d.R, Wc = d.Wc, n_rg = d.n_rg, n_cg = d.n_cg, n_chunks = d.n_chunks;
-  const int RS = d.RS, PS = d.PS, SS = d.SS, nch = d.nch, cshift = d.cshift, RL = d.RL;
+  const int RS = d.RS, PS = d.PS, SS = d.SS, nch = d.nch, cshift = d.cshift;
   const int HW = H * W;
 
   const int c_lo_i = i0 / khkw, c_lo_j = j0 / khkw;
@@ -213,8 +212,6 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
     c.s0 = sg * NS; c.ns = min(NS, N - c.s0);
     c.oh0 = rg * R; c.ra = min(R, Ho - c.oh0);
     c.ow0 = cg * Wc; c.wa = min(Wc, Wo - c.ow0);
-    c.nruns = c.ns * c.ra * ((c.wa + RL - 1) / RL);   // rows are padded to whole runs
-    c.niter = (c.nruns + 1) >> 1;                      // one run per lane half per iteration
     c.rows_in = compact ? c.ra : (c.ra - 1) * sh + kh;
     c.cols_in = compact ? c.wa : (c.wa - 1) * sw + kw;
     c.ih_base = c.oh0 * sh - ph;
@@ -558,82 +555,127 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
 
   f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
 
-  const int cxb = cx * 4;                      // byte step between the elements of a run
-  int bbase[4];                                // operand row bases as LDS byte addresses
-#pragma unroll
-  for (int o = 0; o < 4; ++o) bbase[o] = base[o] * 4;
+  // ---- MFMA loop over a chunk ----
+  // The chunk's k index is (sample s, output row r, output column w); the LDS word of operand row i at k is
+  //   lane_base(i) + s SS + r cy + w cx.
+  // An MFMA consumes two k values, one per lane half h.  They are paired
+  //   along the output row   (wa even, or nothing better): k = (s, r, 2 j + h)   step 2 cx per MFMA group
+  //   along the samples      (wa odd, ns even):            k = (2 s' + h, r, j)   step cx
+  // so that every lane walks an output row with a CONSTANT stride: one address per operand row (a scalar k offset
+  // folded into the lane's base by one v_mad) serves GU consecutive steps through the immediate offsets of the LDS
+  // reads.  The loop runs over units = (row run, group of GU steps); its only vector-ALU work is those four
+  // address instructions per unit of up to 4 GU MFMAs (the table-driven loop it replaces spent ~2 per MFMA on
+  // rebuilding addresses, and vector instructions do not hide behind another wave's MFMAs on this chip).
+  // With an odd row length and an odd sample count the last k of a row has no partner: it gets a unit of its own
+  // (one step) in which the h = 1 lanes of the A operand read the constant zero words instead of the patch.
+  int bbase[4], kmul_[4];                      // operand row bases as LDS byte addresses; 1 for patch rows, 0 for the
+#pragma unroll                                 // bias / padding rows (their address ignores k)
+  for (int o = 0; o < 4; ++o) { bbase[o] = base[o] * 4; kmul_[o] = kmask[o] & 1; }
 
-  struct Ops { float a0[MAX_RL], a1[MAX_RL], b0[MAX_RL], b1[MAX_RL]; int mask; };
-  auto load_ops = [&](auto rl_tag, Ops& op, int e) {
-    constexpr int RLc = decltype(rl_tag)::value;
-    const int koff = (e & 0xfffff) * 4;
-    op.mask = e >> 20;
+  struct Ops { float a0[GU], a1[GU], b0[GU], b1[GU]; };
+  auto load_ops = [&](auto ws_tag, Ops& op, int koff, const int (&hb)[4], const int (&kmul)[4], int ws_rt) {
+    constexpr int WS = decltype(ws_tag)::value;          // words between consecutive steps of a lane (0: run time)
     const char* lds = reinterpret_cast<const char*>(fs);
-    const int pa0 = bbase[0] + (koff & kmask[0]);
-    const int pa1 = bbase[1] + (koff & kmask[1]);
-    const int pb0 = bbase[2] + (koff & kmask[2]);
-    const int pb1 = bbase[3] + (koff & kmask[3]);
+    const unsigned kk = (unsigned)koff & 0xffffffu;      // scalar byte offset of the unit's first k
+    const int pa0 = (int)__umul24(kk, (unsigned)kmul[0]) + hb[0];        // one v_mad_u32_u24 each: the lane's base
+    const int pa1 = (int)__umul24(kk, (unsigned)kmul[1]) + hb[1];        // (+ its half's offset) + k offset, or,
+    const int pb0 = (int)__umul24(kk, (unsigned)kmul[2]) + hb[2];        // for bias / padding rows, the base alone
+    const int pb1 = (int)__umul24(kk, (unsigned)kmul[3]) + hb[3];
 #pragma unroll
-    for (int j = 0; j < RLc; ++j) {
-      op.a0[j] = *reinterpret_cast<const float*>(lds + pa0 + j * cxb);
-      op.a1[j] = *reinterpret_cast<const float*>(lds + pa1 + j * cxb);
-      op.b0[j] = *reinterpret_cast<const float*>(lds + pb0 + j * cxb);
-      op.b1[j] = *reinterpret_cast<const float*>(lds + pb1 + j * cxb);
+    for (int u = 0; u < GU; ++u) {
+      // WS > 0: the step offsets are immediates of the LDS reads.  Bias / padding rows read their GU steps from
+      // the 16 constant words at ONE_OFF / ZERO_OFF (GU * WS <= 16 words)
+      const int so = (WS > 0) ? u * WS * 4 : u * ws_rt * 4;
+      op.a0[u] = *reinterpret_cast<const float*>(lds + pa0 + (WS > 0 ? so : (int)__umul24((unsigned)so, (unsigned)kmul[0])));
+      op.a1[u] = *reinterpret_cast<const float*>(lds + pa1 + (WS > 0 ? so : (int)__umul24((unsigned)so, (unsigned)kmul[1])));
+      op.b0[u] = *reinterpret_cast<const float*>(lds + pb0 + (WS > 0 ? so : (int)__umul24((unsigned)so, (unsigned)kmul[2])));
+      op.b1[u] = *reinterpret_cast<const float*>(lds + pb1 + (WS > 0 ? so : (int)__umul24((unsigned)so, (unsigned)kmul[3])));
     }
   };
-  // SKIP: the wave sits on the diagonal (lower-left 32x32 block redundant); CHECK: some run of the chunk
-  // is padded or missing, so validity masks must be honoured.  Both are wave-uniform per chunk and
-  // compiled as separate loop bodies: the common body is branch-free between its MFMAs.
-  auto compute_ops = [&](auto rl_tag, auto part_tag, auto check_tag, Ops& op) {
-    constexpr int RLc = decltype(rl_tag)::value;
-    constexpr int PART = decltype(part_tag)::value;
-    constexpr bool CHECK = decltype(check_tag)::value;
-    constexpr int FULL = (1 << RLc) - 1;
-    if (CHECK) {
-      if (__ballot(op.mask != FULL) != 0ull) {   // some lane half has padded or missing elements: zero its A
+  // Which of the wave's four 32x32 blocks it accumulates (diagonal tiles: see `part` above) is decided by four
+  // wave-uniform flags, i.e. scalar branches around the MFMAs (a handful of scalar instructions next to 64-cycle
+  // matrix instructions) instead of one compiled loop body per role: with 4 roles x 4 strides x 2 tile sizes
+  // inlined, the register allocator spilled thousands of vector registers.
+  const bool do00 = part != 3, do01 = part != 2, do10 = (part == 0 || part == 2), do11 = part != 2;
+  auto compute_ops = [&](Ops& op, int cnt) {
 #pragma unroll
-        for (int j = 0; j < RLc; ++j) {
-          const bool v = (op.mask >> j) & 1;
-          op.a0[j] = v ? op.a0[j] : 0.0f;
-          op.a1[j] = v ? op.a1[j] : 0.0f;
-        }
+    for (int u = 0; u < GU; ++u) {
+      if (u < cnt) {
+        const float a0 = op.a0[u], a1 = op.a1[u];
+        if (do00) acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, op.b0[u], acc00, 0, 0, 0);
+        if (do01) acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, op.b1[u], acc01, 0, 0, 0);
+        if (do10) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, op.b0[u], acc10, 0, 0, 0);
+        if (do11) acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, op.b1[u], acc11, 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int j = 0; j < RLc; ++j) {
-      if (PART != 3) acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a0[j], op.b0[j], acc00, 0, 0, 0);
-      if (PART != 2) acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a0[j], op.b1[j], acc01, 0, 0, 0);
-      if (PART == 0 || PART == 2) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1[j], op.b0[j], acc10, 0, 0, 0);
-      if (PART != 2) acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1[j], op.b1[j], acc11, 0, 0, 0);
-    }
   };
 
-  auto mfma_runs = [&](auto rl_tag, auto part_tag, auto check_tag, int niter) {
-    Ops A, B;
-    const int last = 2 * niter - 1;          // table entries exist up to here
-    int it = kfirst;
-    load_ops(rl_tag, A, ktab[2 * it + h]);
-    int e = ktab[min(2 * (it + KSTRIDE) + h, last)];   // table entry fetched one iteration ahead
-    // retire the prologue's LDS reads here, so that inside the loop the compiler only has to wait for
-    // operands fetched a full MFMA group earlier
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
-    while (true) {
-      const int it1 = it + KSTRIDE;
-      const bool n1 = it1 < niter;
-      if (n1) { load_ops(rl_tag, B, e); e = ktab[min(2 * (it1 + KSTRIDE) + h, last)]; }
-      compute_ops(rl_tag, part_tag, check_tag, A);
-      if (!n1) break;
-      it = it1 + KSTRIDE;
-      const bool n2 = it < niter;
-      if (n2) { load_ops(rl_tag, A, e); e = ktab[min(2 * (it + KSTRIDE) + h, last)]; }
-      compute_ops(rl_tag, part_tag, check_tag, B);
-      if (!n2) break;
+  auto mfma_chunk = [&](auto ws_tag, const Chunk& c, bool by_sample) {
+    const int ws_rt = by_sample ? cx : 2 * cx;
+    const int nsteps = by_sample ? c.wa : c.wa >> 1;             // MFMA groups (k pairs) per row run
+    const int ngroups = (nsteps + GU - 1) / GU;                  // units per row run
+    const int n_runs = (by_sample ? c.ns >> 1 : c.ns) * c.ra;    // row runs: (sample [pair], output row)
+    const int s_bytes = (by_sample ? 2 * SS : SS) * 4, r_bytes = cy * 4, g_bytes = GU * ws_rt * 4;
+    const int hoff = h ? (by_sample ? SS : cx) * 4 : 0;
+    int hb[4];                                                   // lane bases with the lane half's k offset folded in
+#pragma unroll
+    for (int o = 0; o < 4; ++o) hb[o] = bbase[o] + (hoff & kmask[o]);
+    const int n_units = n_runs * ngroups;
+    // unit -> (sample index, row, group) kept as scalar counters; this wave takes every KSTRIDE-th unit
+    int unit = kfirst;
+    if (unit < n_units) {
+      int g = unit % ngroups, rr = unit / ngroups;
+      int r = rr % c.ra, si = rr / c.ra;
+      auto advance = [&]() {
+        unit += KSTRIDE;
+        g += KSTRIDE;
+        while (g >= ngroups) { g -= ngroups; if (++r == c.ra) { r = 0; ++si; } }
+      };
+      Ops A, B;
+      load_ops(ws_tag, A, si * s_bytes + r * r_bytes + g * g_bytes, hb, kmul_, ws_rt);
+      while (true) {
+        const int cnt_a = min(GU, nsteps - g * GU);
+        advance();
+        const bool more_b = unit < n_units;
+        // retire A's reads (issued a whole unit ago) before B's are issued: the MFMAs below then never wait on LDS
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+        if (more_b) load_ops(ws_tag, B, si * s_bytes + r * r_bytes + g * g_bytes, hb, kmul_, ws_rt);
+        compute_ops(A, cnt_a);
+        if (!more_b) break;
+        const int cnt_b = min(GU, nsteps - g * GU);
+        advance();
+        const bool more_a = unit < n_units;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (more_a) load_ops(ws_tag, A, si * s_bytes + r * r_bytes + g * g_bytes, hb, kmul_, ws_rt);
+        compute_ops(B, cnt_b);
+        if (!more_a) break;
+      }
+    }
+    if (!by_sample && (c.wa & 1)) {
+      // odd row length, no sample to pair with: the last column of every row, one step per row run, with the
+      // h = 1 lanes of the A operand reading the constant zero words.  Rare (odd widths with an odd sample
+      // count), short, and kept out of the loop above so that its operands stay free of selects.
+      const char* lds = reinterpret_cast<const char*>(fs);
+      const int tail_bytes = (c.wa - 1) * cx * 4;
+      for (int rr = kfirst; rr < n_runs; rr += KSTRIDE) {
+        const int r = rr % c.ra, si = rr / c.ra;
+        const unsigned kk = (unsigned)(si * s_bytes + r * r_bytes + tail_bytes) & 0xffffffu;
+        const int pa0 = h ? ZERO_OFF * 4 : (int)__umul24(kk, (unsigned)kmul_[0]) + bbase[0];
+        const int pa1 = h ? ZERO_OFF * 4 : (int)__umul24(kk, (unsigned)kmul_[1]) + bbase[1];
+        const int pb0 = (int)__umul24(kk, (unsigned)kmul_[2]) + bbase[2];
+        const int pb1 = (int)__umul24(kk, (unsigned)kmul_[3]) + bbase[3];
+        const float a0 = *reinterpret_cast<const float*>(lds + pa0), a1 = *reinterpret_cast<const float*>(lds + pa1);
+        const float b0 = *reinterpret_cast<const float*>(lds + pb0), b1 = *reinterpret_cast<const float*>(lds + pb1);
+        if (do00) acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+        if (do01) acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+        if (do10) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+        if (do11) acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+      }
     }
   };
 
   const int ch_begin = slice * d.cpi;
   const int ch_end = min(ch_begin + d.cpi, n_chunks);
-  int cur_ns = -1, cur_ra = -1, cur_wa = -1;
 
   __syncthreads();                       // ZERO/ONE visible
   Chunk cur = decode_chunk(min(ch_begin, n_chunks - 1));
@@ -641,24 +683,6 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
 
   for (int ch = ch_begin; ch < ch_end; ++ch) {
     // (all waves are past the MFMA loop of the previous chunk here)
-    if (cur.ns != cur_ns || cur.ra != cur_ra || cur.wa != cur_wa) {
-      cur_ns = cur.ns; cur_ra = cur.ra; cur_wa = cur.wa;
-      // one entry per k-run: LDS word offset of its first k, validity mask of its RL elements << 20
-      const int rpr = (cur.wa + RL - 1) / RL;          // runs per output row
-      const int rr = cur.ra * rpr;
-      for (int q = tid; q < 2 * cur.niter; q += SYRK_THREADS) {
-        int v = 0;
-        if (q < cur.nruns) {
-          const int s = q / rr;
-          const int rem = q - s * rr;
-          const int r = rem / rpr;
-          const int w = (rem - r * rpr) * RL;
-          const int nvalid = min(RL, cur.wa - w);
-          v = (s * SS + r * cy + w * cx) | (((1 << nvalid) - 1) << 20);
-        }
-        ktab[q] = v;
-      }
-    }
 #ifdef CURV_DIAG
     if (!(d.pad0 & 10) || ch == ch_begin) store_stage(cur);
 #else
@@ -676,29 +700,18 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
 #endif
     }
 
-    // ---- MFMA over this wave's share of the chunk's k-runs ----
-    // Per iteration each lane half owns one run of RL LDS-adjacent k values: one table lookup and one
-    // address per operand row feed RL MFMA groups.  Two register sets alternate so that the operand
-    // reads of iteration t+1 are in flight while the 4*RL MFMAs of iteration t issue.
+    // ---- MFMA over this wave's share of the chunk ----
 #ifdef CURV_DIAG
-    if (!idle && kfirst < work.niter && !(d.pad0 & 1)) {
+    if (!(d.pad0 & 1)) {
 #else
-    if (!idle && kfirst < work.niter) {
+    {
 #endif
-      using T = std::true_type;
-      using F = std::false_type;
-      const bool check = (work.wa % RL != 0) || (work.nruns & 1);
-      auto go = [&](auto rl_tag) {
-        auto with_part = [&](auto part_tag) {
-          if (check) mfma_runs(rl_tag, part_tag, T{}, work.niter); else mfma_runs(rl_tag, part_tag, F{}, work.niter);
-        };
-        if (part == 0) with_part(std::integral_constant<int, 0>{});
-        else if (part == 1) with_part(std::integral_constant<int, 1>{});
-        else if (part == 2) with_part(std::integral_constant<int, 2>{});
-        else with_part(std::integral_constant<int, 3>{});
-      };
-      if (RL == 2) go(std::integral_constant<int, 2>{});
-      else go(std::integral_constant<int, 1>{});
+      const bool by_sample = (work.wa & 1) && !(work.ns & 1) && work.ns > 1;
+      const int ws = by_sample ? cx : 2 * cx;              // words between consecutive steps: 1, 2 or 4
+      if (ws == 1) mfma_chunk(std::integral_constant<int, 1>{}, work, by_sample);
+      else if (ws == 2) mfma_chunk(std::integral_constant<int, 2>{}, work, by_sample);
+      else if (ws == 4) mfma_chunk(std::integral_constant<int, 4>{}, work, by_sample);
+      else mfma_chunk(std::integral_constant<int, 0>{}, work, by_sample);     // strides > 2: step offsets at run time
     }
     __syncthreads();
   }
@@ -914,7 +927,6 @@ static bool chunk_fits(const FactorDev& f, int NS, int R, int Wc, ChunkGeom& g) 
   g.rshift = 0;
   g.lin = 0;
   if ((long long)NS * g.SS + 16 > PANEL_WORDS) return false;       // + slack for padded run elements
-  if ((long long)NS * R * cdiv(Wc, f.RL) > KTAB_MAX) return false;
   if ((long long)NS * R * Wc > 4096) return false;
   if (NS > 127 || g.rows_in > 0xffff) return false;
   if ((long long)NS * f.C * f.H * f.W * 4 > 0x7fff0000ll) return false;   // buffer offsets of a chunk: 31 bits
@@ -1042,19 +1054,7 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     f.flat = (flattened && (f.nch & (f.nch - 1)) == 0) ? 1 : 0;
     f.vec4 = (f.flat && f.W % 4 == 0 && f.W >= 4 && (reinterpret_cast<uintptr_t>(s.src) & 15) == 0) ? 1 : 0;
 
-    // k-run length: 4 LDS-adjacent k values per operand address where the row padding it needs is
-    // cheaper than the address arithmetic it saves
-    {
-      const int cxs = f.compact ? 1 : f.sw;
-      double best = 1e30;
-      f.RL = 1;
-      for (int rl = 1; rl <= MAX_RL; rl *= 2) {
-        if (rl * cxs > 16) break;
-        const double padded = (double)cdiv(f.Wo, rl) * rl / f.Wo;
-        const double cost = padded * (1.0 + 0.5 / rl);
-        if (cost < best - 1e-9) { best = cost; f.RL = rl; }
-      }
-    }
+    f.RL = 1;
 
     // chunk extent: full-width rows if they fit, then as many rows, then as many samples
     ChunkGeom g;
@@ -1095,7 +1095,7 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     f.n_chunks = cdiv(f.N, NS) * f.n_rg * f.n_cg;
     f.P = cdiv(f.dim, f.TM);
     f.n_tiles = f.P * (f.P + 1) / 2;
-    const double kc = (double)NS * R * cdiv(Wc, f.RL) * f.RL;
+    const double kc = (double)NS * R * (Wc + (Wc & 1));
     const double q = f.TM / 64.0;
     chunk_cost[i] = kc * 32.0 * q * q + 1500.0;   // 64x64xk = 32 k CU-cycles; + staging / barriers
     total_cost += chunk_cost[i] * f.n_tiles * f.n_chunks;

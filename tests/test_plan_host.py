@@ -47,7 +47,7 @@ def test_plan_respects_budgets(d):
     flat = compact and d["sh"] == 1 and d["ph"] == 0
     assert p["dim"] == d["C"] * d["kh"] * d["kw"] + d["has_bias"]
     assert (p["Ho"], p["Wo"]) == ((1, Ho * Wo) if flat else (Ho, Wo))
-    assert p["TM"] in (64, 128) and p["RL"] in (1, 2)
+    assert p["TM"] in (64, 128) and p["RL"] == 1
     assert p["NS"] * p["SS"] + 16 <= PANEL_WORDS                      # LDS patch per panel
     rows_in = p["R"] if compact else (p["R"] - 1) * d["sh"] + d["kh"]
     cols_in = p["Wc"] if compact else (p["Wc"] - 1) * d["sw"] + d["kw"]
@@ -69,8 +69,7 @@ def test_plan_respects_budgets(d):
         passes = -(-(p["NS"] * rows_in) // (1 << p["rshift"]))
         groups = -(-p["nch"] // (row_lanes >> p["rshift"]))
         assert passes * groups <= SLOTS and p["SS"] == groups * (row_lanes >> p["rshift"]) * p["PS"]
-    runs = p["NS"] * p["R"] * -(-p["Wc"] // p["RL"])
-    assert runs <= KTAB_MAX
+    assert p["NS"] * p["R"] * p["Wc"] <= 4096            # k values per chunk
     # chunk grid covers all of K = N * Ho * Wo
     n_rg, n_cg, n_sg = -(-p["Ho"] // p["R"]), -(-p["Wo"] // p["Wc"]), -(-d["N"] // p["NS"])
     assert p["nchunks"] == n_rg * n_cg * n_sg

@@ -37,9 +37,9 @@ __device__ __forceinline__ void decode_tile(int t, int P, int& ti, int& tj) {
   tj = ti + t;
 }
 
-template <int PART>
+template <int PART, typename Hook>
 __device__ __forceinline__ void mfma_step(const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1,
-                                          f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, int ne) {
+                                          f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, int ne, Hook hook) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     if (e < ne) {
@@ -48,6 +48,8 @@ __device__ __forceinline__ void mfma_step(const f32x4& a0, const f32x4& a1, cons
       if (PART == 0 || PART == 2) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], c10, 0, 0, 0);
       if (PART != 2) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], c11, 0, 0, 0);
     }
+    if (e == 0) hook(0);          // one LDS-DMA piece behind a group of MFMAs: its issue cost hides under them
+    if (e == 2) hook(1);
   }
 }
 
@@ -94,39 +96,42 @@ __device__ __forceinline__ void flat_body(const Flat& d, int local, __attribute_
     px0 = 8 * (q * d.base_steps + min(q, d.rem_steps));
     last = (q == d.SPS - 1);
   };
-  auto issue = [&](int t) {
+  // next stage's DMA geometry (scalars) and the issue of one piece: piece i = (panel i >> 3, row group i & 7)
+  int n_soff[2] = {0, 0};
+  int n_gmax = 0;
+  unsigned n_buf = 0;
+  auto plan_next = [&](int t) {
     int s, px0, nsteps; bool last;
     stage_geo(t, s, px0, nsteps, last);
-    const int gmax = last ? (HW - px0 + 3) / 4 : 2 * nsteps;       // pixel groups this stage needs
-    const unsigned buf = (unsigned)(t & 1) * PANEL_B;
-    if (g_lane < gmax) {
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        if (p < n_panels) {
-          const int row0 = p ? j0 : i0;
-          int soff = ((s * C + row0) * HW + px0) * 4;
-          const unsigned lbase = (p ? 2u * PANEL_B : 0u) + buf + (unsigned)(4 * wave) * ROW_B;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lbase + i * 16 * ROW_B), 16, voff, soff, 0, 0);
-            soff += 16 * HW * 4;
-          }
-        }
-      }
+    n_gmax = last ? (HW - px0 + 3) / 4 : 2 * nsteps;               // pixel groups this stage needs
+    n_buf = (unsigned)(t & 1) * PANEL_B;
+    n_soff[0] = ((s * C + i0) * HW + px0) * 4;
+    n_soff[1] = ((s * C + j0) * HW + px0) * 4;
+  };
+  auto piece = [&](int i) {
+    const int p = i >> 3, slot = i & 7;
+    if (p < n_panels && g_lane < n_gmax) {
+      const unsigned lbase = (p ? 2u * PANEL_B : 0u) + n_buf + (unsigned)(4 * wave + 16 * slot) * ROW_B;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lbase), 16, voff, n_soff[p] + slot * 16 * HW * 4, 0, 0);
     }
   };
 
-  issue(t0);
+  plan_next(t0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) piece(i);
   for (int t = t0; t < t1; ++t) {
     __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's DMA of stage t has landed
     __syncthreads();                           // everyone's has; everyone is done reading the other buffer
-    if (t + 1 < t1) issue(t + 1);
+    const bool more = t + 1 < t1;
+    if (more) plan_next(t + 1);
     int s, px0, nsteps; bool last;
     stage_geo(t, s, px0, nsteps, last);
     const unsigned buf = (unsigned)(t & 1) * PANEL_B;
     auto rd = [&](int o, int j) { return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lds + addr[o][j] + buf); };
-    // software pipeline over the stage's steps: operands of step j + 1 are read while the MFMAs of step j issue
+    // software pipeline over the stage's steps: operands of step j + 1 are read while the MFMAs of step j issue;
+    // the 16 DMA pieces of stage t + 1 are issued two per step, each behind a group of MFMAs
     f32x4 a0 = rd(0, 0), a1 = rd(1, 0), b0 = rd(2, 0), b1 = rd(3, 0);
+    int next_piece = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j < nsteps) {
@@ -136,6 +141,7 @@ __device__ __forceinline__ void flat_body(const Flat& d, int local, __attribute_
         if (last && j == nsteps - 1 && d.nv_last < 8) {
           // the sample's final step: only nv_last of its 8 pixels exist
           ne = min(4, d.nv_last);
+          asm volatile("; sample tail" ::: "memory");      // keeps this a branch: if-converted, its 16 selects ran at every step
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const bool ok = (4 * h + e) < d.nv_last;
@@ -143,9 +149,14 @@ __device__ __forceinline__ void flat_body(const Flat& d, int local, __attribute_
             b0[e] = ok ? b0[e] : 0.0f; b1[e] = ok ? b1[e] : 0.0f;
           }
         }
-        mfma_step<PART>(a0, a1, b0, b1, c00, c01, c10, c11, ne);
+        mfma_step<PART>(a0, a1, b0, b1, c00, c01, c10, c11, ne, [&](int k) { if (more) piece(2 * j + k); });
+        next_piece = 2 * j + 2;
         if (j + 1 < 8 && j + 1 < nsteps) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
       }
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) if (i >= next_piece) piece(i);      // stages with fewer than 8 steps: the rest
     }
   }
 
