@@ -317,7 +317,9 @@ def main():
                                    "KFAC.update + invert(1.0, 1000.0) + sample_and_replace, 54 layers",
                        "batch": args.batch, "layers": n_layers,
                        "parallelism": f"layer-sharded x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "curv::syrk_patch_kernel", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "curv::syrk_patch_kernel + curv::syrk_flat_kernel (the factor build: "
+                                                       "implicit-im2col kernel + LDS-DMA kernel for flattened factors, timed "
+                                                       "together)", "achieved": achieved,
                          "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_F32_MFMA / 1e12),
                          "traffic": traffic, "traffic_source": traffic_source,
                          "flops_counted": "executed symmetric: sum (n(n+1)+m(m+1)) K over the rank's layers",

@@ -25,6 +25,7 @@
 //   * partial tiles go to fp32 slabs and a second kernel sums the k-slices in a fixed order, applies
 //     the scale and adds into the factor and its mirror image: deterministic, exactly symmetric.
 #include "common.h"
+#include "syrk_plan.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -33,8 +34,6 @@
 
 namespace curv {
 
-constexpr int SYRK_THREADS = 256;
-constexpr int XCD_GROUP = 32;          // consecutive items that share an XCD
 constexpr int GU = 2;                  // k steps (MFMA groups) per operand fetch: one address per operand row serves GU steps
 constexpr int PANEL_WORDS = 8704;      // LDS words per panel patch
 constexpr int PATCH_WORDS = 2 * PANEL_WORDS;   // >= 4 x (64x64) cross-wave reduce scratch
@@ -47,60 +46,6 @@ constexpr int PATCH_OFF = 32;
 constexpr int SMEM_WORDS = PATCH_OFF + PATCH_WORDS;   // 18464 words = 73856 B -> 2 workgroups per CU
 static_assert(PATCH_WORDS >= 4 * 64 * 64, "reduce scratch must fit the patch region");
 static_assert(2 * SMEM_WORDS * 4 <= 160 * 1024, "two workgroups per CU");
-
-struct FactorDev {
-  const float* src;
-  float* dst;
-  int N, C, H, W;          // source geometry (1x1/stride-1 convs arrive flattened to H = 1)
-  int kh, kw, sh, sw, ph, pw;
-  int Ho, Wo;
-  int khkw;
-  int rows, dim, has_bias;
-  int compact;             // kh == kw == 1: patch holds only the sampled pixels
-  int vec4;                // flattened per-pixel factor with 16-B aligned rows: float4 staging
-  int TM;                  // tile edge: 64 or 128
-  int NS, R, Wc;           // chunk extent: samples, output rows, output cols
-  int n_rg, n_cg;          // chunk grid (rows, cols); samples outermost
-  int n_chunks;
-  int RS, PS, SS, nch;     // LDS strides in words, channels per panel
-  int cshift;              // log2 of the padded patch row length (lanes along x)
-  int RL;                  // (reserved; the k loop no longer works with table-driven runs)
-  int P, n_tiles;
-  int cpi, n_slices;       // chunks per item, k-slices
-  int item_base, n_items;
-  int sub_base, n_sub;     // 64x64 sub-tiles for the reduce kernel
-  int first;
-  float scale;
-  int pad0;
-  int rshift;              // general staging: a lane group of 2^rshift folded rows; the other row lanes split channels
-  int flat;                // flattened per-pixel factor whose (sample, channel) rows are staged slot-regularly
-  unsigned rmagic;         // ceil(2^32 / patch rows per sample): folded (sample, row) index -> sample
-  int lin;                 // linear staging: lanes walk the contiguous rows x W source range, `lin` floats each
-  unsigned pmagic, wmagic; // linear staging: ceil(2^32 / lanes per sample), ceil(2^32 / W)
-  int pad2;
-  long long slab_base;     // in floats
-};
-static_assert(sizeof(FactorDev) % 8 == 0, "FactorDev must be 8-byte granular");
-
-__device__ __forceinline__ int find_segment(const FactorDev* __restrict__ descs, int n_factors, int id,
-                                            bool by_sub) {
-  // largest f with base[f] <= id; bases are ascending.  One ballot per 64 factors.
-  const int lane = threadIdx.x & 63;
-  int count = 0;
-  for (int f0 = 0; f0 < n_factors; f0 += 64) {
-    const int f = f0 + lane;
-    bool le = false;
-    if (f < n_factors) le = (by_sub ? descs[f].sub_base : descs[f].item_base) <= id;
-    count += __popcll(__ballot(le));
-  }
-  return __builtin_amdgcn_readfirstlane(count - 1);
-}
-
-__device__ __forceinline__ void decode_tile(int t, int P, int& ti, int& tj) {
-  ti = 0;
-  while (t >= P - ti) { t -= P - ti; ++ti; }
-  tj = ti + t;
-}
 
 typedef __attribute__((address_space(1))) float gfloat;      // global-address-space views
 typedef __attribute__((address_space(1))) f32x4 gf32x4;
@@ -754,11 +699,7 @@ syrk_patch_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_item
   // XCD-aware item order: workgroups that share an XCD (equal blockIdx % 8) take every 8th group of
   // XCD_GROUP consecutive items, i.e. neighbouring tiles of one k-slice of one factor, so the panels
   // they stage hit that XCD's L2, while every XCD still sees an even mix of all factors.
-  int item;
-  {
-    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
-    item = ((j / XCD_GROUP) * 8 + xcd) * XCD_GROUP + (j % XCD_GROUP);
-  }
+  const int item = xcd_item(blockIdx.x);
   if (item >= n_items) return;
   const int f = find_segment(descs, n_factors, item, false);
   const FactorDev& d = descs[f];
@@ -970,9 +911,12 @@ static bool chunk_fits(const FactorDev& f, int NS, int R, int Wc, ChunkGeom& g) 
 
 struct Plan {
   std::vector<FactorDev> f;             // caller order
-  std::vector<int> order;               // device-table order: factors by descending work per item
-  int n_items = 0;
-  int n_sub = 0;
+  // two kernels, two work lists: [0] the implicit-im2col patch kernel below, [1] the LDS-DMA kernel of
+  // syrk_flat.hip (flattened per-pixel factors); each with its own device table (factors by descending work per
+  // item) and item / sub-tile numbering, sharing one slab buffer
+  std::vector<int> order[2];
+  int n_items[2] = {0, 0};
+  int n_sub[2] = {0, 0};
   long long slab_floats = 0;
 };
 
@@ -1048,6 +992,20 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
 #endif
     CURV_REQUIRE((long long)f.N * f.C * f.H * f.W < (1LL << 31), "curv_kfac: factor %d: source too large", i);
 
+    if (flattened && syrk_flat_eligible(f, s.src)) {
+      // LDS-DMA kernel: whole 128-row tiles, K in stages of <= 32 pixels of one sample (syrk_flat.hip)
+      f.dma = 1;
+      f.TM = 128;
+      f.P = f.dim / 128;
+      f.n_tiles = f.P * (f.P + 1) / 2;
+      const int sps = syrk_flat_stages(f.W);
+      f.n_chunks = f.N * sps;
+      f.RL = 1;
+      chunk_cost[i] = (double)f.W / sps * 32.0 * 4.0 + 800.0;     // 128x128xk = 128 k CU-cycles; + barrier / DMA wait
+      total_cost += chunk_cost[i] * f.n_tiles * f.n_chunks;
+      continue;
+    }
+
     // tile edge: 128 where the padding it adds is small, 64 otherwise
     f.TM = (f.dim >= 256 && cdiv(f.dim, 128) * 128 <= f.dim + f.dim / 14) ? 128 : 64;
     f.nch = std::min(f.C, (f.khkw + f.TM - 2) / f.khkw + 1);
@@ -1102,8 +1060,8 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
   }
   // k-slicing: aim at ~16 items per workgroup slot (2 per CU) so that the tail of the launch is
   // a few percent, while keeping the slab traffic negligible.
-  const double target = std::max(total_cost / (512.0 * 16.0), 1.0);
-  long long items = 0, subs = 0, slab = 0;
+  // (floor: a launch that is small as a whole must not be cut into items whose slab traffic exceeds their work)
+  const double target = std::max(total_cost / (512.0 * 16.0), 40000.0);
   std::vector<double> item_cost(n);
   for (int i = 0; i < n; ++i) {
     FactorDev& f = plan.f[i];
@@ -1118,21 +1076,25 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
   }
   // Work items are dispatched in index order: the longest items go first, so that the tail of the
   // launch is made of the shortest ones (the resident workgroups drain within one short item).
-  plan.order.resize(n);
-  for (int i = 0; i < n; ++i) plan.order[i] = i;
-  std::stable_sort(plan.order.begin(), plan.order.end(), [&](int a, int b) { return item_cost[a] > item_cost[b]; });
-  for (int k = 0; k < n; ++k) {
-    FactorDev& f = plan.f[plan.order[k]];
-    f.item_base = (int)items;
-    f.sub_base = (int)subs;
-    f.slab_base = slab;
-    items += f.n_items;
-    subs += f.n_sub;
-    slab += (long long)f.n_items * f.TM * f.TM;
-    CURV_REQUIRE(items < (1LL << 30) && subs < (1LL << 30), "curv_kfac: too many work items");
+  long long slab = 0;
+  for (int k = 0; k < 2; ++k) {
+    plan.order[k].clear();
+    for (int i = 0; i < n; ++i) if (plan.f[i].dma == k) plan.order[k].push_back(i);
+    std::stable_sort(plan.order[k].begin(), plan.order[k].end(), [&](int a, int b) { return item_cost[a] > item_cost[b]; });
+    long long items = 0, subs = 0;
+    for (int idx : plan.order[k]) {
+      FactorDev& f = plan.f[idx];
+      f.item_base = (int)items;
+      f.sub_base = (int)subs;
+      f.slab_base = slab;
+      items += f.n_items;
+      subs += f.n_sub;
+      slab += (long long)f.n_items * f.TM * f.TM;
+      CURV_REQUIRE(items < (1LL << 30) && subs < (1LL << 30), "curv_kfac: too many work items");
+    }
+    plan.n_items[k] = (int)items;
+    plan.n_sub[k] = (int)subs;
   }
-  plan.n_items = (int)items;
-  plan.n_sub = (int)subs;
   plan.slab_floats = slab;
   return CURV_OK;
 }
@@ -1172,6 +1134,7 @@ extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors,
     o[6] = f.n_chunks; o[7] = f.RS; o[8] = f.PS; o[9] = f.SS; o[10] = f.nch;
     o[11] = f.n_tiles; o[12] = f.cpi; o[13] = f.n_slices; o[14] = f.n_items; o[15] = f.item_base;
     o[16] = f.TM; o[17] = f.vec4; o[18] = f.cshift; o[19] = f.n_sub; o[20] = f.RL; o[21] = f.rshift; o[22] = f.lin;
+    o[23] = f.dma;
   }
   return CURV_OK;
 }
@@ -1192,24 +1155,38 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
   FactorDev* table = reinterpret_cast<FactorDev*>(workspace);
   float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + tb);
   float* zeros = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + tb - 256);
+  // device table: the patch kernel's factors, then the LDS-DMA kernel's
+  std::vector<int> all(plan.order[0]);
+  all.insert(all.end(), plan.order[1].begin(), plan.order[1].end());
   for (int b = 0; b < n_factors; b += UPLOAD_CHUNK) {
     TableChunk chunk;
     const int count = std::min(UPLOAD_CHUNK, n_factors - b);
     memset(&chunk, 0, sizeof(chunk));
-    for (int k = 0; k < count; ++k) chunk.f[k] = plan.f[plan.order[b + k]];
+    for (int k = 0; k < count; ++k) chunk.f[k] = plan.f[all[b + k]];
     hipLaunchKernelGGL(upload_table_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count,
                        b == 0 ? zeros : nullptr);
     CURV_LAUNCH_CHECK();
   }
-  const int grid = cdiv(plan.n_items, 8 * XCD_GROUP) * 8 * XCD_GROUP;
+  const int n0 = (int)plan.order[0].size(), n1 = (int)plan.order[1].size();
   if (ev_start) CURV_HIP_CHECK(hipEventRecord((hipEvent_t)ev_start, stream));
-  hipLaunchKernelGGL(syrk_patch_kernel, dim3(grid), dim3(SYRK_THREADS), 0, stream, table, n_factors,
-                     plan.n_items, slabs, zeros);
-  CURV_LAUNCH_CHECK();
+  if (plan.n_items[0] > 0) {
+    const int grid = cdiv(plan.n_items[0], 8 * XCD_GROUP) * 8 * XCD_GROUP;
+    hipLaunchKernelGGL(syrk_patch_kernel, dim3(grid), dim3(SYRK_THREADS), 0, stream, table, n0, plan.n_items[0], slabs, zeros);
+    CURV_LAUNCH_CHECK();
+  }
+  if (plan.n_items[1] > 0) {
+    const int rc1 = launch_syrk_flat(stream, table + n0, n1, plan.n_items[1], slabs);
+    if (rc1 != CURV_OK) return rc1;
+  }
   if (ev_stop) CURV_HIP_CHECK(hipEventRecord((hipEvent_t)ev_stop, stream));
-  hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub), dim3(SYRK_THREADS), 0, stream, table,
-                     n_factors, slabs);
-  CURV_LAUNCH_CHECK();
+  if (plan.n_sub[0] > 0) {
+    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub[0]), dim3(SYRK_THREADS), 0, stream, table, n0, slabs);
+    CURV_LAUNCH_CHECK();
+  }
+  if (plan.n_sub[1] > 0) {
+    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub[1]), dim3(SYRK_THREADS), 0, stream, table + n0, n1, slabs);
+    CURV_LAUNCH_CHECK();
+  }
   return CURV_OK;
 }
 

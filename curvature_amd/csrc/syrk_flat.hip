@@ -1,0 +1,240 @@
+// KFAC factor build for FLATTENED per-pixel factors on gfx950 (1x1 stride-1 convolutions' A side and every G side,
+// curvature/curvatures.py:329-350 with kernel 1x1: X_s = src[s] is a (C x HW) row-major matrix per sample and
+//   slab(tile, slice) = sum over the slice's (sample, pixel) of X[rows_i][k] X[rows_j][k]
+// for every upper-triangular 128x128 tile.  About a third of a ResNet's factor-build flops, and the class the
+// implicit-im2col kernel of syrk.hip serves worst: there is no im2col reuse, so a tile streams 2 x 128 rows x K
+// floats, and staging them through registers (load burst, LDS store pass, barrier) left the matrix pipe idle two
+// thirds of the time.  Here:
+//   * LDS-DMA staging: buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, straight from global memory into a
+//     double-buffered LDS image - no staging registers, no store pass, no vector-ALU work; the pieces of stage t + 1 are
+//     issued behind the first MFMA groups of stage t and have the rest of the stage to land;
+//   * the image is [128 rows][8 x 16 B] (32 pixels per stage) with the 16-byte slots XOR-swizzled by (row >> 1) & 7:
+//     the DMA writes lane-linear bytes, so the swizzle is applied to the per-lane SOURCE address, and operands are
+//     read back with conflict-free ds_read_b128 (one read = one operand row x 4 pixels = the A or B input of 4 MFMAs);
+//   * the k order inside a stage is whatever suits the reads (lane half h takes pixel group 2 j + h): a SYRK only
+//     needs both operands to agree on it;
+//   * every lane's four read addresses per operand are computed once per work item (16 registers); the steady state
+//     has no vector-ALU instructions besides the MFMAs;
+//   * 64 KiB of LDS and <= 128 registers: two workgroups per CU, each covering the other's barriers and DMA waits.
+// Work items, slabs and the wave roles on diagonal tiles are those of syrk.hip; syrk_reduce_kernel sums the slabs.
+#include "syrk_plan.h"
+
+namespace curv {
+
+namespace flat {
+constexpr int TM = 128;
+constexpr int KC = 32;                      // pixels per stage row
+constexpr int ROW_B = KC * 4;               // 128 B
+constexpr int SLOTS = KC / 4;               // 16-byte slots per row
+constexpr int STEPS = KC / 8;               // MFMA steps (8 pixels: 4 per lane half) per full stage
+constexpr int RPP = 1024 / ROW_B;           // rows per DMA piece (one wave-instruction)
+constexpr int PIECES = TM / RPP / 4;        // pieces per panel per wave
+constexpr int PANEL_B = TM * ROW_B;         // 16 KiB
+constexpr int LDS_B = 4 * PANEL_B;          // [Pi buf0][Pi buf1][Pj buf0][Pj buf1]
+constexpr int NP = 2 * PIECES;              // pieces per stage per wave
+constexpr int PPS = (NP + STEPS / 2 - 1) / (STEPS / 2);   // pieces per step when issued during the first half of a stage
+static_assert(PPS <= 4, "at most one DMA piece per MFMA group");
+}  // namespace flat
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(1))) float gfloat_t;
+
+// stages per sample: TS = ceil(HW / 8) steps, split evenly over ceil(TS / STEPS) stages
+int syrk_flat_stages(int HW) {
+  const int TS = (HW + 7) / 8;
+  return (TS + flat::STEPS - 1) / flat::STEPS;
+}
+
+bool syrk_flat_eligible(const FactorDev& f, const void* src) {
+  // flattened per-pixel factor (1x1, stride 1, no padding: H = 1, W = pixels per (sample, channel) row), whole
+  // 128-row tiles, no bias row, and the whole tensor addressable by one buffer descriptor (32-bit byte offsets)
+  if (!(f.compact && f.H == 1 && f.kh == 1 && f.kw == 1 && f.sh == 1 && f.sw == 1 && f.ph == 0 && f.pw == 0)) return false;
+  if (f.has_bias || f.dim < flat::TM || f.dim % flat::TM != 0) return false;
+  if (f.W < 8) return false;
+  if ((long long)f.N * f.C * f.W * 4 >= (1LL << 32) - 4096) return false;
+  return (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+}
+
+template <int PART, typename Hook>
+__device__ __forceinline__ void flat_mfma_step(const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1,
+                                               f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, int ne, Hook hook) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (e < ne) {
+      if (PART != 3) c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], c00, 0, 0, 0);
+      if (PART != 2) c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], c01, 0, 0, 0);
+      if (PART == 0 || PART == 2) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], c10, 0, 0, 0);
+      if (PART != 2) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], c11, 0, 0, 0);
+    }
+    hook(e);                      // one LDS-DMA piece behind a group of MFMAs: its issue cost hides under them
+  }
+}
+
+template <int PART>
+__device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* __restrict__ slabs, lds_char* lds) {
+  using namespace flat;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+  const int slice = local / d.n_tiles, tile = local - slice * d.n_tiles;
+  int ti, tj;
+  decode_tile(tile, d.P, ti, tj);
+  const bool diag = (ti == tj);
+  // wave roles as in syrk.hip: wave (wm, wn) owns a 64x64 quadrant; on a diagonal tile the redundant quadrant's
+  // wave takes half of quadrant (0, 1) (parts 2 / 3) and the diagonal quadrants skip their lower-left block (part 1)
+  int wm = wave >> 1, wn = wave & 1;
+  if (PART >= 2) { wm = 0; wn = 1; }
+  const int i0 = ti * TM, j0 = tj * TM;
+  const int HW = d.W, C = d.C;
+
+  // stage geometry of a sample: TS steps of 8 pixels in SPS stages of base (+1 for the first rem) steps
+  const int TS = (HW + 7) >> 3;
+  const int SPS = (TS + STEPS - 1) / STEPS;
+  const int base_steps = TS / SPS, rem_steps = TS - base_steps * SPS;
+  const int nv_last = HW - 8 * (TS - 1);                  // pixels of a sample's last step: 1 .. 8
+
+  // ---- DMA lane geometry: piece `slot` of this wave covers panel rows 32 slot + 8 wave + (lane >> 3); the lane's
+  // physical 16-byte slot (lane & 7) holds logical pixel group g = slot ^ ((row >> 1) & 7), which does not depend on
+  // the piece index (pieces of a wave are 32 rows apart)
+  const int rsub = RPP * wave + (lane >> 3);
+  const int g_lane = (lane & (SLOTS - 1)) ^ ((rsub >> 1) & 7);
+  const int voff = (rsub * HW + 4 * g_lane) * 4;
+  const unsigned total_b = (unsigned)((long long)d.N * C * HW * 4);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.src, 0, total_b, 0x00020000);
+
+  // ---- operand addresses: row R of a panel, step j: R * 128 + ((2 j + h) ^ ((R >> 1) & 7)) * 16
+  unsigned addr[4][STEPS];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const int R = ((o < 2) ? 64 * wm : 64 * wn) + (o & 1) * 32 + r32;
+    const unsigned pbase = (o < 2 || diag) ? 0u : 2u * PANEL_B;
+    const int rkey = (R >> 1) & 7;
+#pragma unroll
+    for (int j = 0; j < STEPS; ++j) addr[o][j] = pbase + R * ROW_B + (((2 * j + h) ^ rkey) << 4);
+  }
+
+  f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+  const int t0 = slice * d.cpi, t1 = min(t0 + d.cpi, d.n_chunks);
+  const int n_panels = diag ? 1 : 2;
+
+  auto stage_geo = [&](int t, int& s, int& px0, int& nsteps, bool& last) {
+    s = t / SPS;
+    const int q = t - s * SPS;
+    nsteps = base_steps + (q < rem_steps ? 1 : 0);
+    px0 = 8 * (q * base_steps + min(q, rem_steps));
+    last = (q == SPS - 1);
+  };
+  // next stage's DMA geometry (scalars) and the issue of one piece: piece i = (panel i / PIECES, row group i % PIECES)
+  int n_soff[2] = {0, 0};
+  int n_gmax = 0;
+  unsigned n_buf = 0;
+  auto plan_next = [&](int t) {
+    int s, px0, nsteps; bool last;
+    stage_geo(t, s, px0, nsteps, last);
+    n_gmax = last ? (HW - px0 + 3) / 4 : 2 * nsteps;               // pixel groups this stage needs
+    n_buf = (unsigned)(t & 1) * PANEL_B;
+    n_soff[0] = ((s * C + i0) * HW + px0) * 4;
+    n_soff[1] = ((s * C + j0) * HW + px0) * 4;
+  };
+  auto piece = [&](int i) {
+    const int p = i / PIECES, slot = i % PIECES;
+    if (p < n_panels && g_lane < n_gmax) {
+      const unsigned lbase = (p ? 2u * PANEL_B : 0u) + n_buf + (unsigned)(RPP * wave + 4 * RPP * slot) * ROW_B;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lbase), 16, voff, n_soff[p] + slot * 4 * RPP * HW * 4, 0, 0);
+    }
+  };
+
+  plan_next(t0);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) piece(i);
+  for (int t = t0; t < t1; ++t) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's DMA of stage t has landed
+    __syncthreads();                           // everyone's has; everyone is done reading the other buffer
+    const bool more = t + 1 < t1;
+    if (more) plan_next(t + 1);
+    int s, px0, nsteps; bool last;
+    stage_geo(t, s, px0, nsteps, last);
+    const unsigned buf = (unsigned)(t & 1) * PANEL_B;
+    auto rd = [&](int o, int j) { return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lds + addr[o][j] + buf); };
+    // software pipeline over the stage's steps: operands of step j + 1 are read while the MFMAs of step j issue;
+    // the DMA pieces of stage t + 1 go out during the first half of the stage, each behind a group of MFMAs, so
+    // that the last one still has half of the stage's MFMA time to land before the wait at the top
+    f32x4 a0 = rd(0, 0), a1 = rd(1, 0), b0 = rd(2, 0), b1 = rd(3, 0);
+    int next_piece = 0;
+#pragma unroll
+    for (int j = 0; j < STEPS; ++j) {
+      if (j < nsteps) {
+        f32x4 na0, na1, nb0, nb1;
+        if (j + 1 < STEPS && j + 1 < nsteps) { na0 = rd(0, j + 1); na1 = rd(1, j + 1); nb0 = rd(2, j + 1); nb1 = rd(3, j + 1); }
+        int ne = 4;
+        if (last && j == nsteps - 1 && nv_last < 8) {
+          // the sample's final step: only nv_last of its 8 pixels exist (what the DMA fetched beyond them belongs to
+          // the next row): lane half h holds pixels 4 h + e
+          ne = min(4, nv_last);
+          asm volatile("; sample tail" ::: "memory");      // keeps this a branch: if-converted, its 16 selects ran at every step
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = (4 * h + e) < nv_last;
+            a0[e] = ok ? a0[e] : 0.0f; a1[e] = ok ? a1[e] : 0.0f;
+            b0[e] = ok ? b0[e] : 0.0f; b1[e] = ok ? b1[e] : 0.0f;
+          }
+        }
+        flat_mfma_step<PART>(a0, a1, b0, b1, c00, c01, c10, c11, ne,
+                             [&](int k) { if (more && k < PPS && PPS * j + k < NP) piece(PPS * j + k); });
+        next_piece = min(NP, PPS * j + PPS);
+        if (j + 1 < STEPS && j + 1 < nsteps) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) if (i >= next_piece) piece(i);      // short stages: the rest
+    }
+  }
+
+  gfloat_t* slab = (gfloat_t*)slabs + d.slab_base + (long long)local * (TM * TM);
+  gfloat_t* q = slab + (64 * wm) * 128 + 64 * wn;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (PART != 3) q[row * 128 + r32] = c00[reg];
+    if (PART != 2) q[row * 128 + 32 + r32] = c01[reg];
+    if (PART != 3) q[(32 + row) * 128 + r32] = c10[reg];
+    if (PART != 2) q[(32 + row) * 128 + 32 + r32] = c11[reg];
+  }
+}
+
+__global__ void __launch_bounds__(SYRK_THREADS, 2)
+syrk_flat_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_items, float* __restrict__ slabs) {
+  __shared__ __attribute__((aligned(1024))) char smem[flat::LDS_B];
+  const int item = xcd_item(blockIdx.x);
+  if (item >= n_items) return;
+  const int f = find_segment(descs, n_factors, item, false);
+  const FactorDev& d = descs[f];
+  const int local = item - d.item_base;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = local % d.n_tiles;
+  int ti, tj;
+  decode_tile(tile, d.P, ti, tj);
+  int part = 0;
+  if (ti == tj) {
+    const int wm = wave >> 1, wn = wave & 1;
+    part = (wm == wn) ? 1 : (wm == 0 ? 2 : 3);
+  }
+  part = __builtin_amdgcn_readfirstlane(part);
+  lds_char* l3 = (lds_char*)smem;
+  if (part == 0) flat_body<0>(d, local, slabs, l3);
+  else if (part == 1) flat_body<1>(d, local, slabs, l3);
+  else if (part == 2) flat_body<2>(d, local, slabs, l3);
+  else flat_body<3>(d, local, slabs, l3);
+}
+
+int launch_syrk_flat(hipStream_t stream, const FactorDev* table, int n_factors, int n_items, float* slabs) {
+  if (n_items <= 0) return CURV_OK;
+  const int grid = cdiv(n_items, 8 * XCD_GROUP) * 8 * XCD_GROUP;
+  hipLaunchKernelGGL(syrk_flat_kernel, dim3(grid), dim3(SYRK_THREADS), 0, stream, table, n_factors, n_items, slabs);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}
+
+}  // namespace curv

@@ -1,0 +1,80 @@
+// Shared between the two factor-build kernels (syrk.hip: implicit-im2col patch kernel; syrk_flat.hip: LDS-DMA kernel
+// for flattened per-pixel factors): the device descriptor of one Kronecker factor and the work-list helpers.
+#pragma once
+#include "common.h"
+
+namespace curv {
+
+constexpr int SYRK_THREADS = 256;
+constexpr int XCD_GROUP = 32;          // consecutive items that share an XCD
+
+struct FactorDev {
+  const float* src;
+  float* dst;
+  int N, C, H, W;          // source geometry (1x1/stride-1 convs arrive flattened to H = 1)
+  int kh, kw, sh, sw, ph, pw;
+  int Ho, Wo;
+  int khkw;
+  int rows, dim, has_bias;
+  int compact;             // kh == kw == 1: patch holds only the sampled pixels
+  int vec4;                // flattened per-pixel factor with 16-B aligned rows: float4 staging
+  int TM;                  // tile edge: 64 or 128
+  int NS, R, Wc;           // chunk extent: samples, output rows, output cols
+  int n_rg, n_cg;          // chunk grid (rows, cols); samples outermost
+  int n_chunks;
+  int RS, PS, SS, nch;     // LDS strides in words, channels per panel
+  int cshift;              // log2 of the padded patch row length (lanes along x)
+  int RL;                  // (reserved; the k loop no longer works with table-driven runs)
+  int P, n_tiles;
+  int cpi, n_slices;       // chunks per item, k-slices
+  int item_base, n_items;
+  int sub_base, n_sub;     // 64x64 sub-tiles for the reduce kernel
+  int first;
+  float scale;
+  int pad0;
+  int rshift;              // general staging: a lane group of 2^rshift folded rows; the other row lanes split channels
+  int flat;                // flattened per-pixel factor whose (sample, channel) rows are staged slot-regularly
+  unsigned rmagic;         // ceil(2^32 / patch rows per sample): folded (sample, row) index -> sample
+  int lin;                 // linear staging: lanes walk the contiguous rows x W source range, `lin` floats each
+  unsigned pmagic, wmagic; // linear staging: ceil(2^32 / lanes per sample), ceil(2^32 / W)
+  int dma;                 // 1: built by syrk_flat_kernel (n_chunks = stages, cpi = stages per item)
+  long long slab_base;     // in floats
+};
+static_assert(sizeof(FactorDev) % 8 == 0, "FactorDev must be 8-byte granular");
+
+__device__ __forceinline__ int find_segment(const FactorDev* __restrict__ descs, int n_factors, int id,
+                                            bool by_sub) {
+  // largest f with base[f] <= id; bases are ascending.  One ballot per 64 factors.
+  const int lane = threadIdx.x & 63;
+  int count = 0;
+  for (int f0 = 0; f0 < n_factors; f0 += 64) {
+    const int f = f0 + lane;
+    bool le = false;
+    if (f < n_factors) le = (by_sub ? descs[f].sub_base : descs[f].item_base) <= id;
+    count += __popcll(__ballot(le));
+  }
+  return __builtin_amdgcn_readfirstlane(count - 1);
+}
+
+__device__ __forceinline__ void decode_tile(int t, int P, int& ti, int& tj) {
+  ti = 0;
+  while (t >= P - ti) { t -= P - ti; ++ti; }
+  tj = ti + t;
+}
+
+
+// XCD-aware item order: workgroups that share an XCD (equal blockIdx % 8) take every 8th group of XCD_GROUP
+// consecutive items, i.e. neighbouring tiles of one k-slice of one factor, so the panels they stage hit that XCD's
+// L2, while every XCD still sees an even mix of all factors.
+__device__ __forceinline__ int xcd_item(int bid) {
+  const int xcd = bid & 7, j = bid >> 3;
+  return ((j / XCD_GROUP) * 8 + xcd) * XCD_GROUP + (j % XCD_GROUP);
+}
+
+// syrk_flat.hip: host launcher of the LDS-DMA kernel over a device table of dma factors
+int launch_syrk_flat(hipStream_t stream, const FactorDev* table, int n_factors, int n_items, float* slabs);
+// host-side eligibility / stage count of the LDS-DMA kernel
+bool syrk_flat_eligible(const FactorDev& f, const void* src);
+int syrk_flat_stages(int HW);
+
+}  // namespace curv

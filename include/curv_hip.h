@@ -73,8 +73,9 @@ size_t curv_kfac_workspace_bytes(const curv_factor_desc* descs, int n_factors);
  * sample stride, channels per panel, n_tiles, chunks per item, k-slices, n_items, item_base, tile edge,
  * float4 staging flag, log2 padded patch row length, 64x64 sub-tiles, k-run length, log2 row lanes
  * that walk patch rows while staging (the remaining row lanes split channels), floats per lane of the
- * linear full-width staging (0 = not used). */
-#define CURV_PLAN_INFO_FIELDS 23
+ * linear full-width staging (0 = not used), 1 if the factor is built by the LDS-DMA kernel for flattened per-pixel
+ * factors (its own work list: item bases count from 0 per kernel; n_chunks = stages of <= 32 pixels). */
+#define CURV_PLAN_INFO_FIELDS 24
 int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors, long long* out);
 
 /* Grouped launch over all factors of a model (one SYRK launch + one reduce launch). `descs` is a

@@ -7,8 +7,8 @@ import pytest
 
 from curvature_amd import _lib
 
-NF = 23
-NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub RL rshift lin".split()
+NF = 24
+NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub RL rshift lin dma".split()
 PANEL_WORDS, KTAB_MAX, SLOTS, THREADS = 8704, 1024, 32, 256
 
 
@@ -48,6 +48,16 @@ def test_plan_respects_budgets(d):
     assert p["dim"] == d["C"] * d["kh"] * d["kw"] + d["has_bias"]
     assert (p["Ho"], p["Wo"]) == ((1, Ho * Wo) if flat else (Ho, Wo))
     assert p["TM"] in (64, 128) and p["RL"] == 1
+    if p["dma"]:
+        # LDS-DMA kernel (syrk_flat.hip): flattened factor, whole 128-row tiles, no bias row; K in stages of at most
+        # 32 pixels of one sample, ceil(ceil(HW / 8) / 4) stages per sample
+        assert flat and not d["has_bias"] and p["dim"] % 128 == 0 and p["TM"] == 128
+        steps = -(-(Ho * Wo) // 8)
+        assert p["nchunks"] == d["N"] * -(-steps // 4)
+        P = p["dim"] // 128
+        assert p["ntiles"] == P * (P + 1) // 2 and p["nitems"] == p["ntiles"] * p["nslices"]
+        assert p["cpi"] * p["nslices"] >= p["nchunks"] and p["cpi"] * (p["nslices"] - 1) < p["nchunks"]
+        return
     assert p["NS"] * p["SS"] + 16 <= PANEL_WORDS                      # LDS patch per panel
     rows_in = p["R"] if compact else (p["R"] - 1) * d["sh"] + d["kh"]
     cols_in = p["Wc"] if compact else (p["Wc"] - 1) * d["sw"] + d["kw"]
@@ -81,11 +91,13 @@ def test_plan_respects_budgets(d):
 def test_item_bases_tile_the_work_list():
     """Factors are laid out in the work list by descending work per item; together their
     [base, base + nitems) ranges cover the list exactly once."""
-    ps = sorted(plan(CASES), key=lambda p: p["base"])
-    base = 0
-    for p in ps:
-        assert p["base"] == base
-        base += p["nitems"]
+    everything = plan(CASES)
+    assert any(p["dma"] for p in everything) and not all(p["dma"] for p in everything)
+    for kernel in (0, 1):                       # two kernels, two work lists
+        base = 0
+        for p in sorted((p for p in everything if p["dma"] == kernel), key=lambda p: p["base"]):
+            assert p["base"] == base
+            base += p["nitems"]
 
 
 def test_invalid_geometry_is_rejected():

@@ -18,9 +18,16 @@ typedef __attribute__((address_space(1))) float gfloat;
 
 constexpr int THREADS = 256;
 constexpr int TM = 128;
-constexpr int ROW_B = 256;                    // LDS bytes per row per stage: 64 pixels
-constexpr int PANEL_B = TM * ROW_B;           // 32 KiB
-constexpr int LDS_B = 4 * PANEL_B;            // [Pi buf0][Pi buf1][Pj buf0][Pj buf1]
+// KC pixels per stage row: 64 (256-byte rows, 128 KiB LDS, one workgroup per CU) or 32 (128-byte rows, 64 KiB, two per CU)
+template <int KC> struct Geo {
+  static constexpr int ROW_B = KC * 4;                  // LDS bytes per row per stage
+  static constexpr int SLOTS = KC / 4;                  // 16-byte slots per row
+  static constexpr int STEPS = KC / 8;                  // MFMA steps (8 pixels) per full stage
+  static constexpr int ROWS_PER_PIECE = 1024 / ROW_B;   // rows covered by one 1 KiB DMA wave-instruction
+  static constexpr int PIECES = TM / ROWS_PER_PIECE / 4;   // pieces per panel per wave
+  static constexpr int PANEL_B = TM * ROW_B;
+  static constexpr int LDS_B = 4 * PANEL_B;             // [Pi buf0][Pi buf1][Pj buf0][Pj buf1]
+};
 
 struct Flat {
   const float* src;
@@ -48,13 +55,14 @@ __device__ __forceinline__ void mfma_step(const f32x4& a0, const f32x4& a1, cons
       if (PART == 0 || PART == 2) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], c10, 0, 0, 0);
       if (PART != 2) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], c11, 0, 0, 0);
     }
-    if (e == 0) hook(0);          // one LDS-DMA piece behind a group of MFMAs: its issue cost hides under them
-    if (e == 2) hook(1);
+    hook(e);                      // one LDS-DMA piece behind a group of MFMAs: its issue cost hides under them
   }
 }
 
-template <int PART>
+template <int KC, int PART>
 __device__ __forceinline__ void flat_body(const Flat& d, int local, __attribute__((address_space(3))) char* lds) {
+  using G = Geo<KC>;
+  constexpr int ROW_B = G::ROW_B, PANEL_B = G::PANEL_B, STEPS = G::STEPS, PIECES = G::PIECES, RPP = G::ROWS_PER_PIECE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, h = lane >> 5;
@@ -69,20 +77,25 @@ __device__ __forceinline__ void flat_body(const Flat& d, int local, __attribute_
 
   // ---- DMA lane geometry: load slot i of this wave covers panel rows 16 i + 4 wave + (lane >> 4); the lane's
   // physical 16-byte slot (lane & 15) holds logical pixel group g = slot ^ (row & 15)
-  const int rsub = 4 * wave + (lane >> 4);                 // row & 15 for every slot
-  const int g_lane = (lane & 15) ^ rsub;
+  // KC = 64: a piece is 4 rows x 16 slots, slot ^ (row & 15); KC = 32: 8 rows x 8 slots, slot ^ ((row >> 1) & 7).
+  // Either way the XOR key of a lane does not depend on the piece index (pieces of a wave are 16 / 32 rows apart).
+  const int rloc = (KC == 64) ? (lane >> 4) : (lane >> 3);           // row inside the piece
+  const int rsub = RPP * wave + rloc;                                 // row inside the group of 4 pieces (one per wave)
+  const int key = (KC == 64) ? (rsub & 15) : ((rsub >> 1) & 7);
+  const int g_lane = (lane & (G::SLOTS - 1)) ^ key;
   const int voff = (rsub * HW + 4 * g_lane) * 4;
   const long long total_b = (long long)d.N * C * HW * 4;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.src, 0, (unsigned)total_b, 0x00020000);
 
   // ---- operand addresses: row R of a panel, step j: R * 256 + ((2 j + h) ^ (R & 15)) * 16
-  unsigned addr[4][8];
+  unsigned addr[4][STEPS];
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
     const int R = ((o < 2) ? 64 * wm : 64 * wn) + (o & 1) * 32 + r32;
     const unsigned pbase = (o < 2 || diag) ? 0u : 2u * PANEL_B;
+    const int rkey = (KC == 64) ? (R & 15) : ((R >> 1) & 7);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) addr[o][j] = pbase + R * ROW_B + (((2 * j + h) ^ (R & 15)) << 4);
+    for (int j = 0; j < STEPS; ++j) addr[o][j] = pbase + R * ROW_B + (((2 * j + h) ^ rkey) << 4);
   }
 
   f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
@@ -109,16 +122,18 @@ __device__ __forceinline__ void flat_body(const Flat& d, int local, __attribute_
     n_soff[1] = ((s * C + j0) * HW + px0) * 4;
   };
   auto piece = [&](int i) {
-    const int p = i >> 3, slot = i & 7;
+    const int p = i / PIECES, slot = i % PIECES;
     if (p < n_panels && g_lane < n_gmax) {
-      const unsigned lbase = (p ? 2u * PANEL_B : 0u) + n_buf + (unsigned)(4 * wave + 16 * slot) * ROW_B;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lbase), 16, voff, n_soff[p] + slot * 16 * HW * 4, 0, 0);
+      const unsigned lbase = (p ? 2u * PANEL_B : 0u) + n_buf + (unsigned)(RPP * wave + 4 * RPP * slot) * ROW_B;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lbase), 16, voff, n_soff[p] + slot * 4 * RPP * HW * 4, 0, 0);
     }
   };
+  constexpr int NP = 2 * PIECES;             // pieces per stage per wave
+  constexpr int PPS = (NP + STEPS / 2 - 1) / (STEPS / 2) > 4 ? 4 : (NP + STEPS / 2 - 1) / (STEPS / 2);   // per step, in the first half
 
   plan_next(t0);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) piece(i);
+  for (int i = 0; i < NP; ++i) piece(i);
   for (int t = t0; t < t1; ++t) {
     __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's DMA of stage t has landed
     __syncthreads();                           // everyone's has; everyone is done reading the other buffer
@@ -133,10 +148,10 @@ __device__ __forceinline__ void flat_body(const Flat& d, int local, __attribute_
     f32x4 a0 = rd(0, 0), a1 = rd(1, 0), b0 = rd(2, 0), b1 = rd(3, 0);
     int next_piece = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < STEPS; ++j) {
       if (j < nsteps) {
         f32x4 na0, na1, nb0, nb1;
-        if (j + 1 < 8 && j + 1 < nsteps) { na0 = rd(0, j + 1); na1 = rd(1, j + 1); nb0 = rd(2, j + 1); nb1 = rd(3, j + 1); }
+        if (j + 1 < STEPS && j + 1 < nsteps) { na0 = rd(0, j + 1); na1 = rd(1, j + 1); nb0 = rd(2, j + 1); nb1 = rd(3, j + 1); }
         int ne = 4;
         if (last && j == nsteps - 1 && d.nv_last < 8) {
           // the sample's final step: only nv_last of its 8 pixels exist
@@ -149,14 +164,17 @@ __device__ __forceinline__ void flat_body(const Flat& d, int local, __attribute_
             b0[e] = ok ? b0[e] : 0.0f; b1[e] = ok ? b1[e] : 0.0f;
           }
         }
-        mfma_step<PART>(a0, a1, b0, b1, c00, c01, c10, c11, ne, [&](int k) { if (more) piece(2 * j + k); });
-        next_piece = 2 * j + 2;
-        if (j + 1 < 8 && j + 1 < nsteps) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
+        // all 16 pieces go out during the first four steps: the last one then still has half of the stage's
+        // MFMA time to land before the wait at the top of the next stage
+        mfma_step<PART>(a0, a1, b0, b1, c00, c01, c10, c11, ne,
+                        [&](int k) { if (more && k < PPS && PPS * j + k < NP) piece(PPS * j + k); });
+        next_piece = min(NP, PPS * j + PPS);
+        if (j + 1 < STEPS && j + 1 < nsteps) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
       }
     }
     if (more) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) if (i >= next_piece) piece(i);      // stages with fewer than 8 steps: the rest
+      for (int i = 0; i < NP; ++i) if (i >= next_piece) piece(i);      // short stages: the rest
     }
   }
 
@@ -172,8 +190,9 @@ __device__ __forceinline__ void flat_body(const Flat& d, int local, __attribute_
   }
 }
 
-__global__ void __launch_bounds__(THREADS, 1) flat_syrk_kernel(Flat d) {
-  __shared__ __attribute__((aligned(1024))) char lds[LDS_B];
+template <int KC>
+__global__ void __launch_bounds__(THREADS, KC == 64 ? 1 : 2) flat_syrk_kernel(Flat d) {
+  __shared__ __attribute__((aligned(1024))) char lds[Geo<KC>::LDS_B];
   int item;
   {
     const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
@@ -191,10 +210,10 @@ __global__ void __launch_bounds__(THREADS, 1) flat_syrk_kernel(Flat d) {
   }
   part = __builtin_amdgcn_readfirstlane(part);
   auto* l3 = (__attribute__((address_space(3))) char*)lds;
-  if (part == 0) flat_body<0>(d, item, l3);
-  else if (part == 1) flat_body<1>(d, item, l3);
-  else if (part == 2) flat_body<2>(d, item, l3);
-  else flat_body<3>(d, item, l3);
+  if (part == 0) flat_body<KC, 0>(d, item, l3);
+  else if (part == 1) flat_body<KC, 1>(d, item, l3);
+  else if (part == 2) flat_body<KC, 2>(d, item, l3);
+  else flat_body<KC, 3>(d, item, l3);
 }
 
 // reference: one thread per (i, j) of the upper triangle, fp64 accumulation
@@ -210,13 +229,14 @@ __global__ void ref_kernel(const float* src, double* out, int N, int C, int HW, 
   out[(i - i0) * n + (j - j0)] = acc;
 }
 
+template <int KC>
 static void run(int N, int C, int HW, int target_items) {
   Flat d;
   memset(&d, 0, sizeof(d));
   d.N = N; d.C = C; d.HW = HW;
   d.P = C / TM; d.n_tiles = d.P * (d.P + 1) / 2;
   d.TS = (HW + 7) / 8;
-  d.SPS = (d.TS + 7) / 8;
+  d.SPS = (d.TS + KC / 8 - 1) / (KC / 8);
   d.base_steps = d.TS / d.SPS; d.rem_steps = d.TS % d.SPS;
   d.nv_last = HW - 8 * (d.TS - 1);
   d.total_stages = N * d.SPS;
@@ -237,13 +257,13 @@ static void run(int N, int C, int HW, int target_items) {
   const int grid = (d.n_items + 255) / 256 * 256;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  flat_syrk_kernel<<<grid, THREADS>>>(d);
+  flat_syrk_kernel<KC><<<grid, THREADS>>>(d);
   hipError_t err = hipDeviceSynchronize();
   if (err != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(err)); exit(1); }
   float best = 1e30f, sum = 0;
   for (int rep = 0; rep < 6; ++rep) {
     hipEventRecord(e0);
-    flat_syrk_kernel<<<grid, THREADS>>>(d);
+    flat_syrk_kernel<KC><<<grid, THREADS>>>(d);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -281,20 +301,24 @@ static void run(int N, int C, int HW, int target_items) {
       }
     worst = std::max(worst, std::sqrt(num / den));
   }
-  printf("C=%4d HW=%4d N=%d: tiles %d slices %d items %d (spi %d, SPS %d, steps %d+%d)  best %.3f ms avg %.3f ms  %.1f TF executed (%.3f of 157.3)  rel err %.2e\n",
-         C, HW, N, d.n_tiles, d.n_slices, d.n_items, d.spi, d.SPS, d.base_steps, d.rem_steps, best, sum / 5, exec_flops / best / 1e9,
+  printf("KC=%d C=%4d HW=%4d N=%d: tiles %d slices %d items %d (spi %d, SPS %d, steps %d+%d)  best %.3f ms avg %.3f ms  %.1f TF executed (%.3f of 157.3)  rel err %.2e\n",
+         KC, C, HW, N, d.n_tiles, d.n_slices, d.n_items, d.spi, d.SPS, d.base_steps, d.rem_steps, best, sum / 5, exec_flops / best / 1e9,
          exec_flops / best / 1e9 / 157.3, worst);
   hipFree(src); hipFree(slabs);
 }
 
+template <int KC> static void all(int target) {
+  run<KC>(32, 1024, 196, target);
+  run<KC>(32, 256, 3136, target);
+  run<KC>(32, 512, 784, target);
+  run<KC>(32, 2048, 49, target);
+  run<KC>(32, 2048, 196, target);
+  run<KC>(32, 512, 3136, target);
+}
+
 int main(int argc, char** argv) {
   const int target = argc > 1 ? atoi(argv[1]) : 1024;
-  run(32, 1024, 196, target);
-  run(32, 256, 3136, target);
-  run(32, 512, 784, target);
-  run(32, 2048, 49, target);
-  run(32, 128, 784, target);
-  run(32, 2048, 196, target);
-  run(32, 512, 3136, target);
+  all<64>(target);
+  all<32>(target);
   return 0;
 }
