@@ -485,7 +485,12 @@ __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* ba
   for (int p = 0; p < 4; ++p) {
     const int c0 = 16 * p;
     if (wave == 0) {
-      double row[16];
+      // The 16 columns of the panel as ONE straight-line block: no store, no branch and no exec-mask change between
+      // the columns (the failure flag and the pivots' reciprocals stay in registers until the panel is done), so that
+      // the scheduler can start column c + 1's pivot chain - broadcast, rsqrt, two Newton steps: the critical path -
+      // under the 14 remaining rank-1 updates of column c instead of after them.
+      double row[16], dv[16];
+      int first_bad = 0;
 #pragma unroll
       for (int c = 0; c < 16; ++c) row[c] = Ds[lane * LDA + c0 + c];
 #pragma unroll
@@ -493,14 +498,22 @@ __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* ba
         const double piv = readlane_f64(row[c], c0 + c);
         const bool ok = piv > 0.0 && piv < 1.0e300;               // also false for NaN
         const double dinv = ok ? rsqrt_pos(piv) : 1.0;
-        if (!ok && lane == 0 && *bad == 0) *bad = pivot_base + c0 + c + 1;
-        if (lane == c0 + c) dinv_s[c0 + c] = dinv;
+        first_bad = (!ok && first_bad == 0) ? pivot_base + c0 + c + 1 : first_bad;
+        dv[c] = dinv;
         row[c] *= dinv;
+        // the next column first: its pivot is what the next iteration waits for
 #pragma unroll
         for (int q = c + 1; q < 16; ++q) row[q] -= row[c] * readlane_f64(row[c], c0 + q);
       }
 #pragma unroll
       for (int c = 0; c < 16; ++c) Ds[lane * LDA + c0 + c] = row[c];
+      if (lane < 16) {
+        double mine = dv[0];
+#pragma unroll
+        for (int c = 1; c < 16; ++c) mine = (lane == c) ? dv[c] : mine;
+        dinv_s[c0 + lane] = mine;
+      }
+      if (first_bad != 0 && lane == 0 && *bad == 0) *bad = first_bad;
     }
     __syncthreads();
     // trailing update of the 16x16 tiles (ti, tj), p < tj <= ti: T -= A21_ti A21_tj^T  (K = 16)

@@ -1,19 +1,38 @@
 #!/bin/bash
-# Round profiles: run on the GPU box via   gpurun -- 'bash tools/collect_profiles.sh r01'
+# Round profiles: run on the GPU box via   gpurun -- 'bash tools/collect_profiles.sh r02'
 # 1) rocprofv3 --kernel-trace --stats of bench.py        -> gpurun_out/<round>_bench_kernel_stats.csv
-# 2) PMC passes (separate: TCC slots) FETCH_SIZE / WRITE_SIZE / MFMA counters -> gpurun_out/<round>_syrk_pmc.json
-R=${1:-r01}
+# 2) PMC passes of bench.py (separate passes: TCC slots; the program itself after `--`)
+#      FETCH_SIZE | WRITE_SIZE | SQ instruction / MFMA counters | SQ wait counters  -> gpurun_out/<round>_kernels_pmc.json
+# 3) the same passes for the eigensolver (EFB constructor on ResNet-18 factors)      -> gpurun_out/<round>_eigh_pmc.json
+R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT
+B="python3 bench.py --no-cpu-baseline"
 # warm MIOpen's per-user find database first: on a fresh box the first run benchmarks every conv solver
-python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/warm.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/sq.log 2>&1
+$B --steps 1 --warmup 1 > $OUT/warm.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 5 --warmup 2 > $OUT/bench_trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B --steps 2 --warmup 1 > $OUT/fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $B --steps 2 --warmup 1 > $OUT/write.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/sq -- $B --steps 2 --warmup 1 > $OUT/sq.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq2 -- $B --steps 2 --warmup 1 > $OUT/sq2.log 2>&1
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_bench_kernel_stats.csv
 grep '^{"metric"' $OUT/bench_trace.log | tail -1 > gpurun_out/${R}_bench_under_profiler.json
-python tools/parse_pmc.py $OUT > gpurun_out/${R}_syrk_pmc.json
-cat gpurun_out/${R}_syrk_pmc.json
-head -8 gpurun_out/${R}_bench_kernel_stats.csv | cut -c1-140
+python3 tools/parse_pmc.py $OUT > gpurun_out/${R}_kernels_pmc.json
+# eigensolver
+E="python3 tools/prof_eigh.py"
+EO=$OUT/eigh; mkdir -p $EO
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $EO/trace -- $E > $EO/trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $EO/fetch -- $E > $EO/fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $EO/write -- $E > $EO/write.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $EO/sq -- $E > $EO/sq.log 2>&1
+cp $(find $EO/trace -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_eigh_kernel_stats.csv
+python3 tools/parse_pmc.py $EO jacobi_pair_kernel jacobi_rows_kernel jacobi_cols_kernel > gpurun_out/${R}_eigh_pmc.json
+tail -3 $EO/trace.log
+head -12 gpurun_out/${R}_bench_kernel_stats.csv | cut -c1-150
+python3 - <<PY
+import json
+for f in ("gpurun_out/${R}_kernels_pmc.json", "gpurun_out/${R}_eigh_pmc.json"):
+    for k in json.load(open(f)):
+        print(k["kernel"], {x: (round(v, 4) if isinstance(v, float) else v) for x, v in k.items() if x in ("mfma_pipe_utilisation", "clock_GHz", "valu_per_mfma", "hbm_bytes_per_launch", "hbm_GBps_fetch_pass", "avg_kernel_ns_sq_pass", "sq_wait_any_share", "sq_wait_inst_any_share")})
+PY

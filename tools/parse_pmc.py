@@ -1,12 +1,23 @@
 #!/usr/bin/env python
-"""Per-launch PMC summary of curv::syrk_patch_kernel from the rocprofv3 passes of tools/collect_profiles.sh."""
+"""Per-launch PMC summary of the library's kernels from the rocprofv3 passes of tools/collect_profiles.sh.
+
+    python tools/parse_pmc.py <dir with fetch/ write/ sq/ sq2/ sub-directories> [kernel-name-substring ...]
+
+One JSON object per kernel: average launch duration (kernel trace of the same pass), HBM bytes per launch
+(FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 reports half of the bytes of wide coalesced reads: FETCH x 2, per
+/opt/skills/guides/MI355X_MICROARCH.md section HBM), MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
+GRBM_GUI_ACTIVE / 8 XCDs), effective clock, instruction mix per MFMA, wait shares of the wave cycles."""
 import csv
 import glob
 import json
 import sys
 
+DEFAULT = ["syrk_patch_kernel", "syrk_flat_kernel", "syrk_reduce_kernel", "outer_update_kernel", "outer_update_wide_kernel",
+           "inner_update_kernel", "panel_product_kernel", "panel_product_wide_kernel", "chol_diag_kernel", "chol_panel_kernel",
+           "gemm_f32_kernel", "gemm_f64_kernel", "jacobi_pair_kernel", "jacobi_rows_kernel", "jacobi_cols_kernel"]
 
-def collect(d):
+
+def collect(d, kernel):
     files = glob.glob(d + "/*/*counter_collection.csv")
     if not files:
         return {}
@@ -15,40 +26,66 @@ def collect(d):
     acc, n, t = {}, {}, []
     seen = set()
     for r in csv.DictReader(open(files[0])):
-        if "syrk_patch_kernel" not in r["Kernel_Name"]:
+        name = r["Kernel_Name"]
+        if kernel + "(" not in name and not name.endswith(kernel) and ("::" + kernel) not in name:
             continue
         acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         n[r["Counter_Name"]] = n.get(r["Counter_Name"], 0) + 1
         if r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"])
-            t.append(dur[r["Dispatch_Id"]])
+            t.append(dur.get(r["Dispatch_Id"], 0))
+    if not t:
+        return {}
     out = {k: acc[k] / n[k] for k in acc}
     out["_launches"] = len(t)
     out["_avg_ns"] = sum(t) / max(len(t), 1)
     return out
 
 
-def main():
-    root = sys.argv[1]
-    fetch, write, sq = collect(root + "/fetch"), collect(root + "/write"), collect(root + "/sq")
-    res = {"kernel": "curv::syrk_patch_kernel", "per": "launch (average over the profiled launches)"}
+def summarise(root, kernel):
+    fetch, write = collect(root + "/fetch", kernel), collect(root + "/write", kernel)
+    sq, sq2 = collect(root + "/sq", kernel), collect(root + "/sq2", kernel)
+    if not (fetch or write or sq or sq2):
+        return None
+    res = {"kernel": "curv::" + kernel, "per": "launch (average over the profiled launches)"}
     if fetch and write:
-        # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the
-        # bytes of wide coalesced reads -> doubled; WRITE_SIZE exact for 16-B streaming stores
+        res["launches_profiled"] = fetch["_launches"]
         res["FETCH_SIZE_KiB_raw"] = fetch["FETCH_SIZE"]
         res["WRITE_SIZE_KiB_raw"] = write["WRITE_SIZE"]
         res["hbm_bytes_per_launch"] = (2.0 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024.0
         res["avg_kernel_ns_fetch_pass"] = fetch["_avg_ns"]
+        res["hbm_GBps_fetch_pass"] = res["hbm_bytes_per_launch"] / max(fetch["_avg_ns"], 1.0)
     if sq:
-        for k in ("SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES"):
+        for k in ("SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
+                  "SQ_WAVE_CYCLES"):
             if k in sq:
                 res[k] = sq[k]
-        if "GRBM_GUI_ACTIVE" in sq and "SQ_VALU_MFMA_BUSY_CYCLES" in sq:
+        if sq.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in sq:
             cycles = sq["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
             res["clock_GHz"] = cycles / sq["_avg_ns"]
             res["mfma_pipe_utilisation"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cycles)   # 256 CUs x 4 SIMDs
+        m = sq.get("SQ_INSTS_MFMA", 0.0)
+        if m > 0:
+            # SQ_INSTS_VALU counts the MFMAs as well
+            res["valu_per_mfma"] = (sq.get("SQ_INSTS_VALU", 0.0) - m) / m
+            res["salu_per_mfma"] = sq.get("SQ_INSTS_SALU", 0.0) / m
+            res["lds_per_mfma"] = sq.get("SQ_INSTS_LDS", 0.0) / m
         res["avg_kernel_ns_sq_pass"] = sq["_avg_ns"]
-    print(json.dumps(res, indent=1))
+    if sq2 and sq2.get("SQ_WAVE_CYCLES"):
+        w = sq2["SQ_WAVE_CYCLES"]
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
+            if k in sq2:
+                res[k.lower() + "_share"] = sq2[k] / w
+        if sq2.get("SQ_LDS_IDX_ACTIVE"):
+            res["lds_bank_conflict_share"] = sq2.get("SQ_LDS_BANK_CONFLICT", 0.0) / sq2["SQ_LDS_IDX_ACTIVE"]
+    return res
+
+
+def main():
+    root = sys.argv[1]
+    kernels = sys.argv[2:] or DEFAULT
+    out = [s for s in (summarise(root, k) for k in kernels) if s]
+    print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
