@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--per-layer", action="store_true")
     ap.add_argument("--classes", action="store_true", help="time factor classes (grouped per class)")
     ap.add_argument("--only", default="", help="restrict to one class, e.g. 3x3s1:2304 or G:1024")
+    ap.add_argument("--marginal", action="store_true",
+                    help="per class: time of the full launch minus the launch without that class (what the class costs "
+                         "inside the grouped launch; isolated timings of small classes are dominated by launch effects)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     model, chw = {"lenet5": (models.lenet5, (1, 28, 28)), "resnet18": (models.resnet18, (3, 224, 224)),
@@ -104,6 +107,28 @@ def main():
     t = time_jobs(jobs, args.iters)
     print(f"{args.model} N={args.batch}: {t * 1e3:.3f} ms/update  executed {execd / t / 1e12:.1f} TFLOP/s "
           f"({execd / t / PEAK_F32_MFMA * 100:.1f}% of fp32 MFMA peak)  dense-equivalent {dense / t / 1e12:.1f} TFLOP/s")
+    if args.marginal:
+        classes = {}
+        for li, (idx, n, m, K) in enumerate(meta):
+            for side, job, d in (("A", jobs[2 * li], n), ("G", jobs[2 * li + 1], m)):
+                k = job.kernel
+                kind = f"{k[0]}x{k[1]}s{job.stride[0]}" if side == "A" else "G"
+                classes.setdefault((kind, d, K), []).append(job)
+        full = min(time_jobs(jobs, 5, 2) for _ in range(3))
+        print(f"  full launch {full * 1e3:.3f} ms")
+        rows = []
+        for key, js in classes.items():
+            ids = {id(j) for j in js}
+            rest = [j for j in jobs if id(j) not in ids]
+            t = min(time_jobs(rest, 5, 1) for _ in range(3))
+            kind, d, K = key
+            ex = d * (d + 1.0) * K * len(js)
+            rows.append((full - t, kind, d, K, len(js), ex))
+        for dt, kind, d, K, cnt, ex in sorted(rows, reverse=True):
+            tf = ex / dt / 1e12 if dt > 0 else float("inf")
+            print(f"  {kind:6s} dim={d:5d} K={K:7d} x{cnt:2d}: marginal {dt * 1e6:8.1f} us ({dt / full * 100:5.1f}% of the launch)  "
+                  f"{tf:7.1f} TF/s exec  share of flops {ex / execd * 100:4.1f}%")
+        print(f"  sum of marginals {sum(r[0] for r in rows) * 1e3:.3f} ms")
     if args.classes:
         classes = {}
         for li, (idx, n, m, K) in enumerate(meta):
