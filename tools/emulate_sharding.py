@@ -47,6 +47,19 @@ def main():
                 step()
             torch.cuda.synchronize()
             times.append((time.perf_counter() - t0) / 4 * 1e3)
+            if world == 8:
+                # per-phase times of this rank (each phase synchronised: an upper bound of its share of the step)
+                ph = []
+                for fn in (lambda: kfac.update(32), lambda: kfac.invert(1.0, 1000.0), kfac.sample_and_replace):
+                    fn()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(4):
+                        fn()
+                    torch.cuda.synchronize()
+                    ph.append((time.perf_counter() - t1) / 4 * 1e3)
+                own = [i for i, o in enumerate(owner) if o == rank]
+                print(f"      rank {rank}: layers {own} dims {[dims[i][:2] for i in own]}: update {ph[0]:.2f} invert {ph[1]:.2f} sample {ph[2]:.2f} ms")
             for h in kfac.hooks:
                 h.remove()
         mx = max(times)

@@ -36,11 +36,14 @@ def main():
     stage("kfac.update", lambda: kfac.update(N))
     efb = stage("EFB ctor (eigenvectors)", lambda: EFB(model, kfac.state))
     stage("efb.update", lambda: efb.update(N))
-    inf = stage("INF ctor (eigenvectors)", lambda: INF(model, diag.state, kfac.state, efb.state))
+    inf = stage("INF ctor (eigvecs=efb.eigvecs: no second decomposition)",
+                lambda: INF(model, diag.state, kfac.state, efb.state, eigvecs=efb.eigvecs))
     stage("inf.update(100)", lambda: inf.update(rank=100))
     for est, nm in ((diag, "diag"), (kfac, "kfac"), (efb, "efb"), (inf, "inf")):
         stage(f"{nm}.invert(1, 1000)", lambda: est.invert(1.0, 1000.0))
+        stage(f"{nm}.invert(1, 1000) again", lambda: est.invert(1.0, 1000.0))
         stage(f"{nm}.sample_and_replace", est.sample_and_replace)
+        stage(f"{nm}.sample_and_replace again", est.sample_and_replace)
         ok = all(torch.isfinite(p).all().item() for p in model.parameters())
         print(f"  parameters finite: {ok}")
 
