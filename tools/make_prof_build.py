@@ -21,13 +21,13 @@ def main():
     s = sub(s, "  const int h = lane >> 5;\n", "  const int h = lane >> 5;\n  long long tprev = clock64();\n  const unsigned long long wall0 = wall_clock64();\n"
             "  unsigned pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned nmf = 0, pacc8 = 0, nchunk = 0;\n")
     s = sub(s, "  for (int ch = ch_begin; ch < ch_end; ++ch) {\n", "  PROF(0)\n  for (int ch = ch_begin; ch < ch_end; ++ch) {\n")
-    s = sub(s, "    if (!(d.pad0 & 10) || ch == ch_begin) store_stage(cur);\n    __syncthreads();\n",
+    s = sub(s, "#ifdef CURV_DIAG\n    if (!(d.pad0 & 10) || ch == ch_begin) store_stage(cur);\n#else\n    store_stage(cur);\n#endif\n    __syncthreads();\n",
             "    PROF(1)\n    __builtin_amdgcn_s_waitcnt(0x0f70);\n    { long long t_ = clock64(); pacc8 += (unsigned)(t_ - tprev); tprev = t_; }\n"
             "    if (!(d.pad0 & 10) || ch == ch_begin) store_stage(cur);\n    PROF(2)\n    __syncthreads();\n    PROF(3)\n    ++nchunk;\n")
-    s = sub(s, "    // ---- MFMA over this wave's share of the chunk's k-runs ----", "    PROF(4)")
-    s = sub(s, "      else go(std::integral_constant<int, 1>{});\n    }\n    __syncthreads();\n",
-            "      else go(std::integral_constant<int, 1>{});\n"
-            "      nmf += (work.niter - kfirst + KSTRIDE - 1) / KSTRIDE * (part == 0 ? 4 : part == 1 ? 3 : 2) * RL;\n    }\n"
+    s = sub(s, "    // ---- MFMA over this wave's share of the chunk ----", "    PROF(4)")
+    s = sub(s, "      else mfma_chunk(std::integral_constant<int, 0>{}, work, by_sample);     // strides > 2: step offsets at run time\n    }\n    __syncthreads();\n",
+            "      else mfma_chunk(std::integral_constant<int, 0>{}, work, by_sample);\n"
+            "      nmf += work.ns * work.ra * ((work.wa + 1) >> 1) / KSTRIDE * (part == 0 ? 4 : part == 1 ? 3 : 2);\n    }\n"
             "    PROF(5)\n    __syncthreads();\n    PROF(6)\n")
     s = sub(s, "      if (part != 2) q[(32 + row) * 128 + 32 + r32] = acc11[reg];\n    }\n  }\n}\n",
             "      if (part != 2) q[(32 + row) * 128 + 32 + r32] = acc11[reg];\n    }\n  }\n  PROF(7)\n"
@@ -52,8 +52,9 @@ extern "C" int curv_debug_syrk_prof(unsigned long long* out, int reset) {
     src = "/tmp/syrk_prof.hip"
     open(src, "w").write(s)
     out = os.path.join(ROOT, "tools", "micro", "libcurv_prof.so")
-    others = ["api.cpp", "elementwise.hip", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
-    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+    others = ["api.cpp", "elementwise.hip", "syrk_flat.hip", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
+    # -DCURV_DIAG: the only build in which CURV_SYRK_ABLATE (phase ablation switches) is read
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DCURV_DIAG", "-I" + os.path.join(ROOT, "include"),
            "-I" + CSRC, "-o", out, src] + [os.path.join(CSRC, o) for o in others]
     subprocess.check_call(cmd)
     print("built", out)
