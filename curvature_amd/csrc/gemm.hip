@@ -39,6 +39,7 @@ struct GemmDev {
   int tiles_n, tile_base;
   int tm;                 // tile edge: 64 or 128
   int tri;                // CURV_TRI_*: triangular operand -> shorter K range per tile
+  unsigned a_bytes, b_bytes;   // NT kernel: extents of the two operands (buffer range check)
 };
 
 typedef __attribute__((address_space(1))) float gfl;
@@ -204,6 +205,173 @@ gemm_f32_kernel(const GemmDev* __restrict__ table, int n_desc) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// NT products with K-contiguous operands on both sides (A[i][k] at A + i a_rs + k, B[k][j] at B + j b_cs + k):
+// every product of KFAC.sample_and_replace (L_G z^T, then (.) L_A^T) and of EFB.sample.  Staged like the flat factor
+// build (syrk_flat.hip): buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, into a double-buffered
+// [128 rows][8 x 16 B] image per operand, 16-byte slots XOR-swizzled by (row >> 1) & 7 on the SOURCE side, operands
+// back by conflict-free ds_read_b128 (one read = 4 k values of one row = the input of 4 MFMAs); lane half h takes k
+// group 2 j + h of a step; no staging registers, no LDS store pass; 64 KiB of LDS, two workgroups per CU.
+// Rows beyond M / N are clamped to the last row (their results are never stored); k beyond K is zeroed in the last
+// step; triangular operands cut the K range per tile (what lies beyond the cut inside the last step is stored zeros).
+// ------------------------------------------------------------------------------------------------
+namespace nt {
+constexpr int TM = 128, KC = 32, ROW_B = KC * 4, SLOTS = KC / 4, STEPS = KC / 8, RPP = 1024 / ROW_B;
+constexpr int PIECES = TM / RPP / 4, PANEL_B = TM * ROW_B, LDS_B = 4 * PANEL_B, NP = 2 * PIECES;
+constexpr int PPS = (NP + STEPS / 2 - 1) / (STEPS / 2);
+static_assert(PPS <= 4, "at most one DMA piece per MFMA group");
+}  // namespace nt
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) char lds_char_t;
+
+__device__ __forceinline__ void gemm_nt_tile(const GemmDev& d, int local, lds_char_t* lds) {
+  using namespace nt;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
+  if (d.tri == CURV_TRI_A_LOWER) tm = (d.M + TM - 1) / TM - 1 - tm;        // long tiles first
+  else if (d.tri == CURV_TRI_B_UPPER) tn = d.tiles_n - 1 - tn;
+  const int i0 = tm * TM, j0 = tn * TM, M = d.M, N = d.N;
+  int K = d.K;
+  const bool cut = (d.tri == CURV_TRI_A_LOWER && i0 + TM < K) || (d.tri == CURV_TRI_B_UPPER && j0 + TM < K);
+  if (d.tri == CURV_TRI_A_LOWER) K = min(K, i0 + TM);
+  else if (d.tri == CURV_TRI_B_UPPER) K = min(K, j0 + TM);
+  const int TS = (K + 7) >> 3;                       // steps of 8 k
+  const int n_stages = (TS + STEPS - 1) / STEPS;
+  const int nv_last = cut ? 8 : K - 8 * (TS - 1);    // k values of the last step that exist (beyond a cut: stored zeros)
+
+  // DMA lane geometry (see syrk_flat.hip): piece `slot` of this wave covers panel rows 32 slot + 8 wave + (lane >> 3)
+  const int rsub = RPP * wave + (lane >> 3);
+  const int g_lane = (lane & (SLOTS - 1)) ^ ((rsub >> 1) & 7);
+  // per-piece row offsets: rows beyond the matrix are clamped to its last row
+  int voff_a[PIECES], voff_b[PIECES];
+#pragma unroll
+  for (int p = 0; p < PIECES; ++p) {
+    const int ra = min(i0 + 32 * p + rsub, M - 1), rb = min(j0 + 32 * p + rsub, N - 1);
+    voff_a[p] = (int)(((long long)ra * d.a_rs + 4 * g_lane) * 4);
+    voff_b[p] = (int)(((long long)rb * d.b_cs + 4 * g_lane) * 4);
+  }
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, d.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)d.B, 0, d.b_bytes, 0x00020000);
+
+  unsigned addr[4][STEPS];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const int R = ((o < 2) ? 64 * wm : 64 * wn) + (o & 1) * 32 + r32;
+    const unsigned pbase = (o < 2) ? 0u : 2u * PANEL_B;
+    const int rkey = (R >> 1) & 7;
+#pragma unroll
+    for (int j = 0; j < STEPS; ++j) addr[o][j] = pbase + R * ROW_B + (((2 * j + h) ^ rkey) << 4);
+  }
+  f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+
+  int n_k0 = 0, n_gmax = 0;
+  unsigned n_buf = 0;
+  auto plan_next = [&](int t) {
+    n_k0 = t * KC;
+    n_gmax = min(SLOTS, (K - n_k0 + 3) >> 2);      // 16-byte groups this stage needs
+    n_buf = (unsigned)(t & 1) * PANEL_B;
+  };
+  auto piece = [&](int i) {
+    const int p = i / PIECES, slot = i % PIECES;
+    if (g_lane < n_gmax) {
+      const unsigned lbase = (p ? 2u * PANEL_B : 0u) + n_buf + (unsigned)(RPP * wave + 4 * RPP * slot) * ROW_B;
+      if (p == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_void_t*)(lds + lbase), 16, voff_a[slot], n_k0 * 4, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_void_t*)(lds + lbase), 16, voff_b[slot], n_k0 * 4, 0, 0);
+    }
+  };
+
+  if (n_stages > 0) {
+    plan_next(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) piece(i);
+  }
+  for (int t = 0; t < n_stages; ++t) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's DMA of stage t has landed
+    __syncthreads();
+    const bool more = t + 1 < n_stages;
+    if (more) plan_next(t + 1);
+    const int nsteps = min(STEPS, TS - t * STEPS);
+    const bool last = !more;
+    const unsigned buf = (unsigned)(t & 1) * PANEL_B;
+    auto rd = [&](int o, int j) { return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lds + addr[o][j] + buf); };
+    f32x4 a0 = rd(0, 0), a1 = rd(1, 0), b0 = rd(2, 0), b1 = rd(3, 0);
+    int next_piece = 0;
+#pragma unroll
+    for (int j = 0; j < STEPS; ++j) {
+      if (j < nsteps) {
+        f32x4 na0, na1, nb0, nb1;
+        if (j + 1 < STEPS && j + 1 < nsteps) { na0 = rd(0, j + 1); na1 = rd(1, j + 1); nb0 = rd(2, j + 1); nb1 = rd(3, j + 1); }
+        int ne = 4;
+        if (last && j == nsteps - 1 && nv_last < 8) {
+          ne = min(4, nv_last);
+          asm volatile("; k tail" ::: "memory");             // keeps this a branch (see syrk_flat.hip)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = (4 * h + e) < nv_last;
+            a0[e] = ok ? a0[e] : 0.0f; a1[e] = ok ? a1[e] : 0.0f;
+            b0[e] = ok ? b0[e] : 0.0f; b1[e] = ok ? b1[e] : 0.0f;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (e < ne) {
+            c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], c11, 0, 0, 0);
+          }
+          if (more && e < PPS && PPS * j + e < NP) piece(PPS * j + e);
+        }
+        next_piece = min(NP, PPS * j + PPS);
+        if (j + 1 < STEPS && j + 1 < nsteps) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) if (i >= next_piece) piece(i);
+    }
+  }
+
+  // epilogue; C/D map of the 32x32 block: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  gfl* C = (gfl*)d.C;
+  const gfl* E = (const gfl*)d.E;
+  const gfl* F = (const gfl*)d.F;
+  const float alpha = d.alpha, beta = d.beta;
+  const int ep = d.epilogue;
+  auto store_block = [&](const f32x16& acc, int m, int n) {
+    const int j = j0 + 64 * wn + 32 * n + r32;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int i = i0 + 64 * wm + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (i < M && j < N) {
+        const long long ci = i * d.c_rs + j * d.c_cs;
+        float v = alpha * acc[reg];
+        if (ep == CURV_EPI_SQUARE) v = alpha * acc[reg] * acc[reg];
+        else if (ep == CURV_EPI_MUL_E) v *= E[i * d.e_rs + j * d.e_cs];
+        else if (ep == CURV_EPI_ADD_E) v += E[i * d.e_rs + j * d.e_cs];
+        else if (ep == CURV_EPI_MUL_E_ADD_F) v = v * E[i * d.e_rs + j * d.e_cs] + F[i * d.f_rs + j * d.f_cs];
+        if (beta != 0.0f) v += beta * C[ci];
+        C[ci] = v;
+      }
+    }
+  };
+  store_block(c00, 0, 0);
+  store_block(c01, 0, 1);
+  store_block(c10, 1, 0);
+  store_block(c11, 1, 1);
+}
+
+__global__ void __launch_bounds__(GEMM_THREADS, 2)
+gemm_nt_kernel(const GemmDev* __restrict__ table, int n_desc) {
+  __shared__ __attribute__((aligned(1024))) char smem[nt::LDS_B];
+  const int f = gemm_find(table, n_desc, blockIdx.x);
+  const GemmDev& d = table[f];
+  gemm_nt_tile(d, blockIdx.x - d.tile_base, (lds_char_t*)smem);
+}
+
+// ------------------------------------------------------------------------------------------------
 // The same batched strided GEMM in fp64 (v_mfma_f64_16x16x4_f64) for the ill-conditioned products of
 // INF.pre_sampler (L_c = A^-T (I - B^-1) A^-1).  alpha/beta only, no fused epilogue.
 // ------------------------------------------------------------------------------------------------
@@ -303,7 +471,7 @@ gemm_f64_kernel(Gemm64Dev d0, Gemm64Dev d1, Gemm64Dev d2, Gemm64Dev d3, int n_de
       }
 }
 
-constexpr int GEMM_UPLOAD_CHUNK = 20;
+constexpr int GEMM_UPLOAD_CHUNK = 19;
 struct GemmChunk { GemmDev f[GEMM_UPLOAD_CHUNK]; };
 static_assert(sizeof(GemmChunk) <= 3840, "kernel argument block must stay below 4 KB");
 
@@ -375,9 +543,9 @@ extern "C" int curv_gemm_batched(void* stream_, const curv_gemm_desc* descs, int
     set_error("curv_gemm_batched: workspace too small");
     return CURV_ERR_WORKSPACE;
   }
-  std::vector<GemmDev> tab;
+  std::vector<GemmDev> tab, tab_nt;             // two work lists: the general kernel and the NT / LDS-DMA kernel
   tab.reserve(n_desc);
-  long long tiles = 0;
+  long long tiles = 0, tiles_nt = 0;
   for (int i = 0; i < n_desc; ++i) {
     const curv_gemm_desc& s = descs[i];
     CURV_REQUIRE(s.M >= 0 && s.N >= 0 && s.K >= 0, "curv_gemm_batched: desc %d: negative shape", i);
@@ -404,25 +572,48 @@ extern "C" int curv_gemm_batched(void* stream_, const curv_gemm_desc* descs, int
       CURV_REQUIRE((long long)d.tm * s.a_rs + 16 * s.a_cs < lim && (long long)d.tm * s.b_cs + 16 * s.b_rs < lim,
                    "curv_gemm_batched: desc %d: operand stride too large", i);
     }
+    // NT products with K-contiguous rows on both sides and at least one full-width tile edge go to the LDS-DMA
+    // kernel; their operand extents must fit a buffer descriptor (32-bit byte offsets)
+    const long long a_ext = ((long long)(s.M - 1) * s.a_rs + s.K) * 4, b_ext = ((long long)(s.N - 1) * s.b_cs + s.K) * 4;
+    const bool is_nt = s.a_cs == 1 && s.b_rs == 1 && s.M >= 64 && s.N >= 64 && s.K >= 8 &&
+                       a_ext < (1LL << 32) - 64 && b_ext < (1LL << 32) - 64;
+    if (is_nt) {
+      d.tm = 128;
+      d.a_bytes = (unsigned)a_ext; d.b_bytes = (unsigned)b_ext;
+      d.tiles_n = cdiv(s.N, 128);
+      d.tile_base = (int)tiles_nt;
+      tiles_nt += (long long)cdiv(s.M, 128) * d.tiles_n;
+      CURV_REQUIRE(tiles_nt < (1LL << 30), "curv_gemm_batched: too many tiles");
+      tab_nt.push_back(d);
+      continue;
+    }
     d.tiles_n = cdiv(s.N, d.tm);
     d.tile_base = (int)tiles;
     tiles += (long long)cdiv(s.M, d.tm) * d.tiles_n;
     CURV_REQUIRE(tiles < (1LL << 30), "curv_gemm_batched: too many tiles");
     tab.push_back(d);
   }
-  if (tab.empty()) return CURV_OK;
+  if (tab.empty() && tab_nt.empty()) return CURV_OK;
   GemmDev* table = reinterpret_cast<GemmDev*>(workspace);
-  const int n = (int)tab.size();
-  for (int b = 0; b < n; b += GEMM_UPLOAD_CHUNK) {
+  const int n = (int)tab.size(), n_nt = (int)tab_nt.size();
+  std::vector<GemmDev> all(tab);
+  all.insert(all.end(), tab_nt.begin(), tab_nt.end());
+  for (int b = 0; b < n + n_nt; b += GEMM_UPLOAD_CHUNK) {
     GemmChunk chunk;
-    const int count = std::min(GEMM_UPLOAD_CHUNK, n - b);
+    const int count = std::min(GEMM_UPLOAD_CHUNK, n + n_nt - b);
     memset(&chunk, 0, sizeof(chunk));
-    memcpy(chunk.f, tab.data() + b, (size_t)count * sizeof(GemmDev));
+    memcpy(chunk.f, all.data() + b, (size_t)count * sizeof(GemmDev));
     hipLaunchKernelGGL(gemm_upload_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count);
     CURV_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, stream, table, n);
-  CURV_LAUNCH_CHECK();
+  if (n_nt > 0) {
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)tiles_nt), dim3(GEMM_THREADS), 0, stream, table + n, n_nt);
+    CURV_LAUNCH_CHECK();
+  }
+  if (n > 0) {
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, stream, table, n);
+    CURV_LAUNCH_CHECK();
+  }
   return CURV_OK;
 }
 

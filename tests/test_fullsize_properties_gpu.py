@@ -219,19 +219,28 @@ def test_config5_resnet50_inf_chain(gpu, resnet50_kfac):
         for layer in layers:
             ua, ug, r, Pc = inf.inv_state[layer]
             assert torch.isfinite(r).all() and torch.isfinite(Pc).all() and Pc.shape == (ua.shape[1] * ug.shape[1],) * 2
-        # oracle in fp64 on the three smallest layers: r, P_c and a sample for the same noise
+        # oracle in fp64 on the three smallest layers: r, P_c and a sample for the same noise.  The reference keeps
+        # sigma and r as fp32 tensors (curvatures.py:525-526) and P_c is a sensitive function of them when V_s^T V_s
+        # is ill-conditioned (the line printed below says how far the exact P_c moves when r is NOT rounded to fp32),
+        # so the chain is judged on the SAME fp32 sigma and r (what pre_sampler receives, :528), promoted to fp64
+        # inside the oracle
         for layer, st in pre.items():
             ua, ug, lam, corr = (t.double().cpu() for t in st)
-            _, sigma, r64, vtv64, Pc64 = o.inf_invert(ua, ug, lam, corr, add, mul)
+            _, sigma64, r64, _, Pc_exact_r = o.inf_invert(ua, ug, lam, corr, add, mul)
             _, _, r, Pc = inf.inv_state[layer]
             assert rel_fro(r, r64) < 1e-6
+            sigma32 = (mul * st[2]).sqrt().double().cpu()             # fp32 arithmetic, as the reference / the kernel
+            assert rel_fro(sigma32, sigma64) < 1e-6
+            r32 = r.double().cpu()
+            Pc64 = o.inf_pre_sampler_from_vtv(o.inf_vtv(ua, ug, sigma32, r32), sigma32)
             e_pc = rel_fro(Pc, Pc64)
             X = torch.randn(r.numel(), generator=torch.Generator().manual_seed(5))
             s = inf.sample(layer, X=X.to(gpu))
-            e_s = rel_fro(s, o.inf_sampler(ua, ug, r64, Pc64, X.double()))
-            print(f"config 5, ({add}, {mul}), n*m={r.numel()}, ab={Pc.shape[0]}: P_c err {e_pc:.2e}, sample err {e_s:.2e}")
+            e_s = rel_fro(s, o.inf_sampler(ua, ug, r32, Pc64, X.double()))
+            print(f"config 5, ({add}, {mul}), n*m={r.numel()}, ab={Pc.shape[0]}: P_c err {e_pc:.2e}, sample err {e_s:.2e}; "
+                  f"P_c moves by {rel_fro(Pc64, Pc_exact_r):.1e} when r is not rounded to fp32")
             assert e_s < 1e-4, (add, mul, e_s)
-            assert e_pc < 1e-3, (add, mul, e_pc)
+            assert e_pc < 1e-4, (add, mul, e_pc)
         inf.sample_and_replace()
         changed = 0
         for k, v in model.state_dict().items():
