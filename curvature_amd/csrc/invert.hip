@@ -489,30 +489,38 @@ __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* ba
       // the columns (the failure flag and the pivots' reciprocals stay in registers until the panel is done), so that
       // the scheduler can start column c + 1's pivot chain - broadcast, rsqrt, two Newton steps: the critical path -
       // under the 14 remaining rank-1 updates of column c instead of after them.
-      double row[16], dv[16];
+      double row[16], mine = 1.0;      // mine: lane c < 16 collects 1 / L_cc of its column (a VGPR, not 16 SGPR pairs)
       int first_bad = 0;
 #pragma unroll
       for (int c = 0; c < 16; ++c) row[c] = Ds[lane * LDA + c0 + c];
+      // software-pipelined by hand: column c + 1's pivot chain (broadcast, rsqrt, two Newton steps - the critical
+      // path) is started right after the one update it depends on, and the other updates of column c fill its latency;
+      // the scheduling barrier per column keeps the broadcasts (SGPR pairs) of one column from piling up over the next.
+      double dinv;
+      {
+        const double piv = readlane_f64(row[0], c0);
+        const bool ok = piv > 0.0 && piv < 1.0e300;               // also false for NaN
+        dinv = rsqrt_pos(ok ? piv : 1.0);                         // select the INPUT: a select of the result becomes a
+        first_bad = ok ? 0 : pivot_base + c0 + 1;                 // scalar branch that cuts the column into basic blocks
+      }
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        const double piv = readlane_f64(row[c], c0 + c);
-        const bool ok = piv > 0.0 && piv < 1.0e300;               // also false for NaN
-        const double dinv = ok ? rsqrt_pos(piv) : 1.0;
-        first_bad = (!ok && first_bad == 0) ? pivot_base + c0 + c + 1 : first_bad;
-        dv[c] = dinv;
+        mine = (lane == c) ? dinv : mine;
         row[c] *= dinv;
-        // the next column first: its pivot is what the next iteration waits for
+        if (c + 1 < 16) {
+          row[c + 1] -= row[c] * readlane_f64(row[c], c0 + c + 1);
+          const double piv = readlane_f64(row[c + 1], c0 + c + 1);
+          const bool ok = piv > 0.0 && piv < 1.0e300;
+          dinv = rsqrt_pos(ok ? piv : 1.0);
+          first_bad = (!ok && first_bad == 0) ? pivot_base + c0 + c + 2 : first_bad;
+        }
 #pragma unroll
-        for (int q = c + 1; q < 16; ++q) row[q] -= row[c] * readlane_f64(row[c], c0 + q);
+        for (int q = c + 2; q < 16; ++q) row[q] -= row[c] * readlane_f64(row[c], c0 + q);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int c = 0; c < 16; ++c) Ds[lane * LDA + c0 + c] = row[c];
-      if (lane < 16) {
-        double mine = dv[0];
-#pragma unroll
-        for (int c = 1; c < 16; ++c) mine = (lane == c) ? dv[c] : mine;
-        dinv_s[c0 + lane] = mine;
-      }
+      if (lane < 16) dinv_s[c0 + lane] = mine;
       if (first_bad != 0 && lane == 0 && *bad == 0) *bad = first_bad;
     }
     __syncthreads();
