@@ -276,6 +276,96 @@ class Diagonal(Curvature):
         self._allgather_sampled()
 
 
+class BlockDiagonal(Curvature):
+    """Block-diagonal (per-layer, full P x P) Fisher: state += ger(g, g) * batch_size with
+    g = [W.grad.view(-1) ; b.grad] (curvatures.py:196-261).
+
+    * ``update``: the rank-1 accumulation is the factor-build kernel on a one-sample linear "layer" (src (1, P)).
+    * ``invert``: ``(s F + n I).inverse().cholesky()`` (:252-253) is the KFAC factor inversion with (n^2, s^2)
+      passed for (add, multiply) - that routine damps with sqrt(s) F + sqrt(n) I, computed in double on the host.
+    * ``sample``: ``z @ L`` (:258) as one GEMM.  The reference then views the weight part with ``weight.shape`` and
+      concatenates the bias column along dim 1, which raises for Conv2d (4-D with 2-D).  Here the weight part is
+      (out, -1) for every layer type - identical for Linear, and what ``_replace`` consumes for Conv2d.
+    O(P^2) memory per layer: meant for small layers, like the reference's.  MultiheadAttention is not supported
+    (the reference's branch, :220-239, concatenates a 2-D gradient with a 1-D bias and raises)."""
+
+    def update(self, batch_size: int):
+        jobs = []
+        for _, layer in self._owned():
+            parts = [layer.weight.grad.contiguous().view(-1)]
+            if layer.bias is not None:
+                parts.append(layer.bias.grad.contiguous())
+            g = ops.concat(parts) if len(parts) > 1 else parts[0]
+            first = layer not in self.state
+            if first:
+                self.state[layer] = torch.empty(g.numel(), g.numel(), dtype=torch.float32, device=g.device)
+            jobs.append(ops.FactorJob(g.view(1, -1), self.state[layer], scale=float(batch_size), first=first))
+        ops.kfac_accumulate(jobs)
+
+    def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
+        assert self.state, "State dict is empty. Did you call 'update' prior to this?"
+        gindex = self._global_index()
+        adds, muls = [], []
+        for position, layer in enumerate(self.state.keys()):
+            n, s = self._hyper(add, multiply, gindex.get(layer, position), max(len(gindex), len(self.state)))
+            adds.append(n * n)
+            muls.append(s * s)
+        prev = [self.inv_state.get(layer) for layer in self.state.keys()]
+        chols = ops.chol_inv_lower(list(self.state.values()), adds, muls, outs=prev)
+        for layer, chol in zip(self.state.keys(), chols):
+            self.inv_state[layer] = chol
+
+    def _draw(self, layer: Module, z: Optional[Tensor]) -> Tensor:
+        inv = self.inv_state[layer]
+        if z is None:
+            z = self._randn(inv.shape[0], device=inv.device)
+        x = torch.empty(1, inv.shape[0], dtype=torch.float32, device=inv.device)
+        ops.gemm_batched([ops.Gemm(z.view(1, -1), inv, x)])
+        return x.view(-1)
+
+    def sample(self, layer: Module, z: Optional[Tensor] = None) -> Tensor:
+        assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
+        x = self._draw(layer, z)
+        n_w = layer.weight.numel()
+        rows = layer.weight.shape[0]
+        out = torch.empty(rows, n_w // rows + int(layer.bias is not None), dtype=torch.float32, device=x.device)
+        out[:, :n_w // rows] = x[:n_w].view(rows, -1)         # the reference's torch.cat (:260-261): API plumbing
+        if layer.bias is not None:
+            out[:, -1] = x[n_w:]
+        return out
+
+    def sample_and_replace(self):
+        """The base-class loop fused: one noise launch and one batched GEMM launch for all owned layers.  The draw
+        z @ L is written straight onto the parameters in g's order (weights, then biases) with the mean added in the
+        epilogue: no [W | b] detour, and the reload of the mean skips the parameters that are overwritten here."""
+        assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
+        owned = [(i, l) for i, l in self._owned() if l in self.inv_state]
+        jobs, skip = [], []
+        if owned:
+            dev = self.inv_state[owned[0][1]].device
+            flat = self._randn(sum(self.inv_state[l].shape[0] for _, l in owned), device=dev)
+            pos = 0
+            for _, layer in owned:
+                inv = self.inv_state[layer]
+                P, n_w = inv.shape[0], layer.weight.numel()
+                z = flat[pos:pos + P].view(1, P)
+                pos += P
+                w = layer.weight.data
+                if not w.is_contiguous():
+                    raise RuntimeError("BlockDiagonal.sample_and_replace: parameters must be contiguous")
+                jobs.append(ops.Gemm(z, inv[:, :n_w], w.view(1, n_w), epilogue=ops.EPI_ADD_E,
+                                     E=self.model_state_of(layer, 'weight').view(1, n_w)))
+                skip.append(w)
+                if layer.bias is not None:
+                    b = layer.bias.data
+                    jobs.append(ops.Gemm(z, inv[:, n_w:], b.view(1, P - n_w), epilogue=ops.EPI_ADD_E,
+                                         E=self.model_state_of(layer, 'bias').view(1, P - n_w)))
+                    skip.append(b)
+        self._reload_mean(skip=skip)
+        ops.gemm_batched(jobs)
+        self._allgather_sampled()
+
+
 class KFAC(Curvature):
     """Kronecker-factored Fisher (curvatures.py:264-392).
 

@@ -156,6 +156,43 @@ def efb_sample(U_A: Tensor, U_G: Tensor, inv_lambda: Tensor, z: Tensor) -> Tenso
 
 
 # --------------------------------------------------------------------------------------------
+# BlockDiagonal                                            curvature/curvatures.py:196-261
+# --------------------------------------------------------------------------------------------
+def block_grad_vector(grad_w: Tensor, grad_b: Optional[Tensor]) -> Tensor:
+    """[W.grad.view(-1) ; b.grad]: all weights first, the biases at the END (curvatures.py:215-217) - not the
+    [W | b] matrix layout of the other estimators."""
+    g = grad_w.contiguous().view(-1)
+    if grad_b is not None:
+        g = torch.cat([g, grad_b])
+    return g
+
+
+def block_update(grad_w: Tensor, grad_b: Optional[Tensor], batch_size) -> Tensor:
+    """ger(g, g) * batch_size (curvatures.py:218)."""
+    g = block_grad_vector(grad_w, grad_b)
+    return torch.ger(g, g) * batch_size
+
+
+def block_invert(value: Tensor, add, multiply) -> Tensor:
+    """(s * F + diag(n)).inverse().cholesky()  - lower factor (curvatures.py:252-253)."""
+    reg = torch.diag(value.new(value.shape[0]).fill_(add))
+    return torch.linalg.cholesky((multiply * value + reg).inverse())
+
+
+def block_sample(inv_state: Tensor, z: Tensor, weight_shape, has_bias: bool = True) -> Tensor:
+    """x = z @ L, weights reshaped, bias as the last column (curvatures.py:258-261).  The reference views the
+    weight part with ``weight.shape`` and then concatenates along dim 1, which only works for Linear layers (a
+    4-D Conv2d weight cannot be concatenated with the 2-D bias column: SURVEY.md section 2 row 6); the form here
+    - weight part as (out, -1) - is the same thing for Linear and is what `_replace` needs for Conv2d."""
+    x = z @ inv_state
+    n_w = int(np.prod(weight_shape))
+    w = x[:n_w].contiguous().view(weight_shape[0], -1)
+    if not has_bias:
+        return w
+    return torch.cat([w, torch.unsqueeze(x[n_w:], dim=1)], dim=1)
+
+
+# --------------------------------------------------------------------------------------------
 # INF                                                      curvature/curvatures.py:487-672
 # --------------------------------------------------------------------------------------------
 def inf_select(lambda_vec: Tensor, m: int, rank: int) -> Tuple[np.ndarray, np.ndarray]:

@@ -162,3 +162,23 @@ def test_noise_seed_is_lazy_and_per_instance():
     assert sa != sb and a._seed() == sa                              # two draws from torch's generator; then pinned
     torch.manual_seed(5)
     assert KFAC(m)._seed() == sa
+
+
+def test_block_diagonal_api():
+    """BlockDiagonal has the reference's surface (curvatures.py:196-261); MultiheadAttention is rejected (the
+    reference's branch for it raises inside torch.cat); nothing computes on the CPU."""
+    from curvature_amd.curvatures import BlockDiagonal, Curvature
+    assert issubclass(BlockDiagonal, Curvature)
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3))
+    est = BlockDiagonal(m)
+    with pytest.raises(AssertionError):
+        est.invert()
+    with pytest.raises(AssertionError):
+        est.sample(m[0])
+    m.add_module("attn", torch.nn.MultiheadAttention(4, 2))
+    with pytest.raises(NotImplementedError):
+        BlockDiagonal(m).update(batch_size=1)
+    m[0].weight.grad = torch.zeros(3, 4)
+    m[0].bias.grad = torch.zeros(3)
+    with pytest.raises(RuntimeError):
+        BlockDiagonal(m, 'Linear').update(batch_size=1)           # CPU tensors: no fallback

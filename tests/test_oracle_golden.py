@@ -223,3 +223,27 @@ def test_inf_sampler_gauge_dependence_of_the_reference():
         assert _rel(out[0], g9[f"sample_l{li}"]) < 1e-6          # unflipped: the reference's sample
         moved.append(_rel(out[1], out[0]))
     assert moved[0] > 5e-3 and moved[1] > 2e-2, moved                # 1.7e-2 and 8.2e-2 measured
+
+
+def test_block_diagonal():
+    """BlockDiagonal (curvatures.py:196-261) against golden g13: state after one and two batches, both inverse sets,
+    the Linear layers' samples."""
+    g = load("g13_block_diagonal.npz")
+    for li in range(3):
+        state = None
+        for b in range(2):
+            upd = o.block_update(g[f"b{b}_l{li}_gw"], g[f"b{b}_l{li}_gb"], 4)
+            state = upd if state is None else state + upd
+            assert torch.equal(state, g[f"state_after{b + 1}_l{li}"])
+        assert rel_fro(o.block_invert(state, 0.5, 2.0), g[f"a_inv_l{li}"]) < 1e-5
+        n, s = float(g["b_add"][li]), float(g["b_mul"][li])
+        assert rel_fro(o.block_invert(state, n, s), g[f"b_inv_l{li}"]) < 1e-5
+        if li > 0:        # the reference's sample only works for Linear layers
+            smp = o.block_sample(g[f"a_inv_l{li}"], g[f"z_l{li}"], g[f"w_l{li}"].shape)
+            assert torch.allclose(smp, g[f"sample_l{li}"], rtol=0, atol=1e-6)
+            assert smp.shape == (g[f"w_l{li}"].shape[0], g[f"w_l{li}"].shape[1] + 1)
+    # Conv2d: weight part as (out, -1), bias as the last column - what `_replace` consumes
+    smp = o.block_sample(g["a_inv_l0"], g["z_l0"], g["w_l0"].shape)
+    assert smp.shape == (2, 10)
+    x = g["z_l0"] @ g["a_inv_l0"]
+    assert torch.equal(smp[:, :9].reshape(-1), x[:18]) and torch.equal(smp[:, 9], x[18:])

@@ -58,7 +58,7 @@ torch.tensor = _compat_tensor
 
 sys.path.insert(0, REF)
 os.chdir(REF)  # lenet5(pretrained=...) resolves its checkpoint relative to cwd (curvature/lenet5.py:27)
-from curvature.curvatures import KFAC, EFB, INF, Diagonal  # noqa: E402
+from curvature.curvatures import KFAC, EFB, INF, Diagonal, BlockDiagonal  # noqa: E402
 from curvature.lenet5 import lenet5  # noqa: E402
 from curvature import resnet as ref_resnet  # noqa: E402
 from curvature.utils import kron as ref_kron  # noqa: E402
@@ -377,11 +377,57 @@ def gen_kron():
     save("g10_kron.npz", a=npf(a), b=npf(b), ab=npf(ref_kron(a, b)), c=npf(c), d=npf(d), cd=npf(ref_kron(c, d)))
 
 
+def gen_block_diagonal():
+    """G13: BlockDiagonal (curvature/curvatures.py:196-261) on a small conv + linear net: per-layer P x P state after
+    one and two batches, the inverse factors for a scalar and a per-layer hyper-parameter pair, and samples of the
+    Linear layers (the reference's `sample` cannot handle Conv2d: it concatenates a 4-D view with a 2-D column)."""
+    N = 4
+    torch.manual_seed(13)
+    model = torch.nn.Sequential(torch.nn.Conv2d(1, 2, 3), torch.nn.ReLU(), torch.nn.Flatten(),
+                                torch.nn.Linear(2 * 4 * 4, 6), torch.nn.ReLU(), torch.nn.Linear(6, 4)).eval()
+    est = BlockDiagonal(model)
+    g = {}
+    for li, layer in enumerate(layers_of(est)):
+        g[f"w_l{li}"] = npf(layer.weight)
+        g[f"bias_l{li}"] = npf(layer.bias)
+    for b in range(2):
+        torch.manual_seed(600 + b)
+        x = torch.rand(N, 1, 6, 6)
+        labels = fwd_bwd(model, x, 700 + b)
+        est.update(batch_size=N)
+        g[f"b{b}_x"] = npf(x)
+        g[f"b{b}_labels"] = npf(labels)
+        for li, layer in enumerate(layers_of(est)):
+            g[f"b{b}_l{li}_gw"] = npf(layer.weight.grad)
+            g[f"b{b}_l{li}_gb"] = npf(layer.bias.grad)
+            g[f"state_after{b + 1}_l{li}"] = npf(est.state[layer])
+    per_layer_add = [0.5, 1.0, 2.0]
+    per_layer_mul = [1.0, 10.0, 100.0]
+    for tag, (add, mul) in {"a": (0.5, 2.0), "b": (per_layer_add, per_layer_mul)}.items():
+        est.inv_state = {}
+        est.invert(add=add, multiply=mul)
+        for li, layer in enumerate(layers_of(est)):
+            g[f"{tag}_inv_l{li}"] = npf(est.inv_state[layer])
+    g["b_add"], g["b_mul"] = np.array(per_layer_add), np.array(per_layer_mul)
+    est.inv_state = {}
+    est.invert(add=0.5, multiply=2.0)
+    torch.manual_seed(1313)
+    for li, layer in enumerate(layers_of(est)):
+        g[f"z_l{li}"] = npf(torch.randn(est.inv_state[layer].shape[0]))       # the stream `.normal_()` draws from
+    torch.manual_seed(1313)
+    for li, layer in enumerate(layers_of(est)):
+        if isinstance(layer, torch.nn.Linear):
+            g[f"sample_l{li}"] = npf(est.sample(layer))
+        else:
+            est.inv_state[layer].new(est.inv_state[layer].shape[0]).normal_()   # keep the stream aligned with z_l*
+    save("g13_block_diagonal.npz", **g)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]                      # e.g. `python tools/make_golden.py mc_fisher` regenerates one set
     gens = {"kron": gen_kron, "conv_shapes": gen_conv_shapes, "lenet": gen_lenet, "layer_tables": gen_layer_tables,
-            "mc_fisher": gen_mc_fisher}
+            "mc_fisher": gen_mc_fisher, "block_diagonal": gen_block_diagonal}
     for name, fn in gens.items():
         if not only or name in only:
             fn()
