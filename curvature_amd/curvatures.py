@@ -144,6 +144,17 @@ class Curvature(ABC):
         self.noise_offset += (numel + 3) // 4
         return out
 
+    def _sample_plans(self) -> dict:
+        """Launch plans of sample_and_replace, keyed by the addresses they were described for.  TWO are kept: the
+        overlapped inference loop (evaluate.eval_bnn) alternates between two parameter buffer sets."""
+        return self.__dict__.setdefault("_sample_plan_cache", {})
+
+    def _keep_plan(self, key, plan) -> None:
+        plans = self._sample_plans()
+        while len(plans) >= 2:
+            plans.pop(next(iter(plans)))
+        plans[key] = plan
+
     def _reload_mean(self, skip: Sequence[Tensor] = ()):
         """``model.load_state_dict(model_state)`` (curvatures.py:119) as one batched copy: a ResNet-50 has
         ~320 state tensors, i.e. ~320 copy launches (3 ms) through torch.  `skip`: live tensors the
@@ -164,7 +175,8 @@ class Curvature(ABC):
         key = (ptrs, means, tuple(sorted(t.data_ptr() for t in skip)))
         plan = self._reload_plans.get(key)
         if plan is None:
-            self._reload_plans.clear()
+            while len(self._reload_plans) >= 2:                  # two parameter buffer sets (evaluate.eval_bnn)
+                self._reload_plans.pop(next(iter(self._reload_plans)))
             skipped = set(key[2])
             pairs = [(v.data, self.model_state[k]) for k, v in live if v.data_ptr() not in skipped]
             plan = ops.CopyPlan([d for d, _ in pairs], [s_ for _, s_ in pairs])
@@ -515,8 +527,8 @@ class KFAC(Curvature):
                tuple(self.model_state_of(l, nm).data_ptr() for _, l in owned for nm in ('weight', 'bias')
                      if getattr(l, nm) is not None),
                tuple(z.data_ptr() for z in noise.values()) if noise is not None else ())
-        plan = getattr(self, "_sample_plan", None)
-        if plan is None or plan[0] != key:
+        plan = self._sample_plans().get(key)
+        if plan is None:
             stage1, stage2 = [], []
             flat, pos = None, 0
             if noise is None and owned:        # one generator launch for the whole model
@@ -546,7 +558,7 @@ class KFAC(Curvature):
             stage1.sort(key=lambda j: -(j.A.shape[0] * j.A.shape[1] * j.B.shape[1]))
             stage2.sort(key=lambda j: -(j.A.shape[0] * j.A.shape[1] * j.B.shape[1]))
             plan = (key, flat, ops.GemmPlan(stage1), ops.GemmPlan(stage2))
-            self._sample_plan = plan
+            self._keep_plan(key, plan)
         if plan[1] is not None:
             self._randn(plan[1].numel(), device=plan[1].device, out=plan[1])
         plan[2].run()
@@ -696,8 +708,8 @@ class EFB(Curvature):
                tuple(p.data_ptr() for l in layers for p in (l.weight, l.bias) if p is not None),
                tuple(self.model_state_of(l, nm).data_ptr() for l in layers for nm in ('weight', 'bias')
                      if getattr(l, nm) is not None))
-        plan = getattr(self, "_sample_plan", None)
-        if plan is None or plan[0] != key:
+        plan = self._sample_plans().get(key)
+        if plan is None:
             dev = self.inv_state[layers[0]].device
             shapes = [tuple(self.inv_state[l].shape) for l in layers]               # (m, n)
             zflat, zts = _arena(shapes, dev)
@@ -722,7 +734,7 @@ class EFB(Curvature):
             whole = _is_arena(inv_flat, [self.inv_state[l] for l in layers]) and \
                 sum(self.inv_state[l].numel() for l in layers) == zflat.numel()
             plan = (key, zflat, zts, ops.GemmPlan(stage1), ops.GemmPlan(stage2), inv_flat if whole else None)
-            self._sample_plan = plan
+            self._keep_plan(key, plan)
         _, zflat, zts, plan1, plan2, inv_flat = plan
         if noise is None:
             # z^T of the reference drawn directly in (m, n) layout: the transpose of iid noise is iid noise
@@ -802,7 +814,7 @@ class INF(Curvature):
             self.state[layer] = (ua, ug, lam, corr.view(-1))
         ops.gemm_batched(stage1)
         ops.gemm_batched(stage2)
-        self._sample_plan = None
+        self.__dict__.pop("_sample_plan_cache", None)
 
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
         assert self.state, "State dict is empty. Did you call 'update' prior to this?"
@@ -919,8 +931,8 @@ class INF(Curvature):
             return
         key = (tuple(t.data_ptr() for l in layers for t in self.inv_state[l]),
                tuple(p.data_ptr() for l in layers for p in (l.weight, l.bias) if p is not None))
-        plan = getattr(self, "_sample_plan", None)
-        if plan is None or plan[0] != key:
+        plan = self._sample_plans().get(key)
+        if plan is None:
             dev = self.inv_state[layers[0]][0].device
             dims = [(self.inv_state[l][0].shape, self.inv_state[l][1].shape) for l in layers]
             xflat, Xs = _arena([(n * m,) for (n, _), (m, _) in dims], dev)
@@ -952,7 +964,7 @@ class INF(Curvature):
                 sum(self.inv_state[l][2].numel() for l in layers) == xflat.numel()
             plan = (key, xflat, Xs, yflat, Ys, r2flat, r2s, [ops.GemmPlan(st) for st in stages],
                     self._r_flat if r_whole else None)
-            self._sample_plan = plan
+            self._keep_plan(key, plan)
         _, xflat, Xs, yflat, Ys, r2flat, r2s, gemms, r_flat = plan
         if noise is None:
             self._randn(xflat.numel(), device=xflat.device, out=xflat)

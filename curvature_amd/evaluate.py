@@ -6,10 +6,24 @@ batched GEMM launches + one batched copy here) and a forward pass over the data;
 distribution is the mean of the per-sample softmax outputs.  Unlike the reference, probabilities are
 accumulated on the device and cross to the host once at the end (the reference concatenates logits batch
 by batch and converts every sample to numpy).  SURVEY.md section 8(f), rank 3.
+
+``overlap=True`` software-pipelines the loop: the model's state tensors get a second buffer set, and weight sample
+k + 1 (and, with a layer shard, its all-gather) is produced on a second HIP stream into the set the forward sweep of
+sample k is NOT reading.  Two events per set order the streams (sample written -> forward may read; forward done ->
+next sample may overwrite).  The noise stream and every launch are the serial loop's, so the predictions are the
+same bit for bit (tests/test_round2_gpu.py).  Measured on one MI355X (tools/bench_bnn_loop.py, KFAC, ms per
+Monte-Carlo sample, serial -> overlapped): ResNet-50 batch 32: 6.36 -> 6.28; batch 32 x 4 sweeps: 21.6 -> 21.8; batch
+256: 37.9 -> 37.9; LeNet-5 batch 100: 0.30 -> 0.64.  On one GPU there is nothing to win: a throughput-bound forward
+sweep leaves no idle CUs for the 1.5 ms of sampling work, a launch-bound one (batch 32) is bound by the same Python
+thread that enqueues the sample, and a tiny model pays for re-pointing its state tensors.  The default is therefore
+the serial loop, and the pipelined one is switched on only for a layer-sharded estimator, where it takes the
+all-gather of the sampled parameters (a wait on the other ranks, not local work) off the forward stream.
 """
-from typing import Iterable, Tuple
+from typing import Iterable, List, Tuple
 
 import torch
+
+from . import ops
 
 
 def eval_nn(model: torch.nn.Module, dataset: Iterable, device=None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -30,19 +44,80 @@ def eval_nn(model: torch.nn.Module, dataset: Iterable, device=None) -> Tuple[tor
     return predictions, labels
 
 
-def eval_bnn(model: torch.nn.Module, dataset: Iterable, estimator, samples: int = 30, device=None):
+class _StateBufferSets:
+    """Two storage sets for every state tensor of a model (parameters and buffers); `activate(i)` points the
+    model at set i.  Set 0 is the storage the model came with."""
+
+    def __init__(self, model: torch.nn.Module):
+        self.live: List[torch.Tensor] = list(model.state_dict(keep_vars=True).values())
+        first = [t.data for t in self.live]
+        self.sets = [first, [t.clone() for t in first]]
+
+    def activate(self, index: int) -> None:
+        for t, buf in zip(self.live, self.sets[index]):
+            t.data = buf
+
+    def copy(self, dst: int, src: int) -> None:
+        pairs = [(d, s_) for d, s_ in zip(self.sets[dst], self.sets[src]) if d.numel()]
+        batched = [(d, s_) for d, s_ in pairs if d.is_contiguous() and s_.is_contiguous()]
+        ops.CopyPlan([d for d, _ in batched], [s_ for _, s_ in batched]).run()      # one launch group, any dtype
+        for d, s_ in pairs:
+            if not (d.is_contiguous() and s_.is_contiguous()):
+                d.copy_(s_)
+
+
+def eval_bnn(model: torch.nn.Module, dataset: Iterable, estimator, samples: int = 30, device=None,
+             overlap: bool = None):
     """Mean predictive distribution over `samples` posterior weight samples (scripts/evaluate.py:121-152,
     ``stats=False`` path).  Returns ``(mean_predictions, labels)`` as numpy arrays like the reference.
-    The model is left at the last sampled weights, as in the reference."""
+    The model is left at the last sampled weights, as in the reference, in its original storage.
+
+    `overlap`: produce sample k + 1 on a second stream while the forward sweep of sample k runs (see the module
+    docstring for what that does and does not buy); default: only for a layer-sharded estimator on the GPU.
+    ``overlap=False`` is the reference's serial loop."""
     if device is None:
         device = next(model.parameters()).device
+    device = torch.device(device)
+    if overlap is None:
+        shard = getattr(estimator, "shard", None)
+        overlap = device.type == "cuda" and shard is not None and shard.world > 1
     model.eval()
     mean_predictions = None
     labels = None
     with torch.no_grad():
-        for _ in range(samples):
-            estimator.sample_and_replace()
-            predictions, labels = eval_nn(model, dataset, device)
-            mean_predictions = predictions if mean_predictions is None else mean_predictions + predictions
+        if not overlap or samples < 2:
+            for _ in range(samples):
+                estimator.sample_and_replace()
+                predictions, labels = eval_nn(model, dataset, device)
+                mean_predictions = predictions if mean_predictions is None else mean_predictions + predictions
+        else:
+            main = torch.cuda.current_stream(device)
+            side = torch.cuda.Stream(device)
+            sets = _StateBufferSets(model)
+            written = [torch.cuda.Event(), torch.cuda.Event()]     # sample is complete in set i
+            consumed = [torch.cuda.Event(), torch.cuda.Event()]    # the forward sweep has finished reading set i
+            side.wait_stream(main)                                 # invert() etc. enqueued by the caller
+            with torch.cuda.stream(side):
+                estimator.sample_and_replace()                     # sample 0 -> set 0
+                written[0].record(side)
+            cur = 0
+            for k in range(samples):
+                cur, nxt = k % 2, 1 - k % 2
+                if k + 1 < samples:
+                    sets.activate(nxt)
+                    with torch.cuda.stream(side):
+                        if k >= 1:
+                            side.wait_event(consumed[nxt])         # sweep k - 1 read set nxt
+                        estimator.sample_and_replace()             # sample k + 1 -> set nxt, concurrent with sweep k
+                        written[nxt].record(side)
+                sets.activate(cur)
+                main.wait_event(written[cur])
+                predictions, labels = eval_nn(model, dataset, device)
+                consumed[cur].record(main)
+                mean_predictions = predictions if mean_predictions is None else mean_predictions + predictions
+            if cur != 0:                                           # leave the last sample in the original storage
+                sets.copy(0, 1)
+                sets.activate(0)
+            main.wait_stream(side)
         mean_predictions = mean_predictions / samples
     return mean_predictions.cpu().numpy(), labels.numpy()

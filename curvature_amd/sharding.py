@@ -84,8 +84,9 @@ class Shard:
             return
         ref = params_per_layer[0][0]
         key = tuple(p.data_ptr() for ps in params_per_layer for p in ps)
-        cache = getattr(self, "_plan", None)
-        if cache is None or cache["key"] != key:
+        plans = self.__dict__.setdefault("_plans", {})       # two kept: evaluate.eval_bnn alternates two buffer sets
+        cache = plans.get(key)
+        if cache is None:
             sizes = [0] * self.world
             for i, ps in enumerate(params_per_layer):
                 sizes[self.owner[i]] += sum(p.numel() for p in ps)
@@ -113,7 +114,9 @@ class Shard:
                 from . import ops
                 cache["pack_plan"] = ops.CopyPlan([d for d, _ in pack], [s_ for _, s_ in pack])
                 cache["unpack_plan"] = ops.CopyPlan([d for d, _ in unpack], [s_ for _, s_ in unpack])
-            self._plan = cache
+            while len(plans) >= 2:
+                plans.pop(next(iter(plans)))
+            plans[key] = cache
         mine, gathered = cache["mine"], cache["gathered"]
         if cache["pack_plan"] is not None:
             cache["pack_plan"].run()

@@ -399,3 +399,76 @@ def test_ablation_variable_is_inert_in_the_shipped_library(gpu, tmp_path):
         subprocess.run([sys.executable, str(script), str(out)], check=True, env=env, timeout=300)
         outs.append(torch.load(out))
     assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().sum()) > 0
+
+
+# ------------------------------------------------------------------------------------------------ f3: overlapped BNN loop
+@pytest.mark.parametrize("kind", ["kfac", "diag", "efb", "inf"])
+def test_eval_bnn_overlap_is_the_serial_loop(gpu, kind):
+    """evaluate.eval_bnn(overlap=True) produces weight sample k + 1 on a second stream, into a second buffer set,
+    while the forward sweep of sample k runs.  Same noise stream, same launches: the mean
+    predictive distribution must equal the serial loop's bit for bit, for an odd and an even number of samples, and
+    the model must end at the last sample in its ORIGINAL storage."""
+    from curvature_amd.curvatures import KFAC, EFB, INF, Diagonal
+    from curvature_amd.evaluate import eval_bnn
+    g1 = load("g1_kfac_lenet.npz")
+    model, layers = lenet(gpu, g1)
+    kfac, diag = KFAC(model), Diagonal(model)
+    for b in range(2):
+        n = backward(model, g1, b, gpu)
+        kfac.update(n)
+        diag.update(n)
+    if kind == "kfac":
+        est = kfac
+    elif kind == "diag":
+        est = diag
+    else:
+        efb = EFB(model, kfac.state)
+        backward(model, g1, 0, gpu)
+        efb.update(8)
+        est = efb if kind == "efb" else INF(model, diag.state, kfac.state, efb.state, eigvecs=efb.eigvecs)
+        if kind == "inf":
+            est.update(rank=10)
+    est.invert(add=0.5, multiply=2.0)
+    torch.manual_seed(3)
+    data = [(torch.rand(16, 1, 28, 28), torch.arange(16) % 10) for _ in range(3)]
+    ptrs = [p.data_ptr() for p in model.parameters()]
+    for samples in (3, 4):
+        outs = []
+        for overlap in (False, True):
+            est.noise_seed, est.noise_offset = 1234, 0
+            pred, labels = eval_bnn(model, data, est, samples=samples, device=gpu, overlap=overlap)
+            outs.append((pred, [p.detach().clone() for p in model.parameters()]))
+            assert [p.data_ptr() for p in model.parameters()] == ptrs
+        assert np.array_equal(outs[0][0], outs[1][0]), (kind, samples)
+        for a, b_ in zip(outs[0][1], outs[1][1]):
+            assert torch.equal(a, b_)
+        assert outs[0][0].shape == (48, 10) and abs(float(outs[0][0].sum(1).mean()) - 1.0) < 1e-5
+    # and sampling afterwards (plans cached for both buffer sets) still works on the original storage
+    est.sample_and_replace()
+    torch.cuda.synchronize()
+
+
+def test_eval_bnn_overlap_with_batchnorm_buffers(gpu):
+    """A network with BatchNorm: the second buffer set must carry running statistics and num_batches_tracked too
+    (sample_and_replace reloads the whole state dict to its mean)."""
+    from curvature_amd import models
+    from curvature_amd.curvatures import KFAC
+    from curvature_amd.evaluate import eval_bnn
+    torch.manual_seed(0)
+    model = models.resnet18().to(gpu)
+    x = torch.randn(4, 3, 64, 64, device=gpu)
+    model.train()
+    model(x)                                              # non-trivial running statistics
+    model.eval()
+    kfac = KFAC(model)
+    logits = model(x)
+    torch.nn.functional.cross_entropy(logits, logits.argmax(1)).backward()
+    kfac.update(4)
+    kfac.invert(add=10.0, multiply=100.0)
+    data = [(torch.randn(4, 3, 64, 64), torch.zeros(4, dtype=torch.long)) for _ in range(2)]
+    outs = []
+    for overlap in (False, True):
+        kfac.noise_seed, kfac.noise_offset = 99, 0
+        outs.append(eval_bnn(model, data, kfac, samples=3, device=gpu, overlap=overlap)[0])
+    assert np.array_equal(outs[0], outs[1])
+    assert np.isfinite(outs[0]).all()
