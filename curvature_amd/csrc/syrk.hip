@@ -722,10 +722,11 @@ syrk_reduce_kernel(const FactorDev* __restrict__ descs, int n_factors, const flo
   const int qq = sub - t * (q * q);
   const int qi = qq / q, qj = qq - qi * q;
   int ti, tj;
-  decode_tile(t, d.P, ti, tj);
+  decode_tile_of(d, t, ti, tj);
   const int bi = ti * q + qi, bj = tj * q + qj;  // 64-granular block coordinates
-  if (bi > bj) return;                          // mirror of (bj, bi)
-  const bool diag = (bi == bj);
+  const bool nonsym = d.nonsym != 0;            // correlation (syrk_corr.hip): every block is its own, no mirror
+  if (bi > bj && !nonsym) return;               // mirror of (bj, bi)
+  const bool diag = (bi == bj) && !nonsym;
   const int i0 = bi * 64, j0 = bj * 64, dim = d.dim;
   if (i0 >= dim || j0 >= dim) return;
   const int n_tiles = d.n_tiles, n_slices = d.n_slices;
@@ -755,7 +756,7 @@ syrk_reduce_kernel(const FactorDev* __restrict__ descs, int n_factors, const flo
       dst[idx] = first ? v : dst[idx] + v;
     }
   }
-  if (!diag) {
+  if (!diag && !nonsym) {
     for (int e = tid; e < 64 * 64; e += SYRK_THREADS) {
       const int r = e >> 6, c = e & 63;      // r indexes panel j, c panel i
       const int gi = j0 + r, gj = i0 + c;
@@ -918,6 +919,11 @@ struct Plan {
   int n_items[2] = {0, 0};
   int n_sub[2] = {0, 0};
   long long slab_floats = 0;
+  // f[0 .. n_user) are the caller's factors; 3x3 / stride 1 / pad 1 ones (dma = 2) are built from shifted
+  // correlations (syrk_corr.hip): their virtual factors follow in f[n_user ...) and join the LDS-DMA work list
+  int n_user = 0;
+  std::vector<CorrLayer> corr;
+  long long area_floats = 0;
 };
 
 static int build_plan(const curv_factor_desc* descs, int n, Plan& plan);
@@ -941,7 +947,7 @@ static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
                           (int)(reinterpret_cast<uintptr_t>(s.src) & 15)};
     key.insert(key.end(), vals, vals + 12);
   }
-  if (key == cached_key && (int)cached_plan.f.size() == n) {
+  if (key == cached_key && cached_plan.n_user == n) {
     plan = cached_plan;
     for (int i = 0; i < n; ++i) {
       CURV_REQUIRE(descs[i].src != nullptr && descs[i].dst != nullptr, "curv_kfac: factor %d: null pointer", i);
@@ -957,6 +963,9 @@ static int make_plan(const curv_factor_desc* descs, int n, Plan& plan) {
 
 static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
   plan.f.resize(n);
+  plan.n_user = n;
+  plan.corr.clear();
+  plan.area_floats = 0;
   std::vector<double> chunk_cost(n);   // MFMA CU-cycles of one (tile, chunk)
   double total_cost = 0.0;
   for (int i = 0; i < n; ++i) {
@@ -992,9 +1001,15 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
 #endif
     CURV_REQUIRE((long long)f.N * f.C * f.H * f.W < (1LL << 31), "curv_kfac: factor %d: source too large", i);
 
+    if (syrk_corr_eligible(s)) {       // no work items of its own: expanded into virtual factors below
+      f.dma = 2;
+      chunk_cost[i] = 0.0;
+      continue;
+    }
     if (flattened && syrk_flat_eligible(f, s.src)) {
       // LDS-DMA kernel: whole 128-row tiles, K in stages of <= 32 pixels of one sample (syrk_flat.hip)
       f.dma = 1;
+      f.pitch = f.W;
       f.TM = 128;
       f.P = f.dim / 128;
       f.n_tiles = f.P * (f.P + 1) / 2;
@@ -1058,13 +1073,28 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     chunk_cost[i] = kc * 32.0 * q * q + 1500.0;   // 64x64xk = 32 k CU-cycles; + staging / barriers
     total_cost += chunk_cost[i] * f.n_tiles * f.n_chunks;
   }
+  for (int i = 0; i < n; ++i) {
+    if (plan.f[i].dma != 2) continue;
+    CorrLayer layer;
+    syrk_corr_expand(descs[i], i, plan.f, layer, plan.area_floats);
+    plan.corr.push_back(layer);
+    for (int k = 0; k < CORR_COMPONENTS; ++k) {
+      const FactorDev& v = plan.f[layer.vf0 + k];
+      const int sps = syrk_flat_stages(v.W);
+      const double cost = (double)v.W / sps * 32.0 * 4.0 + 800.0;
+      chunk_cost.push_back(cost);
+      total_cost += cost * v.n_tiles * v.n_chunks;
+    }
+  }
+  const int n_all = (int)plan.f.size();
   // k-slicing: aim at ~16 items per workgroup slot (2 per CU) so that the tail of the launch is
   // a few percent, while keeping the slab traffic negligible.
   // (floor: a launch that is small as a whole must not be cut into items whose slab traffic exceeds their work)
   const double target = std::max(total_cost / (512.0 * 16.0), 40000.0);
-  std::vector<double> item_cost(n);
-  for (int i = 0; i < n; ++i) {
+  std::vector<double> item_cost(n_all, 0.0);
+  for (int i = 0; i < n_all; ++i) {
     FactorDev& f = plan.f[i];
+    if (f.dma == 2) continue;
     int cpi = (int)(target / chunk_cost[i] + 0.5);
     cpi = std::max(1, std::min(cpi, f.n_chunks));
     f.n_slices = cdiv(f.n_chunks, cpi);
@@ -1079,7 +1109,7 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
   long long slab = 0;
   for (int k = 0; k < 2; ++k) {
     plan.order[k].clear();
-    for (int i = 0; i < n; ++i) if (plan.f[i].dma == k) plan.order[k].push_back(i);
+    for (int i = 0; i < n_all; ++i) if (plan.f[i].dma == k) plan.order[k].push_back(i);
     std::stable_sort(plan.order[k].begin(), plan.order[k].end(), [&](int a, int b) { return item_cost[a] > item_cost[b]; });
     long long items = 0, subs = 0;
     for (int idx : plan.order[k]) {
@@ -1117,10 +1147,12 @@ static int plan_without_pointers(const curv_factor_desc* descs, int n_factors, P
 
 using namespace curv;
 
+static size_t slab_bytes(const Plan& plan) { return align_up((size_t)plan.slab_floats * sizeof(float), 256); }
+
 extern "C" size_t curv_kfac_workspace_bytes(const curv_factor_desc* descs, int n_factors) {
   Plan plan;
   if (plan_without_pointers(descs, n_factors, plan) != CURV_OK) return 0;
-  return table_bytes(n_factors) + (size_t)plan.slab_floats * sizeof(float);
+  return table_bytes((int)plan.f.size()) + slab_bytes(plan) + (size_t)plan.area_floats * sizeof(float);
 }
 
 extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors, long long* out) {
@@ -1146,8 +1178,8 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
   Plan plan;
   int rc = make_plan(descs, n_factors, plan);
   if (rc != CURV_OK) return rc;
-  const size_t tb = table_bytes(n_factors);
-  const size_t need = tb + (size_t)plan.slab_floats * sizeof(float);
+  const size_t tb = table_bytes((int)plan.f.size());
+  const size_t need = tb + slab_bytes(plan) + (size_t)plan.area_floats * sizeof(float);
   if (workspace == nullptr || workspace_bytes < need) {
     set_error("curv_kfac_accumulate: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
     return CURV_ERR_WORKSPACE;
@@ -1155,12 +1187,15 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
   FactorDev* table = reinterpret_cast<FactorDev*>(workspace);
   float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + tb);
   float* zeros = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + tb - 256);
-  // device table: the patch kernel's factors, then the LDS-DMA kernel's
+  float* area = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + tb + slab_bytes(plan));
+  for (const CorrLayer& layer : plan.corr) syrk_corr_bind(layer, plan.f, area);
+  // device table: the patch kernel's factors, then the LDS-DMA kernel's (the caller's and the virtual ones)
   std::vector<int> all(plan.order[0]);
   all.insert(all.end(), plan.order[1].begin(), plan.order[1].end());
-  for (int b = 0; b < n_factors; b += UPLOAD_CHUNK) {
+  const int n_table = (int)all.size();
+  for (int b = 0; b < n_table; b += UPLOAD_CHUNK) {
     TableChunk chunk;
-    const int count = std::min(UPLOAD_CHUNK, n_factors - b);
+    const int count = std::min(UPLOAD_CHUNK, n_table - b);
     memset(&chunk, 0, sizeof(chunk));
     for (int k = 0; k < count; ++k) chunk.f[k] = plan.f[all[b + k]];
     hipLaunchKernelGGL(upload_table_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count,
@@ -1171,6 +1206,10 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
   // the two kernels run back to back on the caller's stream (launching the LDS-DMA kernel on a second stream beside
   // the patch kernel was measured: 8.29 vs 8.26 ms for the pair, no gain)
   if (ev_start) CURV_HIP_CHECK(hipEventRecord((hipEvent_t)ev_start, stream));
+  if (!plan.corr.empty()) {
+    const int rcp = launch_corr_prep(stream, plan.corr, plan.f, area);
+    if (rcp != CURV_OK) return rcp;
+  }
   if (plan.n_items[0] > 0) {
     const int grid = cdiv(plan.n_items[0], 8 * XCD_GROUP) * 8 * XCD_GROUP;
     hipLaunchKernelGGL(syrk_patch_kernel, dim3(grid), dim3(SYRK_THREADS), 0, stream, table, n0, plan.n_items[0], slabs, zeros);
@@ -1189,6 +1228,7 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
     hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub[1]), dim3(SYRK_THREADS), 0, stream, table + n0, n1, slabs);
     CURV_LAUNCH_CHECK();
   }
+  if (!plan.corr.empty()) return launch_corr_assemble(stream, plan.corr, plan.f, area);
   return CURV_OK;
 }
 

@@ -1,0 +1,278 @@
+// KFAC A factor of a 3x3 / stride 1 / padding 1 convolution from SHIFTED CORRELATIONS on gfx950.
+//
+// The factor is the Gram matrix of the im2col rows (curvature/curvatures.py:329-337):
+//   A[(c, kh, kw), (c', kh', kw')] = sum over samples and output pixels (y, x) of
+//                                    X[c, y + kh - 1, x + kw - 1] * X[c', y + kh' - 1, x + kw' - 1]      (zero outside).
+// With u = y + kh - 1, v = x + kw - 1 the summand is X[c, u, v] * X[c', u + dh, v + dw] for the RELATIVE shift
+// (dh, dw) = (kh' - kh, kw' - kw): the 81 (45 by symmetry) C x C blocks of A share their products, and differ only in
+// which border row / column of (u, v) the window of (kh, kw) leaves out.  For the blocks p = (kh, kw) >= q = (kh', kw')
+// (row-major order; the rest is the transpose) there are 13 shifts, all with dh < 0 or (dh = 0, dw <= 0), and
+//   block(p, q) = F[dh, dw] - [kh = 0] RB[dw] - [kh = 2] RT[dw] - [kw = 0] CR[dh] - [kw = 2] CL[dh] + corner terms
+// with   F[dh, dw][c, c'] = sum_{n, u, v} X[c, u, v] X[c', u + dh, v + dw]        (whole image: 13 correlations)
+//        RB / RT [dw]     = the same sum over the bottom / top row only (needed for dh = 0 only: 3 + 3)
+//        CR / CL [dh]     = over the right / left column only           (needed for dw = 0 only: 3 + 3)
+//        4 corner terms   = sum_n X[c, corner] X[c', corner]            (shift (0, 0) only)
+// (tools / tests: the decomposition is checked against F.unfold in fp64).  29 C x C matrices with together
+// 13 x C^2 x (N H W) multiply-adds instead of 40.5 x C^2 x (N H W) for the 45 blocks computed one by one: 3.1 x fewer
+// flops, and every one of them is a plain "rows times shifted rows" product that the LDS-DMA kernel of syrk_flat.hip
+// runs (operand panels at different offsets of the same rows), which is also the more efficient of the two kernels.
+//
+// Data flow per eligible layer (all inside curv_kfac_accumulate, in its workspace):
+//   corr_prep_kernel      X (N, C, H, W) -> Xp (N, C, H, W + 2): two zero columns behind every image row, so that a flat
+//                         offset dh * (W + 2) + dw never pairs pixels of different rows; and the gathered border rows /
+//                         columns / corner pixels as (C, samples x length) arrays with the same zero separators
+//   syrk_flat_kernel      29 "virtual factors" per layer in the ordinary work list of the LDS-DMA kernel
+//   syrk_reduce_kernel    k-slices summed into the 29 component matrices
+//   corr_assemble_kernel  dst (+)= scale * A, both triangles, through LDS tiles so that the 9-interleaved rows of A
+//                         are written as contiguous runs
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "syrk_plan.h"
+
+namespace curv {
+
+namespace corr {
+constexpr int CT = 8;                        // channels per assembly tile edge: a (9 CT) x (9 CT) output tile
+constexpr int OUT = 9 * CT;
+constexpr int LEAD = 4;                      // zero floats in front of every gathered row (negative shifts of sample 0)
+
+// component index of F[dh, dw]: dh = 0: dw = 0, -1, -2 -> 0..2; dh = -1: dw = -2..2 -> 3..7; dh = -2 -> 8..12
+__host__ __device__ __forceinline__ int f_index(int dh, int dw) { return dh == 0 ? -dw : 3 + 5 * (-dh - 1) + (dw + 2); }
+constexpr int RB0 = 13, RT0 = 16, CR0 = 19, CL0 = 22, PT0 = 25;      // + |dw| / |dh|; corners: BR, BL, TR, TL
+}  // namespace corr
+
+struct CorrDev {
+  const float* src;
+  float* dst;
+  float* xp;
+  float* rowb; float* rowt; float* colr; float* coll; float* pt;
+  const float* comp;
+  int N, C, H, W, Wp, Hq;
+  int row_pitch, col_pitch, pt_pitch;
+  int first;
+  float scale;
+  long long prep_base;       // first element of this layer in the prep grid
+  int tile_base;             // first workgroup of this layer in the assembly grid
+  int pad;
+};
+constexpr int CORR_CHUNK = 16;
+struct CorrChunk { CorrDev l[CORR_CHUNK]; };
+static_assert(sizeof(CorrChunk) <= 3840, "kernel argument block must stay below 4 KB");
+
+typedef __attribute__((address_space(1))) float gfl;
+
+// one thread per element of Xp; the border rows / columns / corners are scattered from the same value
+__global__ void __launch_bounds__(256) corr_prep_kernel(CorrChunk chunk, int count, long long total) {
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    int l = 0;
+    while (l + 1 < count && chunk.l[l + 1].prep_base <= idx) ++l;
+    const CorrDev& d = chunk.l[l];
+    const long long e = idx - d.prep_base;
+    const int Wp = d.Wp, H = d.H, W = d.W, C = d.C;
+    const int v = (int)(e % Wp);
+    const long long r = e / Wp;
+    const int u = (int)(r % H);
+    const long long sc = r / H;                 // n * C + c
+    const int c = (int)(sc % C), n = (int)(sc / C);
+    const float val = v < W ? d.src[(sc * H + u) * W + v] : 0.0f;
+    d.xp[e] = val;
+    if (u == H - 1) d.rowb[(long long)c * d.row_pitch + corr::LEAD + n * Wp + v] = val;
+    if (u == 0) d.rowt[(long long)c * d.row_pitch + corr::LEAD + n * Wp + v] = val;
+    if (v == W - 1 || v == 0) {
+      float* col = (v == 0 ? d.coll : d.colr) + (long long)c * d.col_pitch + corr::LEAD + n * d.Hq;
+      col[u] = val;
+      if (u == H - 1) { col[H] = 0.0f; col[H + 1] = 0.0f; }
+    }
+    if ((u == 0 || u == H - 1) && (v == 0 || v == W - 1)) {
+      const int k = (u == 0 ? 2 : 0) + (v == 0 ? 1 : 0);            // BR, BL, TR, TL
+      d.pt[((long long)k * C + c) * d.pt_pitch + n] = val;
+    }
+    if (n == 0 && u == 0 && v < corr::LEAD) {
+      d.rowb[(long long)c * d.row_pitch + v] = 0.0f;
+      d.rowt[(long long)c * d.row_pitch + v] = 0.0f;
+      d.colr[(long long)c * d.col_pitch + v] = 0.0f;
+      d.coll[(long long)c * d.col_pitch + v] = 0.0f;
+    }
+  }
+}
+
+// dst tile (OUT x OUT) of channel tile (cb, cb2): rows (c, p), columns (c', q).  p >= q reads the components at
+// [c][c'], p < q is the transposed block (q, p) and reads them at [c'][c] (the mirrored channel tile).
+__global__ void __launch_bounds__(256) corr_assemble_kernel(CorrChunk chunk, int count) {
+  using namespace corr;
+  __shared__ float ta[29][CT][CT + 1];        // components at channel tile (cb, cb2)
+  __shared__ float tb[29][CT][CT + 1];        // ... at (cb2, cb)
+  int l = 0;
+  while (l + 1 < count && chunk.l[l + 1].tile_base <= (int)blockIdx.x) ++l;
+  const CorrDev& d = chunk.l[l];
+  const int C = d.C, nct = C / CT;
+  const int t = blockIdx.x - d.tile_base;
+  const int cb = t / nct, cb2 = t - cb * nct;
+  const long long C2 = (long long)C * C;
+  for (int e = threadIdx.x; e < 29 * CT * CT; e += 256) {
+    const int k = e / (CT * CT), rc = e - k * (CT * CT), r = rc / CT, c = rc - r * CT;
+    const float* m = d.comp + k * C2;
+    ta[k][r][c] = m[(long long)(cb * CT + r) * C + cb2 * CT + c];
+    tb[k][r][c] = m[(long long)(cb2 * CT + r) * C + cb * CT + c];
+  }
+  __syncthreads();
+  const int dim = 9 * C;
+  const float scale = d.scale;
+  const bool first = d.first != 0;
+  gfl* dst = (gfl*)d.dst;
+  for (int e = threadIdx.x; e < OUT * OUT; e += 256) {
+    const int R = e / OUT, Q = e - R * OUT;
+    int c = R / 9, p = R - 9 * c, c2 = Q / 9, q = Q - 9 * c2;
+    const bool lower = p >= q;
+    const float (*T)[CT][CT + 1] = lower ? ta : tb;
+    if (!lower) { int s_ = p; p = q; q = s_; s_ = c; c = c2; c2 = s_; }      // block (q, p) transposed
+    const int kh = p / 3, kw = p - 3 * kh, kh2 = q / 3, kw2 = q - 3 * kh2;
+    const int dh = kh2 - kh, dw = kw2 - kw;
+    float v = T[f_index(dh, dw)][c][c2];
+    if (dh == 0) {
+      if (kh == 0) v -= T[RB0 - dw][c][c2];
+      if (kh == 2) v -= T[RT0 - dw][c][c2];
+    }
+    if (dw == 0) {
+      if (kw == 0) v -= T[CR0 - dh][c][c2];
+      if (kw == 2) v -= T[CL0 - dh][c][c2];
+    }
+    if (dh == 0 && dw == 0 && kh != 1 && kw != 1) v += T[PT0 + (kh == 2 ? 2 : 0) + (kw == 2 ? 1 : 0)][c][c2];
+    const long long o = (long long)(cb * OUT + R) * dim + cb2 * OUT + Q;
+    v *= scale;
+    dst[o] = first ? v : dst[o] + v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static long long round_up4(long long v) { return (v + 3) & ~3LL; }
+
+bool syrk_corr_eligible(const curv_factor_desc& s) {
+  if (!(s.kh == 3 && s.kw == 3 && s.sh == 1 && s.sw == 1 && s.ph == 1 && s.pw == 1) || s.has_bias) return false;
+  if (s.C < 128 || s.C % 128 != 0 || s.N < 8 || s.H < 3 || s.W < 3) return false;
+  // every operand array addressable by one buffer descriptor of the LDS-DMA kernel
+  if ((long long)s.N * s.C * s.H * (s.W + 2) * 4 >= (1LL << 32) - 4096) return false;
+  return true;
+}
+
+// Append the 29 virtual factors of one eligible user factor to `f` (pointers are filled in by syrk_corr_bind) and
+// reserve its part of the correlation area (`area_floats` advances).
+void syrk_corr_expand(const curv_factor_desc& s, int user, std::vector<FactorDev>& f, CorrLayer& L,
+                      long long& area_floats) {
+  using namespace corr;
+  memset(&L, 0, sizeof(L));
+  L.user = user;
+  L.vf0 = (int)f.size();
+  L.N = s.N; L.C = s.C; L.H = s.H; L.W = s.W; L.Wp = s.W + 2; L.Hq = s.H + 2;
+  L.row_pitch = (int)round_up4(LEAD + (long long)s.N * L.Wp) + 4;
+  L.col_pitch = (int)round_up4(LEAD + (long long)s.N * L.Hq) + 4;
+  L.pt_pitch = (int)round_up4(s.N) + 4;
+  auto take = [&](long long n) { const long long o = area_floats; area_floats += round_up4(n) + 64; return o; };
+  L.xp_off = take((long long)s.N * s.C * s.H * L.Wp);
+  L.rowb_off = take((long long)s.C * L.row_pitch);
+  L.rowt_off = take((long long)s.C * L.row_pitch);
+  L.colr_off = take((long long)s.C * L.col_pitch);
+  L.coll_off = take((long long)s.C * L.col_pitch);
+  L.pt_off = take(4LL * s.C * L.pt_pitch);
+  L.comp_off = take((long long)CORR_COMPONENTS * s.C * s.C);
+
+  auto add = [&](int comp, long long src_off, int samples, int pitch, int K, int off_i, int off_j, bool nonsym) {
+    FactorDev v;
+    memset(&v, 0, sizeof(v));
+    v.N = samples; v.C = s.C; v.H = 1; v.W = K;
+    v.kh = v.kw = v.sh = v.sw = 1;
+    v.Ho = 1; v.Wo = K; v.khkw = 1;
+    v.rows = v.dim = s.C;
+    v.compact = 1;
+    v.first = 1; v.scale = 1.0f;
+    v.dma = 1;
+    v.pitch = pitch; v.off_i = off_i; v.off_j = off_j; v.nonsym = nonsym ? 1 : 0;
+    v.TM = 128;
+    v.P = s.C / 128;
+    v.n_tiles = nonsym ? v.P * v.P : v.P * (v.P + 1) / 2;
+    v.n_chunks = samples * syrk_flat_stages(K);
+    v.RL = 1;
+    // src / dst: offsets into the correlation area for now (syrk_corr_bind turns them into pointers)
+    v.src = reinterpret_cast<const float*>(src_off);
+    v.dst = reinterpret_cast<float*>(L.comp_off + (long long)comp * s.C * s.C);
+    f.push_back(v);
+  };
+  const int plane = s.H * L.Wp;
+  // the 13 whole-image correlations, in component order
+  for (int k = 0; k < 13; ++k) {
+    int dh, dw;
+    if (k < 3) { dh = 0; dw = -k; } else { dh = -1 - (k - 3) / 5; dw = (k - 3) % 5 - 2; }
+    const int delta = -(dh * L.Wp + dw);
+    add(f_index(dh, dw), L.xp_off, s.N, plane, plane - delta, delta, 0, delta != 0);
+  }
+  for (int a = 0; a < 3; ++a) add(RB0 + a, L.rowb_off, 1, L.row_pitch, s.N * L.Wp, LEAD, LEAD - a, a != 0);
+  for (int a = 0; a < 3; ++a) add(RT0 + a, L.rowt_off, 1, L.row_pitch, s.N * L.Wp, LEAD, LEAD - a, a != 0);
+  for (int a = 0; a < 3; ++a) add(CR0 + a, L.colr_off, 1, L.col_pitch, s.N * L.Hq, LEAD, LEAD - a, a != 0);
+  for (int a = 0; a < 3; ++a) add(CL0 + a, L.coll_off, 1, L.col_pitch, s.N * L.Hq, LEAD, LEAD - a, a != 0);
+  for (int k = 0; k < 4; ++k) add(PT0 + k, L.pt_off + (long long)k * s.C * L.pt_pitch, 1, L.pt_pitch, s.N, 0, 0, false);
+}
+
+// area-relative offsets of a layer's virtual factors -> device pointers
+void syrk_corr_bind(const CorrLayer& L, std::vector<FactorDev>& f, float* area) {
+  for (int k = 0; k < CORR_COMPONENTS; ++k) {
+    FactorDev& v = f[L.vf0 + k];
+    v.src = area + reinterpret_cast<intptr_t>(v.src);
+    v.dst = area + reinterpret_cast<intptr_t>(v.dst);
+  }
+}
+
+static void fill_dev(const CorrLayer& L, const FactorDev& user, float* area, CorrDev& d) {
+  memset(&d, 0, sizeof(d));
+  d.src = user.src; d.dst = user.dst;
+  d.xp = area + L.xp_off;
+  d.rowb = area + L.rowb_off; d.rowt = area + L.rowt_off;
+  d.colr = area + L.colr_off; d.coll = area + L.coll_off;
+  d.pt = area + L.pt_off;
+  d.comp = area + L.comp_off;
+  d.N = L.N; d.C = L.C; d.H = L.H; d.W = L.W; d.Wp = L.Wp; d.Hq = L.Hq;
+  d.row_pitch = L.row_pitch; d.col_pitch = L.col_pitch; d.pt_pitch = L.pt_pitch;
+  d.first = user.first; d.scale = user.scale;
+}
+
+int launch_corr_prep(hipStream_t stream, const std::vector<CorrLayer>& layers, const std::vector<FactorDev>& f,
+                     float* area) {
+  for (size_t b = 0; b < layers.size(); b += CORR_CHUNK) {
+    CorrChunk chunk;
+    memset(&chunk, 0, sizeof(chunk));
+    const int count = (int)std::min<size_t>(CORR_CHUNK, layers.size() - b);
+    long long total = 0;
+    for (int k = 0; k < count; ++k) {
+      const CorrLayer& L = layers[b + k];
+      fill_dev(L, f[L.user], area, chunk.l[k]);
+      chunk.l[k].prep_base = total;
+      total += (long long)L.N * L.C * L.H * L.Wp;
+    }
+    const int grid = (int)std::min<long long>((total + 255) / 256, 1 << 20);
+    hipLaunchKernelGGL(corr_prep_kernel, dim3(grid), dim3(256), 0, stream, chunk, count, total);
+    CURV_LAUNCH_CHECK();
+  }
+  return CURV_OK;
+}
+
+int launch_corr_assemble(hipStream_t stream, const std::vector<CorrLayer>& layers, const std::vector<FactorDev>& f,
+                         float* area) {
+  for (size_t b = 0; b < layers.size(); b += CORR_CHUNK) {
+    CorrChunk chunk;
+    memset(&chunk, 0, sizeof(chunk));
+    const int count = (int)std::min<size_t>(CORR_CHUNK, layers.size() - b);
+    int tiles = 0;
+    for (int k = 0; k < count; ++k) {
+      const CorrLayer& L = layers[b + k];
+      fill_dev(L, f[L.user], area, chunk.l[k]);
+      chunk.l[k].tile_base = tiles;
+      tiles += (L.C / corr::CT) * (L.C / corr::CT);
+    }
+    hipLaunchKernelGGL(corr_assemble_kernel, dim3(tiles), dim3(256), 0, stream, chunk, count);
+    CURV_LAUNCH_CHECK();
+  }
+  return CURV_OK;
+}
+
+}  // namespace curv

@@ -79,14 +79,14 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
   const int r32 = lane & 31, h = lane >> 5;
   const int slice = local / d.n_tiles, tile = local - slice * d.n_tiles;
   int ti, tj;
-  decode_tile(tile, d.P, ti, tj);
-  const bool diag = (ti == tj);
+  decode_tile_of(d, tile, ti, tj);
+  const bool diag = (ti == tj) && !d.nonsym;       // a correlation's diagonal tiles have two different operand panels
   // wave roles as in syrk.hip: wave (wm, wn) owns a 64x64 quadrant; on a diagonal tile the redundant quadrant's
   // wave takes half of quadrant (0, 1) (parts 2 / 3) and the diagonal quadrants skip their lower-left block (part 1)
   int wm = wave >> 1, wn = wave & 1;
   if (PART >= 2) { wm = 0; wn = 1; }
   const int i0 = ti * TM, j0 = tj * TM;
-  const int HW = d.W, C = d.C;
+  const int HW = d.W, C = d.C, pitch = d.pitch;
 
   // stage geometry of a sample: TS steps of 8 pixels in SPS stages of base (+1 for the first rem) steps
   const int TS = (HW + 7) >> 3;
@@ -99,8 +99,8 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
   // the piece index (pieces of a wave are 32 rows apart)
   const int rsub = RPP * wave + (lane >> 3);
   const int g_lane = (lane & (SLOTS - 1)) ^ ((rsub >> 1) & 7);
-  const int voff = (rsub * HW + 4 * g_lane) * 4;
-  const unsigned total_b = (unsigned)((long long)d.N * C * HW * 4);
+  const int voff = (rsub * pitch + 4 * g_lane) * 4;
+  const unsigned total_b = (unsigned)((long long)d.N * C * pitch * 4);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.src, 0, total_b, 0x00020000);
 
   // ---- operand addresses: row R of a panel, step j: R * 128 + ((2 j + h) ^ ((R >> 1) & 7)) * 16
@@ -134,14 +134,14 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
     stage_geo(t, s, px0, nsteps, last);
     n_gmax = last ? (HW - px0 + 3) / 4 : 2 * nsteps;               // pixel groups this stage needs
     n_buf = (unsigned)(t & 1) * PANEL_B;
-    n_soff[0] = ((s * C + i0) * HW + px0) * 4;
-    n_soff[1] = ((s * C + j0) * HW + px0) * 4;
+    n_soff[0] = ((s * C + i0) * pitch + d.off_i + px0) * 4;
+    n_soff[1] = ((s * C + j0) * pitch + d.off_j + px0) * 4;
   };
   auto piece = [&](int i) {
     const int p = i / PIECES, slot = i % PIECES;
     if (p < n_panels && g_lane < n_gmax) {
       const unsigned lbase = (p ? 2u * PANEL_B : 0u) + n_buf + (unsigned)(RPP * wave + 4 * RPP * slot) * ROW_B;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lbase), 16, voff, n_soff[p] + slot * 4 * RPP * HW * 4, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lbase), 16, voff, n_soff[p] + slot * 4 * RPP * pitch * 4, 0, 0);
     }
   };
 
@@ -215,9 +215,9 @@ syrk_flat_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_items
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = local % d.n_tiles;
   int ti, tj;
-  decode_tile(tile, d.P, ti, tj);
+  decode_tile_of(d, tile, ti, tj);
   int part = 0;
-  if (ti == tj) {
+  if (ti == tj && !d.nonsym) {
     const int wm = wave >> 1, wn = wave & 1;
     part = (wm == wn) ? 1 : (wm == 0 ? 2 : 3);
   }

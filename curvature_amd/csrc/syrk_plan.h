@@ -1,6 +1,8 @@
 // Shared between the two factor-build kernels (syrk.hip: implicit-im2col patch kernel; syrk_flat.hip: LDS-DMA kernel
 // for flattened per-pixel factors): the device descriptor of one Kronecker factor and the work-list helpers.
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 namespace curv {
@@ -37,7 +39,13 @@ struct FactorDev {
   unsigned rmagic;         // ceil(2^32 / patch rows per sample): folded (sample, row) index -> sample
   int lin;                 // linear staging: lanes walk the contiguous rows x W source range, `lin` floats each
   unsigned pmagic, wmagic; // linear staging: ceil(2^32 / lanes per sample), ceil(2^32 / W)
-  int dma;                 // 1: built by syrk_flat_kernel (n_chunks = stages, cpi = stages per item)
+  int dma;                 // 1: built by syrk_flat_kernel (n_chunks = stages, cpi = stages per item);
+                           // 2: a 3x3 factor assembled from shifted correlations (syrk_corr.hip): no work items of its own
+  // syrk_flat_kernel operands: row r of sample s starts at src + (s * C + r) * pitch floats; panel i reads
+  // [off_i, off_i + W) of its rows, panel j [off_j, off_j + W) of its rows.  Plain flattened factors: pitch = W,
+  // offsets 0.  nonsym: a correlation X_i X_j^T between differently shifted rows - every (ti, tj) tile is computed
+  // and nothing is mirrored.
+  int pitch, off_i, off_j, nonsym;
   long long slab_base;     // in floats
 };
 static_assert(sizeof(FactorDev) % 8 == 0, "FactorDev must be 8-byte granular");
@@ -76,5 +84,28 @@ int launch_syrk_flat(hipStream_t stream, const FactorDev* table, int n_factors, 
 // host-side eligibility / stage count of the LDS-DMA kernel
 bool syrk_flat_eligible(const FactorDev& f, const void* src);
 int syrk_flat_stages(int HW);
+
+__device__ __forceinline__ void decode_tile_of(const FactorDev& d, int t, int& ti, int& tj) {
+  if (d.nonsym) { ti = t / d.P; tj = t - ti * d.P; }
+  else decode_tile(t, d.P, ti, tj);
+}
+
+// syrk_corr.hip: 3x3 / stride 1 / padding 1 factors assembled from shifted correlations
+constexpr int CORR_COMPONENTS = 29;
+struct CorrLayer {
+  int user;                  // index of the user factor in Plan::f
+  int vf0;                   // its CORR_COMPONENTS virtual factors are Plan::f[vf0 ...]
+  int N, C, H, W, Wp, Hq;
+  int row_pitch, col_pitch, pt_pitch;
+  long long xp_off, rowb_off, rowt_off, colr_off, coll_off, pt_off, comp_off;    // floats from the area base
+};
+bool syrk_corr_eligible(const curv_factor_desc& s);
+void syrk_corr_expand(const curv_factor_desc& s, int user, std::vector<FactorDev>& f, CorrLayer& layer,
+                      long long& area_floats);
+void syrk_corr_bind(const CorrLayer& layer, std::vector<FactorDev>& f, float* area);
+int launch_corr_prep(hipStream_t stream, const std::vector<CorrLayer>& layers, const std::vector<FactorDev>& f,
+                     float* area);
+int launch_corr_assemble(hipStream_t stream, const std::vector<CorrLayer>& layers, const std::vector<FactorDev>& f,
+                         float* area);
 
 }  // namespace curv

@@ -27,6 +27,11 @@ CONV_CASES = [
     (3, 256, 7, 7, 3, 1, 1, False),     # linear staging, odd width (1 float per lane), 16 channels per panel
     (2, 5, 9, 9, 3, 1, 1, True),        # linear staging, channel count that is neither 8 nor 16
     (2, 40, 10, 10, 3, 2, 1, False),    # linear staging, stride 2, even width (2 floats per lane)
+    # 3x3 / stride 1 / pad 1 with C % 128 == 0 and N >= 8: assembled from shifted correlations (syrk_corr.hip)
+    (8, 128, 14, 14, 3, 1, 1, False),   # ResNet layer3-like
+    (8, 256, 7, 7, 3, 1, 1, False),     # layer4-like: odd size, border strips are half of the image
+    (9, 128, 12, 21, 3, 1, 1, False),   # non-square, odd width, odd sample count
+    (8, 128, 3, 3, 3, 1, 1, False),     # smallest image: every pixel is a border pixel
 ]
 
 
