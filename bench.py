@@ -252,8 +252,10 @@ def main():
             e[3].record()
 
     kfac._timing_events = hip_ev[0]
-    for _ in range(args.warmup):
+    kfac._count_flops = True              # first warm-up update: ask the launch plan what it executes
+    for _ in range(max(args.warmup, 1)):
         step(None)
+        kfac._count_flops = False
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -278,11 +280,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
-    # algorithmic work of the dominant kernel (SYRK) on this rank, symmetric-executed count
-    exec_flops = sum((dims[i][0] * (dims[i][0] + 1.0) + dims[i][1] * (dims[i][1] + 1.0)) * dims[i][2] for i in owned)
+    # work of the dominant kernels (the factor build) on this rank.  `plan_flops`: the multiply-add flops the launch
+    # plan really executes (curv_kfac_plan_info): n (n + 1) K per symmetric factor, and for the 3x3 / stride 1 / pad 1
+    # A factors - assembled from 13 shifted correlations + border strips instead of 45 blocks - the flops of those
+    # correlations (3.1x fewer).  `direct_flops`: SURVEY 8(d)'s figure, every factor as one symmetric product.
+    direct_flops = sum((dims[i][0] * (dims[i][0] + 1.0) + dims[i][1] * (dims[i][1] + 1.0)) * dims[i][2] for i in owned)
     dense_flops = sum(2.0 * (dims[i][0] ** 2 + dims[i][1] ** 2) * dims[i][2] for i in owned)
+    plan_flops = float(getattr(kfac, "_last_flops", direct_flops))
     syrk_s = syrk_ms / args.steps * 1e-3
-    achieved = exec_flops / syrk_s / 1e12
+    achieved = plan_flops / syrk_s / 1e12
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they are
     # collected by tools/collect_profiles.sh (rocprofv3, separate FETCH_SIZE / WRITE_SIZE passes, gfx950
@@ -318,11 +324,16 @@ def main():
                        "batch": args.batch, "layers": n_layers,
                        "parallelism": f"layer-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "curv::syrk_patch_kernel + curv::syrk_flat_kernel (the factor build: "
-                                                       "implicit-im2col kernel + LDS-DMA kernel for flattened factors, timed "
-                                                       "together)", "achieved": achieved,
+                                                       "implicit-im2col kernel + LDS-DMA kernel for flattened factors and "
+                                                       "the shifted correlations of 3x3 factors, timed together with the "
+                                                       "padding pass in front of them)", "achieved": achieved,
                          "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_F32_MFMA / 1e12),
                          "traffic": traffic, "traffic_source": traffic_source,
-                         "flops_counted": "executed symmetric: sum (n(n+1)+m(m+1)) K over the rank's layers",
+                         "flops_counted": "what the launch plan executes (curv_kfac_plan_info): n(n+1)K per symmetric "
+                                          "factor; 3x3/s1/p1 A factors as 13 shifted correlations + border strips",
+                         "plan_gflop": plan_flops / 1e9,
+                         "direct_symmetric_gflop": direct_flops / 1e9,
+                         "direct_symmetric_tflops": direct_flops / syrk_s / 1e12,
                          "dense_equivalent_tflops": dense_flops / syrk_s / 1e12,
                          "kernel_ms": syrk_s * 1e3},
             "phases_ms": {"update": phase[0] / args.steps, "invert": phase[1] / args.steps,

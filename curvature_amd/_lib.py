@@ -143,7 +143,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 2                     # CURV_ABI_VERSION of include/curv_hip.h
+ABI_VERSION = 3                     # CURV_ABI_VERSION of include/curv_hip.h
 ERR_NOT_PD, ERR_INVALID, ERR_WORKSPACE, ERR_HIP, ERR_NOT_CONVERGED = 1, 2, 3, 4, 5     # CURV_ERR_* of the header
 
 

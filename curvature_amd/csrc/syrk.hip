@@ -1167,6 +1167,19 @@ extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors,
     o[11] = f.n_tiles; o[12] = f.cpi; o[13] = f.n_slices; o[14] = f.n_items; o[15] = f.item_base;
     o[16] = f.TM; o[17] = f.vec4; o[18] = f.cshift; o[19] = f.n_sub; o[20] = f.RL; o[21] = f.rshift; o[22] = f.lin;
     o[23] = f.dma;
+    auto flops_of = [](const FactorDev& v) {
+      const double K = (double)v.N * v.Ho * v.Wo;
+      return v.nonsym ? 2.0 * v.dim * v.dim * K : (double)v.dim * (v.dim + 1.0) * K;
+    };
+    double fl = 0.0;
+    if (f.dma == 2) {
+      for (const CorrLayer& layer : plan.corr)
+        if (layer.user == i)
+          for (int k = 0; k < CORR_COMPONENTS; ++k) fl += flops_of(plan.f[layer.vf0 + k]);
+    } else {
+      fl = flops_of(f);
+    }
+    o[24] = (long long)fl;
   }
   return CURV_OK;
 }

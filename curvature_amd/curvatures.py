@@ -479,6 +479,8 @@ class KFAC(Curvature):
                 first = (layer, 1) in fresh
                 fresh.discard((layer, 1))
                 jobs.append(ops.FactorJob(g, G, (1, 1), (1, 1), (0, 0), False, float(N) / L, first))
+        if getattr(self, "_count_flops", False):                 # bench.py: what the launch plan executes
+            self._last_flops = sum(ops.kfac_plan_flops(jobs))
         ops.kfac_accumulate(jobs, events=getattr(self, "_timing_events", None))
 
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):

@@ -64,13 +64,7 @@ class FactorJob:
         self.has_bias, self.scale, self.first = bool(has_bias), float(scale), bool(first)
 
 
-def kfac_accumulate(jobs: Sequence[FactorJob], events=None) -> None:
-    """Grouped factor build over any number of factors: one SYRK launch + one reduce launch.
-
-    `events` = (start, stop) handles from ``_lib.lib().curv_event_create()`` are recorded around the SYRK
-    kernel (bench.py's roofline measurement)."""
-    if not jobs:
-        return
+def _factor_descs(jobs: Sequence[FactorJob]):
     n = len(jobs)
     arr = (curv_factor_desc * n)()
     for d, j in zip(arr, jobs):
@@ -90,6 +84,32 @@ def kfac_accumulate(jobs: Sequence[FactorJob], events=None) -> None:
         d.sh, d.sw = j.stride
         d.ph, d.pw = j.padding
         d.has_bias, d.first, d.scale = int(j.has_bias), int(j.first), j.scale
+    return arr
+
+
+PLAN_INFO_FIELDS = 25                 # CURV_PLAN_INFO_FIELDS
+
+
+def kfac_plan_flops(jobs: Sequence[FactorJob]) -> List[int]:
+    """Multiply-add FLOPs the launch plan executes for each job (curv_kfac_plan_info, last field): dim (dim + 1) K for
+    a symmetric product; the sum over its 29 shifted correlations for a 3x3 / stride 1 / pad 1 factor."""
+    if not jobs:
+        return []
+    arr = _factor_descs(jobs)
+    out = (ctypes.c_longlong * (PLAN_INFO_FIELDS * len(jobs)))()
+    _lib.check(_lib.lib().curv_kfac_plan_info(arr, len(jobs), out), "curv_kfac_plan_info")
+    return [int(out[PLAN_INFO_FIELDS * i + PLAN_INFO_FIELDS - 1]) for i in range(len(jobs))]
+
+
+def kfac_accumulate(jobs: Sequence[FactorJob], events=None) -> None:
+    """Grouped factor build over any number of factors: one SYRK launch + one reduce launch.
+
+    `events` = (start, stop) handles from ``_lib.lib().curv_event_create()`` are recorded around the SYRK
+    kernel (bench.py's roofline measurement)."""
+    if not jobs:
+        return
+    n = len(jobs)
+    arr = _factor_descs(jobs)
     L = _lib.lib()
     need = L.curv_kfac_workspace_bytes(arr, n)
     if need == 0:

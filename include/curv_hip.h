@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CURV_ABI_VERSION 2
+#define CURV_ABI_VERSION 3
 
 #define CURV_OK 0
 #define CURV_ERR_NOT_PD 1
@@ -74,8 +74,12 @@ size_t curv_kfac_workspace_bytes(const curv_factor_desc* descs, int n_factors);
  * float4 staging flag, log2 padded patch row length, 64x64 sub-tiles, k-run length, log2 row lanes
  * that walk patch rows while staging (the remaining row lanes split channels), floats per lane of the
  * linear full-width staging (0 = not used), 1 if the factor is built by the LDS-DMA kernel for flattened per-pixel
- * factors (its own work list: item bases count from 0 per kernel; n_chunks = stages of <= 32 pixels). */
-#define CURV_PLAN_INFO_FIELDS 24
+ * factors (its own work list: item bases count from 0 per kernel; n_chunks = stages of <= 32 pixels), 2 if it is a
+ * 3x3 / stride 1 / padding 1 factor assembled from 29 shifted correlations that run as virtual factors of the LDS-DMA
+ * kernel (no items of its own), and last the multiply-add FLOPs (2 per multiply-add) the plan executes for the
+ * factor: dim (dim + 1) K for a symmetric product over K = samples x output pixels, the sum over its correlations
+ * (C (C + 1) K' for the symmetric ones, 2 C^2 K' for the others) for an assembled factor. */
+#define CURV_PLAN_INFO_FIELDS 25
 int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors, long long* out);
 
 /* Grouped launch over all factors of a model (one SYRK launch + one reduce launch). `descs` is a

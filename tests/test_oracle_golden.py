@@ -247,3 +247,44 @@ def test_block_diagonal():
     assert smp.shape == (2, 10)
     x = g["z_l0"] @ g["a_inv_l0"]
     assert torch.equal(smp[:, :9].reshape(-1), x[:18]) and torch.equal(smp[:, 9], x[18:])
+
+
+def test_shifted_correlation_decomposition_of_a_3x3_factor():
+    """The identity behind csrc/syrk_corr.hip, in fp64 on the CPU: the A factor of a 3x3 / stride 1 / pad 1
+    convolution (oracle.unfold_input, i.e. F.unfold as in curvatures.py:329-337) equals, block by block for
+    p = (kh, kw) >= q = (kh', kw'), the whole-image correlation at the relative shift minus the border row / column the
+    window of (kh, kw) leaves out, plus the corner counted twice: 13 + 12 + 4 component matrices instead of 45 blocks."""
+    import itertools
+    torch.manual_seed(0)
+    N, C, H, W = 3, 4, 6, 5
+    x = torch.randn(N, C, H, W, dtype=torch.float64)
+    U = o.unfold_input(x, (3, 3), (1, 1), (1, 1), False)            # (9 C, N H W), rows (c, kh, kw)
+    A = U @ U.t()
+
+    def corr(us, vs, dh, dw):
+        out = torch.zeros(C, C, dtype=torch.float64)
+        for u, v in itertools.product(us, vs):
+            if 0 <= u + dh < H and 0 <= v + dw < W:
+                out += torch.einsum('nc,nd->cd', x[:, :, u, v], x[:, :, u + dh, v + dw])
+        return out
+    rows, cols = range(H), range(W)
+    components = set()
+    for kh, kw, kh2, kw2 in itertools.product(range(3), repeat=4):
+        if 3 * kh + kw < 3 * kh2 + kw2:
+            continue
+        dh, dw = kh2 - kh, kw2 - kw
+        assert dh < 0 or (dh == 0 and dw <= 0)
+        blk = corr(rows, cols, dh, dw)
+        components.add(("F", dh, dw))
+        if kh == 0 and dh == 0:
+            blk -= corr([H - 1], cols, 0, dw); components.add(("RB", dw))
+        if kh == 2 and dh == 0:
+            blk -= corr([0], cols, 0, dw); components.add(("RT", dw))
+        if kw == 0 and dw == 0:
+            blk -= corr(rows, [W - 1], dh, 0); components.add(("CR", dh))
+        if kw == 2 and dw == 0:
+            blk -= corr(rows, [0], dh, 0); components.add(("CL", dh))
+        if dh == 0 and dw == 0 and kh != 1 and kw != 1:
+            blk += corr([H - 1 if kh == 0 else 0], [W - 1 if kw == 0 else 0], 0, 0); components.add(("PT", kh, kw))
+        assert torch.allclose(blk, A[3 * kh + kw::9][:, 3 * kh2 + kw2::9], rtol=0, atol=1e-12)
+    assert len(components) == 29

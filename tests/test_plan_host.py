@@ -7,8 +7,8 @@ import pytest
 
 from curvature_amd import _lib
 
-NF = 24
-NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub RL rshift lin dma".split()
+NF = 25
+NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub RL rshift lin dma flops".split()
 PANEL_WORDS, KTAB_MAX, SLOTS, THREADS = 8704, 1024, 32, 256
 
 
@@ -47,6 +47,22 @@ def test_plan_respects_budgets(d):
     flat = compact and d["sh"] == 1 and d["ph"] == 0
     assert p["dim"] == d["C"] * d["kh"] * d["kw"] + d["has_bias"]
     assert (p["Ho"], p["Wo"]) == ((1, Ho * Wo) if flat else (Ho, Wo))
+    K = d["N"] * Ho * Wo
+    if p["dma"] == 2:
+        # assembled from shifted correlations (syrk_corr.hip): no items of its own; 13 whole-image correlations over
+        # rows padded to W + 2 (one symmetric) + 12 border strips (four symmetric) + 4 corner products
+        assert (d["kh"], d["kw"], d["sh"], d["ph"], d["has_bias"]) == (3, 3, 1, 1, 0) and d["C"] % 128 == 0 and d["N"] >= 8
+        assert p["nitems"] == 0 and p["nsub"] == 0
+        C, N, H, W = d["C"], d["N"], d["H"], d["W"]
+        sym, full = C * (C + 1), 2 * C * C
+        plane = H * (W + 2)
+        shifts = [dh * (W + 2) + dw for dh in (-1, -2) for dw in range(-2, 3)] + [-1, -2]
+        want = sym * N * plane + sum(full * N * (plane + sft) for sft in shifts)
+        want += 2 * (sym + 2 * full) * N * (W + 2) + 2 * (sym + 2 * full) * N * (H + 2) + 4 * sym * N
+        assert p["flops"] == want
+        assert p["flops"] < 0.4 * p["dim"] * (p["dim"] + 1) * K          # the point of it
+        return
+    assert p["flops"] == p["dim"] * (p["dim"] + 1) * K
     assert p["TM"] in (64, 128) and p["RL"] == 1
     if p["dma"]:
         # LDS-DMA kernel (syrk_flat.hip): flattened factor, whole 128-row tiles, no bias row; K in stages of at most
@@ -89,15 +105,19 @@ def test_plan_respects_budgets(d):
 
 
 def test_item_bases_tile_the_work_list():
-    """Factors are laid out in the work list by descending work per item; together their
-    [base, base + nitems) ranges cover the list exactly once."""
+    """Factors are laid out in the work list by descending work per item; together their [base, base + nitems) ranges
+    cover the patch kernel's list exactly once.  In the LDS-DMA kernel's list the caller's factors share the list with
+    the virtual factors of assembled 3x3 factors (not reported): ranges are disjoint and ascending, and without such
+    a factor in the set they tile it exactly as well."""
     everything = plan(CASES)
-    assert any(p["dma"] for p in everything) and not all(p["dma"] for p in everything)
-    for kernel in (0, 1):                       # two kernels, two work lists
+    assert any(p["dma"] == 1 for p in everything) and any(p["dma"] == 0 for p in everything)
+    assert any(p["dma"] == 2 for p in everything)
+    for kernel, subset in ((0, everything), (1, everything), (1, [p for p in plan([c for c in CASES if not (c["kh"] == 3 and c["sh"] == 1 and c["C"] % 128 == 0)])])):
         base = 0
-        for p in sorted((p for p in everything if p["dma"] == kernel), key=lambda p: p["base"]):
-            assert p["base"] == base
-            base += p["nitems"]
+        exact = kernel == 0 or not any(p["dma"] == 2 for p in subset)
+        for p in sorted((p for p in subset if p["dma"] == kernel), key=lambda p: p["base"]):
+            assert p["base"] == base if exact else p["base"] >= base
+            base = p["base"] + p["nitems"]
 
 
 def test_invalid_geometry_is_rejected():
