@@ -8,7 +8,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from curvature_amd import _lib, models  # noqa: E402
 
-NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub RL rshift lin".split()
+NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub RL rshift lin dma flops".split()
 
 
 def main():
@@ -40,7 +40,7 @@ def main():
             setattr(a, k, v)
         a.scale = 1.0
     L = _lib.lib()
-    nf = 23
+    nf = 25                  # CURV_PLAN_INFO_FIELDS
     out = (ctypes.c_longlong * (nf * n))()
     rc = L.curv_kfac_plan_info(arr, n, out)
     print("rc", rc, L.curv_last_error())
