@@ -82,7 +82,7 @@ class curv_cholinv_desc(ctypes.Structure):
 class curv_gemm64_desc(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p)] + \
                [(k, ctypes.c_longlong) for k in ("a_rs", "a_cs", "b_rs", "b_cs", "c_rs", "c_cs")] + \
-               [("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("reserved", ctypes.c_int32),
+               [("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("tri", ctypes.c_int32),
                 ("alpha", ctypes.c_double), ("beta", ctypes.c_double)]
 
 

@@ -381,7 +381,7 @@ struct Gemm64Dev {
   double* C;
   long long a_rs, a_cs, b_rs, b_cs, c_rs, c_cs;
   int M, N, K;
-  int tiles_n, tile_base, pad;
+  int tiles_n, tile_base, tri;
   double alpha, beta;
 };
 
@@ -430,15 +430,23 @@ gemm_f64_kernel(Gemm64Dev d0, Gemm64Dev d1, Gemm64Dev d2, Gemm64Dev d3, int n_de
       rb[u] = (j0 + bc[u] < N && k0 + bk[u] < K) ? Bk[ob[u]] : 0.0;
     }
   };
-  if (K > 0) fetch(0);
-  for (int k0 = 0; k0 < K; k0 += GK) {
+  // triangular operands (CURV_TRI64_*): the K range that can contribute to this tile
+  int k_lo = 0, k_hi = K;
+  if (d.tri & 1) k_hi = min(k_hi, i0 + GT);      // A lower: a[i][k] = 0 for k > i
+  if (d.tri & 2) k_lo = max(k_lo, i0);           // A upper: a[i][k] = 0 for k < i
+  if (d.tri & 4) k_lo = max(k_lo, j0);           // B lower: b[k][j] = 0 for k < j
+  if (d.tri & 8) k_hi = min(k_hi, j0 + GT);      // B upper: b[k][j] = 0 for k > j
+  k_lo &= ~(GK - 1);
+  if (k_lo >= k_hi && d.beta == 1.0) return;     // nothing to add
+  if (k_lo < k_hi) fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += GK) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       As[ak[u] * GP + ar[u]] = ra[u];
       Bs[bk[u] * GP + bc[u]] = rb[u];
     }
     __syncthreads();
-    if (k0 + GK < K) fetch(k0 + GK);
+    if (k0 + GK < k_hi) fetch(k0 + GK);
 #pragma unroll
     for (int ks = 0; ks < GK / 4; ++ks) {
       const int k = 4 * ks + kq;
@@ -643,6 +651,8 @@ extern "C" int curv_gemm_f64_batched(void* stream_, const curv_gemm64_desc* desc
       d[i].A = s.A; d[i].B = s.B; d[i].C = s.C;
       d[i].a_rs = s.a_rs; d[i].a_cs = s.a_cs; d[i].b_rs = s.b_rs; d[i].b_cs = s.b_cs; d[i].c_rs = s.c_rs; d[i].c_cs = s.c_cs;
       d[i].M = s.M; d[i].N = s.N; d[i].K = s.K; d[i].alpha = s.alpha; d[i].beta = s.beta;
+      CURV_REQUIRE((s.tri & ~15) == 0 && (s.tri & 3) != 3 && (s.tri & 12) != 12, "curv_gemm_f64_batched: desc %d: bad tri flags", base + i);
+      d[i].tri = s.tri;
       d[i].tiles_n = cdiv(s.N, GT);
       d[i].tile_base = (int)tiles;
       tiles += (long long)cdiv(s.M, GT) * d[i].tiles_n;

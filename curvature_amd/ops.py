@@ -526,12 +526,17 @@ def concat(parts: Sequence[torch.Tensor]) -> torch.Tensor:
     return out
 
 
-class Gemm64:
-    """float64 C = alpha * A @ B [+ beta * C] on strided 2-D GPU views; C = None allocates the output."""
-    __slots__ = ("A", "B", "C", "alpha", "beta")
+TRI64_A_LOWER, TRI64_A_UPPER, TRI64_B_LOWER, TRI64_B_UPPER = 1, 2, 4, 8      # CURV_TRI64_*
 
-    def __init__(self, A, B, C=None, alpha=1.0, beta=0.0):
-        self.A, self.B, self.C, self.alpha, self.beta = A, B, C, float(alpha), float(beta)
+
+class Gemm64:
+    """float64 C = alpha * A @ B [+ beta * C] on strided 2-D GPU views; C = None allocates the output.
+    `tri`: TRI64_* flags for triangular operands (their other triangle must hold zeros; only the K range that can
+    contribute to a tile is visited)."""
+    __slots__ = ("A", "B", "C", "alpha", "beta", "tri")
+
+    def __init__(self, A, B, C=None, alpha=1.0, beta=0.0, tri=0):
+        self.A, self.B, self.C, self.alpha, self.beta, self.tri = A, B, C, float(alpha), float(beta), int(tri)
 
 
 def gemm_f64_batched(jobs: Sequence[Gemm64]) -> List[torch.Tensor]:
@@ -561,7 +566,7 @@ def gemm_f64_batched(jobs: Sequence[Gemm64]) -> List[torch.Tensor]:
         d[k].a_rs, d[k].a_cs = j.A.stride()
         d[k].b_rs, d[k].b_cs = j.B.stride()
         d[k].c_rs, d[k].c_cs = C.stride()
-        d[k].M, d[k].N, d[k].K, d[k].alpha, d[k].beta = M, N, K, j.alpha, j.beta
+        d[k].M, d[k].N, d[k].K, d[k].alpha, d[k].beta, d[k].tri = M, N, K, j.alpha, j.beta, j.tri
     _lib.check(_lib.lib().curv_gemm_f64_batched(_lib.stream_ptr(), d, n), "curv_gemm_f64_batched")
     return outs
 

@@ -171,14 +171,22 @@ size_t curv_gemm_workspace_bytes(int n_desc);
 int curv_gemm_batched(void* stream, const curv_gemm_desc* descs, int n_desc, void* workspace,
                       size_t workspace_bytes);
 
-/* fp64 variant (alpha/beta only) for the ill-conditioned products of INF.pre_sampler. */
+/* fp64 variant (alpha/beta only) for the ill-conditioned products of INF.pre_sampler.  `tri`: triangular operands -
+ * entries outside the triangle are neither read nor multiplied (they must be zero in memory where a tile straddles the
+ * diagonal): the products of the two triangular inverses of pre_sampler (curvatures.py:566-572) are 2/3 of INF.invert's
+ * flops when done densely.  A lower x B lower leaves the tiles above the diagonal of C untouched for beta = 1 and
+ * zero for beta = 0. */
+#define CURV_TRI64_A_LOWER 1
+#define CURV_TRI64_A_UPPER 2
+#define CURV_TRI64_B_LOWER 4
+#define CURV_TRI64_B_UPPER 8
 typedef struct curv_gemm64_desc {
   const double* A;
   const double* B;
   double* C;
   long long a_rs, a_cs, b_rs, b_cs, c_rs, c_cs;
   int32_t M, N, K;
-  int32_t reserved;
+  int32_t tri;      /* CURV_TRI64_* flags, 0 = dense */
   double alpha, beta;
 } curv_gemm64_desc;
 int curv_gemm_f64_batched(void* stream, const curv_gemm64_desc* descs, int n_desc);

@@ -183,3 +183,33 @@ def test_inf_invert_and_sample(gpu):
             assert rel_fro(layer.bias.data - b_mean, ref[:, -1]) < TOL
     inf.sample_and_replace()
     assert all(torch.isfinite(l.weight).all() for l in layers)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 130, 333])
+def test_gemm_f64_triangular_operands(gpu, n):
+    """curv_gemm_f64_batched with CURV_TRI64_* flags (the two products of INF.pre_sampler's triangular inverses):
+    same result as the dense product when the operands really are triangular, all flag combinations, with the
+    accumulating form (beta = 1) leaving the tiles above the diagonal untouched."""
+    from curvature_amd import ops
+    torch.manual_seed(n)
+    full = [torch.randn(n, n, dtype=torch.float64, device=gpu) for _ in range(2)]
+    lower = [torch.tril(f) for f in full]
+    upper = [torch.triu(f) for f in full]
+    cases = [(lower[0], lower[1], ops.TRI64_A_LOWER | ops.TRI64_B_LOWER),
+             (upper[0], lower[1], ops.TRI64_A_UPPER | ops.TRI64_B_LOWER),
+             (lower[0], upper[1], ops.TRI64_A_LOWER | ops.TRI64_B_UPPER),
+             (upper[0], upper[1], ops.TRI64_A_UPPER | ops.TRI64_B_UPPER),
+             (lower[0], full[1], ops.TRI64_A_LOWER), (full[0], upper[1], ops.TRI64_B_UPPER),
+             (lower[0].t(), lower[1], ops.TRI64_A_UPPER | ops.TRI64_B_LOWER)]       # transposed view, as in pre_sampler
+    outs = ops.gemm_f64_batched([ops.Gemm64(a, b, tri=t) for a, b, t in cases])
+    for (a, b, _), c in zip(cases, outs):
+        want = a @ b
+        assert float((c - want).abs().max()) <= 1e-12 * float(want.abs().max())
+    # T = A^-1 - B^-1 A^-1 exactly as pre_sampler_many does it
+    T = lower[1].clone()
+    ops.gemm_f64_batched([ops.Gemm64(lower[0], lower[1], T, alpha=-1.0, beta=1.0,
+                                     tri=ops.TRI64_A_LOWER | ops.TRI64_B_LOWER)])
+    want = lower[1] - lower[0] @ lower[1]
+    assert float((T - want).abs().max()) <= 1e-12 * float(want.abs().max())
+    assert float(torch.triu(T, 1).abs().max()) == 0.0
