@@ -28,8 +28,13 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA = 157.3e12      # /opt/skills/guides/MI355X_MICROARCH.md: f32-input MFMA, dense
 
 
+def sharding_build_flops(n, m, K, layer, batch):
+    from curvature_amd import sharding
+    return sharding.conv_build_flops(n, m, K, layer, batch)
+
+
 def layer_dims(layers, record):
-    """(n, m, K) per layer from the recorded activations / gradients."""
+    """(n, m, K, build flops) per layer from the recorded activations / gradients."""
     dims = []
     for layer in layers:
         x, g = record[layer]
@@ -40,7 +45,7 @@ def layer_dims(layers, record):
         else:
             n = layer.in_features + bias
             K = g.shape[0]
-        dims.append((n, g.shape[1], K))
+        dims.append((n, g.shape[1], K, sharding_build_flops(n, g.shape[1], K, layer, g.shape[0])))
     return dims
 
 

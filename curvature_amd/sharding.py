@@ -34,18 +34,33 @@ def lpt_partition(costs: Sequence[float], world: int) -> List[int]:
     return owner
 
 
-def rank_cost(dims: Sequence[Sequence[int]]) -> float:
-    """Estimated step time (s) of a rank that owns the layers `dims` = [(n, m, K), ...].  Not additive: the
-    factors of a rank are inverted in one batched sweep, so the serial chains of 64-column steps overlap and
-    only the longest one counts (calibrated on MI355X: single 4608^2 factor 3.9 ms = 72 steps x 54 us, three of
-    them 6.6 ms, all 108 ResNet-50 factors 9.6 ms; build 85 TFLOP/s executed, sampling GEMMs 95 TFLOP/s)."""
+def rank_cost(dims: Sequence[Sequence[float]]) -> float:
+    """Estimated step time (s) of a rank that owns the layers `dims` = [(n, m, K) or (n, m, K, build_flops), ...].
+    Not additive: the factors of a rank are inverted in one batched sweep, so the serial chains of 64-column steps
+    overlap and only the longest one counts (calibrated on MI355X: single 4608^2 factor 3.9 ms = 72 steps x 54 us,
+    three of them 6.6 ms, all 108 ResNet-50 factors 9.6 ms; build 85 TFLOP/s executed, sampling GEMMs 95 TFLOP/s).
+    `build_flops`: what the factor build of the layer executes when that is not (n (n + 1) + m (m + 1)) K - a 3x3 /
+    stride 1 A factor assembled from shifted correlations costs a third of it (`conv_build_flops`)."""
     if not dims:
         return 0.0
-    build = sum((n * (n + 1.0) + m * (m + 1.0)) * K for n, m, K in dims) / 85e12
-    sample = sum(2.0 * (n * n * m + n * m * m) for n, m, _ in dims) / 95e12
-    chain = max(max(n, m) for n, m, _ in dims) / 64.0 * 54e-6
-    invert = 0.7 * chain + sum((2.0 / 3.0) * (n ** 3 + m ** 3) for n, m, _ in dims) / 42e12
+    build = sum(d[3] if len(d) > 3 else (d[0] * (d[0] + 1.0) + d[1] * (d[1] + 1.0)) * d[2] for d in dims) / 85e12
+    sample = sum(2.0 * (d[0] * d[0] * d[1] + d[0] * d[1] * d[1]) for d in dims) / 95e12
+    chain = max(max(d[0], d[1]) for d in dims) / 64.0 * 54e-6
+    invert = 0.7 * chain + sum((2.0 / 3.0) * (d[0] ** 3 + d[1] ** 3) for d in dims) / 42e12
     return build + invert + sample + 1.0e-3
+
+
+def conv_build_flops(n: int, m: int, K: int, layer=None, batch: int = 0) -> float:
+    """Multiply-add flops the factor build executes for a layer (both factors).  The library assembles the A factor
+    of a 3x3 / stride 1 / padding 1 convolution without bias whose channel count is a multiple of 128 from 13 shifted
+    correlations + border strips (csrc/syrk_corr.hip; needs >= 8 samples): about 13 / 40.5 of the symmetric product,
+    more on small images because of the two zero columns per row (curv_kfac_plan_info gives the exact figure)."""
+    direct_a, direct_g = n * (n + 1.0) * K, m * (m + 1.0) * K
+    if layer is not None and layer.__class__.__name__ == "Conv2d" and tuple(layer.kernel_size) == (3, 3) and \
+            tuple(layer.stride) == (1, 1) and tuple(layer.padding) == (1, 1) and layer.bias is None and \
+            layer.in_channels % 128 == 0 and batch >= 8:
+        return direct_a * 0.36 + direct_g
+    return direct_a + direct_g
 
 
 def partition_layers(dims: Sequence[Sequence[int]], world: int) -> List[int]:

@@ -20,7 +20,9 @@ def main():
     rows = models.layer_table(models.resnet50(), (3, 224, 224))
     x = torch.randn(32, 3, 224, 224, device=dev)
     for world in (1, 2, 4, 8):
-        dims = [(r["n"], r["m"], 32 * r["L"]) for r in rows]
+        mods = dict(model.named_modules())
+        dims = [(r["n"], r["m"], 32 * r["L"], sharding.conv_build_flops(r["n"], r["m"], 32 * r["L"], mods[r["name"]], 32))
+                for r in rows]
         costs = [sharding.rank_cost([d]) for d in dims]
         owner = sharding.partition_layers(dims, world)
         est = [sharding.rank_cost([d for d, o in zip(dims, owner) if o == r]) * 1e3 for r in range(world)]
@@ -59,7 +61,7 @@ def main():
                     torch.cuda.synchronize()
                     ph.append((time.perf_counter() - t1) / 4 * 1e3)
                 own = [i for i, o in enumerate(owner) if o == rank]
-                print(f"      rank {rank}: layers {own} dims {[dims[i][:2] for i in own]}: update {ph[0]:.2f} invert {ph[1]:.2f} sample {ph[2]:.2f} ms")
+                print(f"      rank {rank}: layers {own} dims {[tuple(dims[i][:2]) for i in own]}: update {ph[0]:.2f} invert {ph[1]:.2f} sample {ph[2]:.2f} ms")
             for h in kfac.hooks:
                 h.remove()
         mx = max(times)
