@@ -472,3 +472,46 @@ def test_eval_bnn_overlap_with_batchnorm_buffers(gpu):
         outs.append(eval_bnn(model, data, kfac, samples=3, device=gpu, overlap=overlap)[0])
     assert np.array_equal(outs[0], outs[1])
     assert np.isfinite(outs[0]).all()
+
+
+# ------------------------------------------------------------------------------------------------ config 2 at N = 100
+def test_lenet_config2_at_the_reference_batch_size(gpu):
+    """BASELINE config 2 as scripts/test.py:25 runs it: LeNet-5, batch size 100, one GPU - update from the path's own
+    hooks (the recorded activations / gradients are handed to the oracle, so MIOpen's backward is common to both),
+    invert(0.5, 1) against the oracle in fp64, sample with common noise."""
+    import oracle.curvature_oracle as o
+    from curvature_amd.curvatures import KFAC
+    g1 = load("g1_kfac_lenet.npz")
+    model, layers = lenet(gpu, g1)
+    kfac = KFAC(model)
+    N = 100
+    torch.manual_seed(11)
+    state64 = {}
+    for _ in range(2):
+        x = torch.rand(N, 1, 28, 28, device=gpu)
+        logits = model(x)
+        labels = torch.distributions.Categorical(logits=logits.detach()).sample()
+        model.zero_grad()
+        torch.nn.functional.cross_entropy(logits, labels).backward()
+        kfac.update(batch_size=N)
+        for layer in layers:
+            xin, gout = kfac.record[layer]
+            a, gg = o.kfac_factors(xin.detach().double().cpu(), gout.detach().double().cpu(),
+                                   has_bias=True, **o.layer_geometry(layer))
+            if layer in state64:
+                state64[layer][0] += a
+                state64[layer][1] += gg
+            else:
+                state64[layer] = [a, gg]
+    for layer in layers:
+        for got, want in zip(kfac.state[layer], state64[layer]):
+            assert rel_fro(got, want) < 1e-5
+            assert torch.equal(got, got.t())
+    kfac.invert(add=0.5, multiply=1)
+    torch.manual_seed(12)
+    for layer in layers:
+        A32, G32 = (f.cpu() for f in kfac.state[layer])
+        LA, LG = o.kfac_invert(A32.double(), G32.double(), 0.5, 1)             # the path's own fp32 factors, fp64 chain
+        assert rel_fro(kfac.inv_state[layer][0], LA) < 1e-5 and rel_fro(kfac.inv_state[layer][1], LG) < 1e-5
+        z = torch.randn(A32.shape[0], G32.shape[0])
+        assert rel_fro(kfac.sample(layer, z=z.to(gpu)), o.kfac_sample(LA, LG, z.double())) < TOL
