@@ -82,8 +82,10 @@ size_t curv_kfac_workspace_bytes(const curv_factor_desc* descs, int n_factors);
 #define CURV_PLAN_INFO_FIELDS 25
 int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors, long long* out);
 
-/* Grouped launch over all factors of a model (one SYRK launch + one reduce launch). `descs` is a
- * host array; it may be reused as soon as the call returns. */
+/* Grouped build of all factors of a model: a fixed, small number of launches whatever the number of factors (the
+ * implicit-im2col kernel, the LDS-DMA kernel for flattened factors and the shifted correlations of 3x3 / stride 1 /
+ * padding 1 factors, one reduce launch for each, plus a padding pass and an assembly pass when such 3x3 factors are
+ * present).  `descs` is a host array; it may be reused as soon as the call returns. */
 int curv_kfac_accumulate(void* stream, const curv_factor_desc* descs, int n_factors, void* workspace,
                          size_t workspace_bytes);
 
