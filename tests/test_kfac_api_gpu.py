@@ -371,3 +371,54 @@ def test_eval_bnn_matches_oracle(gpu):
             ref += torch.cat([torch.softmax(cpu_model(x), dim=1) for x, _ in data]).double()
     ref /= n_samples
     assert float(np.abs(mean_pred - ref.numpy()).max()) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(130, 200, 40), (128, 128, 1536), (200, 300, 2000), (64, 520, 3100), (512, 1100, 2304)])
+def test_gemm_nt_kernel(gpu, shape):
+    """curv_gemm_batched on products with K-contiguous operands (the LDS-DMA kernel): plain, with every epilogue, with
+    the triangular cuts of the samplers, ragged M / N / K; against fp64 torch, and bit-reproducible."""
+    from curvature_amd import ops
+    M, N, K = shape
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=gpu)
+    Bt = torch.randn(N, K, device=gpu)                     # B = Bt.t(): K-contiguous columns
+    E = torch.randn(M, N, device=gpu)
+    F = torch.randn(M, N, device=gpu)
+    ref = A.double() @ Bt.double().t()
+    scale = float(ref.abs().max())
+    cases = [(ops.EPI_NONE, None, None, 1.0, 0.0, ref),
+             (ops.EPI_SQUARE, None, None, 0.5, 0.0, 0.5 * ref * ref),
+             (ops.EPI_MUL_E, E, None, 2.0, 0.0, 2.0 * ref * E.double()),
+             (ops.EPI_ADD_E, E, None, -1.0, 0.0, -ref + E.double()),
+             (ops.EPI_MUL_E_ADD_F, E, F, 1.5, 0.0, 1.5 * ref * E.double() + F.double())]
+    jobs, wants = [], []
+    for ep, e, f, alpha, beta, want in cases:
+        C = torch.full((M, N), float("nan"), device=gpu)
+        jobs.append(ops.Gemm(A, Bt.t(), C, alpha=alpha, beta=beta, epilogue=ep, E=e, F=f))
+        wants.append(want)
+    # accumulate onto an existing C (beta = 1)
+    C0 = torch.randn(M, N, device=gpu)
+    Cb = C0.clone()
+    jobs.append(ops.Gemm(A, Bt.t(), Cb, alpha=1.0, beta=1.0))
+    wants.append(ref + C0.double())
+    ops.gemm_batched(jobs)
+    for j, want in zip(jobs, wants):
+        assert float((j.C.double() - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), scale), j.epilogue
+    first = [j.C.clone() for j in jobs[:5]]
+    ops.gemm_batched(jobs[:5])
+    for a, j in zip(first, jobs[:5]):
+        assert torch.equal(a, j.C)
+    # triangular operands as in KFAC.sample: lower-triangular A (square, K = M), upper-triangular B (K = N)
+    if K >= 1536:
+        L = torch.tril(torch.randn(K, K, device=gpu))
+        Z = torch.randn(N, K, device=gpu)
+        out = torch.empty(K, N, device=gpu)
+        ops.gemm_batched([ops.Gemm(L, Z.t(), out, tri=ops.TRI_A_LOWER)])
+        want = L.double() @ Z.double().t()
+        assert float((out.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+        out3 = torch.empty(M, K, device=gpu)
+        Lt = torch.tril(torch.randn(K, K, device=gpu))      # B = Lt.t() is upper triangular with K-contiguous columns
+        ops.gemm_batched([ops.Gemm(A, Lt.t(), out3, tri=ops.TRI_B_UPPER)])
+        want3 = A.double() @ Lt.double().t()
+        assert float((out3.double() - want3).abs().max()) <= 2e-5 * float(want3.abs().max())
