@@ -33,6 +33,8 @@ struct EighDev {
   double* Q;            // (Nb/2) x 64 x 64 rotation blocks of the current step
   double* norms;        // per 64x64 tile {off^2, diag^2} partial sums (P*P pairs), summed in a fixed order
   int* flags;           // {state, own sweeps}: state 0 = iterating, 1 = converged, 2 = max_sweeps reached
+  double* scale;        // ||A||_F^2 at the matrix's last convergence test (0 before the first)
+  int* skip;            // per pair of the current round: 1 = its 64x64 sub-problem is already diagonal enough
   int n, np, Nb, spf;   // spf: steps per own sweep (Nb - 1): the matrix is tested - and frozen - after each of ITS sweeps
 };
 // Every matrix follows its own schedule: round r of its tournament is step % (Nb - 1), its convergence test runs
@@ -102,7 +104,7 @@ eigh_prepare_kernel(const EighDev* __restrict__ t, int nf) {
 // (1) per block pair: diagonalise the 64x64 sub-matrix by cyclic Jacobi in LDS, store Q
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(EIG_THREADS)
-jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sweeps, double inner_tol2) {
+jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sweeps, double inner_tol2, double outer_tol2) {
   __shared__ double S[NB * LDA];
   __shared__ double Qs[NB * LDA];
   __shared__ double cs[2 * 32];
@@ -129,6 +131,27 @@ jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sw
   for (int o = EIG_THREADS / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
   const double fro2 = red[0];
   __syncthreads();
+  // Threshold Jacobi at block level: if the sub-problem's off-diagonal part is already below this matrix's share of
+  // the convergence bound (off(A)^2 <= tol^2 ||A||^2 summed over the Nb (Nb - 1) / 2 sub-problems of a sweep, with a
+  // factor 4 to spare), the pair is left alone and the row / column updates of this round skip it - for Kronecker
+  // factors, whose many near-zero eigenvalues couple only through tiny entries, that is most pairs from early on.
+  // The decision uses the matrix's own data only (results stay independent of the batch).
+  {
+    double o2 = 0.0;
+    for (int e = tid; e < NB * NB; e += EIG_THREADS) {
+      const int x = e >> 6, y = e & 63;
+      if (x != y) { const double v = S[x * LDA + y]; o2 += v * v; }
+    }
+    red[tid] = o2;
+    __syncthreads();
+    for (int o = EIG_THREADS / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const double off0 = red[0];
+    __syncthreads();
+    const double scale = d.scale[0];
+    const bool skip = scale > 0.0 && off0 <= (0.5 * outer_tol2 / ((double)d.Nb * d.Nb)) * scale;
+    if (tid == 0) d.skip[tp] = skip ? 1 : 0;
+    if (skip) return;
+  }
 
   for (int sweep = 0; sweep < inner_sweeps; ++sweep) {
     for (int rr = 0; rr < NB - 1; ++rr) {
@@ -207,6 +230,7 @@ jacobi_rows_kernel(const EighDev* __restrict__ t, int nf, int step) {
   const EighDev& d = t[f];
   const int nct = d.np / NB, ng = eig_groups(nct), etw = eig_etw(nct), tp = local / ng, ct0 = (local - tp * ng) * etw, np = d.np, tid = threadIdx.x;
   const int ct1 = ct0 + etw < nct ? ct0 + etw : nct;
+  if (d.skip[tp]) return;                                 // the pair kernel left this pair alone
   int p, q;
   rr_pair(d.Nb, step, tp, p, q);
   gdouble* A = (gdouble*)d.A;
@@ -255,6 +279,7 @@ jacobi_cols_kernel(const EighDev* __restrict__ t, int nf, int step) {
   const int l2 = local - which * (d.Nb / 2) * ng;
   const int etw = eig_etw(nrt), tp = l2 / ng, rt0 = (l2 - tp * ng) * etw;
   const int rt1 = rt0 + etw < nrt ? rt0 + etw : nrt;
+  if (d.skip[tp]) return;
   int p, q;
   rr_pair(d.Nb, step, tp, p, q);
   gdouble* Mx = which ? (gdouble*)d.V : (gdouble*)d.A;
@@ -335,6 +360,7 @@ eigh_check_kernel(const EighDev* __restrict__ t, int nf, int step1, double tol2,
     const int sweeps = d.flags[1] + 1;
     d.flags[1] = sweeps;
     const double off2 = r0[0], all2 = r0[0] + r1[0];
+    d.scale[0] = all2;
     if (off2 <= tol2 * all2) d.flags[0] = 1;
     else if (sweeps >= max_sweeps || !(all2 == all2)) d.flags[0] = 2;
   }
@@ -392,7 +418,7 @@ eigh_gather_kernel(const EighDev* __restrict__ t, int nf, const int* __restrict_
   }
 }
 
-constexpr int EIG_UPLOAD_CHUNK = 48;
+constexpr int EIG_UPLOAD_CHUNK = 40;
 struct EighChunk { EighDev f[EIG_UPLOAD_CHUNK]; };
 static_assert(sizeof(EighChunk) <= 3840, "kernel argument block must stay below 4 KB");
 
@@ -420,7 +446,7 @@ static bool eigh_layout(const curv_eigh_desc* descs, int n, EighLayout& L) {
     nmax = std::max(nmax, descs[i].n);
     const size_t P = (size_t)cdiv(descs[i].n, NB);
     L.norm_off[i] = norm_doubles;
-    norm_doubles += 2 * P * P;
+    norm_doubles += 2 * P * P + 2;                 // + the matrix's scale
   }
   L.norms = align_up(std::max<size_t>(norm_doubles, 2) * sizeof(double), 256);
   L.flags = align_up((size_t)std::max(n, 1) * 2 * sizeof(int), 256);
@@ -433,6 +459,7 @@ static bool eigh_layout(const curv_eigh_desc* descs, int n, EighLayout& L) {
     L.a_off[i] = off; off += np * np * sizeof(double);
     L.v_off[i] = off; off += np * np * sizeof(double);
     L.q_off[i] = off; off += (np / NB) * NB * NB * sizeof(double);
+    off += align_up((np / NB) * sizeof(int), 256);          // skip flags, one per pair, behind the rotation blocks
   }
   L.total = off;
   return true;
@@ -482,6 +509,11 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
     d.Q = reinterpret_cast<double*>(base + L.q_off[i]);
     d.norms = norms + L.norm_off[i];
     d.flags = flags + 2 * i;
+    {
+      const size_t P = (size_t)cdiv(descs[i].n, NB), np_ = P * NB;
+      d.scale = d.norms + 2 * P * P;
+      d.skip = reinterpret_cast<int*>(base + L.q_off[i] + (np_ / NB) * NB * NB * sizeof(double));
+    }
     d.spf = std::max(1, d.Nb - 1);
     maxNb = std::max(maxNb, d.Nb);
     const long long P = d.np / NB;
@@ -502,6 +534,7 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
   hipLaunchKernelGGL(eigh_prepare_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats);
   CURV_LAUNCH_CHECK();
   CURV_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)n_mats * 2 * sizeof(int), stream));
+  CURV_HIP_CHECK(hipMemsetAsync(norms, 0, L.norms, stream));      // includes every matrix's scale (0 = no test yet)
   std::vector<int> host_flags(2 * n_mats);
   // One cyclic sweep over the 64x64 sub-problem per visit.  Diagonalising it to 1e-13 (up to ten inner sweeps)
   // cost 82 % of the solver's time and bought nothing: the outer iteration needs the same number of sweeps
@@ -516,7 +549,7 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
   bool all_done = false;
   int sweeps = 0;
   for (long long step = 0; step < max_steps && !all_done; ++step) {
-    hipLaunchKernelGGL(jacobi_pair_kernel, dim3((unsigned)pair_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step, inner_sweeps, inner_tol2);
+    hipLaunchKernelGGL(jacobi_pair_kernel, dim3((unsigned)pair_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step, inner_sweeps, inner_tol2, tol * tol);
     CURV_LAUNCH_CHECK();
     hipLaunchKernelGGL(jacobi_rows_kernel, dim3((unsigned)row_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step);
     CURV_LAUNCH_CHECK();
