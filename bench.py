@@ -243,7 +243,18 @@ def main():
     hip_ev = [(L.curv_event_create(), L.curv_event_create()) for _ in range(max(args.steps, 1))]
     tev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(max(args.steps, 1))]
 
+    # The bench repeats ONE batch.  update() accumulates (the reference's `+=`), so the rank-deficient factors of that
+    # batch grow linearly with the step count while the damping of invert(1, 1000) stays: after ~200 accumulations
+    # the fp32 rounding noise of the largest factor exceeds the damping and its Cholesky factorisation fails, as it
+    # would in the reference (tools/accumulation_limit.py).  Every RESTART-th step therefore starts the accumulation
+    # again (its update() overwrites instead of adding); 15 of 16 steps time the accumulating form.
+    RESTART = 16
+    counter = {"steps": 0}
+
     def step(e):
+        if counter["steps"] % RESTART == 0 and counter["steps"] > 0:
+            kfac._fresh.update((layer, side) for layer in kfac.state for side in (0, 1))
+        counter["steps"] += 1
         if e is not None:
             e[0].record()
         kfac.update(batch_size=args.batch)
@@ -326,7 +337,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "ResNet-50 random-init (seed 0), synthetic 3x224x224 N(0,1) inputs, N=32: "
                                    "KFAC.update + invert(1.0, 1000.0) + sample_and_replace, 54 layers",
-                       "batch": args.batch, "layers": n_layers,
+                       "batch": args.batch, "layers": n_layers, "accumulation_restarts_every": 16,
                        "parallelism": f"layer-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "curv::syrk_patch_kernel + curv::syrk_flat_kernel (the factor build: "
                                                        "implicit-im2col kernel + LDS-DMA kernel for flattened factors and "
