@@ -255,11 +255,21 @@ class Diagonal(Curvature):
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
         assert self.state, "State dict is empty. Did you call 'update' prior to this?"
         gindex = self._global_index()
+        # first inversion: all inverse-state tensors of the Linear / Conv2d layers in ONE arena, so that sampling can
+        # scale the whole model's noise with one launch (later calls overwrite them in place)
+        arena = {}
+        fresh = [l for l in self.state if l not in self.inv_state and not isinstance(l, str)]
+        if fresh:
+            self._inv_flat, views = _arena([tuple(self.state[l].shape) for l in fresh], self.state[fresh[0]].device)
+            arena = dict(zip(fresh, views))
         for position, (layer, value) in enumerate(self.state.items()):
             # Diagonal uses lists when both are list/tuple (curvatures.py:183); same outcome as _hyper.
             # Keys that are not layers of this model (a foreign state dict) fall back to their position.
             n, s = self._hyper(add, multiply, gindex.get(layer, position), max(len(gindex), len(self.state)))
-            self.inv_state[layer] = ops.rsqrt_affine(value, n, s, out=self._reuse(self.inv_state.get(layer), value))
+            out = self._reuse(self.inv_state.get(layer), value)
+            if out is None and layer in arena:
+                out = arena[layer]
+            self.inv_state[layer] = ops.rsqrt_affine(value, n, s, out=out)
 
     @staticmethod
     def _reuse(prev: Optional[Tensor], like: Tensor) -> Optional[Tensor]:
@@ -277,10 +287,53 @@ class Diagonal(Curvature):
         return ops.mul(z, inv)
 
     def sample_and_replace(self):
-        """curvatures.py:117-129 including the MultiheadAttention branch."""
-        self._reload_mean()
-        for _, layer in self._owned():
-            self._replace(self.sample(layer), layer.weight, layer.bias)
+        """curvatures.py:117-129 including the MultiheadAttention branch.  For the Linear / Conv2d layers the
+        per-layer loop (draw, multiply, two adds: ~5 launches per layer, launch-bound for a ResNet) is one noise
+        launch, one multiply over an arena and one batched launch that writes ``mean + z * inv_state`` through the
+        [W | b] split straight onto the parameters (a K = 1 product with the `MUL_E_ADD_F` epilogue)."""
+        assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
+        layers = [l for _, l in self._owned() if l in self.inv_state]
+        self._reload_mean(skip=[p for l in layers for p in (l.weight, l.bias) if p is not None])
+        if layers:
+            key = (tuple(self.inv_state[l].data_ptr() for l in layers),
+                   tuple(p.data_ptr() for l in layers for p in (l.weight, l.bias) if p is not None),
+                   tuple(self.model_state_of(l, nm).data_ptr() for l in layers for nm in ('weight', 'bias')
+                         if getattr(l, nm) is not None))
+            plan = self._sample_plans().get(key)
+            if plan is None:
+                dev = self.inv_state[layers[0]].device
+                zflat, zs = _arena([tuple(self.inv_state[l].shape) for l in layers], dev)
+                rows = max(self.inv_state[l].shape[0] for l in layers)
+                cols = max(self.inv_state[l].shape[1] for l in layers)
+                ones_r = torch.ones(rows, 1, dtype=torch.float32, device=dev)
+                ones_c = torch.ones(1, cols, dtype=torch.float32, device=dev)
+                scale, jobs = [], []
+                for layer, z in zip(layers, zs):
+                    m, n = z.shape
+                    n0 = n - int(layer.bias is not None)
+                    scale.append((z, self.inv_state[layer]))
+                    w = layer.weight.data
+                    if not w.is_contiguous():
+                        raise RuntimeError("Diagonal.sample_and_replace: parameters must be contiguous")
+                    jobs.append(ops.Gemm(ones_r[:m], ones_c[:, :n0], w.view(m, n0), epilogue=ops.EPI_MUL_E_ADD_F,
+                                         E=z[:, :n0], F=self.model_state_of(layer, 'weight').view(m, n0)))
+                    if layer.bias is not None:
+                        jobs.append(ops.Gemm(ones_r[:m], ones_c[:, :1], layer.bias.data.view(m, 1),
+                                             epilogue=ops.EPI_MUL_E_ADD_F, E=z[:, n0:],
+                                             F=self.model_state_of(layer, 'bias').view(m, 1)))
+                inv_flat = getattr(self, "_inv_flat", None)
+                whole = _is_arena(inv_flat, [self.inv_state[l] for l in layers]) and \
+                    sum(self.inv_state[l].numel() for l in layers) == zflat.numel()
+                plan = (key, zflat, scale, ops.GemmPlan(jobs), inv_flat if whole else None)
+                self._keep_plan(key, plan)
+            _, zflat, scale, gemms, inv_flat = plan
+            self._randn(zflat.numel(), device=zflat.device, out=zflat)
+            if inv_flat is not None:                               # z *= inv_state: one launch over the arena
+                ops.mul(zflat, inv_flat[:zflat.numel()], out=zflat)
+            else:
+                for z, inv in scale:
+                    ops.mul(z, inv, out=z)
+            gemms.run()
         for layer in self._attention():
             for weight, bias, key in ((layer.in_proj_weight, layer.in_proj_bias, 'attn_in'),
                                       (layer.out_proj.weight, layer.out_proj.bias, 'attn_out')):

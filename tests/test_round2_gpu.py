@@ -515,3 +515,34 @@ def test_lenet_config2_at_the_reference_batch_size(gpu):
         assert rel_fro(kfac.inv_state[layer][0], LA) < 1e-5 and rel_fro(kfac.inv_state[layer][1], LG) < 1e-5
         z = torch.randn(A32.shape[0], G32.shape[0])
         assert rel_fro(kfac.sample(layer, z=z.to(gpu)), o.kfac_sample(LA, LG, z.double())) < TOL
+
+
+def test_diagonal_fused_sample_and_replace(gpu):
+    """Diagonal.sample_and_replace as three launches for the whole model (noise, scale, batched write through the
+    [W | b] split) gives exactly mean + z * inv_state with z the estimator's own Philox stream, laid out layer after
+    layer in (m, n + 1) blocks; a second call starts from the mean again; MultiheadAttention entries are untouched by
+    the batching (they keep the per-key path, covered by test_diagonal_multihead_attention)."""
+    from curvature_amd import ops
+    from curvature_amd.curvatures import Diagonal
+    g1 = load("g1_kfac_lenet.npz")
+    model, layers = lenet(gpu, g1)
+    diag = Diagonal(model)
+    for b in range(2):
+        diag.update(backward(model, g1, b, gpu))
+    diag.invert(add=0.5, multiply=2.0)
+    diag.noise_seed = 777
+    for call in range(2):
+        offset = diag.noise_offset
+        total = sum(diag.inv_state[l].numel() for l in layers)
+        z = ops.randn((total,), gpu, diag.noise_seed, offset)
+        diag.sample_and_replace()
+        pos = 0
+        for li, layer in enumerate(layers):
+            inv = diag.inv_state[layer]
+            m, n = inv.shape
+            s = (z[pos:pos + m * n].view(m, n) * inv)
+            pos += m * n
+            want_w = g1[f"w_l{li}"].to(gpu).view(m, n - 1) + s[:, :-1]
+            want_b = g1[f"bias_l{li}"].to(gpu) + s[:, -1]
+            assert torch.allclose(layer.weight.data.view(m, n - 1), want_w, rtol=0, atol=1e-6), (call, li)
+            assert torch.allclose(layer.bias.data, want_b, rtol=0, atol=1e-6), (call, li)
