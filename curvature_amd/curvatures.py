@@ -237,6 +237,15 @@ class Diagonal(Curvature):
         # one pass over modules() so that `state` gets the reference's insertion order (curvatures.py:149-174),
         # which is the order per-layer hyper-parameter lists are indexed by
         owned = {l for _, l in self._owned()}
+        # the state of all (new) Linear / Conv2d layers in one arena: invert() with one pair of hyper-parameters is
+        # then a single launch over it
+        new = [l for _, l in self._owned() if l not in self.state and l.weight.grad is not None]
+        fresh = {}
+        if new:
+            self._state_flat, views = _arena(
+                [(l.weight.shape[0], l.weight.numel() // l.weight.shape[0] + int(l.bias is not None)) for l in new],
+                new[0].weight.device)
+            fresh = dict(zip(new, views))
         for layer in self.model.modules():
             name = layer.__class__.__name__
             if name not in self.layer_types:
@@ -245,7 +254,8 @@ class Diagonal(Curvature):
                 if layer in owned:
                     bias_grad = layer.bias.grad if layer.bias is not None else None
                     self.state[layer] = ops.sq_accumulate(layer.weight.grad.contiguous(), bias_grad, batch_size,
-                                                          self.state.get(layer))
+                                                          fresh.get(layer, self.state.get(layer)),
+                                                          first=True if layer in fresh else None)
             elif name == 'MultiheadAttention':
                 for key, weight, bias in (('attn_in', layer.in_proj_weight, layer.in_proj_bias),
                                           ('attn_out', layer.out_proj.weight, layer.out_proj.bias)):
@@ -262,6 +272,17 @@ class Diagonal(Curvature):
         if fresh:
             self._inv_flat, views = _arena([tuple(self.state[l].shape) for l in fresh], self.state[fresh[0]].device)
             arena = dict(zip(fresh, views))
+        plain = [l for l in self.state if not isinstance(l, str)]
+        state_flat, inv_flat = getattr(self, "_state_flat", None), getattr(self, "_inv_flat", None)
+        whole = _is_scalar(add) and _is_scalar(multiply) and len(plain) == len(self.state) and \
+            _is_arena(state_flat, [self.state[l] for l in plain]) and \
+            _is_arena(inv_flat, [self.inv_state.get(l, arena.get(l)) for l in plain]) and \
+            state_flat.numel() == inv_flat.numel() == sum(self.state[l].numel() for l in plain)
+        if whole:      # one pair of hyper-parameters, both dicts whole arenas (no attention entries): one launch
+            for l in plain:
+                self.inv_state.setdefault(l, arena.get(l))
+            ops.rsqrt_affine(state_flat, float(add), float(multiply), out=inv_flat)
+            return
         for position, (layer, value) in enumerate(self.state.items()):
             # Diagonal uses lists when both are list/tuple (curvatures.py:183); same outcome as _hyper.
             # Keys that are not layers of this model (a foreign state dict) fall back to their position.
@@ -690,8 +711,8 @@ class EFB(Curvature):
         missing = [k for k, layer in enumerate(layers) if layer not in self.state]
         if missing:
             # Lambda of all (new) layers in one zeroed arena: every update is then the same accumulate launch pair
-            _, views = _arena([(grads[k][0].shape[0], grads[k][0].numel() // grads[k][0].shape[0] +
-                                int(grads[k][1] is not None)) for k in missing], dev, zero=True)
+            self._state_flat, views = _arena([(grads[k][0].shape[0], grads[k][0].numel() // grads[k][0].shape[0] +
+                                               int(grads[k][1] is not None)) for k in missing], dev, zero=True)
             for k, v in zip(missing, views):
                 self.state[layers[k]] = v
         key = tuple(t.data_ptr() for gw, gb in grads for t in (gw, gb) if t is not None) + \
@@ -729,6 +750,12 @@ class EFB(Curvature):
             self._inv_flat, views = _arena([tuple(v.shape) for v in values], values[0].device)
             for layer, v in zip(layers, views):
                 self.inv_state[layer] = v
+        state_flat = getattr(self, "_state_flat", None)
+        if _is_scalar(add) and _is_scalar(multiply) and _is_arena(state_flat, values) and \
+                sum(v.numel() for v in values) == self._inv_flat.numel() == state_flat.numel():
+            # one pair of hyper-parameters for every layer and both dicts are whole arenas: one launch
+            ops.rsqrt_affine(state_flat, float(add), float(multiply), out=self._inv_flat)
+            return
         for position, (layer, value) in enumerate(zip(layers, values)):
             n, s = self._hyper(add, multiply, gindex.get(layer, position), max(len(gindex), len(layers)))
             ops.rsqrt_affine(value, n, s, out=self.inv_state[layer])

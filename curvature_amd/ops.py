@@ -132,14 +132,18 @@ def rsqrt_affine(value: torch.Tensor, add: float, multiply: float, out: Optional
 
 
 def sq_accumulate(grad_w: torch.Tensor, grad_b: Optional[torch.Tensor], batch_size: float,
-                  state: Optional[torch.Tensor]) -> torch.Tensor:
-    """state (+)= batch_size * [grad_w.view(m,-1) | grad_b]**2 ; allocates when state is None."""
+                  state: Optional[torch.Tensor], first: Optional[bool] = None) -> torch.Tensor:
+    """state (+)= batch_size * [grad_w.view(m,-1) | grad_b]**2 ; allocates when state is None.  `first`: overwrite a
+    given (preallocated, uninitialised) state instead of adding to it; default: only when it is allocated here."""
     _require_gpu(grad_w, grad_b, state)
     rows = grad_w.shape[0]
     cols_w = grad_w.numel() // rows
-    first = state is None
-    if first:
+    if first is None:
+        first = state is None
+    if state is None:
         state = torch.empty(rows, cols_w + (grad_b is not None), dtype=torch.float32, device=grad_w.device)
+    elif tuple(state.shape) != (rows, cols_w + (grad_b is not None)) or not state.is_contiguous():
+        raise RuntimeError("sq_accumulate: state does not match the gradient's [W | b] shape")
     _lib.check(_lib.lib().curv_sq_accumulate(_lib.stream_ptr(), grad_w.data_ptr(),
                                              grad_b.data_ptr() if grad_b is not None else None,
                                              rows, cols_w, float(batch_size), state.data_ptr(), int(first)),
