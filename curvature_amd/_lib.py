@@ -86,6 +86,12 @@ class curv_gemm64_desc(ctypes.Structure):
                 ("alpha", ctypes.c_double), ("beta", ctypes.c_double)]
 
 
+class curv_sq_desc(ctypes.Structure):
+    _fields_ = [("grad_w", ctypes.c_void_p), ("grad_b", ctypes.c_void_p), ("state", ctypes.c_void_p),
+                ("rows", ctypes.c_int32), ("cols_w", ctypes.c_int32), ("first", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
 class curv_copy_desc(ctypes.Structure):
     _fields_ = [("dst", ctypes.c_void_p), ("src", ctypes.c_void_p), ("bytes", ctypes.c_ulonglong)]
 
@@ -136,6 +142,7 @@ SIGNATURES = {
     "curv_randn": (_i, [_vp, _vp, _ll, ctypes.c_ulonglong, ctypes.c_ulonglong]),
     "curv_rsqrt_affine": (_i, [_vp, _vp, _d, _d, _vp, _ll]),
     "curv_sq_accumulate": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _i]),
+    "curv_sq_accumulate_batched": (_i, [_vp, ctypes.POINTER(curv_sq_desc), _i, _d]),
     "curv_clamp_min0": (_i, [_vp, _vp, _ll]),
     "curv_sqrt_scale": (_i, [_vp, _vp, _d, _vp, _ll]),
     "curv_mul": (_i, [_vp, _vp, _vp, _vp, _ll]),

@@ -1,6 +1,8 @@
 // HBM-bound elementwise kernels of the Diagonal / EFB / INF estimators.
 // Reference arithmetic: curvature/curvatures.py:141-193 (Diagonal), :431-434 (EFB diags),
 // :449 (EFB invert), :523-526 (INF invert).
+#include <cstring>
+
 #include "common.h"
 #include "../../include/curv_hip.h"
 
@@ -59,6 +61,38 @@ sq_accumulate_kernel(const float* __restrict__ gw, const float* __restrict__ gb,
     const float g = (c < cols_w) ? gw[(long long)r * cols_w + c] : gb[r];
     const float val = g * g * bs;
     state[j] = first ? val : state[j] + val;
+  }
+}
+
+// The same for many layers in one launch: descriptors travel in the kernel arguments; a workgroup finds its layer by
+// the prefix of 1024-element blocks (first_block ascending).
+struct SqDev {
+  const float* gw; const float* gb; float* state;
+  int rows, cols_w, first, first_block;
+};
+constexpr int SQ_CHUNK = 96;
+struct SqChunk { SqDev d[SQ_CHUNK]; };
+static_assert(sizeof(SqChunk) <= 3840, "kernel argument block must stay below 4 KB");
+__global__ void __launch_bounds__(256) sq_accumulate_batched_kernel(SqChunk chunk, int count, float bs) {
+  int lo = 0, hi = count - 1;                       // last layer with first_block <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (chunk.d[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SqDev& d = chunk.d[lo];
+  const int cols = d.cols_w + (d.gb != nullptr ? 1 : 0);
+  const long long n = (long long)d.rows * cols;
+  const long long j0 = (long long)((int)blockIdx.x - d.first_block) * 1024 + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long j = j0 + 256 * u;
+    if (j < n) {
+      const int r = (int)(j / cols);
+      const int c = (int)(j - (long long)r * cols);
+      const float g = (c < d.cols_w) ? d.gw[(long long)r * d.cols_w + c] : d.gb[r];
+      const float val = g * g * bs;
+      d.state[j] = d.first ? val : d.state[j] + val;
+    }
   }
 }
 
@@ -137,6 +171,34 @@ extern "C" int curv_sq_accumulate(void* stream, const float* grad_w, const float
   hipLaunchKernelGGL(sq_accumulate_kernel, sweep_grid(count, 1), dim3(256), 0, (hipStream_t)stream,
                      grad_w, grad_b, rows, cols_w, (float)batch_size, state, first);
   CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}
+
+extern "C" int curv_sq_accumulate_batched(void* stream, const curv_sq_desc* descs, int n, double batch_size) {
+  CURV_REQUIRE(n >= 0 && (n == 0 || descs != nullptr), "curv_sq_accumulate_batched: bad arguments");
+  for (int b = 0; b < n; b += SQ_CHUNK) {
+    SqChunk chunk;
+    memset(&chunk, 0, sizeof(chunk));
+    int count = 0;
+    long long blocks = 0;
+    for (int i = b; i < n && i < b + SQ_CHUNK; ++i) {
+      const curv_sq_desc& s = descs[i];
+      CURV_REQUIRE(s.rows >= 0 && s.cols_w >= 0, "curv_sq_accumulate_batched: desc %d: negative shape", i);
+      const long long elems = (long long)s.rows * (s.cols_w + (s.grad_b ? 1 : 0));
+      if (elems == 0) continue;
+      CURV_REQUIRE(s.grad_w && s.state, "curv_sq_accumulate_batched: desc %d: null pointer", i);
+      SqDev& d = chunk.d[count++];
+      d.gw = s.grad_w; d.gb = s.grad_b; d.state = s.state;
+      d.rows = s.rows; d.cols_w = s.cols_w; d.first = s.first;
+      d.first_block = (int)blocks;
+      blocks += (elems + 1023) / 1024;
+      CURV_REQUIRE(blocks < (1LL << 31), "curv_sq_accumulate_batched: too many elements");
+    }
+    if (count == 0) continue;
+    hipLaunchKernelGGL(sq_accumulate_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, chunk,
+                       count, (float)batch_size);
+    CURV_LAUNCH_CHECK();
+  }
   return CURV_OK;
 }
 

@@ -246,21 +246,34 @@ class Diagonal(Curvature):
                 [(l.weight.shape[0], l.weight.numel() // l.weight.shape[0] + int(l.bias is not None)) for l in new],
                 new[0].weight.device)
             fresh = dict(zip(new, views))
+        keys, items = [], []
         for layer in self.model.modules():
             name = layer.__class__.__name__
             if name not in self.layer_types:
                 continue
             if name in ('Linear', 'Conv2d'):
                 if layer in owned:
-                    bias_grad = layer.bias.grad if layer.bias is not None else None
-                    self.state[layer] = ops.sq_accumulate(layer.weight.grad.contiguous(), bias_grad, batch_size,
-                                                          fresh.get(layer, self.state.get(layer)),
-                                                          first=True if layer in fresh else None)
+                    bias_grad = layer.bias.grad.contiguous() if layer.bias is not None else None
+                    keys.append(layer)
+                    items.append((layer.weight.grad.contiguous(), bias_grad, fresh.get(layer, self.state.get(layer)),
+                                  True if layer in fresh else None))
             elif name == 'MultiheadAttention':
                 for key, weight, bias in (('attn_in', layer.in_proj_weight, layer.in_proj_bias),
                                           ('attn_out', layer.out_proj.weight, layer.out_proj.bias)):
-                    self.state[key] = ops.sq_accumulate(weight.grad.contiguous(), bias.grad, batch_size,
-                                                        self.state.get(key))
+                    keys.append(key)
+                    items.append((weight.grad.contiguous(), bias.grad.contiguous(), self.state.get(key), None))
+        # several modules may share the 'attn_*' keys (one pair for the whole model, as in the reference): the first
+        # occurrence of every key goes into ONE launch, later ones accumulate onto it afterwards
+        firsts, later = {}, []
+        for key, item in zip(keys, items):
+            if key in firsts:
+                later.append((key, item))
+            else:
+                firsts[key] = item
+        for key, st in zip(firsts, ops.sq_accumulate_many(firsts.values(), batch_size)):
+            self.state[key] = st                   # new keys enter in modules() order, like the reference's
+        for key, item in later:
+            self.state[key] = ops.sq_accumulate(item[0], item[1], batch_size, self.state[key])
 
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
         assert self.state, "State dict is empty. Did you call 'update' prior to this?"
@@ -734,8 +747,10 @@ class EFB(Curvature):
             self._update_plan = plan
         plan[1].run()
         plan[2].run()
-        for layer, (gw, gb) in zip(layers, grads):
-            self.diags[layer] = ops.sq_accumulate(gw, gb, batch_size, self.diags.get(layer))
+        done = ops.sq_accumulate_many([(gw, gb.contiguous() if gb is not None else None, self.diags.get(layer), None)
+                                       for layer, (gw, gb) in zip(layers, grads)], batch_size)      # one launch
+        for layer, st in zip(layers, done):
+            self.diags[layer] = st
 
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
         assert self.state, "State dict is empty. Did you call 'update' prior to this?"

@@ -11,7 +11,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import curv_factor_desc, curv_gemm_desc, curv_inv_desc
+from ._lib import curv_factor_desc, curv_gemm_desc, curv_inv_desc, curv_sq_desc
 
 _workspaces = {}
 _workspace_lock = threading.Lock()
@@ -149,6 +149,34 @@ def sq_accumulate(grad_w: torch.Tensor, grad_b: Optional[torch.Tensor], batch_si
                                              rows, cols_w, float(batch_size), state.data_ptr(), int(first)),
                "curv_sq_accumulate")
     return state
+
+
+def sq_accumulate_many(items, batch_size: float) -> List[torch.Tensor]:
+    """`sq_accumulate` for a list of (grad_w, grad_b or None, state or None, first or None) in ONE launch
+    (curv_sq_accumulate_batched); returns the state tensors (allocated where None was given)."""
+    items = list(items)
+    if not items:
+        return []
+    arr = (curv_sq_desc * len(items))()
+    states = []
+    for d, (grad_w, grad_b, state, first) in zip(arr, items):
+        _require_gpu(grad_w, grad_b, state)
+        if not grad_w.is_contiguous() or (grad_b is not None and not grad_b.is_contiguous()):
+            raise RuntimeError("sq_accumulate_many: gradients must be contiguous")
+        rows = grad_w.shape[0]
+        cols_w = grad_w.numel() // rows
+        if first is None:
+            first = state is None
+        if state is None:
+            state = torch.empty(rows, cols_w + (grad_b is not None), dtype=torch.float32, device=grad_w.device)
+        elif tuple(state.shape) != (rows, cols_w + (grad_b is not None)) or not state.is_contiguous():
+            raise RuntimeError("sq_accumulate_many: state does not match the gradient's [W | b] shape")
+        states.append(state)
+        d.grad_w, d.grad_b, d.state = grad_w.data_ptr(), (grad_b.data_ptr() if grad_b is not None else None), state.data_ptr()
+        d.rows, d.cols_w, d.first = rows, cols_w, int(first)
+    _lib.check(_lib.lib().curv_sq_accumulate_batched(_lib.stream_ptr(), arr, len(items), float(batch_size)),
+               "curv_sq_accumulate_batched")
+    return states
 
 
 def chol_inv_lower(factors: Sequence[torch.Tensor], adds: Sequence[float], multiplies: Sequence[float],

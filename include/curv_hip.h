@@ -206,6 +206,17 @@ int curv_rsqrt_affine(void* stream, const float* v, double s, double n, float* o
  * grad_w is (rows x cols_w), grad_b (rows) or NULL; state is (rows x (cols_w + (grad_b != NULL))). */
 int curv_sq_accumulate(void* stream, const float* grad_w, const float* grad_b, int rows, int cols_w,
                        double batch_size, float* state, int first);
+
+/* The same for many layers in one launch (Diagonal.update, the `diags` of EFB.update).  first: overwrite `state`
+ * instead of adding to it. */
+typedef struct curv_sq_desc {
+  const float* grad_w;
+  const float* grad_b;     /* may be NULL */
+  float* state;            /* (rows, cols_w + (grad_b != NULL)) contiguous */
+  int32_t rows, cols_w;
+  int32_t first, reserved;
+} curv_sq_desc;
+int curv_sq_accumulate_batched(void* stream, const curv_sq_desc* descs, int n, double batch_size);
 /* v = max(v, 0) in place      curvatures.py:523 */
 int curv_clamp_min0(void* stream, float* v, long long count);
 /* out = sqrt(s*v)             curvatures.py:525 */
