@@ -110,3 +110,50 @@ def test_many_k_slices(gpu):
         outs.append(A)
     assert rel_fro(outs[0], A_ref) < TOL
     assert torch.equal(outs[0], outs[1])          # fixed-order slab reduction: bitwise reproducible
+
+
+def test_mixed_launch_with_several_assembled_factors(gpu):
+    """One grouped call holding three 3x3 / stride 1 factors of different widths (assembled from shifted correlations:
+    their 3 x 29 virtual factors share the LDS-DMA work list), their G sides, a stride-2 3x3, a 1x1 and a Linear pair:
+    every factor against the oracle, accumulation on the second call, bit-reproducible."""
+    from curvature_amd import ops
+    o = _oracle()
+    torch.manual_seed(99)
+    specs = [(8, 128, 14, 14, 3, 1, 1), (8, 256, 7, 7, 3, 1, 1), (8, 512, 7, 9, 3, 1, 1), (8, 128, 14, 14, 3, 2, 1),
+             (8, 256, 7, 7, 1, 1, 0)]
+    jobs, refs = [], []
+    for N, C, H, W, k, s, p in specs:
+        x = torch.relu(torch.randn(N, C, H, W))
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        g = torch.randn(N, 96, Ho, Wo) / N
+        A_ref, G_ref = o.kfac_factors(x.double(), g.double(), (k, k), (s, s), (p, p), False)
+        n = C * k * k
+        A = torch.full((n, n), float("nan"), device=gpu)
+        G = torch.full((96, 96), float("nan"), device=gpu)
+        L = Ho * Wo
+        jobs += [ops.FactorJob(x.to(gpu), A, (k, k), (s, s), (p, p), False, 1.0 / (N * L), True),
+                 ops.FactorJob(g.to(gpu), G, (1, 1), (1, 1), (0, 0), False, N / L, True)]
+        refs += [A_ref, G_ref]
+    x = torch.randn(8, 300)
+    g = torch.randn(8, 40) / 8
+    A_ref, G_ref = o.kfac_factors(x.double(), g.double(), has_bias=True)
+    jobs += [ops.FactorJob(x.to(gpu), torch.empty(301, 301, device=gpu), has_bias=True, scale=1.0 / 8, first=True),
+             ops.FactorJob(g.to(gpu), torch.empty(40, 40, device=gpu), scale=8.0, first=True)]
+    refs += [A_ref, G_ref]
+    flops = ops.kfac_plan_flops(jobs)
+    assert flops[0] < 0.4 * (1152 * 1153) * 8 * 196 and flops[6] == (1152 * 1153) * 8 * 49      # assembled vs direct (stride 2)
+    ops.kfac_accumulate(jobs)
+    first = [j.dst.clone() for j in jobs]
+    for j, ref in zip(jobs, refs):
+        assert rel_fro(j.dst, ref) < TOL, (tuple(j.dst.shape), rel_fro(j.dst, ref))
+        assert torch.equal(j.dst, j.dst.t())
+    for j in jobs:
+        j.first = False
+    ops.kfac_accumulate(jobs)
+    for j, ref in zip(jobs, refs):
+        assert rel_fro(j.dst, 2 * ref) < TOL
+    for j, f in zip(jobs, first):                      # same inputs, fresh outputs: bit-identical to the first call
+        j.first = True
+    ops.kfac_accumulate(jobs)
+    for j, f in zip(jobs, first):
+        assert torch.equal(j.dst, f)
