@@ -157,3 +157,22 @@ def test_mixed_launch_with_several_assembled_factors(gpu):
     ops.kfac_accumulate(jobs)
     for j, f in zip(jobs, first):
         assert torch.equal(j.dst, f)
+
+
+def test_more_assembled_factors_than_one_argument_block(gpu):
+    """The padding / assembly passes carry 16 layer descriptors per kernel-argument block: 19 assembled factors in one
+    call take two launches of each (a ResNet-34 has 23 such layers)."""
+    from curvature_amd import ops
+    o = _oracle()
+    torch.manual_seed(5)
+    jobs, refs = [], []
+    for i in range(19):
+        H, W = 4 + i % 3, 5 + i % 2
+        x = torch.relu(torch.randn(8, 128, H, W))
+        A_ref, _ = o.kfac_factors(x.double(), torch.zeros(8, 1, H, W, dtype=torch.float64), (3, 3), (1, 1), (1, 1), False)
+        jobs.append(ops.FactorJob(x.to(gpu), torch.empty(1152, 1152, device=gpu), (3, 3), (1, 1), (1, 1), False,
+                                  1.0 / (8 * H * W), True))
+        refs.append(A_ref)
+    ops.kfac_accumulate(jobs)
+    for j, ref in zip(jobs, refs):
+        assert rel_fro(j.dst, ref) < TOL and torch.equal(j.dst, j.dst.t())
