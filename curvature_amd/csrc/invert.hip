@@ -484,6 +484,16 @@ __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* ba
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int c0 = 16 * p;
+    if (p == 0 && wave != 0) {
+      // while wave 0 factorises the first panel the other three clear what nobody computes: all of Is and the 16x16
+      // tiles of Ds strictly above the diagonal (never written by the trailing updates; wave 0 only ever reads them
+      // as rows of a panel it ignores) - 2.5 k cycles that used to sit behind the last panel
+      for (int e = tid - 64; e < NB * NB; e += MMA_THREADS - 64) {
+        const int r = e >> 6, q = e & 63;
+        Is[r * LDA + q] = 0.0;
+        if ((q >> 4) > (r >> 4)) Ds[r * LDA + q] = 0.0;
+      }
+    }
     if (wave == 0) {
       // The 16 columns of the panel as ONE straight-line block: no store, no branch and no exec-mask change between
       // the columns (the failure flag and the pivots' reciprocals stay in registers until the panel is done), so that
@@ -539,10 +549,9 @@ __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* ba
     }
     __syncthreads();
   }
-  for (int e = tid; e < NB * NB; e += MMA_THREADS) {
-    const int r = e >> 6, q = e & 63;
-    if (q > r) Ds[r * LDA + q] = 0.0;
-    Is[r * LDA + q] = 0.0;
+  for (int e = tid; e < 4 * 16 * 16; e += MMA_THREADS) {      // the upper halves of the four diagonal 16x16 tiles
+    const int b = e >> 8, r = (e >> 4) & 15, q = e & 15;
+    if (q > r) Ds[(16 * b + r) * LDA + 16 * b + q] = 0.0;
   }
   __syncthreads();
   // diagonal 16x16 blocks of the inverse: wave w, lane j < 16 owns column j (forward substitution)

@@ -19,12 +19,12 @@ def main():
     s = open(os.path.join(CSRC, "invert.hip")).read()
     s = sub(s, "namespace curv {\n", "namespace curv {\n__device__ unsigned long long g_probe[16];\n"
             "#define PROBE(k) { if (threadIdx.x == 0) { long long t_ = clock64(); g_probe[k] += (unsigned long long)(t_ - tprev); tprev = t_; } }\n")
-    s = sub(s, "  const int r16 = lane & 15, kq = lane >> 4;\n#pragma unroll\n  for (int p = 0; p < 4; ++p) {\n    const int c0 = 16 * p;\n    if (wave == 0) {",
-            "  const int r16 = lane & 15, kq = lane >> 4;\n  long long tprev = clock64();\n#pragma unroll\n  for (int p = 0; p < 4; ++p) {\n    const int c0 = 16 * p;\n    PROBE(7)\n    if (wave == 0) {")
+    s = sub(s, "  const int r16 = lane & 15, kq = lane >> 4;\n#pragma unroll\n  for (int p = 0; p < 4; ++p) {\n    const int c0 = 16 * p;\n",
+            "  const int r16 = lane & 15, kq = lane >> 4;\n  long long tprev = clock64();\n#pragma unroll\n  for (int p = 0; p < 4; ++p) {\n    const int c0 = 16 * p;\n    PROBE(7)\n")
     s = sub(s, "      if (first_bad != 0 && lane == 0 && *bad == 0) *bad = first_bad;\n    }\n    __syncthreads();\n",
             "      if (first_bad != 0 && lane == 0 && *bad == 0) *bad = first_bad;\n    }\n    PROBE(0)\n    __syncthreads();\n    PROBE(1)\n")
-    s = sub(s, "    __syncthreads();\n  }\n  for (int e = tid; e < NB * NB; e += MMA_THREADS) {",
-            "    __syncthreads();\n    PROBE(2)\n  }\n  for (int e = tid; e < NB * NB; e += MMA_THREADS) {")
+    s = sub(s, "    __syncthreads();\n  }\n  for (int e = tid; e < 4 * 16 * 16; e += MMA_THREADS) {",
+            "    __syncthreads();\n    PROBE(2)\n  }\n  for (int e = tid; e < 4 * 16 * 16; e += MMA_THREADS) {")
     s = sub(s, "  // diagonal 16x16 blocks of the inverse", "  PROBE(3)\n  // diagonal 16x16 blocks of the inverse")
     s = sub(s, "  // off-diagonal blocks by distance d", "  PROBE(4)\n  // off-diagonal blocks by distance d")
     s = sub(s, "    __syncthreads();\n  }\n}\n\n// ------------------------------------------------------------------------------------------------\n// (1a)",
