@@ -771,7 +771,7 @@ syrk_reduce_kernel(const FactorDev* __restrict__ descs, int n_factors, const flo
 
 // The descriptor table travels as kernel arguments (copied by the runtime at launch time), so the
 // call is fully asynchronous and needs neither pinned staging memory nor a stream synchronisation.
-constexpr int UPLOAD_CHUNK = 16;
+constexpr int UPLOAD_CHUNK = 15;
 constexpr int ZERO_PAD_FLOATS = 64;    // dummy load target of masked staging slots
 struct TableChunk { FactorDev f[UPLOAD_CHUNK]; };
 static_assert(sizeof(TableChunk) <= 3840, "kernel argument block must stay below 4 KB");
@@ -1104,6 +1104,23 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     f.n_sub = f.n_tiles * (f.TM / 64) * (f.TM / 64);
     item_cost[i] = chunk_cost[i] * f.cpi;
   }
+  // groups (FactorDev::group_n): one slicing for all members - that of the member with the most chunks; a member
+  // with fewer chunks finds its last slices empty and writes zero slabs for them
+  for (int i = 0; i < n_all; ++i) {
+    if (plan.f[i].group_n <= 0 || plan.f[i].group_pos != 0) continue;
+    const int gn = plan.f[i].group_n;
+    int lead = i;
+    for (int j = i; j < i + gn; ++j) if (plan.f[j].n_chunks > plan.f[lead].n_chunks) lead = j;
+    double cost = 0.0;
+    for (int j = i; j < i + gn; ++j) {
+      FactorDev& f = plan.f[j];
+      f.cpi = plan.f[lead].cpi;
+      f.n_slices = plan.f[lead].n_slices;
+      f.n_items = j == i ? gn * f.n_slices * f.n_tiles : 0;       // the range belongs to the first member
+      cost = std::max(cost, chunk_cost[j] * f.cpi);
+    }
+    for (int j = i; j < i + gn; ++j) item_cost[j] = cost;         // equal keys: the stable sort keeps them together
+  }
   // Work items are dispatched in index order: the longest items go first, so that the tail of the
   // launch is made of the shortest ones (the resident workgroups drain within one short item).
   long long slab = 0;
@@ -1114,12 +1131,13 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     long long items = 0, subs = 0;
     for (int idx : plan.order[k]) {
       FactorDev& f = plan.f[idx];
-      f.item_base = (int)items;
+      // members of a group sit behind its first entry, whose range they share (bases stay ascending)
+      f.item_base = f.group_n > 0 && f.group_pos > 0 ? plan.f[idx - f.group_pos].item_base + f.group_pos : (int)items;
       f.sub_base = (int)subs;
       f.slab_base = slab;
       items += f.n_items;
       subs += f.n_sub;
-      slab += (long long)f.n_items * f.TM * f.TM;
+      slab += (long long)f.n_slices * f.n_tiles * f.TM * f.TM;
       CURV_REQUIRE(items < (1LL << 30) && subs < (1LL << 30), "curv_kfac: too many work items");
     }
     plan.n_items[k] = (int)items;

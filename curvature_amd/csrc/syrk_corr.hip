@@ -206,6 +206,7 @@ void syrk_corr_expand(const curv_factor_desc& s, int user, std::vector<FactorDev
     if (k < 3) { dh = 0; dw = -k; } else { dh = -1 - (k - 3) / 5; dw = (k - 3) % 5 - 2; }
     const int delta = -(dh * L.Wp + dw);
     add(f_index(dh, dw), L.xp_off, s.N, plane, plane - delta, delta, 0, delta != 0);
+    if (k >= 1) { f.back().group_n = 12; f.back().group_pos = k - 1; }      // the 12 non-symmetric ones: one item range
   }
   for (int a = 0; a < 3; ++a) add(RB0 + a, L.rowb_off, 1, L.row_pitch, s.N * L.Wp, LEAD, LEAD - a, a != 0);
   for (int a = 0; a < 3; ++a) add(RT0 + a, L.rowt_off, 1, L.row_pitch, s.N * L.Wp, LEAD, LEAD - a, a != 0);

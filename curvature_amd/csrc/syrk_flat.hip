@@ -209,9 +209,16 @@ syrk_flat_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_items
   __shared__ __attribute__((aligned(1024))) char smem[flat::LDS_B];
   const int item = xcd_item(blockIdx.x);
   if (item >= n_items) return;
-  const int f = find_segment(descs, n_factors, item, false);
+  int f = find_segment(descs, n_factors, item, false);
+  int local = item - descs[f].item_base;
+  if (descs[f].group_n > 0) {                  // a group's shared range: item -> (k-slice, member, tile)
+    const int head = f - descs[f].group_pos;
+    const int gi = item - descs[head].item_base, nt = descs[head].n_tiles, gt = descs[head].group_n * nt;
+    const int slice = gi / gt, rem = gi - slice * gt, member = rem / nt;
+    f = head + member;
+    local = slice * nt + (rem - member * nt);
+  }
   const FactorDev& d = descs[f];
-  const int local = item - d.item_base;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = local % d.n_tiles;
   int ti, tj;

@@ -46,6 +46,11 @@ struct FactorDev {
   // offsets 0.  nonsym: a correlation X_i X_j^T between differently shifted rows - every (ti, tj) tile is computed
   // and nothing is mirrored.
   int pitch, off_i, off_j, nonsym;
+  // group: group_n consecutive table entries (this one is number group_pos) with equal n_tiles / cpi / n_slices share
+  // one item range, enumerated (k-slice, member, tile): the workgroups that stream the same slice of one source - the
+  // shifted correlations of a layer - are then neighbours in launch order and meet in an XCD's L2.  The range starts
+  // at the first member's item_base; member j carries item_base + j only to keep the table's bases ascending.
+  int group_n, group_pos;
   long long slab_base;     // in floats
 };
 static_assert(sizeof(FactorDev) % 8 == 0, "FactorDev must be 8-byte granular");
