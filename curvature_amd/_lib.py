@@ -138,6 +138,7 @@ SIGNATURES = {
     "curv_kron": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
     "curv_mul2d": (_i, [_vp, _vp, _ll, _ll, _vp, _ll, _ll, _vp, _i, _i]),
     "curv_gemm_workspace_bytes": (_sz, [_i]),
+    "curv_gemm_workspace_bytes_for": (_sz, [ctypes.POINTER(curv_gemm_desc), _i]),
     "curv_gemm_batched": (_i, [_vp, ctypes.POINTER(curv_gemm_desc), _i, _vp, _sz]),
     "curv_randn": (_i, [_vp, _vp, _ll, ctypes.c_ulonglong, ctypes.c_ulonglong]),
     "curv_rsqrt_affine": (_i, [_vp, _vp, _d, _d, _vp, _ll]),

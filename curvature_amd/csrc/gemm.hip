@@ -40,6 +40,11 @@ struct GemmDev {
   int tm;                 // tile edge: 64 or 128
   int tri;                // CURV_TRI_*: triangular operand -> shorter K range per tile
   unsigned a_bytes, b_bytes;   // NT kernel: extents of the two operands (buffer range check)
+  // NT kernel, split K: a tile's K range is cut into slices of kslice elements; item = tile * n_slices + slice, raw
+  // partial tiles go to slabs and gemm_nt_reduce_kernel sums them in slice order and applies the epilogue
+  int kslice, n_slices;        // n_slices <= 1: no split
+  int red_base, pad2;          // first workgroup of this product in the reduce launch (-1: not split)
+  long long slab_base;         // floats into the slab area
 };
 
 typedef __attribute__((address_space(1))) float gfl;
@@ -223,12 +228,32 @@ static_assert(PPS <= 4, "at most one DMA piece per MFMA group");
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(3))) char lds_char_t;
 
-__device__ __forceinline__ void gemm_nt_tile(const GemmDev& d, int local, lds_char_t* lds) {
+// C[i][j] = epilogue(alpha * acc) [+ beta * C[i][j]]
+__device__ __forceinline__ void nt_epilogue(const GemmDev& d, int i, int j, float acc) {
+  gfl* C = (gfl*)d.C;
+  const gfl* E = (const gfl*)d.E;
+  const gfl* F = (const gfl*)d.F;
+  const int ep = d.epilogue;
+  const long long ci = i * d.c_rs + j * d.c_cs;
+  float v = d.alpha * acc;
+  if (ep == CURV_EPI_SQUARE) v = d.alpha * acc * acc;
+  else if (ep == CURV_EPI_MUL_E) v *= E[i * d.e_rs + j * d.e_cs];
+  else if (ep == CURV_EPI_ADD_E) v += E[i * d.e_rs + j * d.e_cs];
+  else if (ep == CURV_EPI_MUL_E_ADD_F) v = v * E[i * d.e_rs + j * d.e_cs] + F[i * d.f_rs + j * d.f_cs];
+  if (d.beta != 0.0f) v += d.beta * C[ci];
+  C[ci] = v;
+}
+
+__device__ __forceinline__ void gemm_nt_tile(const GemmDev& d, int local, lds_char_t* lds, float* __restrict__ slabs) {
   using namespace nt;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
+  const bool split = d.n_slices > 1;
+  const int item = local;
+  int slice = 0;
+  if (split) { slice = local % d.n_slices; local /= d.n_slices; }
   int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
   if (d.tri == CURV_TRI_A_LOWER) tm = (d.M + TM - 1) / TM - 1 - tm;        // long tiles first
   else if (d.tri == CURV_TRI_B_UPPER) tn = d.tiles_n - 1 - tn;
@@ -237,9 +262,18 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmDev& d, int local, lds_ch
   const bool cut = (d.tri == CURV_TRI_A_LOWER && i0 + TM < K) || (d.tri == CURV_TRI_B_UPPER && j0 + TM < K);
   if (d.tri == CURV_TRI_A_LOWER) K = min(K, i0 + TM);
   else if (d.tri == CURV_TRI_B_UPPER) K = min(K, j0 + TM);
-  const int TS = (K + 7) >> 3;                       // steps of 8 k
+  // this item's part of the K range: [kb, K) (K becomes the slice's end)
+  int kb = 0;
+  bool inner = false;                                // a slice that ends inside the tile's K range: whole steps
+  if (split) {
+    kb = slice * d.kslice;
+    if (kb >= K) return;                             // the triangle cut this slice away
+    inner = kb + d.kslice < K;
+    K = min(K, kb + d.kslice);
+  }
+  const int TS = (K - kb + 7) >> 3;                  // steps of 8 k
   const int n_stages = (TS + STEPS - 1) / STEPS;
-  const int nv_last = cut ? 8 : K - 8 * (TS - 1);    // k values of the last step that exist (beyond a cut: stored zeros)
+  const int nv_last = (cut || inner) ? 8 : K - kb - 8 * (TS - 1);   // k values of the last step that exist (beyond a cut: stored zeros)
 
   // DMA lane geometry (see syrk_flat.hip): piece `slot` of this wave covers panel rows 32 slot + 8 wave + (lane >> 3)
   const int rsub = RPP * wave + (lane >> 3);
@@ -269,7 +303,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmDev& d, int local, lds_ch
   int n_k0 = 0, n_gmax = 0;
   unsigned n_buf = 0;
   auto plan_next = [&](int t) {
-    n_k0 = t * KC;
+    n_k0 = kb + t * KC;
     n_gmax = min(SLOTS, (K - n_k0 + 3) >> 2);      // 16-byte groups this stage needs
     n_buf = (unsigned)(t & 1) * PANEL_B;
   };
@@ -334,27 +368,30 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmDev& d, int local, lds_ch
     }
   }
 
-  // epilogue; C/D map of the 32x32 block: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  gfl* C = (gfl*)d.C;
-  const gfl* E = (const gfl*)d.E;
-  const gfl* F = (const gfl*)d.F;
-  const float alpha = d.alpha, beta = d.beta;
-  const int ep = d.epilogue;
+  // C/D map of the 32x32 block: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  if (split) {
+    // raw partial tile, row-major 128 x 128, to this item's slab
+    gfl* slab = (gfl*)slabs + d.slab_base + (long long)item * (TM * TM);
+    auto store_raw = [&](const f32x16& acc, int m, int n) {
+      const int c = 64 * wn + 32 * n + r32;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = 64 * wm + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        slab[r * TM + c] = acc[reg];
+      }
+    };
+    store_raw(c00, 0, 0);
+    store_raw(c01, 0, 1);
+    store_raw(c10, 1, 0);
+    store_raw(c11, 1, 1);
+    return;
+  }
   auto store_block = [&](const f32x16& acc, int m, int n) {
     const int j = j0 + 64 * wn + 32 * n + r32;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int i = i0 + 64 * wm + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      if (i < M && j < N) {
-        const long long ci = i * d.c_rs + j * d.c_cs;
-        float v = alpha * acc[reg];
-        if (ep == CURV_EPI_SQUARE) v = alpha * acc[reg] * acc[reg];
-        else if (ep == CURV_EPI_MUL_E) v *= E[i * d.e_rs + j * d.e_cs];
-        else if (ep == CURV_EPI_ADD_E) v += E[i * d.e_rs + j * d.e_cs];
-        else if (ep == CURV_EPI_MUL_E_ADD_F) v = v * E[i * d.e_rs + j * d.e_cs] + F[i * d.f_rs + j * d.f_cs];
-        if (beta != 0.0f) v += beta * C[ci];
-        C[ci] = v;
-      }
+      if (i < M && j < N) nt_epilogue(d, i, j, acc[reg]);
     }
   };
   store_block(c00, 0, 0);
@@ -364,11 +401,48 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmDev& d, int local, lds_ch
 }
 
 __global__ void __launch_bounds__(GEMM_THREADS, 2)
-gemm_nt_kernel(const GemmDev* __restrict__ table, int n_desc) {
+gemm_nt_kernel(const GemmDev* __restrict__ table, int n_desc, float* __restrict__ slabs) {
   __shared__ __attribute__((aligned(1024))) char smem[nt::LDS_B];
   const int f = gemm_find(table, n_desc, blockIdx.x);
   const GemmDev& d = table[f];
-  gemm_nt_tile(d, blockIdx.x - d.tile_base, (lds_char_t*)smem);
+  gemm_nt_tile(d, blockIdx.x - d.tile_base, (lds_char_t*)smem, slabs);
+}
+
+// Split products: one workgroup per output tile sums the tile's partial slabs in slice order (deterministic) and
+// applies the epilogue.  Slices beyond the tile's (triangle-cut) K range were never written and are not read.
+__global__ void __launch_bounds__(256)
+gemm_nt_reduce_kernel(const GemmDev* __restrict__ table, int n_desc, const float* __restrict__ slabs) {
+  constexpr int TM = nt::TM;
+  const int lane = threadIdx.x & 63;
+  int f = -1;
+  for (int f0 = 0; f0 < n_desc; f0 += 64) {            // the split product with the largest red_base <= blockIdx
+    const int g = f0 + lane;
+    const bool hit = g < n_desc && table[g].red_base >= 0 && table[g].red_base <= (int)blockIdx.x;
+    const unsigned long long m = __ballot(hit);
+    if (m) f = f0 + 63 - __builtin_clzll(m);
+  }
+  f = __builtin_amdgcn_readfirstlane(f);
+  const GemmDev& d = table[f];
+  const int tile = blockIdx.x - d.red_base;
+  int tm = tile / d.tiles_n, tn = tile - tm * d.tiles_n;
+  if (d.tri == CURV_TRI_A_LOWER) tm = (d.M + TM - 1) / TM - 1 - tm;
+  else if (d.tri == CURV_TRI_B_UPPER) tn = d.tiles_n - 1 - tn;
+  const int i0 = tm * TM, j0 = tn * TM;
+  int K = d.K;
+  if (d.tri == CURV_TRI_A_LOWER) K = min(K, i0 + TM);
+  else if (d.tri == CURV_TRI_B_UPPER) K = min(K, j0 + TM);
+  const int valid = (K + d.kslice - 1) / d.kslice;
+  const float* base = slabs + d.slab_base + (long long)tile * d.n_slices * (TM * TM);
+  for (int e = threadIdx.x; e < TM * TM / 4; e += 256) {
+    const int r = e / (TM / 4), c = (e - r * (TM / 4)) * 4;
+    const int i = i0 + r;
+    if (i >= d.M) continue;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int sl = 0; sl < valid; ++sl) v += *reinterpret_cast<const f32x4*>(base + (long long)sl * (TM * TM) + r * TM + c);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (j0 + c + q < d.N) nt_epilogue(d, i, j0 + c + q, v[q]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -479,7 +553,7 @@ gemm_f64_kernel(Gemm64Dev d0, Gemm64Dev d1, Gemm64Dev d2, Gemm64Dev d3, int n_de
       }
 }
 
-constexpr int GEMM_UPLOAD_CHUNK = 19;
+constexpr int GEMM_UPLOAD_CHUNK = 17;
 struct GemmChunk { GemmDev f[GEMM_UPLOAD_CHUNK]; };
 static_assert(sizeof(GemmChunk) <= 3840, "kernel argument block must stay below 4 KB");
 
@@ -542,6 +616,39 @@ extern "C" size_t curv_gemm_workspace_bytes(int n_desc) {
   return align_up((size_t)std::max(n_desc, 1) * sizeof(GemmDev), 256);
 }
 
+// K slices of an NT product.  A launch with fewer tiles than the chip has workgroup slots lasts as long as its
+// longest tile: a layer-sharded rank that samples one 512 x 4608 layer runs 144 tiles with K up to 4608.  Such
+// launches - and only such: with a whole model's tiles in flight slicing buys nothing (measured) - cut their long
+// products into slices of NT_KSLICE, summed deterministically by a second launch that applies the epilogue.
+constexpr int NT_KSLICE = 768;
+constexpr long long NT_SPLIT_BELOW_TILES = 1024;       // 2 workgroup slots per CU x 256 CUs x 2
+static bool nt_eligible(const curv_gemm_desc& s) {
+  const long long a_ext = ((long long)(s.M - 1) * s.a_rs + s.K) * 4, b_ext = ((long long)(s.N - 1) * s.b_cs + s.K) * 4;
+  return s.a_cs == 1 && s.b_rs == 1 && s.M >= 64 && s.N >= 64 && s.K >= 8 && a_ext < (1LL << 32) - 64 &&
+         b_ext < (1LL << 32) - 64;
+}
+static long long nt_tiles_of(const curv_gemm_desc* descs, int n_desc) {
+  long long t = 0;
+  for (int i = 0; i < n_desc; ++i)
+    if (descs[i].M > 0 && descs[i].N > 0 && nt_eligible(descs[i])) t += (long long)cdiv(descs[i].M, 128) * cdiv(descs[i].N, 128);
+  return t;
+}
+static int nt_slices(const curv_gemm_desc& s, bool underfilled) {
+  return (underfilled && nt_eligible(s) && s.K >= 2 * NT_KSLICE) ? cdiv(s.K, NT_KSLICE) : 1;
+}
+
+extern "C" size_t curv_gemm_workspace_bytes_for(const curv_gemm_desc* descs, int n_desc) {
+  size_t total = curv_gemm_workspace_bytes(n_desc);
+  const bool underfilled = nt_tiles_of(descs, n_desc) < NT_SPLIT_BELOW_TILES;
+  for (int i = 0; i < n_desc; ++i) {
+    const curv_gemm_desc& s = descs[i];
+    if (s.M <= 0 || s.N <= 0) continue;
+    const int sl = nt_slices(s, underfilled);
+    if (sl > 1) total += (size_t)cdiv(s.M, 128) * cdiv(s.N, 128) * sl * 128 * 128 * sizeof(float);
+  }
+  return total;
+}
+
 extern "C" int curv_gemm_batched(void* stream_, const curv_gemm_desc* descs, int n_desc, void* workspace,
                                  size_t workspace_bytes) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -553,7 +660,10 @@ extern "C" int curv_gemm_batched(void* stream_, const curv_gemm_desc* descs, int
   }
   std::vector<GemmDev> tab, tab_nt;             // two work lists: the general kernel and the NT / LDS-DMA kernel
   tab.reserve(n_desc);
-  long long tiles = 0, tiles_nt = 0;
+  long long tiles = 0, tiles_nt = 0, red_tiles = 0, slab_floats = 0;
+  // K slicing needs the slab area behind the table: only with a workspace sized by curv_gemm_workspace_bytes_for
+  const bool underfilled = nt_tiles_of(descs, n_desc) < NT_SPLIT_BELOW_TILES;
+  const bool may_split = underfilled && workspace_bytes >= curv_gemm_workspace_bytes_for(descs, n_desc);
   for (int i = 0; i < n_desc; ++i) {
     const curv_gemm_desc& s = descs[i];
     CURV_REQUIRE(s.M >= 0 && s.N >= 0 && s.K >= 0, "curv_gemm_batched: desc %d: negative shape", i);
@@ -583,14 +693,23 @@ extern "C" int curv_gemm_batched(void* stream_, const curv_gemm_desc* descs, int
     // NT products with K-contiguous rows on both sides and at least one full-width tile edge go to the LDS-DMA
     // kernel; their operand extents must fit a buffer descriptor (32-bit byte offsets)
     const long long a_ext = ((long long)(s.M - 1) * s.a_rs + s.K) * 4, b_ext = ((long long)(s.N - 1) * s.b_cs + s.K) * 4;
-    const bool is_nt = s.a_cs == 1 && s.b_rs == 1 && s.M >= 64 && s.N >= 64 && s.K >= 8 &&
-                       a_ext < (1LL << 32) - 64 && b_ext < (1LL << 32) - 64;
+    const bool is_nt = nt_eligible(s);
     if (is_nt) {
       d.tm = 128;
       d.a_bytes = (unsigned)a_ext; d.b_bytes = (unsigned)b_ext;
       d.tiles_n = cdiv(s.N, 128);
       d.tile_base = (int)tiles_nt;
-      tiles_nt += (long long)cdiv(s.M, 128) * d.tiles_n;
+      const long long nt_tiles = (long long)cdiv(s.M, 128) * d.tiles_n;
+      d.n_slices = may_split ? nt_slices(s, true) : 1;
+      d.kslice = NT_KSLICE;
+      d.red_base = -1;
+      if (d.n_slices > 1) {
+        d.red_base = (int)red_tiles;
+        d.slab_base = slab_floats;
+        red_tiles += nt_tiles;
+        slab_floats += nt_tiles * d.n_slices * 128 * 128;
+      }
+      tiles_nt += nt_tiles * d.n_slices;
       CURV_REQUIRE(tiles_nt < (1LL << 30), "curv_gemm_batched: too many tiles");
       tab_nt.push_back(d);
       continue;
@@ -614,9 +733,14 @@ extern "C" int curv_gemm_batched(void* stream_, const curv_gemm_desc* descs, int
     hipLaunchKernelGGL(gemm_upload_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count);
     CURV_LAUNCH_CHECK();
   }
+  float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + curv_gemm_workspace_bytes(n_desc));
   if (n_nt > 0) {
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)tiles_nt), dim3(GEMM_THREADS), 0, stream, table + n, n_nt);
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)tiles_nt), dim3(GEMM_THREADS), 0, stream, table + n, n_nt, slabs);
     CURV_LAUNCH_CHECK();
+    if (red_tiles > 0) {
+      hipLaunchKernelGGL(gemm_nt_reduce_kernel, dim3((unsigned)red_tiles), dim3(256), 0, stream, table + n, n_nt, slabs);
+      CURV_LAUNCH_CHECK();
+    }
   }
   if (n > 0) {
     hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, stream, table, n);

@@ -285,7 +285,9 @@ class GemmPlan:
         if not self.n:
             return
         L = _lib.lib()
-        ws = workspace(L.curv_gemm_workspace_bytes(self.n), self.jobs[0].C.device, "gemm")
+        if getattr(self, "_ws_bytes", None) is None:        # table + slabs of K-sliced products (underfilled launches)
+            self._ws_bytes = L.curv_gemm_workspace_bytes_for(self.descs, self.n)
+        ws = workspace(self._ws_bytes, self.jobs[0].C.device, "gemm")
         _lib.check(L.curv_gemm_batched(_lib.stream_ptr(), self.descs, self.n, ws.data_ptr(), ws.numel()),
                    "curv_gemm_batched")
 

@@ -170,6 +170,11 @@ typedef struct curv_gemm_desc {
 } curv_gemm_desc;
 
 size_t curv_gemm_workspace_bytes(int n_desc);
+/* The same plus room for K slicing: when a call holds fewer output tiles of K-contiguous products than the chip has
+ * workgroup slots (a layer-sharded rank sampling one wide layer), products with K >= 1536 are cut into K slices whose
+ * partial tiles are summed in a fixed order by a second launch.  With a workspace of only
+ * curv_gemm_workspace_bytes the call still works, unsliced. */
+size_t curv_gemm_workspace_bytes_for(const curv_gemm_desc* descs, int n_desc);
 int curv_gemm_batched(void* stream, const curv_gemm_desc* descs, int n_desc, void* workspace,
                       size_t workspace_bytes);
 
