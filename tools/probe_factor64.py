@@ -19,16 +19,20 @@ def main():
     s = open(os.path.join(CSRC, "invert.hip")).read()
     s = sub(s, "namespace curv {\n", "namespace curv {\n__device__ unsigned long long g_probe[16];\n"
             "#define PROBE(k) { if (threadIdx.x == 0) { long long t_ = clock64(); g_probe[k] += (unsigned long long)(t_ - tprev); tprev = t_; } }\n")
-    s = sub(s, "  const int r16 = lane & 15, kq = lane >> 4;\n#pragma unroll\n  for (int p = 0; p < 4; ++p) {\n    const int c0 = 16 * p;\n",
-            "  const int r16 = lane & 15, kq = lane >> 4;\n  long long tprev = clock64();\n#pragma unroll\n  for (int p = 0; p < 4; ++p) {\n    const int c0 = 16 * p;\n    PROBE(7)\n")
-    s = sub(s, "      if (first_bad != 0 && lane == 0 && *bad == 0) *bad = first_bad;\n    }\n    __syncthreads();\n",
-            "      if (first_bad != 0 && lane == 0 && *bad == 0) *bad = first_bad;\n    }\n    PROBE(0)\n    __syncthreads();\n    PROBE(1)\n")
-    s = sub(s, "    __syncthreads();\n  }\n  for (int e = tid; e < 4 * 16 * 16; e += MMA_THREADS) {",
-            "    __syncthreads();\n    PROBE(2)\n  }\n  for (int e = tid; e < 4 * 16 * 16; e += MMA_THREADS) {")
-    s = sub(s, "  // diagonal 16x16 blocks of the inverse", "  PROBE(3)\n  // diagonal 16x16 blocks of the inverse")
-    s = sub(s, "  // off-diagonal blocks by distance d", "  PROBE(4)\n  // off-diagonal blocks by distance d")
-    s = sub(s, "    __syncthreads();\n  }\n}\n\n// ------------------------------------------------------------------------------------------------\n// (1a)",
-            "    __syncthreads();\n  }\n  PROBE(5)\n}\n\n// ------------------------------------------------------------------------------------------------\n// (1a)")
+    # probes inside factor_invert_64 (thread 0 = wave 0, lane 0): cycles between consecutive probe points, summed
+    k = s.index("__device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base) {")
+    head, body = s[:k], s[k:]
+    body = sub(body, "  const int r16 = lane & 15, kq = lane >> 4;\n", "  const int r16 = lane & 15, kq = lane >> 4;\n  long long tprev = clock64();\n")
+    body = sub(body, "    const int c0 = 16 * p;\n", "    const int c0 = 16 * p;\n    PROBE(7)\n")
+    body = sub(body, "      if (first_bad != 0 && lane == 0 && *bad == 0) *bad = first_bad;\n    }\n    __syncthreads();\n",
+               "      if (first_bad != 0 && lane == 0 && *bad == 0) *bad = first_bad;\n    }\n    PROBE(0)\n    __syncthreads();\n    PROBE(1)\n")
+    body = sub(body, "    __syncthreads();\n  }\n  // behind the last panel", "    __syncthreads();\n    PROBE(2)\n  }\n  // behind the last panel")
+    body = sub(body, "    diag_inverse(3);\n  } else {", "    diag_inverse(3);\n    PROBE(3)\n  } else {")
+    body = sub(body, "  __syncthreads();\n  if (wave != 0) {\n    f64x4 out = {0.0, 0.0, 0.0, 0.0};\n    mma16<false>(Is + 16 * 3 * LDA + 16 * 3",
+               "  __syncthreads();\n  PROBE(4)\n  if (wave != 0) {\n    f64x4 out = {0.0, 0.0, 0.0, 0.0};\n    mma16<false>(Is + 16 * 3 * LDA + 16 * 3")
+    body = sub(body, "  __syncthreads();\n}\n\n// ------------------------------------------------------------------------------------------------\n// (1a)",
+               "  __syncthreads();\n  PROBE(5)\n}\n\n// ------------------------------------------------------------------------------------------------\n// (1a)")
+    s = head + body
     s += r'''
 namespace curv {
 __global__ void __launch_bounds__(INV_THREADS) probe_kernel(const double* __restrict__ A, double* __restrict__ X, unsigned long long* out) {
@@ -69,7 +73,7 @@ int main() {
     hipMemcpy(o, dout, 32, hipMemcpyDeviceToHost);
     hipMemcpyFromSymbol(p, HIP_SYMBOL(curv::g_probe), sizeof(p));
     printf("run %d: load %llu  factor_invert_64 %llu  store %llu cycles (clock64 = 100 MHz ticks? see below) bad %llu\n", it, o[0], o[1], o[2], o[3]);
-    printf("   panel columns (wave 0, 4 panels) %llu | barrier after %llu | trailing MFMA + barrier %llu | pre-panel %llu | zero fill %llu | diag inverse %llu | off-diag inverse %llu\n",
+    printf("   panel columns (wave 0, 4 panels) %llu | barrier after (incl. waiting for the side work of waves 1-3) %llu | trailing MFMA + barrier %llu | pre-panel %llu | X_33 %llu | barrier %llu | last products + barrier %llu\n",
            p[0], p[1], p[2], p[7], p[3], p[4], p[5]);
   }
   // check: X * L = I where L = chol(A) -> X A X^T = I
