@@ -116,9 +116,17 @@ class Curvature(ABC):
         return {k: i for i, k in enumerate(order)}
 
     def _allgather_sampled(self):
-        """Multi-GPU: the single collective of the path, reassembling every layer's sampled parameters."""
-        if self.shard is not None and self.shard.world > 1:
-            self.shard.allgather_params([[p.data for p in (l.weight, l.bias) if p is not None] for l in self._layers()])
+        """Multi-GPU: the single collective of the path, reassembling every layer's sampled parameters.
+        Attention modules (Diagonal only) are not part of the layer partition: rank 0 samples them and their
+        projection parameters travel in the same all-gather, so that every rank ends with the same weights."""
+        if self.shard is not None and (self.shard.world > 1 or self.shard.force_collective):
+            entries = [[p.data for p in (l.weight, l.bias) if p is not None] for l in self._layers()]
+            owners = list(self.shard.owner)
+            for layer in (self._attention() if self._supports_mha else []):
+                entries.append([p.data for p in (layer.in_proj_weight, layer.in_proj_bias, layer.out_proj.weight,
+                                                 layer.out_proj.bias) if p is not None])
+                owners.append(0)
+            self.shard.allgather_params(entries, owners)
 
     @staticmethod
     def _hyper(add, multiply, index: int, count: int):
@@ -229,7 +237,9 @@ class Diagonal(Curvature):
     ``nn.MultiheadAttention`` modules are handled as in the reference (:159-174, 125-129): their input and
     output projections accumulate under the string keys ``'attn_in'`` / ``'attn_out'`` (ONE pair of keys for
     the whole model, as in the reference).  With a layer shard every rank owns a disjoint set of the
-    Linear / Conv2d layers; the attention entries are small and kept on every rank."""
+    Linear / Conv2d layers; the attention entries are small: every rank accumulates and inverts them, rank 0
+    draws their sample and the all-gather of `sample_and_replace` distributes it (each rank has its own noise
+    stream, so sampling them everywhere would leave the ranks with different attention weights)."""
 
     _supports_mha = True
 
@@ -368,10 +378,11 @@ class Diagonal(Curvature):
                 for z, inv in scale:
                     ops.mul(z, inv, out=z)
             gemms.run()
-        for layer in self._attention():
-            for weight, bias, key in ((layer.in_proj_weight, layer.in_proj_bias, 'attn_in'),
-                                      (layer.out_proj.weight, layer.out_proj.bias, 'attn_out')):
-                self._replace(self.sample(key), weight, bias)
+        if self.shard is None or self.shard.rank == 0:         # one owner for the attention entries
+            for layer in self._attention():
+                for weight, bias, key in ((layer.in_proj_weight, layer.in_proj_bias, 'attn_in'),
+                                          (layer.out_proj.weight, layer.out_proj.bias, 'attn_out')):
+                    self._replace(self.sample(key), weight, bias)
         self._allgather_sampled()
 
 

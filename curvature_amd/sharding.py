@@ -84,27 +84,35 @@ def partition_layers(dims: Sequence[Sequence[int]], world: int) -> List[int]:
 class Shard:
     """Which layers this rank owns, and the all-gather that reassembles sampled parameters."""
 
-    def __init__(self, owner: Sequence[int], rank: int, world: int, group=None):
+    def __init__(self, owner: Sequence[int], rank: int, world: int, group=None, *, force_collective: bool = False):
         self.owner, self.rank, self.world, self.group = list(owner), rank, world, group
+        # world == 1 normally skips packing and the collective; `force_collective` runs them anyway (a one-rank
+        # process group: the RCCL branch can then be exercised on a box with a single GPU)
+        self.force_collective = force_collective
 
     def owns(self, index: int) -> bool:
         return self.owner[index] == self.rank
 
-    def allgather_params(self, params_per_layer: List[List[torch.Tensor]]) -> None:
+    def allgather_params(self, params_per_layer: List[List[torch.Tensor]],
+                         owners: Optional[Sequence[int]] = None) -> None:
         """params_per_layer[i] = parameter tensors of layer i (same shapes on every rank).  After the call
         every rank holds the owner's values for every layer.  One all-gather of equal-sized packed shards;
         on the GPU the packing and unpacking are one batched copy each (curv_copy_batched) and the buffers
-        and copy plans are kept while the parameter tensors stay where they are."""
-        if self.world == 1:
+        and copy plans are kept while the parameter tensors stay where they are.  `owners`: owner rank per
+        entry when the list is not the layer list of the partition (Diagonal appends its attention entries)."""
+        if self.world == 1 and not self.force_collective:
             return
+        owner = list(owners) if owners is not None else self.owner
+        if len(owner) != len(params_per_layer):
+            raise RuntimeError("allgather_params: one owner per entry expected")
         ref = params_per_layer[0][0]
-        key = tuple(p.data_ptr() for ps in params_per_layer for p in ps)
+        key = tuple(p.data_ptr() for ps in params_per_layer for p in ps) + tuple(owner)
         plans = self.__dict__.setdefault("_plans", {})       # two kept: evaluate.eval_bnn alternates two buffer sets
         cache = plans.get(key)
         if cache is None:
             sizes = [0] * self.world
             for i, ps in enumerate(params_per_layer):
-                sizes[self.owner[i]] += sum(p.numel() for p in ps)
+                sizes[owner[i]] += sum(p.numel() for p in ps)
             cap = max(max(sizes), 1)
             mine = torch.zeros(cap, dtype=ref.dtype, device=ref.device)
             gathered = torch.empty(self.world * cap, dtype=ref.dtype, device=ref.device)
@@ -112,7 +120,7 @@ class Shard:
             cursor = [r * cap for r in range(self.world)]
             pos = 0
             for i, ps in enumerate(params_per_layer):
-                r = self.owner[i]
+                r = owner[i]
                 for p in ps:
                     if not p.is_contiguous():
                         raise RuntimeError("sharded parameters must be contiguous")

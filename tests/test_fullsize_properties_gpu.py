@@ -79,6 +79,41 @@ def test_factor_build_properties(gpu, resnet50_kfac):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", [
+    "conv1",                # 7x7 stride 2 pad 3 stem, n = 147, L = 12544           (patch kernel)
+    "layer2.0.conv2",       # 3x3 stride 2, C = 128, 56x56 -> 28x28                 (patch kernel)
+    "layer2.1.conv2",       # 3x3 stride 1, C = 128, 28x28: shifted correlations    (syrk_corr + flat kernel)
+    "layer3.1.conv2",       # 3x3 stride 1, C = 256, 14x14: shifted correlations
+    "layer4.1.conv2",       # 3x3 stride 1, C = 512, 7x7:   shifted correlations
+    "layer1.0.conv2",       # 3x3 stride 1, C = 64, 56x56                           (patch kernel)
+    "layer3.0.downsample.0",  # 1x1 stride 2, 512 -> 1024
+])
+def test_factor_build_matches_the_oracle_at_resnet50_geometry(gpu, resnet50_kfac, name):
+    """The factors of the full-size N = 32 batch against the fp64 oracle (curvatures.py:329-350 restated in
+    oracle.kfac_factors) at ResNet-50's real geometries — in particular the three shifted-correlation classes,
+    whose k-slicing, Xp row pitch and stage counts differ from every small test geometry.  1e-4 relative Frobenius
+    (north_star); all blocks of A are compared, not only its diagonal."""
+    import oracle.curvature_oracle as o
+    model, kfac = resnet50_kfac
+    layer = dict(model.named_modules())[name]
+    x, g = kfac.record[layer]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, threads))          # the box's 256 logical CPUs make torch's CPU GEMM crawl
+    try:
+        A, G = o.kfac_factors(x.detach().double().cpu(), g.detach().double().cpu(),
+                              has_bias=layer.bias is not None, **o.layer_geometry(layer))
+    finally:
+        torch.set_num_threads(threads)
+    ea, eg = rel_fro(kfac.state[layer][0], A), rel_fro(kfac.state[layer][1], G)
+    assert ea < 1e-4 and eg < 1e-4, (name, ea, eg)
+    # off-diagonal (kh, kw) blocks on their own: a wrong shift or border strip would hide behind the diagonal's mass
+    n0 = A.shape[0]
+    off = ~torch.eye(n0, dtype=torch.bool)
+    d = (kfac.state[layer][0].double().cpu() - A)[off]
+    assert float(d.norm() / A[off].norm()) < 1e-4
+
+
+@pytest.mark.gpu
 def test_invert_and_sample_properties(gpu, resnet50_kfac):
     model, kfac = resnet50_kfac
     kfac.invert(add=1.0, multiply=1000.0)

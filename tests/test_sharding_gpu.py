@@ -89,3 +89,107 @@ def test_sharded_chain_world2_equals_unsharded(tmp_path):
         for part in parts:                                   # after the all-gather every rank holds every layer
             for (w, b), (wf, bf) in zip(part[name], full[name]):
                 assert torch.equal(w, wf) and torch.equal(b, bf), name
+
+
+def _rccl_world1(rank, port, out_dir):
+    """backend "nccl" (= RCCL) with a one-rank group on the box's single GPU: process-group init with a bound
+    device, then KFAC.sample_and_replace through Shard.allgather_params' all_gather_into_tensor branch."""
+    from curvature_amd import models, sharding
+    from curvature_amd.curvatures import KFAC
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)          # as bench.py does for N > 1
+    assert dist.get_backend() == "nccl"
+    torch.manual_seed(0)
+    model = models.lenet5().to(dev).eval()
+    layers = [m for m in model.modules() if m.__class__.__name__ in ("Conv2d", "Linear")]
+    shard = sharding.Shard([0] * len(layers), 0, 1, force_collective=True)
+    kfac = KFAC(model, shard=shard)
+    x = torch.rand(8, 1, 28, 28, device=dev)
+    torch.nn.functional.cross_entropy(model(x), torch.randint(0, 10, (8,), device=dev)).backward()
+    kfac.update(8)
+    kfac.invert(0.5, 1.0)
+    noise = {l: torch.randn(kfac.inv_state[l][0].shape[0], kfac.inv_state[l][1].shape[0], device=dev) for l in layers}
+    kfac.sample_and_replace(noise=noise)
+    torch.cuda.synchronize()
+    got = [p.detach().clone() for l in layers for p in (l.weight, l.bias)]
+    # the same sample without any shard: the collective must have left the parameters as the sampler wrote them
+    plain = KFAC(model)
+    plain.model_state = kfac.model_state
+    plain.state, plain.inv_state = kfac.state, kfac.inv_state
+    plain.sample_and_replace(noise=noise)
+    torch.cuda.synchronize()
+    want = [p.detach().clone() for l in layers for p in (l.weight, l.bias)]
+    cache = next(iter(shard._plans.values()))
+    packed = torch.cat([t.reshape(-1) for t in want])
+    ok = all(torch.equal(a, b) for a, b in zip(got, want))
+    ok_gather = torch.equal(cache["gathered"][:packed.numel()], packed) and cache["gathered"].numel() == cache["cap"]
+    # and the collective on its own, with a payload the ranks did not already hold in place
+    src = torch.arange(1 << 20, dtype=torch.float32, device=dev)
+    dst = torch.zeros_like(src)
+    dist.all_gather_into_tensor(dst, src)
+    t = torch.tensor([3.0], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                                     # bench.py's max-over-ranks timing
+    dist.barrier()
+    torch.cuda.synchronize()
+    torch.save({"ok": ok, "ok_gather": bool(ok_gather), "copy": bool(torch.equal(dst, src)), "max": float(t)},
+               os.path.join(out_dir, "rccl.pt"))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_runs_the_allgather_branch(tmp_path):
+    """the one collective of the path is an RCCL all-gather.  The box has one GPU (RCCL refuses two
+    ranks on one device), so the nccl backend is initialised with world_size 1 and `force_collective` sends
+    sample_and_replace through pack -> all_gather_into_tensor -> unpack instead of the world == 1 early return."""
+    mp.spawn(_rccl_world1, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(os.path.join(tmp_path, "rccl.pt"))
+    assert res == {"ok": True, "ok_gather": True, "copy": True, "max": 3.0}, res
+
+
+class _AttnNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.inp = torch.nn.Linear(6, 8)
+        self.attn = torch.nn.MultiheadAttention(8, 2)
+        self.out = torch.nn.Linear(8, 3)
+
+    def forward(self, x):                       # x: (seq, batch, 6)
+        h = self.inp(x)
+        h, _ = self.attn(h, h, h)
+        return self.out(h.mean(dim=0))
+
+
+def _mha_rank(rank, world, port, out_dir):
+    from curvature_amd import sharding
+    from curvature_amd.curvatures import Diagonal
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = _AttnNet().to(dev)
+    shard = sharding.Shard([0, 1], rank, world)                     # inp -> rank 0, out -> rank 1
+    diag = Diagonal(model, shard=shard)
+    x = torch.randn(5, 4, 6, device=dev)
+    labels = torch.tensor([0, 1, 2, 1], device=dev)
+    torch.nn.functional.cross_entropy(model(x), labels).backward()
+    diag.update(batch_size=4)
+    diag.invert(add=1.0, multiply=10.0)
+    mean = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    diag.sample_and_replace()
+    torch.cuda.synchronize()
+    torch.save({"after": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, "mean": mean},
+               os.path.join(out_dir, f"mha_r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_diagonal_attention_entries_agree_across_ranks(tmp_path):
+    """Diagonal + nn.MultiheadAttention under a layer shard (curvatures.py:125-129, 159-174): the attention entries
+    are outside the layer partition, each rank has its own noise stream - rank 0 draws them and the all-gather
+    carries them, so both ranks must end with identical (and actually sampled) attention weights."""
+    mp.spawn(_mha_rank, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f"mha_r{r}.pt")) for r in range(2))
+    for k in r0["after"]:
+        assert torch.equal(r0["after"][k], r1["after"][k]), k
+        assert not torch.equal(r0["after"][k], r0["mean"][k]), k           # every parameter received a sample
