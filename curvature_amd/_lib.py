@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(CSRC, "libcurv_hip.so")
-SOURCES = ["api.cpp", "elementwise.hip", "syrk.hip", "syrk_flat.hip", "syrk_corr.hip", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
+SOURCES = ["api.cpp", "elementwise.hip", "syrk.hip", "syrk_flat.hip", "syrk_corr.hip", "syrk_pre.hip", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall",
                "-Wno-unused-function"]
 
@@ -117,6 +117,7 @@ SIGNATURES = {
     "curv_kfac_plan_info": (_i, [ctypes.POINTER(curv_factor_desc), _i, ctypes.POINTER(ctypes.c_longlong)]),
     "curv_kfac_accumulate": (_i, [_vp, ctypes.POINTER(curv_factor_desc), _i, _vp, _sz]),
     "curv_kfac_accumulate_timed": (_i, [_vp, ctypes.POINTER(curv_factor_desc), _i, _vp, _sz, _vp, _vp]),
+    "curv_kfac_accumulate_ex": (_i, [_vp, ctypes.POINTER(curv_factor_desc), _i, _vp, _sz, ctypes.c_uint, _vp, _vp]),
     "curv_event_create": (_vp, []),
     "curv_event_destroy": (None, [_vp]),
     "curv_event_elapsed_ms": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
@@ -151,7 +152,8 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 3                     # CURV_ABI_VERSION of include/curv_hip.h
+ABI_VERSION = 4                     # CURV_ABI_VERSION of include/curv_hip.h
+KFAC_TABLE_RESIDENT = 1             # CURV_KFAC_TABLE_RESIDENT
 ERR_NOT_PD, ERR_INVALID, ERR_WORKSPACE, ERR_HIP, ERR_NOT_CONVERGED = 1, 2, 3, 4, 5     # CURV_ERR_* of the header
 
 

@@ -15,10 +15,16 @@
 //     immediate offsets of the LDS reads;
 //     row/plane strides are padded so that 32 consecutive unfolded rows hit 32 distinct banks;
 //   * the bias row of ones and the zero padding rows are two constant LDS words;
-//   * raw buffer loads of chunk t+1 are issued into registers before the MFMA loop of chunk t and written
-//     to LDS after it, so HBM/L2 latency hides under the matrix pipe; padding lanes carry an out-of-range
-//     offset and get their zeros from the hardware range check; two workgroups per CU cover each other's
-//     staging phases;
+//   * staging, convolutions with kh x kw > 1 whose chunks span the full output width (every 3x3 / 5x5 / 7x7 layer
+//     of the benchmark networks): a pass in front of the kernel (syrk_pre.hip) writes the source once more in
+//     PATCH-IMAGE order - per (chunk, sample, channel) one zero-padded plane with the LDS strides - so that the
+//     image of a panel is one contiguous run and the kernel fills it with buffer_load_dwordx4 ... lds (1 KiB per
+//     wave-instruction, no staging registers, no address arithmetic, no LDS store pass); the staging phase of a
+//     chunk shrinks from ~11 k to ~2 k wave-cycles, which the other workgroup on the CU covers with its MFMAs;
+//   * staging, everything else (flattened per-pixel factors that are not whole 128-row tiles, strided 1x1
+//     convolutions, chunks narrower than the output): raw buffer loads of chunk t+1 are issued into registers
+//     before the MFMA loop of chunk t and written to LDS after it; padding lanes carry an out-of-range
+//     offset and get their zeros from the hardware range check;
 //   * tile 64x64 (four waves split the K range of a chunk, each owning the full tile) for small or
 //     awkward dims, tile 128x128 (2x2 waves of 64x64) for large ones; every wave works on 2x2
 //     v_mfma_f32_32x32x2_f32 blocks and skips the redundant lower-left block on the diagonal;
@@ -31,6 +37,11 @@
 #include <type_traits>
 #include <cstdlib>
 #include <vector>
+
+#ifndef CURV_PRE_PANEL_WORDS
+#define CURV_PRE_PANEL_WORDS 6528
+#define CURV_PRE_WGS 3
+#endif
 
 namespace curv {
 
@@ -46,6 +57,13 @@ constexpr int PATCH_OFF = 32;
 constexpr int SMEM_WORDS = PATCH_OFF + PATCH_WORDS;   // 18464 words = 73856 B -> 2 workgroups per CU
 static_assert(PATCH_WORDS >= 4 * 64 * 64, "reduce scratch must fit the patch region");
 static_assert(2 * SMEM_WORDS * 4 <= 160 * 1024, "two workgroups per CU");
+// the pre-tiled variant (LDS-DMA staging, no staging registers): smaller panels, THREE workgroups per CU - while one
+// waits for its DMA pieces or sits at a barrier, two others keep the matrix pipe of every SIMD busy
+constexpr int PRE_PANEL_WORDS = CURV_PRE_PANEL_WORDS;
+constexpr int PRE_WGS = CURV_PRE_WGS;
+constexpr int PRE_SMEM_WORDS = PATCH_OFF + 2 * PRE_PANEL_WORDS;
+static_assert(2 * PRE_PANEL_WORDS >= 2 * 64 * 64, "two-round reduce scratch must fit the patch region");
+static_assert(PRE_WGS * PRE_SMEM_WORDS * 4 <= 160 * 1024, "workgroups per CU of the pre-tiled variant");
 
 typedef __attribute__((address_space(1))) float gfloat;      // global-address-space views
 typedef __attribute__((address_space(1))) f32x4 gf32x4;
@@ -55,13 +73,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Position and extent of one K chunk.
 struct Chunk {
   int s0, ns, oh0, ra, ow0, wa, rows_in, cols_in, ih_base, iw_base;
+  int plane0;                          // pre-tiled source: first (sample) plane group of the chunk
 };
 
-template <int TMv>
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) char lds_char;
+
+template <int TMv, bool PRE>
 __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, float* __restrict__ slabs,
-                                          const float* __restrict__ zeros_, int* smem) {
+                                          const float* __restrict__ zeros_, int* smem, lds_char* l3) {
   (void)zeros_;            // (zeroed pad of the workspace: unused since padding comes from the buffer range check)
   float* fs = reinterpret_cast<float*>(smem);
+  constexpr int PW = PRE ? PRE_PANEL_WORDS : PANEL_WORDS;          // LDS words per panel image
+  constexpr int SMW = PATCH_OFF + 2 * PW;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -105,7 +129,7 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   const int HW = H * W;
 
   const int c_lo_i = i0 / khkw, c_lo_j = j0 / khkw;
-  const int off_j = diag ? 0 : PANEL_WORDS;
+  const int off_j = diag ? 0 : PW;
   const int n_panels = diag ? 1 : 2;
 
   const int cy = compact ? RS : sh * RS;     // LDS step per output row / col
@@ -117,7 +141,7 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   const int rows_in_full = compact ? R : (R - 1) * sh + kh;
 
   // every LDS word a masked run element may touch must be finite (0 * NaN would poison the tile)
-  for (int w = tid; w < SMEM_WORDS; w += SYRK_THREADS) fs[w] = (w >= ONE_OFF && w < ONE_OFF + 16) ? 1.0f : 0.0f;
+  for (int w = tid; w < SMW; w += SYRK_THREADS) fs[w] = (w >= ONE_OFF && w < ONE_OFF + 16) ? 1.0f : 0.0f;
 
   // Per-lane operand rows: A0/A1 = panel i rows (64 wm) + r32, + 32; B0/B1 = panel j rows (64 wn) + ...
   int base[4], kmask[4];
@@ -161,6 +185,19 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
     c.cols_in = compact ? c.wa : (c.wa - 1) * sw + kw;
     c.ih_base = c.oh0 * sh - ph;
     c.iw_base = c.ow0 * sw - pw;
+    c.plane0 = ch * NS;
+    return c;
+  };
+  // pre-tiled variant: chunks are full-width (n_cg == 1) and an item walks them in order, so the (sample group, row
+  // group) pair is carried along instead of being divided out of the chunk number every time
+  auto next_chunk_pre = [&](const Chunk& p, int ch) {
+    Chunk c = p;
+    c.oh0 = p.oh0 + R;
+    if (c.oh0 >= Ho) { c.oh0 = 0; c.s0 = p.s0 + NS; c.ns = min(NS, N - c.s0); }
+    c.ra = min(R, Ho - c.oh0);
+    c.rows_in = (c.ra - 1) * sh + kh;
+    c.ih_base = c.oh0 * sh - ph;
+    c.plane0 = ch * NS;
     return c;
   };
 
@@ -206,101 +243,7 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
     return g;
   };
 
-  // linear path (chunks spanning the full width): the patch rows of one channel are ONE contiguous
-  // source range of rows_in * W floats, so lanes walk it linearly, V floats per lane: every wave load is
-  // a fully coalesced 256 * V bytes (a (row, x)-mapped load touches 2 cache lines per 56-byte row), and
-  // V = 2 halves the load and the LDS-store instruction counts.  The left/right halo columns are never
-  // written and stay zero from the fill above; rows above/below the image come back 0 from the range
-  // check.
-  const int lin = d.lin;                               // 0, or V
-  const unsigned pmagic = d.pmagic, wmagic = d.wmagic;
-  const int lin_P = lin ? rows_in_full * W / lin : 1;  // lanes per sample
-  auto lin_geo = [&](const Chunk& c, int k, int t) {
-    RowGeo g;
-    const int q = t + k * SYRK_THREADS;
-    const int s = (NS == 1) ? 0 : (lin_P == 1) ? q : (int)__umulhi((unsigned)q, pmagic);
-    const int e0 = (q - s * lin_P) * lin;              // first element of the lane inside the sample's range
-    const int y = (W == 1) ? e0 : (int)__umulhi((unsigned)e0, wmagic);
-    const int x = e0 - y * W;
-    const int ih = c.ih_base + y;
-    g.inr = q < NS * lin_P && s < c.ns && y < c.rows_in && x + pw < c.cols_in;
-    const bool ok = g.inr && (unsigned)ih < (unsigned)H;
-    g.voff = ok ? (s * C * HW + ih * W + x) * 4 : OOB;
-    g.laddr = s * SS + y * RS + x + pw;
-    return g;
-  };
-
   float st[2 * STAGE_SLOTS];
-
-  auto lin_load = [&](auto v_tag, __amdgpu_buffer_rsrc_t rs, int voff, int soff, int slot) {
-    constexpr int V = decltype(v_tag)::value;
-    if constexpr (V == 2) {
-      const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
-      st[slot] = v.x; st[slot + 1] = v.y;
-    } else {
-      st[slot] = bload(rs, voff, soff);
-    }
-  };
-  auto issue_lin = [&](auto ncg_tag, auto v_tag, const Chunk& c, __amdgpu_buffer_rsrc_t rs, int pnl, int c_lo, int t) {
-    constexpr int NCG = decltype(ncg_tag)::value;
-    constexpr int V = decltype(v_tag)::value;
-    const int step = HW * 4;
-    int soff0 = c_lo * HW * 4;
-    asm volatile("" : "+s"(soff0));
-    if constexpr (NCG > 0) {
-#pragma unroll
-      for (int k = 0; k < STAGE_SLOTS / V / NCG; ++k) {
-        const RowGeo g = lin_geo(c, k, t);
-        int soff = soff0;
-#pragma unroll
-        for (int cc = 0; cc < NCG; ++cc) {
-          lin_load(v_tag, rs, g.voff, soff, pnl * STAGE_SLOTS + (k * NCG + cc) * V);
-          soff += step;
-        }
-      }
-    } else {
-      int cc = 0, k = 0, soff = soff0;
-      RowGeo g = lin_geo(c, 0, t);
-#pragma unroll
-      for (int j = 0; j < STAGE_SLOTS / V; ++j) {
-        lin_load(v_tag, rs, g.voff, soff, pnl * STAGE_SLOTS + j * V);
-        soff += step;
-        if (++cc == nch) { cc = 0; soff = soff0; ++k; g = lin_geo(c, k, t); }
-      }
-    }
-  };
-  auto store_lin = [&](auto ncg_tag, auto v_tag, const Chunk& c, float* lbase, int pnl, int t) {
-    constexpr int NCG = decltype(ncg_tag)::value;
-    constexpr int V = decltype(v_tag)::value;
-    int lstep = PS;
-    asm volatile("" : "+s"(lstep));
-    if constexpr (NCG > 0) {
-#pragma unroll
-      for (int k = 0; k < STAGE_SLOTS / V / NCG; ++k) {
-        const RowGeo g = lin_geo(c, k, t);
-        if (g.inr) {
-          float* l = lbase + g.laddr;
-#pragma unroll
-          for (int cc = 0; cc < NCG; ++cc) {
-#pragma unroll
-            for (int v = 0; v < V; ++v) l[v] = st[pnl * STAGE_SLOTS + (k * NCG + cc) * V + v];
-            l += lstep;
-          }
-        }
-      }
-    } else {
-      int cc = 0, k = 0;
-      RowGeo g = lin_geo(c, 0, t);
-#pragma unroll
-      for (int j = 0; j < STAGE_SLOTS / V; ++j) {
-        if (g.inr) {
-#pragma unroll
-          for (int v = 0; v < V; ++v) lbase[g.laddr + cc * lstep + v] = st[pnl * STAGE_SLOTS + j * V + v];
-        }
-        if (++cc == nch) { cc = 0; ++k; g = lin_geo(c, k, t); }
-      }
-    }
-  };
 
   // NCG > 0: channel groups per row pass known at compile time (slot -> (pass, group) is static and the
   // loop is straight-line); NCG == 0: run-time counters with a uniform branch per slot.
@@ -362,19 +305,19 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   // the first channel of a slot are wave-uniform.
   const int flat_rows = NS * nch;
 
-  // staging path of this factor as one scalar: 0 float4 flat, 1 scalar flat, 2-4 linear V = 2 (16 / 8 / other
-  // channels), 5-6 linear V = 1 (16 / other), 7-9 general (16 / 8 / other channel groups)
+  // register staging path of this factor as one scalar: 0 float4 flat, 1 scalar flat, 7-9 general (16 / 8 / other
+  // channel groups); the pre-tiled variant stages by LDS-DMA (dma_stage) and has none of this
   const int path_id = __builtin_amdgcn_readfirstlane(
-      vec4 ? 0 : flat1 ? 1 : lin == 2 ? (nch == 16 ? 2 : nch == 8 ? 3 : 4) : lin ? (nch == 16 ? 5 : 6)
-      : n_cgs == 16 ? 7 : n_cgs == 8 ? 8 : 9);
+      vec4 ? 0 : flat1 ? 1 : n_cgs == 16 ? 7 : n_cgs == 8 ? 8 : 9);
   auto issue_loads = [&](const Chunk& c) {
+    if constexpr (PRE) { (void)c; return; } else {          // LDS-DMA staging: everything happens in store_stage
     // lane geometry made opaque per call: otherwise per-slot values are hoisted out of the chunk loop
     // and pinned in registers, which spills
     int lx = lx_, prow0 = prow0_;
     asm volatile("" : "+v"(lx), "+v"(prow0));
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(c);
-    // one scalar code for the staging path, re-read per chunk: the individual tests (vec4, flat1, lin == 2,
-    // nch == 16, ...) are loop invariants the compiler turns into a dozen 64-bit lane masks, spills, and
+    // one scalar code for the staging path, re-read per chunk: the individual tests (vec4, flat1,
+    // n_cgs == 16, ...) are loop invariants the compiler turns into a dozen 64-bit lane masks, spills, and
     // reloads with v_readlane in every chunk - vector instructions that wait for the other wave's MFMAs
     int path = path_id;
     asm volatile("" : "+s"(path));
@@ -419,16 +362,6 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
             rows += prow_step; soff += step; cb += prow_step;
             if (cb == nch) { cb = 0; soff += wrap; }
           }
-        } else if (path <= 6) {
-          int t = tid;
-          asm volatile("" : "+v"(t));
-          using I2 = std::integral_constant<int, 2>;
-          using I1 = std::integral_constant<int, 1>;
-          if (path == 2) issue_lin(std::integral_constant<int, 16>{}, I2{}, c, rs, pnl, c_lo, t);
-          else if (path == 3) issue_lin(std::integral_constant<int, 8>{}, I2{}, c, rs, pnl, c_lo, t);
-          else if (path == 4) issue_lin(std::integral_constant<int, 0>{}, I2{}, c, rs, pnl, c_lo, t);
-          else if (path == 5) issue_lin(std::integral_constant<int, 16>{}, I1{}, c, rs, pnl, c_lo, t);
-          else issue_lin(std::integral_constant<int, 0>{}, I1{}, c, rs, pnl, c_lo, t);
         } else if (path == 7) {
           issue_general(std::integral_constant<int, 16>{}, c, rs, pnl, c_lo, lx, prow0);
         } else if (path == 8) {
@@ -438,10 +371,37 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
         }
       }
     }
+    }
+  };
+
+  // pre-tiled source: the image of (panel, sample) is the run of SS words that starts at plane (plane0 + s) * C + c_lo
+  // of the copy; the four waves take its 1 KiB pieces in turn (lane l of a piece moves bytes [16 l, 16 l + 16)), the
+  // last piece is cut to the lanes inside the run.  Words of the image past the run (and the 16 slack words behind the
+  // panel) keep the zeros of the initial fill.
+  const int ppr = d.ppr, tail_lanes = d.tail_lanes;
+  auto dma_stage = [&](const Chunk& c) {
+    const long long bytes = ((long long)n_chunks * NS * C + nch) * PS * 4 + 64;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)d.src, 0, (unsigned)min(bytes, 0xfffff000ll), 0x00020000);
+    const int voff = lane * 16;
+    const int plane_b = PS * 4;
+    for (int pnl = 0; pnl < n_panels; ++pnl) {
+      const int c_lo = pnl ? c_lo_j : c_lo_i;
+      const unsigned lpanel = (unsigned)(PATCH_OFF + (pnl ? off_j : 0)) * 4u;
+      for (int s = 0; s < c.ns; ++s) {
+        const int run = ((c.plane0 + s) * C + c_lo) * plane_b;            // bytes (the planner keeps the copy < 2 GB)
+        const unsigned lrun = lpanel + (unsigned)(s * SS) * 4u;
+        for (int j = wave; j < ppr; j += 4) {
+          if (j < ppr - 1 || lane < tail_lanes)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void*)(l3 + lrun + j * 1024), 16, voff, run + j * 1024, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0): this wave's pieces have landed
   };
 
   // registers -> LDS patch
   auto store_stage = [&](const Chunk& c) {
+    if constexpr (PRE) { dma_stage(c); return; } else {
     int lx = lx_, prow0 = prow0_;
     asm volatile("" : "+v"(lx), "+v"(prow0));
     int path = path_id;                                   // see issue_loads
@@ -477,16 +437,6 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
               rows += prow_step; l += lstep;
             }
           }
-        } else if (path <= 6) {
-          int t = tid;
-          asm volatile("" : "+v"(t));
-          using I2 = std::integral_constant<int, 2>;
-          using I1 = std::integral_constant<int, 1>;
-          if (path == 2) store_lin(std::integral_constant<int, 16>{}, I2{}, c, lbase, pnl, t);
-          else if (path == 3) store_lin(std::integral_constant<int, 8>{}, I2{}, c, lbase, pnl, t);
-          else if (path == 4) store_lin(std::integral_constant<int, 0>{}, I2{}, c, lbase, pnl, t);
-          else if (path == 5) store_lin(std::integral_constant<int, 16>{}, I1{}, c, lbase, pnl, t);
-          else store_lin(std::integral_constant<int, 0>{}, I1{}, c, lbase, pnl, t);
         } else if (path == 7) {
           store_general(std::integral_constant<int, 16>{}, c, lbase, pnl, lx, prow0);
         } else if (path == 8) {
@@ -495,6 +445,7 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
           store_general(std::integral_constant<int, 0>{}, c, lbase, pnl, lx, prow0);
         }
       }
+    }
     }
   };
 
@@ -637,7 +588,8 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
 
     const Chunk work = cur;
     if (ch + 1 < ch_end) {
-      cur = decode_chunk(ch + 1);
+      if constexpr (PRE) cur = next_chunk_pre(work, ch + 1);
+      else cur = decode_chunk(ch + 1);
 #ifdef CURV_DIAG
       if (!(d.pad0 & 6)) issue_loads(cur);
 #else
@@ -662,7 +614,38 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
   }
 
   gfloat* slab = (gfloat*)slabs + d.slab_base + (long long)local * (TMv * TMv);
-  if (TMv == 64) {
+  if (TMv == 64 && PRE) {
+    // cross-wave reduction of the four K shares in two rounds (the smaller patch region holds two 64x64 tiles):
+    // waves 2, 3 park theirs, waves 0, 1 add them to their own and park the sums, then one coalesced slab write
+    auto park = [&](float* red) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        red[row * 64 + r32] = acc00[reg];
+        red[row * 64 + 32 + r32] = acc01[reg];
+        red[(32 + row) * 64 + r32] = acc10[reg];
+        red[(32 + row) * 64 + 32 + r32] = acc11[reg];
+      }
+    };
+    float* red = fs + PATCH_OFF + (wave & 1) * (64 * 64);
+    if (wave >= 2) park(red);
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        acc00[reg] += red[row * 64 + r32];
+        acc01[reg] += red[row * 64 + 32 + r32];
+        acc10[reg] += red[(32 + row) * 64 + r32];
+        acc11[reg] += red[(32 + row) * 64 + 32 + r32];
+      }
+      park(red);
+    }
+    __syncthreads();
+    const f32x4* r0 = reinterpret_cast<const f32x4*>(fs + PATCH_OFF);
+    gf32x4* slab4 = reinterpret_cast<gf32x4*>(slab);
+    for (int e = tid; e < 64 * 64 / 4; e += SYRK_THREADS) slab4[e] = r0[e] + r0[1024 + e];
+  } else if (TMv == 64) {
     // cross-wave reduction of the four K shares, then one coalesced slab write
     float* red = fs + PATCH_OFF + wave * (64 * 64);
 #pragma unroll
@@ -704,8 +687,21 @@ syrk_patch_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_item
   const int f = find_segment(descs, n_factors, item, false);
   const FactorDev& d = descs[f];
   const int local = item - d.item_base;
-  if (d.TM == 128) syrk_body<128>(d, local, slabs, zeros, smem);
-  else syrk_body<64>(d, local, slabs, zeros, smem);
+  if (d.TM == 128) syrk_body<128, false>(d, local, slabs, zeros, smem, (lds_char*)smem);
+  else syrk_body<64, false>(d, local, slabs, zeros, smem, (lds_char*)smem);
+}
+
+// the same body with LDS-DMA staging from the pre-tiled copies (syrk_pre.hip): its own work list
+__global__ void __launch_bounds__(SYRK_THREADS, PRE_WGS)
+syrk_pre_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_items, float* __restrict__ slabs) {
+  __shared__ __attribute__((aligned(1024))) int smem[PRE_SMEM_WORDS];
+  const int item = xcd_item(blockIdx.x);
+  if (item >= n_items) return;
+  const int f = find_segment(descs, n_factors, item, false);
+  const FactorDev& d = descs[f];
+  const int local = item - d.item_base;
+  if (d.TM == 128) syrk_body<128, true>(d, local, slabs, nullptr, smem, (lds_char*)smem);
+  else syrk_body<64, true>(d, local, slabs, nullptr, smem, (lds_char*)smem);
 }
 
 // Sum the k-slices of one 64x64 sub-tile in slice order, scale, add into the factor and its mirror.
@@ -801,7 +797,7 @@ static int ceil_log2(int v) {
   return s;
 }
 
-struct ChunkGeom { int rows_in, cols_in, RS, PS, SS, cshift, rshift, lin; };
+struct ChunkGeom { int rows_in, cols_in, RS, PS, SS, cshift, rshift, pre; };
 
 // Bank multiplicity of the per-lane operand gather for LDS strides RS = r, PS = p (mod 32): the 32
 // lanes of a half-wave read rows i .. i+31 of the unfolded matrix, i.e. words c*PS + a*RS + b with
@@ -867,8 +863,10 @@ static bool chunk_fits(const FactorDev& f, int NS, int R, int Wc, ChunkGeom& g) 
   }
   g.SS = f.nch * g.PS;
   g.rshift = 0;
-  g.lin = 0;
-  if ((long long)NS * g.SS + 16 > PANEL_WORDS) return false;       // + slack for padded run elements
+  g.pre = 0;
+  const bool pre = !f.compact && Wc == f.Wo;                        // full-width chunk of a kh x kw > 1 convolution
+  if (pre) g.SS = (g.SS + 3) & ~3;                                  // DMA pieces are whole 16-byte lanes
+  if ((long long)NS * g.SS + 16 > (pre ? PRE_PANEL_WORDS : PANEL_WORDS)) return false;   // + slack for padded run elements
   if ((long long)NS * R * Wc > 4096) return false;
   if (NS > 127 || g.rows_in > 0xffff) return false;
   if ((long long)NS * f.C * f.H * f.W * 4 > 0x7fff0000ll) return false;   // buffer offsets of a chunk: 31 bits
@@ -882,12 +880,13 @@ static bool chunk_fits(const FactorDev& f, int NS, int R, int Wc, ChunkGeom& g) 
     if (g.cshift > 6) return false;                                    // <= 64 lanes along x4
     if ((prow << g.cshift) * 4 > PANEL_SLOT_ELEMS) return false;       // float4 slots per lane
   } else {
-    if (!f.compact && Wc == f.Wo) {
-      // full-width chunk: linear staging, V floats per lane (V = 2 keeps both in one image row)
-      const int V = (f.W % 2 == 0) ? 2 : 1;
-      const long long lanes = (long long)NS * g.rows_in * f.W / V;
-      if (cdivll(lanes, SYRK_THREADS) * f.nch * V > STAGE_SLOTS) return false;
-      g.lin = V;
+    if (pre) {
+      // staged by LDS-DMA from the pre-tiled copy (syrk_pre.hip): no staging registers to budget; the copy
+      // ((chunks x NS x C + nch) planes of PS floats) must stay addressable with 31-bit byte offsets
+      const long long chunks = cdivll(f.N, NS) * cdivll(f.Ho, R);
+      if (((chunks * NS * f.C + f.nch) * g.PS + 64) * 4 > 0x7ff00000ll) return false;
+      if (chunks * NS * f.C * f.C >= (1LL << 32)) return false;        // plane numbers are divided by multiply-high
+      g.pre = 1;
       g.cshift = 0;
       return true;
     }
@@ -915,9 +914,9 @@ struct Plan {
   // two kernels, two work lists: [0] the implicit-im2col patch kernel below, [1] the LDS-DMA kernel of
   // syrk_flat.hip (flattened per-pixel factors); each with its own device table (factors by descending work per
   // item) and item / sub-tile numbering, sharing one slab buffer
-  std::vector<int> order[2];
-  int n_items[2] = {0, 0};
-  int n_sub[2] = {0, 0};
+  std::vector<int> order[3];           // [2]: the patch kernel's pre-tiled variant (syrk_pre_kernel, LDS-DMA staging)
+  int n_items[3] = {0, 0, 0};
+  int n_sub[3] = {0, 0, 0};
   long long slab_floats = 0;
   // f[0 .. n_user) are the caller's factors; 3x3 / stride 1 / pad 1 ones (dma = 2) are built from shifted
   // correlations (syrk_corr.hip): their virtual factors follow in f[n_user ...) and join the LDS-DMA work list
@@ -1056,16 +1055,19 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     }
     CURV_REQUIRE(chunk_fits(f, NS, R, Wc, g), "curv_kfac: factor %d: internal chunk planning error", i);
     f.NS = NS; f.R = R; f.Wc = Wc;
-    f.RS = g.RS; f.PS = g.PS; f.SS = g.SS; f.cshift = g.cshift; f.rshift = g.rshift; f.lin = g.lin;
-    if (f.lin) {
-      const unsigned lanes_per_sample = (unsigned)(g.rows_in * f.W / f.lin);
-      f.pmagic = (unsigned)(((1ull << 32) + lanes_per_sample - 1) / lanes_per_sample);
-      f.wmagic = (unsigned)(((1ull << 32) + (unsigned)f.W - 1) / (unsigned)f.W);
+    f.RS = g.RS; f.PS = g.PS; f.SS = g.SS; f.cshift = g.cshift; f.rshift = g.rshift; f.pre = g.pre;
+    if (f.pre) {
+      f.ppr = cdiv(f.SS, 256);                                   // 1 KiB pieces per (panel, sample) run
+      f.tail_lanes = (f.SS - 256 * (f.ppr - 1)) / 4;             // SS is a multiple of 4 words
     }
     f.rmagic = (unsigned)(((1ull << 32) + (unsigned)g.rows_in - 1) / (unsigned)g.rows_in);   // unused when rows_in == 1
     f.n_rg = cdiv(f.Ho, R);
     f.n_cg = cdiv(f.Wo, Wc);
     f.n_chunks = cdiv(f.N, NS) * f.n_rg * f.n_cg;
+    if (f.pre) {                                                  // its pre-tiled copy lives in the workspace area
+      f.xq_off = plan.area_floats;
+      plan.area_floats += (syrk_pre_floats(f) + 63) & ~63LL;
+    }
     f.P = cdiv(f.dim, f.TM);
     f.n_tiles = f.P * (f.P + 1) / 2;
     const double kc = (double)NS * R * (Wc + (Wc & 1));
@@ -1124,10 +1126,42 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
   // Work items are dispatched in index order: the longest items go first, so that the tail of the
   // launch is made of the shortest ones (the resident workgroups drain within one short item).
   long long slab = 0;
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 3; ++k) {
     plan.order[k].clear();
-    for (int i = 0; i < n_all; ++i) if (plan.f[i].dma == k) plan.order[k].push_back(i);
+    for (int i = 0; i < n_all; ++i) {
+      const FactorDev& v = plan.f[i];
+      const int list = v.dma == 2 ? -1 : v.dma == 1 ? 1 : v.pre ? 2 : 0;
+      if (list == k) plan.order[k].push_back(i);
+    }
     std::stable_sort(plan.order[k].begin(), plan.order[k].end(), [&](int a, int b) { return item_cost[a] > item_cost[b]; });
+    // Graded items: a launch ends when its last item does, and with ~16 equal items per workgroup slot the slots
+    // drain over the length of one item (measured: 6-10 % of both big kernels at a quarter of the slots).  The
+    // factors that are dispatched last are therefore cut finer: half-length items past 70 % of the list's work,
+    // quarter-length items past 90 % (a few more slabs for the reduce pass, none of it in the bulk of the launch).
+    if (k != 0 && plan.order[k].size() > 1) {
+      double list_cost = 0.0, seen = 0.0;
+      for (int idx : plan.order[k]) if (plan.f[idx].n_items > 0 || plan.f[idx].group_n > 0)
+        list_cost += chunk_cost[idx] * plan.f[idx].n_tiles * plan.f[idx].n_chunks;
+      if (list_cost > 512.0 * 8.0 * target) {          // a launch of several items per slot: otherwise nothing to grade
+        for (int idx : plan.order[k]) {
+          FactorDev& f = plan.f[idx];
+          const double mine = chunk_cost[idx] * f.n_tiles * f.n_chunks;
+          const double start = seen / list_cost;
+          seen += mine;
+          if (f.group_n > 0 || start < 0.7) continue;  // (groups share one slicing: left alone)
+          const double t = start < 0.9 ? target * 0.5 : target * 0.25;
+          int cpi = (int)(t / chunk_cost[idx] + 0.5);
+          cpi = std::max(1, std::min(cpi, f.n_chunks));
+          if (cpi >= f.cpi) continue;
+          f.n_slices = cdiv(f.n_chunks, cpi);
+          f.cpi = cdiv(f.n_chunks, f.n_slices);
+          f.n_slices = cdiv(f.n_chunks, f.cpi);
+          f.n_items = f.n_slices * f.n_tiles;
+          item_cost[idx] = chunk_cost[idx] * f.cpi;
+        }
+        std::stable_sort(plan.order[k].begin(), plan.order[k].end(), [&](int a, int b) { return item_cost[a] > item_cost[b]; });
+      }
+    }
     long long items = 0, subs = 0;
     for (int idx : plan.order[k]) {
       FactorDev& f = plan.f[idx];
@@ -1183,7 +1217,7 @@ extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors,
     o[0] = f.dim; o[1] = f.Ho; o[2] = f.Wo; o[3] = f.NS; o[4] = f.R; o[5] = f.Wc;
     o[6] = f.n_chunks; o[7] = f.RS; o[8] = f.PS; o[9] = f.SS; o[10] = f.nch;
     o[11] = f.n_tiles; o[12] = f.cpi; o[13] = f.n_slices; o[14] = f.n_items; o[15] = f.item_base;
-    o[16] = f.TM; o[17] = f.vec4; o[18] = f.cshift; o[19] = f.n_sub; o[20] = f.RL; o[21] = f.rshift; o[22] = f.lin;
+    o[16] = f.TM; o[17] = f.vec4; o[18] = f.cshift; o[19] = f.n_sub; o[20] = f.RL; o[21] = f.rshift; o[22] = f.pre;
     o[23] = f.dma;
     auto flops_of = [](const FactorDev& v) {
       const double K = (double)v.N * v.Ho * v.Wo;
@@ -1202,8 +1236,30 @@ extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors,
   return CURV_OK;
 }
 
+// side stream for the register-staged patch kernel (few, long, latency-bound items: flattened factors narrower than a
+// 128-row tile, strided 1x1 convolutions, Linear layers): it runs beside the padding / pre-tiling passes and the two
+// LDS-DMA kernels instead of in front of them with a tail of its own
+struct SyrkStreams { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static int syrk_streams(SyrkStreams** out) {
+  static thread_local std::vector<std::pair<int, SyrkStreams>> cache;
+  int dev = 0;
+  CURV_HIP_CHECK(hipGetDevice(&dev));
+  for (auto& e : cache) if (e.first == dev) { *out = &e.second; return CURV_OK; }
+  SyrkStreams s;
+  CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking));
+  CURV_HIP_CHECK(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+  CURV_HIP_CHECK(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+  cache.emplace_back(dev, s);
+  *out = &cache.back().second;
+  return CURV_OK;
+}
+
+// what the device table of a workspace held after the previous call (CURV_KFAC_TABLE_RESIDENT: the caller vouches
+// that nobody else wrote to the head of that workspace since): unchanged argument blocks are not uploaded again
+struct TableShadow { const void* ws = nullptr; std::vector<FactorDev> rows; };
+
 static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, int n_factors, void* workspace,
-                                size_t workspace_bytes, void* ev_start, void* ev_stop) {
+                                size_t workspace_bytes, unsigned flags, void* ev_start, void* ev_stop) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_factors == 0) return CURV_OK;
   Plan plan;
@@ -1220,36 +1276,75 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
   float* zeros = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + tb - 256);
   float* area = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + tb + slab_bytes(plan));
   for (const CorrLayer& layer : plan.corr) syrk_corr_bind(layer, plan.f, area);
-  // device table: the patch kernel's factors, then the LDS-DMA kernel's (the caller's and the virtual ones)
+  // device table: the patch kernel's factors, then the LDS-DMA kernel's (the caller's and the virtual ones), then
+  // those of the patch kernel's pre-tiled variant
   std::vector<int> all(plan.order[0]);
   all.insert(all.end(), plan.order[1].begin(), plan.order[1].end());
+  all.insert(all.end(), plan.order[2].begin(), plan.order[2].end());
   const int n_table = (int)all.size();
+  static thread_local TableShadow shadow;
+  const bool resident = (flags & CURV_KFAC_TABLE_RESIDENT) && shadow.ws == workspace;
+  if (!resident) shadow.rows.clear();
+  shadow.ws = workspace;
+  if ((int)shadow.rows.size() < n_table) {
+    FactorDev none;
+    memset(&none, 0xff, sizeof(none));
+    shadow.rows.resize(n_table, none);
+  }
   for (int b = 0; b < n_table; b += UPLOAD_CHUNK) {
     TableChunk chunk;
     const int count = std::min(UPLOAD_CHUNK, n_table - b);
     memset(&chunk, 0, sizeof(chunk));
-    for (int k = 0; k < count; ++k) chunk.f[k] = plan.f[all[b + k]];
+    for (int k = 0; k < count; ++k) {
+      chunk.f[k] = plan.f[all[b + k]];
+      if (chunk.f[k].pre) chunk.f[k].src = area + chunk.f[k].xq_off;        // the kernel stages from the pre-tiled copy
+      chunk.f[k].xq_off = 0;
+    }
+    if (resident && memcmp(&shadow.rows[b], chunk.f, (size_t)count * sizeof(FactorDev)) == 0) continue;
+    memcpy(&shadow.rows[b], chunk.f, (size_t)count * sizeof(FactorDev));
     hipLaunchKernelGGL(upload_table_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count,
                        b == 0 ? zeros : nullptr);
     CURV_LAUNCH_CHECK();
   }
-  const int n0 = (int)plan.order[0].size(), n1 = (int)plan.order[1].size();
-  // the two kernels run back to back on the caller's stream (launching the LDS-DMA kernel on a second stream beside
-  // the patch kernel was measured: 8.29 vs 8.26 ms for the pair, no gain)
+  const int n0 = (int)plan.order[0].size(), n1 = (int)plan.order[1].size(), n2 = (int)plan.order[2].size();
   if (ev_start) CURV_HIP_CHECK(hipEventRecord((hipEvent_t)ev_start, stream));
+  // launch order on the caller's stream: padding pass, pre-tiling pass, pre-tiled patch kernel, LDS-DMA kernel; the
+  // register-staged patch kernel beside them on the side stream (when there is anything for it to run beside)
   if (!plan.corr.empty()) {
     const int rcp = launch_corr_prep(stream, plan.corr, plan.f, area);
     if (rcp != CURV_OK) return rcp;
   }
+  if (n2 > 0) {
+    const int rcq = launch_patch_prep(stream, plan.f, plan.order[2], area);
+    if (rcq != CURV_OK) return rcq;
+  }
+  // the register-staged kernel starts beside the MFMA kernels, behind the two HBM-bound passes (beside those it
+  // slowed them down by more than it gained)
+  SyrkStreams* ss = nullptr;
+  const bool fork = plan.n_items[0] > 0 && (plan.n_items[1] > 0 || plan.n_items[2] > 0);
+  if (fork) {
+    rc = syrk_streams(&ss);
+    if (rc != CURV_OK) return rc;
+    CURV_HIP_CHECK(hipEventRecord(ss->fork, stream));
+    CURV_HIP_CHECK(hipStreamWaitEvent(ss->side, ss->fork, 0));
+  }
   if (plan.n_items[0] > 0) {
     const int grid = cdiv(plan.n_items[0], 8 * XCD_GROUP) * 8 * XCD_GROUP;
-    hipLaunchKernelGGL(syrk_patch_kernel, dim3(grid), dim3(SYRK_THREADS), 0, stream, table, n0, plan.n_items[0], slabs, zeros);
+    hipLaunchKernelGGL(syrk_patch_kernel, dim3(grid), dim3(SYRK_THREADS), 0, fork ? ss->side : stream, table, n0,
+                       plan.n_items[0], slabs, zeros);
+    CURV_LAUNCH_CHECK();
+    if (fork) CURV_HIP_CHECK(hipEventRecord(ss->join, ss->side));
+  }
+  if (n2 > 0) {
+    const int grid = cdiv(plan.n_items[2], 8 * XCD_GROUP) * 8 * XCD_GROUP;
+    hipLaunchKernelGGL(syrk_pre_kernel, dim3(grid), dim3(SYRK_THREADS), 0, stream, table + n0 + n1, n2, plan.n_items[2], slabs);
     CURV_LAUNCH_CHECK();
   }
   if (plan.n_items[1] > 0) {
     const int rc1 = launch_syrk_flat(stream, table + n0, n1, plan.n_items[1], slabs);
     if (rc1 != CURV_OK) return rc1;
   }
+  if (fork) CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->join, 0));
   if (ev_stop) CURV_HIP_CHECK(hipEventRecord((hipEvent_t)ev_stop, stream));
   if (plan.n_sub[0] > 0) {
     hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub[0]), dim3(SYRK_THREADS), 0, stream, table, n0, slabs);
@@ -1259,16 +1354,25 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
     hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub[1]), dim3(SYRK_THREADS), 0, stream, table + n0, n1, slabs);
     CURV_LAUNCH_CHECK();
   }
+  if (plan.n_sub[2] > 0) {
+    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub[2]), dim3(SYRK_THREADS), 0, stream, table + n0 + n1, n2, slabs);
+    CURV_LAUNCH_CHECK();
+  }
   if (!plan.corr.empty()) return launch_corr_assemble(stream, plan.corr, plan.f, area);
   return CURV_OK;
 }
 
 extern "C" int curv_kfac_accumulate(void* stream, const curv_factor_desc* descs, int n_factors, void* workspace,
                                     size_t workspace_bytes) {
-  return kfac_accumulate_impl(stream, descs, n_factors, workspace, workspace_bytes, nullptr, nullptr);
+  return kfac_accumulate_impl(stream, descs, n_factors, workspace, workspace_bytes, 0u, nullptr, nullptr);
+}
+
+extern "C" int curv_kfac_accumulate_ex(void* stream, const curv_factor_desc* descs, int n_factors, void* workspace,
+                                       size_t workspace_bytes, unsigned flags, void* ev_start, void* ev_stop) {
+  return kfac_accumulate_impl(stream, descs, n_factors, workspace, workspace_bytes, flags, ev_start, ev_stop);
 }
 
 extern "C" int curv_kfac_accumulate_timed(void* stream, const curv_factor_desc* descs, int n_factors,
                                           void* workspace, size_t workspace_bytes, void* ev_start, void* ev_stop) {
-  return kfac_accumulate_impl(stream, descs, n_factors, workspace, workspace_bytes, ev_start, ev_stop);
+  return kfac_accumulate_impl(stream, descs, n_factors, workspace, workspace_bytes, 0u, ev_start, ev_stop);
 }

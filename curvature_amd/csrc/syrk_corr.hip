@@ -53,9 +53,9 @@ struct CorrDev {
   int row_pitch, col_pitch, pt_pitch;
   int first;
   float scale;
-  long long prep_base;       // first element of this layer in the prep grid
+  long long prep_base;       // first workgroup of this layer in the prep grid
   int tile_base;             // first workgroup of this layer in the assembly grid
-  int pad;
+  unsigned wp_magic, h_magic, c_magic;      // ceil(2^32 / d) for W + 2, H, C
 };
 constexpr int CORR_CHUNK = 16;
 struct CorrChunk { CorrDev l[CORR_CHUNK]; };
@@ -63,21 +63,36 @@ static_assert(sizeof(CorrChunk) <= 3840, "kernel argument block must stay below 
 
 typedef __attribute__((address_space(1))) float gfl;
 
-// one thread per element of Xp; the border rows / columns / corners are scattered from the same value
+// one workgroup per PREP_SEG consecutive elements of a layer's Xp (one exact division per workgroup, multiply-high
+// arithmetic per element); the border rows / columns / corners are scattered from the same value
+constexpr int PREP_SEG = 4096;
+__device__ __forceinline__ int corr_divu(int x, int d, unsigned magic) { return d == 1 ? x : (int)__umulhi((unsigned)x, magic); }
+static unsigned corr_magic(int d) { return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
+
 __global__ void __launch_bounds__(256) corr_prep_kernel(CorrChunk chunk, int count, long long total) {
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    int l = 0;
-    while (l + 1 < count && chunk.l[l + 1].prep_base <= idx) ++l;
-    const CorrDev& d = chunk.l[l];
-    const long long e = idx - d.prep_base;
-    const int Wp = d.Wp, H = d.H, W = d.W, C = d.C;
-    const int v = (int)(e % Wp);
-    const long long r = e / Wp;
-    const int u = (int)(r % H);
-    const long long sc = r / H;                 // n * C + c
-    const int c = (int)(sc % C), n = (int)(sc / C);
-    const float val = v < W ? d.src[(sc * H + u) * W + v] : 0.0f;
-    d.xp[e] = val;
+  (void)total;
+  int l = 0;
+  while (l + 1 < count && chunk.l[l + 1].prep_base <= (long long)blockIdx.x) ++l;
+  const CorrDev& d = chunk.l[l];
+  const int Wp = d.Wp, H = d.H, W = d.W, C = d.C;
+  const long long words = (long long)d.N * C * H * Wp;
+  const long long e0 = ((long long)blockIdx.x - d.prep_base) * PREP_SEG;
+  const int row0 = (int)(e0 / Wp);
+  const int v0 = (int)(e0 - (long long)row0 * Wp);
+  const int cnt = (int)min((long long)PREP_SEG, words - e0);
+  const unsigned wp_magic = d.wp_magic, h_magic = d.h_magic, c_magic = d.c_magic;
+  gfl* xp = (gfl*)d.xp + e0;
+  for (int t = threadIdx.x; t < cnt; t += 256) {
+    const int off = v0 + t;                                 // < PREP_SEG + Wp
+    const int drow = (int)__umulhi((unsigned)off, wp_magic);
+    const int v = off - drow * Wp;
+    const int r = row0 + drow;                              // (n * C + c) * H + u
+    const int sc = corr_divu(r, H, h_magic);
+    const int u = r - sc * H;
+    const int n = corr_divu(sc, C, c_magic);
+    const int c = sc - n * C;
+    const float val = v < W ? d.src[(long long)r * W + v] : 0.0f;
+    xp[t] = val;
     if (u == H - 1) d.rowb[(long long)c * d.row_pitch + corr::LEAD + n * Wp + v] = val;
     if (u == 0) d.rowt[(long long)c * d.row_pitch + corr::LEAD + n * Wp + v] = val;
     if (v == W - 1 || v == 0) {
@@ -154,6 +169,7 @@ bool syrk_corr_eligible(const curv_factor_desc& s) {
   if (s.C < 128 || s.C % 128 != 0 || s.N < 8 || s.H < 3 || s.W < 3) return false;
   // every operand array addressable by one buffer descriptor of the LDS-DMA kernel
   if ((long long)s.N * s.C * s.H * (s.W + 2) * 4 >= (1LL << 32) - 4096) return false;
+  if ((long long)s.N * s.C * s.H * std::max(s.H, s.C) >= (1LL << 32)) return false;     // row numbers are divided by multiply-high
   return true;
 }
 
@@ -235,6 +251,7 @@ static void fill_dev(const CorrLayer& L, const FactorDev& user, float* area, Cor
   d.N = L.N; d.C = L.C; d.H = L.H; d.W = L.W; d.Wp = L.Wp; d.Hq = L.Hq;
   d.row_pitch = L.row_pitch; d.col_pitch = L.col_pitch; d.pt_pitch = L.pt_pitch;
   d.first = user.first; d.scale = user.scale;
+  d.wp_magic = corr_magic(L.Wp); d.h_magic = corr_magic(L.H); d.c_magic = corr_magic(L.C);
 }
 
 int launch_corr_prep(hipStream_t stream, const std::vector<CorrLayer>& layers, const std::vector<FactorDev>& f,
@@ -248,10 +265,10 @@ int launch_corr_prep(hipStream_t stream, const std::vector<CorrLayer>& layers, c
       const CorrLayer& L = layers[b + k];
       fill_dev(L, f[L.user], area, chunk.l[k]);
       chunk.l[k].prep_base = total;
-      total += (long long)L.N * L.C * L.H * L.Wp;
+      total += ((long long)L.N * L.C * L.H * L.Wp + PREP_SEG - 1) / PREP_SEG;
     }
-    const int grid = (int)std::min<long long>((total + 255) / 256, 1 << 20);
-    hipLaunchKernelGGL(corr_prep_kernel, dim3(grid), dim3(256), 0, stream, chunk, count, total);
+    CURV_REQUIRE(total < (1LL << 31), "curv_kfac: too many padding segments");
+    hipLaunchKernelGGL(corr_prep_kernel, dim3((unsigned)total), dim3(256), 0, stream, chunk, count, total);
     CURV_LAUNCH_CHECK();
   }
   return CURV_OK;

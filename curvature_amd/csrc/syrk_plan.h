@@ -37,8 +37,10 @@ struct FactorDev {
   int rshift;              // general staging: a lane group of 2^rshift folded rows; the other row lanes split channels
   int flat;                // flattened per-pixel factor whose (sample, channel) rows are staged slot-regularly
   unsigned rmagic;         // ceil(2^32 / patch rows per sample): folded (sample, row) index -> sample
-  int lin;                 // linear staging: lanes walk the contiguous rows x W source range, `lin` floats each
-  unsigned pmagic, wmagic; // linear staging: ceil(2^32 / lanes per sample), ceil(2^32 / W)
+  int pre;                 // full-width chunks of a kh x kw > 1 convolution: the patch images are staged by LDS-DMA from a
+                           // pre-tiled, zero-padded copy of the source (syrk_pre.hip), one contiguous run of SS words per
+                           // (chunk, sample, panel); `src` of the device table entry points at that copy
+  int ppr, tail_lanes;     // ... 1 KiB DMA pieces per run, and the lanes of the last piece that lie inside the run
   int dma;                 // 1: built by syrk_flat_kernel (n_chunks = stages, cpi = stages per item);
                            // 2: a 3x3 factor assembled from shifted correlations (syrk_corr.hip): no work items of its own
   // syrk_flat_kernel operands: row r of sample s starts at src + (s * C + r) * pitch floats; panel i reads
@@ -52,6 +54,7 @@ struct FactorDev {
   // at the first member's item_base; member j carries item_base + j only to keep the table's bases ascending.
   int group_n, group_pos;
   long long slab_base;     // in floats
+  long long xq_off;        // pre: offset of the pre-tiled copy in the workspace area, in floats (host side only)
 };
 static_assert(sizeof(FactorDev) % 8 == 0, "FactorDev must be 8-byte granular");
 
@@ -94,6 +97,10 @@ __device__ __forceinline__ void decode_tile_of(const FactorDev& d, int t, int& t
   if (d.nonsym) { ti = t / d.P; tj = t - ti * d.P; }
   else decode_tile(t, d.P, ti, tj);
 }
+
+// syrk_pre.hip: pre-tiled copies of the sources of `pre` factors (one pass in front of the patch kernel)
+long long syrk_pre_floats(const FactorDev& f);
+int launch_patch_prep(hipStream_t stream, const std::vector<FactorDev>& f, const std::vector<int>& which, float* area);
 
 // syrk_corr.hip: 3x3 / stride 1 / padding 1 factors assembled from shifted correlations
 constexpr int CORR_COMPONENTS = 29;

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CURV_ABI_VERSION 3
+#define CURV_ABI_VERSION 4
 
 #define CURV_OK 0
 #define CURV_ERR_NOT_PD 1
@@ -72,8 +72,8 @@ size_t curv_kfac_workspace_bytes(const curv_factor_desc* descs, int n_factors);
  * factor: dim, Ho, Wo, chunk samples, chunk rows, chunk cols, n_chunks, LDS row stride, plane stride,
  * sample stride, channels per panel, n_tiles, chunks per item, k-slices, n_items, item_base, tile edge,
  * float4 staging flag, log2 padded patch row length, 64x64 sub-tiles, k-run length, log2 row lanes
- * that walk patch rows while staging (the remaining row lanes split channels), floats per lane of the
- * linear full-width staging (0 = not used), 1 if the factor is built by the LDS-DMA kernel for flattened per-pixel
+ * that walk patch rows while staging (the remaining row lanes split channels), 1 if the patch images are staged
+ * by LDS-DMA from a pre-tiled copy of the source (full-width chunks of a kh x kw > 1 convolution), 1 if the factor is built by the LDS-DMA kernel for flattened per-pixel
  * factors (its own work list: item bases count from 0 per kernel; n_chunks = stages of <= 32 pixels), 2 if it is a
  * 3x3 / stride 1 / padding 1 factor assembled from 29 shifted correlations that run as virtual factors of the LDS-DMA
  * kernel (no items of its own), and last the multiply-add FLOPs (2 per multiply-add) the plan executes for the
@@ -93,6 +93,14 @@ int curv_kfac_accumulate(void* stream, const curv_factor_desc* descs, int n_fact
  * SYRK kernel, so that a benchmark can time exactly that kernel without a profiler. */
 int curv_kfac_accumulate_timed(void* stream, const curv_factor_desc* descs, int n_factors, void* workspace,
                                size_t workspace_bytes, void* ev_start, void* ev_stop);
+
+/* Same with flags (ev_start / ev_stop may be NULL).  CURV_KFAC_TABLE_RESIDENT: the caller vouches that the head of
+ * `workspace` (the device descriptor table) has not been written by anybody else since this thread's previous
+ * curv_kfac_accumulate* call with the same workspace; argument blocks of the table that did not change (same
+ * pointers, geometry, scale and `first` flags - the steady state of a training loop) are then not uploaded again. */
+#define CURV_KFAC_TABLE_RESIDENT 1u
+int curv_kfac_accumulate_ex(void* stream, const curv_factor_desc* descs, int n_factors, void* workspace,
+                            size_t workspace_bytes, unsigned flags, void* ev_start, void* ev_stop);
 void* curv_event_create(void);
 void curv_event_destroy(void* event);
 int curv_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* waits for ev_stop */

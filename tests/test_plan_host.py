@@ -8,8 +8,8 @@ import pytest
 from curvature_amd import _lib
 
 NF = 25
-NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub RL rshift lin dma flops".split()
-PANEL_WORDS, KTAB_MAX, SLOTS, THREADS = 8704, 1024, 32, 256
+NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub RL rshift pre dma flops".split()
+PANEL_WORDS, PRE_PANEL_WORDS, KTAB_MAX, SLOTS, THREADS = 8704, 6528, 1024, 32, 256
 
 
 def plan(descs):
@@ -74,18 +74,19 @@ def test_plan_respects_budgets(d):
         assert p["ntiles"] == P * (P + 1) // 2 and p["nitems"] == p["ntiles"] * p["nslices"]
         assert p["cpi"] * p["nslices"] >= p["nchunks"] and p["cpi"] * (p["nslices"] - 1) < p["nchunks"]
         return
-    assert p["NS"] * p["SS"] + 16 <= PANEL_WORDS                      # LDS patch per panel
+    assert p["NS"] * p["SS"] + 16 <= (PRE_PANEL_WORDS if p["pre"] else PANEL_WORDS)      # LDS patch per panel
     rows_in = p["R"] if compact else (p["R"] - 1) * d["sh"] + d["kh"]
     cols_in = p["Wc"] if compact else (p["Wc"] - 1) * d["sw"] + d["kw"]
     assert p["RS"] >= cols_in and p["PS"] >= rows_in * p["RS"] and p["SS"] >= p["nch"] * p["PS"]
     prow = p["NS"] * p["nch"] * rows_in
     if p["vec4"]:
         assert p["Wc"] % 4 == 0 and (prow << p["cshift"]) * 4 <= SLOTS * THREADS
-    elif p["lin"]:
-        # linear staging of full-width chunks: V floats per lane over the contiguous rows x W source range
-        assert not compact and p["Wc"] == Wo and p["lin"] == (2 if d["W"] % 2 == 0 else 1)
-        lanes = p["NS"] * rows_in * d["W"] // p["lin"]
-        assert -(-lanes // THREADS) * p["nch"] * p["lin"] <= SLOTS
+    elif p["pre"]:
+        # full-width chunks of a kh x kw > 1 convolution: LDS-DMA from the pre-tiled copy (syrk_pre.hip); the image of
+        # a (panel, sample) is one run of SS words moved in 16-byte lanes
+        assert not compact and p["Wc"] == Wo and p["pre"] == 1 and p["SS"] % 4 == 0 and p["SS"] < p["nch"] * p["PS"] + 4
+        n_sg, n_rg = -(-d["N"] // p["NS"]), -(-p["Ho"] // p["R"])
+        assert ((n_sg * n_rg * p["NS"] * d["C"] + p["nch"]) * p["PS"] + 64) * 4 < 2 ** 31
     elif flat and p["nch"] & (p["nch"] - 1) == 0:
         assert (prow << p["cshift"]) <= SLOTS * THREADS and (1 << p["cshift"]) >= cols_in
     else:
@@ -106,16 +107,18 @@ def test_plan_respects_budgets(d):
 
 def test_item_bases_tile_the_work_list():
     """Factors are laid out in the work list by descending work per item; together their [base, base + nitems) ranges
-    cover the patch kernel's list exactly once.  In the LDS-DMA kernel's list the caller's factors share the list with
+    cover the patch kernel's list exactly once (two lists: register-staged factors and the pre-tiled variant's).  In
+    the LDS-DMA kernel's list the caller's factors share the list with
     the virtual factors of assembled 3x3 factors (not reported): ranges are disjoint and ascending, and without such
     a factor in the set they tile it exactly as well."""
     everything = plan(CASES)
     assert any(p["dma"] == 1 for p in everything) and any(p["dma"] == 0 for p in everything)
-    assert any(p["dma"] == 2 for p in everything)
-    for kernel, subset in ((0, everything), (1, everything), (1, [p for p in plan([c for c in CASES if not (c["kh"] == 3 and c["sh"] == 1 and c["C"] % 128 == 0)])])):
+    assert any(p["dma"] == 2 for p in everything) and any(p["pre"] for p in everything)
+    for kernel, pre, subset in ((0, 0, everything), (0, 1, everything), (1, 0, everything),
+                                (1, 0, [p for p in plan([c for c in CASES if not (c["kh"] == 3 and c["sh"] == 1 and c["C"] % 128 == 0)])])):
         base = 0
         exact = kernel == 0 or not any(p["dma"] == 2 for p in subset)
-        for p in sorted((p for p in subset if p["dma"] == kernel), key=lambda p: p["base"]):
+        for p in sorted((p for p in subset if p["dma"] == kernel and p["pre"] == pre), key=lambda p: p["base"]):
             assert p["base"] == base if exact else p["base"] >= base
             base = p["base"] + p["nitems"]
 

@@ -24,9 +24,15 @@ CONV_CASES = [
     (5, 4, 6, 6, (3, 1), (1, 2), (0, 1), True),  # anisotropic kernel/stride/padding
     (2, 64, 8, 8, 1, 1, 0, False),      # flattened 1x1, 16-byte rows: float4 staging, 64x64 tiles
     (2, 256, 4, 4, 1, 1, 0, False),     # float4 staging, 128x128 tiles, several samples per chunk
-    (3, 256, 7, 7, 3, 1, 1, False),     # linear staging, odd width (1 float per lane), 16 channels per panel
-    (2, 5, 9, 9, 3, 1, 1, True),        # linear staging, channel count that is neither 8 nor 16
-    (2, 40, 10, 10, 3, 2, 1, False),    # linear staging, stride 2, even width (2 floats per lane)
+    # kh x kw > 1 with full-width chunks: patch images staged by LDS-DMA from the pre-tiled copy (syrk_pre.hip)
+    (3, 256, 7, 7, 3, 1, 1, False),     # odd width, 16 channels per panel, several samples per chunk (ragged group)
+    (2, 5, 9, 9, 3, 1, 1, True),        # channel count below a panel's, bias row
+    (2, 40, 10, 10, 3, 2, 1, False),    # stride 2, even width
+    (5, 64, 7, 7, 3, 2, 1, False),      # stride 2, odd sample count in sample groups
+    (3, 32, 30, 30, 3, 1, 1, False),    # several output-row groups, the last one ragged
+    (2, 3, 64, 64, 7, 2, 3, True),      # stem-like 7x7 / stride 2 with a bias row, 64x64 tiles
+    (3, 512, 14, 14, 3, 2, 1, False),   # ResNet-50 layer4.0.conv2 geometry: 4608-wide factor, panels ending past C
+    (2, 20, 11, 23, 5, 1, 2, True),     # 5x5, non-square, odd sizes
     # 3x3 / stride 1 / pad 1 with C % 128 == 0 and N >= 8: assembled from shifted correlations (syrk_corr.hip)
     (8, 128, 14, 14, 3, 1, 1, False),   # ResNet layer3-like
     (8, 256, 7, 7, 3, 1, 1, False),     # layer4-like: odd size, border strips are half of the image
@@ -157,6 +163,26 @@ def test_mixed_launch_with_several_assembled_factors(gpu):
     ops.kfac_accumulate(jobs)
     for j, f in zip(jobs, first):
         assert torch.equal(j.dst, f)
+
+
+def test_more_pretiled_factors_than_one_argument_block(gpu):
+    """The pre-tiling pass carries 32 factor descriptors per kernel-argument block: 37 convolution factors in one call
+    take two launches of it."""
+    from curvature_amd import ops
+    o = _oracle()
+    torch.manual_seed(6)
+    jobs, refs = [], []
+    for i in range(37):
+        C, H, W, s = 3 + i % 5, 6 + i % 4, 7 + i % 3, 1 + i % 2
+        x = torch.relu(torch.randn(3, C, H, W))
+        Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+        A_ref, _ = o.kfac_factors(x.double(), torch.zeros(3, 1, Ho, Wo, dtype=torch.float64), (3, 3), (s, s), (1, 1), False)
+        jobs.append(ops.FactorJob(x.to(gpu), torch.empty(9 * C, 9 * C, device=gpu), (3, 3), (s, s), (1, 1), False,
+                                  1.0 / (3 * Ho * Wo), True))
+        refs.append(A_ref)
+    ops.kfac_accumulate(jobs)
+    for j, ref in zip(jobs, refs):
+        assert rel_fro(j.dst, ref) < TOL and torch.equal(j.dst, j.dst.t())
 
 
 def test_more_assembled_factors_than_one_argument_block(gpu):
