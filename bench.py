@@ -161,6 +161,224 @@ def cpu_baseline_subprocess(batch_full, timeout_s=300):
                 "sample": f"CPU leg did not finish within {timeout_s} s on this host and was stopped"}
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json's other configurations (2: LeNet-5 on one GPU, 3: ResNet-18 KFAC + EFB, 5: the ResNet-50 EFB / INF
+# chain), measured AFTER the headline timed region and never inside it.  Each entry is a wall-clock time around the
+# call with the GPU idle before and after (torch.cuda.synchronize on both sides), median of a few repeats.
+# ------------------------------------------------------------------------------------------------------------------
+PEAK_HBM = 8.0e12             # MI355X_MICROARCH.md: HBM3E spec (6.3e12 achievable)
+PEAK_F64_MFMA = 48.0e12       # measured (tools/micro/mfma_f64_peak.hip); AMD's datasheet figure is 78.6e12
+
+
+def _timed_gpu(fn, reps=3, warm=1):
+    import statistics
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts) * 1e3
+
+
+def _backward_once(model, x):
+    logits = model(x)
+    labels = torch.distributions.Categorical(logits=logits.detach()).sample()
+    model.zero_grad()
+    torch.nn.functional.cross_entropy(logits, labels).backward()
+
+
+def other_configs_gpu(dev, model50, kfac50, batch):
+    """Configs 2, 3 and 5 on this GPU.  `kfac50` holds the headline workload's factors (ResNet-50, N = batch)."""
+    from curvature_amd import models, ops
+    from curvature_amd.curvatures import KFAC, EFB, INF
+    out = {}
+
+    # ---- config 2: LeNet-5, N = 100, synthetic 28x28 U[0,1) inputs: update + invert(0.5, 1) + sample_and_replace
+    torch.manual_seed(0)
+    lenet = models.lenet5().to(dev).eval()
+    k2 = KFAC(lenet)
+    _backward_once(lenet, torch.rand(100, 1, 28, 28, device=dev))
+
+    def lenet_step():
+        k2.update(batch_size=100)
+        k2.invert(add=0.5, multiply=1)
+        k2.sample_and_replace()
+    for _ in range(5):
+        lenet_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        lenet_step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 50 * 1e3
+    out["config2_lenet5_n100"] = {"workload": "LeNet-5 N=100: KFAC.update + invert(0.5, 1) + sample_and_replace, 5 layers",
+                                  "ms_per_step": ms, "layers_per_s": 5 / ms * 1e3,
+                                  "bound": "launch latency (0.6 GFLOP and 0.04 MB per sample: ~20 launches per step)"}
+    del k2, lenet
+
+    # ---- config 3: ImageNet ResNet-18, N = 32: KFAC step, then EFB (eigenvectors, update, invert, sample)
+    torch.manual_seed(0)
+    r18 = models.resnet18().to(dev).train()
+    k3 = KFAC(r18)
+    _backward_once(r18, torch.randn(32, 3, 224, 224, device=dev))
+    c3 = {"workload": "ResNet-18 N=32, 21 layers: KFAC update / invert(1, 1000) / sample_and_replace; EFB constructor "
+                      "(eigenvectors of the 42 factors), update, invert(1, 1000), sample_and_replace"}
+    k3.update(batch_size=32)
+    c3["kfac_update_ms"] = _timed_gpu(lambda: k3.update(batch_size=32))
+    k3._fresh.update((layer, side) for layer in k3.state for side in (0, 1))        # back to one batch
+    k3.update(batch_size=32)
+    c3["kfac_invert_ms"] = _timed_gpu(lambda: k3.invert(1.0, 1000.0))
+    c3["kfac_sample_and_replace_ms"] = _timed_gpu(k3.sample_and_replace)
+    c3["kfac_step_ms"] = c3["kfac_update_ms"] + c3["kfac_invert_ms"] + c3["kfac_sample_and_replace_ms"]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e3 = EFB(r18, k3.state)
+    torch.cuda.synchronize()
+    c3["efb_eigenvectors_ms"] = (time.perf_counter() - t0) * 1e3
+    c3["efb_eigensolver_sweeps"] = int(getattr(ops.eigh, "last_sweeps", 0))
+    r18.load_state_dict(k3.model_state)
+    _backward_once(r18, torch.randn(32, 3, 224, 224, device=dev))
+    c3["efb_update_ms"] = _timed_gpu(lambda: e3.update(32))
+    c3["efb_invert_ms"] = _timed_gpu(lambda: e3.invert(1.0, 1000.0))
+    c3["efb_sample_and_replace_ms"] = _timed_gpu(e3.sample_and_replace)
+    out["config3_resnet18_kfac_efb"] = c3
+    del e3, k3, r18
+    torch.cuda.empty_cache()
+
+    # ---- config 5: ResNet-50 chain on the headline's factors: eigenvectors, EFB update, INF update / invert / sample
+    c5 = {"workload": f"ResNet-50 N={batch}, 54 layers, on the headline run's KFAC factors: EFB constructor (eigenvectors of "
+                      "the 108 factors), efb.update, INF(..., eigvecs=efb.eigvecs).update(rank=100), inf.invert at "
+                      "(1, 1000) and at the README's (145307, 60), inf.sample_and_replace"}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e5 = EFB(model50, kfac50.state)
+    torch.cuda.synchronize()
+    c5["eigenvectors_ms"] = (time.perf_counter() - t0) * 1e3
+    c5["eigensolver_sweeps"] = int(getattr(ops.eigh, "last_sweeps", 0))
+    model50.load_state_dict(kfac50.model_state)
+    _backward_once(model50, torch.randn(batch, 3, 224, 224, device=dev))
+    c5["efb_update_ms"] = _timed_gpu(lambda: e5.update(batch))
+    inf = INF(model50, e5.diags, kfac50.state, e5.state, eigvecs=e5.eigvecs)
+    c5["inf_update_rank100_ms"] = _timed_gpu(lambda: inf.update(rank=100), reps=2)
+    c5["inf_invert_1_1000_ms"] = _timed_gpu(lambda: inf.invert(1.0, 1000.0), reps=2)
+    c5["inf_invert_145307_60_ms"] = _timed_gpu(lambda: inf.invert(145307.0, 60.0), reps=2)
+    c5["inf_sample_and_replace_ms"] = _timed_gpu(inf.sample_and_replace)
+    c5["efb_invert_ms"] = _timed_gpu(lambda: e5.invert(1.0, 1000.0))
+    c5["efb_sample_and_replace_ms"] = _timed_gpu(e5.sample_and_replace)
+    out["config5_resnet50_efb_inf_chain"] = c5
+    return out
+
+
+def other_configs_cpu(budget_s=100.0):
+    """The oracle on the host cores for the other configurations, bounded: a leg whose predicted time exceeds 60 s
+    (eigendecompositions and the explicit Kronecker chain of INF at ResNet size) is skipped and says so."""
+    import oracle.curvature_oracle as o
+    from curvature_amd import models
+    cores, total, _ = _probe_threads()
+    torch.set_num_threads(cores)
+    res = {"cores": cores, "host_cpu_count": total, "kind": "port"}
+    t_start = time.perf_counter()
+
+    def left():
+        return budget_s - (time.perf_counter() - t_start)
+
+    # config 2 (and BASELINE.json's config 1: the reference's own CPU-runnable case): LeNet-5, N = 100
+    torch.manual_seed(0)
+    lenet = models.lenet5().eval()
+    rec, _, _ = o.capture(lenet, torch.rand(100, 1, 28, 28), seed=0)
+
+    def lenet_step():
+        st = o.model_kfac_update({}, lenet, rec)
+        inv = o.model_kfac_invert(st, 0.5, 1.0)
+        for layer, smp in o.model_kfac_sample(inv, lenet).items():
+            o.replace(smp, layer.weight.data, layer.bias.data)
+    for _ in range(3):
+        lenet_step()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        lenet_step()
+    res["config2_lenet5_n100_ms_per_step"] = (time.perf_counter() - t0) / 20 * 1e3
+
+    # how fast is a symmetric eigendecomposition here?  (n = 768, scaled with n^3 for the predictions below)
+    M = torch.randn(768, 768)
+    M = M @ M.t()
+    torch.linalg.eigh(M)
+    t0 = time.perf_counter()
+    torch.linalg.eigh(M)
+    eigh_unit = (time.perf_counter() - t0) / 768.0 ** 3
+
+    # config 3: ResNet-18, N = 32
+    if left() > 40:
+        torch.manual_seed(0)
+        r18 = models.resnet18().train()
+        rec, _, _ = o.capture(r18, torch.randn(32, 3, 224, 224), seed=0)
+        t0 = time.perf_counter()
+        st = o.model_kfac_update({}, r18, rec)
+        res["config3_resnet18_kfac_update_ms"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        inv = o.model_kfac_invert(st, 1.0, 1000.0)
+        res["config3_resnet18_kfac_invert_ms"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        for layer, smp in o.model_kfac_sample(inv, r18).items():
+            o.replace(smp, layer.weight.data, layer.bias.data if layer.bias is not None else None)
+        res["config3_resnet18_kfac_sample_and_replace_ms"] = (time.perf_counter() - t0) * 1e3
+        est = eigh_unit * sum(f.shape[0] ** 3 for pair in st.values() for f in pair)
+        if est < min(60.0, left()):
+            t0 = time.perf_counter()
+            for pair in st.values():
+                for f in pair:
+                    o.eigenvectors(f)
+            res["config3_resnet18_eigenvectors_ms"] = (time.perf_counter() - t0) * 1e3
+        else:
+            res["config3_resnet18_eigenvectors_ms"] = None
+            res["config3_resnet18_eigenvectors_note"] = (f"skipped: torch.linalg.eigh of the 42 factors predicted at {est:.0f} s "
+                                                         "on this host (n^3 scaling of a measured 768-wide decomposition)")
+        del st, inv, rec, r18
+    else:
+        res["config3_note"] = "skipped: CPU budget of the other-configs leg exhausted"
+
+    # config 5: eigenvectors of the 108 ResNet-50 factors; the reference's explicit-Kronecker pre_sampler is out of reach
+    n3 = 4.528e11                                          # SURVEY 8(d): sum of n^3 + m^3 over ResNet-50's 54 layers
+    est = eigh_unit * n3
+    res["config5_resnet50_eigenvectors_ms"] = None
+    if est < 60.0 and left() > est + 25.0:
+        torch.manual_seed(0)
+        r50 = models.resnet50().train()
+        rec, _, _ = o.capture(r50, torch.randn(32, 3, 224, 224), seed=0)
+        st = o.model_kfac_update({}, r50, rec)
+        t0 = time.perf_counter()
+        for pair in st.values():
+            for f in pair:
+                o.eigenvectors(f)
+        res["config5_resnet50_eigenvectors_ms"] = (time.perf_counter() - t0) * 1e3
+        del st, rec, r50
+    else:
+        res["config5_resnet50_eigenvectors_note"] = (f"skipped: torch.linalg.eigh of the 108 factors predicted at {est:.0f} s on this "
+                                                     f"host, {left():.0f} s of the leg's budget left")
+    res["config5_inf_note"] = ("INF.invert / sample: no CPU figure - the reference's pre_sampler materialises a (n m) x (a b) matrix "
+                               "per layer (SURVEY 3.3: 18-46 s and 1.2-4 GB per layer on 8 cores; fp32 Cholesky fails on some "
+                               "layers), far beyond the 60 s bound of this leg")
+    res["seconds_used"] = time.perf_counter() - t_start
+    return res
+
+
+def other_configs_cpu_subprocess(timeout_s=240):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-other-only"]
+    try:
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+        for line in reversed(proc.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"note": f"CPU leg failed (rc {proc.returncode}): {proc.stderr.strip()[-300:]}"}
+    except subprocess.TimeoutExpired:
+        return {"note": f"CPU leg did not finish within {timeout_s} s on this host and was stopped"}
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` without a torchrun environment: start N fresh rank processes (one per GPU) with
     torch.distributed.run and return its exit code.  Called before this process has made any HIP call (torch is
@@ -178,6 +396,8 @@ def spawn_ranks(args) -> int:
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
+    if args.no_other_configs:
+        cmd.append("--no-other-configs")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
@@ -190,10 +410,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the untimed-region legs for BASELINE.json's configs 2, 3 and 5 (`other_configs`)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-other-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:                      # child of cpu_baseline_subprocess: CPU only, no GPU call
         print(json.dumps(cpu_baseline(args.batch, 0)))
+        return
+    if args.cpu_other_only:                         # child of other_configs_cpu_subprocess: CPU only, no GPU call
+        print(json.dumps(other_configs_cpu()))
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -339,10 +565,13 @@ def main():
                                    "KFAC.update + invert(1.0, 1000.0) + sample_and_replace, 54 layers",
                        "batch": args.batch, "layers": n_layers, "accumulation_restarts_every": 16,
                        "parallelism": f"layer-sharded x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "curv::syrk_patch_kernel + curv::syrk_flat_kernel (the factor build: "
-                                                       "implicit-im2col kernel + LDS-DMA kernel for flattened factors and "
-                                                       "the shifted correlations of 3x3 factors, timed together with the "
-                                                       "padding pass in front of them)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "curv::syrk_flat_kernel + curv::syrk_pre_kernel + curv::syrk_patch_kernel: the "
+                                                       "MFMA kernels of the factor build (LDS-DMA kernel for flattened factors and "
+                                                       "the shifted correlations of 3x3 factors; implicit-im2col kernel with LDS-DMA "
+                                                       "staging from pre-tiled copies; its register-staged variant on a side stream), "
+                                                       "HIP events from the padding / pre-tiling passes in front of them to the end of "
+                                                       "the last one.  NOT inside: the k-slice reduction and assembly passes behind "
+                                                       "them (build_ms_with_reduce has them)", "achieved": achieved,
                          "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_F32_MFMA / 1e12),
                          "traffic": traffic, "traffic_source": traffic_source,
                          "flops_counted": "what the launch plan executes (curv_kfac_plan_info): n(n+1)K per symmetric "
@@ -351,12 +580,23 @@ def main():
                          "direct_symmetric_gflop": direct_flops / 1e9,
                          "direct_symmetric_tflops": direct_flops / syrk_s / 1e12,
                          "dense_equivalent_tflops": dense_flops / syrk_s / 1e12,
-                         "kernel_ms": syrk_s * 1e3},
+                         "kernel_ms": syrk_s * 1e3,
+                         "build_ms_with_reduce": phase[0] / args.steps,
+                         "frac_with_reduce": plan_flops / (phase[0] / args.steps * 1e-3) / PEAK_F32_MFMA},
             "phases_ms": {"update": phase[0] / args.steps, "invert": phase[1] / args.steps,
                           "sample_and_replace": phase[2] / args.steps},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args.batch)
+        if world == 1 and not args.no_other_configs:
+            # BASELINE.json's configs 2, 3 and 5: after the timed region, never inside it
+            try:
+                other = other_configs_gpu(dev, model, kfac, args.batch)
+            except Exception as exc:                         # the headline line must survive a failure here
+                other = {"error": f"{type(exc).__name__}: {exc}"}
+            if not args.no_cpu_baseline:
+                other["cpu_oracle"] = other_configs_cpu_subprocess()
+            out["other_configs"] = other
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -1239,7 +1239,7 @@ extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors,
 // side stream for the register-staged patch kernel (few, long, latency-bound items: flattened factors narrower than a
 // 128-row tile, strided 1x1 convolutions, Linear layers): it runs beside the padding / pre-tiling passes and the two
 // LDS-DMA kernels instead of in front of them with a tail of its own
-struct SyrkStreams { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+struct SyrkStreams { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr, join_r = nullptr; };
 static int syrk_streams(SyrkStreams** out) {
   static thread_local std::vector<std::pair<int, SyrkStreams>> cache;
   int dev = 0;
@@ -1249,6 +1249,7 @@ static int syrk_streams(SyrkStreams** out) {
   CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking));
   CURV_HIP_CHECK(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
   CURV_HIP_CHECK(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+  CURV_HIP_CHECK(hipEventCreateWithFlags(&s.join_r, hipEventDisableTiming));
   cache.emplace_back(dev, s);
   *out = &cache.back().second;
   return CURV_OK;
@@ -1328,36 +1329,41 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
     CURV_HIP_CHECK(hipEventRecord(ss->fork, stream));
     CURV_HIP_CHECK(hipStreamWaitEvent(ss->side, ss->fork, 0));
   }
+  auto reduce = [&](hipStream_t on, int list, int first, int count) -> int {
+    if (plan.n_sub[list] <= 0) return CURV_OK;
+    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub[list]), dim3(SYRK_THREADS), 0, on, table + first, count, slabs);
+    CURV_LAUNCH_CHECK();
+    return CURV_OK;
+  };
   if (plan.n_items[0] > 0) {
     const int grid = cdiv(plan.n_items[0], 8 * XCD_GROUP) * 8 * XCD_GROUP;
     hipLaunchKernelGGL(syrk_patch_kernel, dim3(grid), dim3(SYRK_THREADS), 0, fork ? ss->side : stream, table, n0,
                        plan.n_items[0], slabs, zeros);
     CURV_LAUNCH_CHECK();
-    if (fork) CURV_HIP_CHECK(hipEventRecord(ss->join, ss->side));
+    if (fork) {
+      CURV_HIP_CHECK(hipEventRecord(ss->join, ss->side));
+      // its k-slices are summed on the side stream too, beside the MFMA kernels of the caller's stream
+      if ((rc = reduce(ss->side, 0, 0, n0)) != CURV_OK) return rc;
+    }
   }
   if (n2 > 0) {
     const int grid = cdiv(plan.n_items[2], 8 * XCD_GROUP) * 8 * XCD_GROUP;
     hipLaunchKernelGGL(syrk_pre_kernel, dim3(grid), dim3(SYRK_THREADS), 0, stream, table + n0 + n1, n2, plan.n_items[2], slabs);
     CURV_LAUNCH_CHECK();
   }
+  // (summing the pre-tiled kernel's k-slices on the side stream as well, beside the LDS-DMA kernel, was measured on one
+  // box: update() 6.85 -> 6.79 ms, the MFMA kernels 5.98 -> 6.05 ms - a wash; they stay behind the kernels)
+  if (fork) CURV_HIP_CHECK(hipEventRecord(ss->join_r, ss->side));
   if (plan.n_items[1] > 0) {
     const int rc1 = launch_syrk_flat(stream, table + n0, n1, plan.n_items[1], slabs);
     if (rc1 != CURV_OK) return rc1;
   }
-  if (fork) CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->join, 0));
+  if (fork) CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->join, 0));           // the register-staged MFMA kernel is done
   if (ev_stop) CURV_HIP_CHECK(hipEventRecord((hipEvent_t)ev_stop, stream));
-  if (plan.n_sub[0] > 0) {
-    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub[0]), dim3(SYRK_THREADS), 0, stream, table, n0, slabs);
-    CURV_LAUNCH_CHECK();
-  }
-  if (plan.n_sub[1] > 0) {
-    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub[1]), dim3(SYRK_THREADS), 0, stream, table + n0, n1, slabs);
-    CURV_LAUNCH_CHECK();
-  }
-  if (plan.n_sub[2] > 0) {
-    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub[2]), dim3(SYRK_THREADS), 0, stream, table + n0 + n1, n2, slabs);
-    CURV_LAUNCH_CHECK();
-  }
+  if (fork) CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->join_r, 0));
+  if (!fork && (rc = reduce(stream, 0, 0, n0)) != CURV_OK) return rc;
+  if ((rc = reduce(stream, 1, n0, n1)) != CURV_OK) return rc;
+  if ((rc = reduce(stream, 2, n0 + n1, n2)) != CURV_OK) return rc;
   if (!plan.corr.empty()) return launch_corr_assemble(stream, plan.corr, plan.f, area);
   return CURV_OK;
 }
