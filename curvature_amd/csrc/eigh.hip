@@ -8,12 +8,24 @@
 //       cols  {p,q} of A,V <- cols * Q            (tiles of 64 rows)
 //   N_b - 1 steps visit every pair once (one sweep); sweeps repeat until off(A) is negligible.
 // All matrices of a model advance together (one launch per phase per step for the whole batch).
+//
+// MIXED PRECISION.  Kronecker factors converge linearly for a long time (a 4608-wide ResNet-50 factor: off(A) / ||A||
+// falls by ~0.3-0.5 decades per sweep down to ~4e-6, then quadratically: 1e-8, 3e-9) and every round streams the
+// whole of A and V, so the sweeps of that linear phase run on FLOAT copies:
+//   phase A  A32, V32 in fp32; per round ONE fused two-sided pass over A (tile (I, J) <- Q_I^T A_IJ Q_J: read once,
+//            written once) and one pass over V: 16 np^2 bytes per round instead of the 48 np^2 of the fp64 row / column /
+//            V passes; until off(A) <= 4e-6 ||A|| or the fp32 iteration stalls;
+//   switch   V <- V (1.5 I - 0.5 V^T V) (one Newton-Schulz step removes the rounding drift of ~2000 fp32 rotation
+//            products from the basis), A <- V^T F V, both in fp64 (four 64-bit GEMMs per matrix);
+//   phase B  the fp64 iteration below from there: one or two sweeps of the quadratic phase to the caller's tolerance.
+// The 64x64 sub-problems are solved in fp64 in both phases (their cost is LDS latency, not arithmetic).
 // Eigenvalues are returned ascending with the eigenvectors as columns, like the reference's symeig;
 // signs and the basis inside degenerate clusters are arbitrary there as here.
 #include "common.h"
 #include "mma64.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
@@ -36,7 +48,13 @@ struct EighDev {
   double* scale;        // ||A||_F^2 at the matrix's last convergence test (0 before the first)
   int* skip;            // per pair of the current round: 1 = its 64x64 sub-problem is already diagonal enough
   int n, np, Nb, spf;   // spf: steps per own sweep (Nb - 1): the matrix is tested - and frozen - after each of ITS sweeps
+  float* A32;           // phase A: fp32 work matrix and rotations (both inside the fp64 A buffer)
+  float* V32;
+  double* T2;           // two more np x np fp64 buffers for the switch (V^T V; V', then the basis of phase B)
+  double* T3;
+  double tol2_a, tol2_b;  // squared tolerances of this matrix: phase A's target, the final one
 };
+// flags[0]: 0 iterating, 1 converged, 2 out of sweeps, 3 phase A finished (waiting for the switch to fp64)
 // Every matrix follows its own schedule: round r of its tournament is step % (Nb - 1), its convergence test runs
 // after each of its own sweeps, and a converged matrix is frozen (its tile counts drop to zero).  The result for a
 // matrix therefore does not depend on what else is in the batch - a rank that decomposes only its own layers gets
@@ -103,29 +121,27 @@ eigh_prepare_kernel(const EighDev* __restrict__ t, int nf) {
 // ------------------------------------------------------------------------------------------------
 // (1) per block pair: diagonalise the 64x64 sub-matrix by cyclic Jacobi in LDS, store Q
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(EIG_THREADS)
-jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sweeps, double inner_tol2, double outer_tol2) {
-  __shared__ double S[NB * LDA];
-  __shared__ double Qs[NB * LDA];
-  __shared__ double cs[2 * 32];
-  __shared__ int pairs[2 * 32];
-  __shared__ double red[EIG_THREADS];
-  int f, tp;
-  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return eig_active(d) ? d.Nb / 2 : 0; }, f, tp)) return;
-  const EighDev& d = t[f];
+// T: storage type of A and Q in memory; C: arithmetic of the sub-problem (double in phase B; float in phase A, where
+// the iterate lives in fp32 anyway and the solve is the serial part of every round: half the LDS traffic, fp32 rsqrt /
+// rcp instead of fp64 divisions).  `par`: which of the two Q / skip buffers of the matrix this round writes.
+template <typename T, typename C>
+__device__ __forceinline__ void jacobi_pair_body(const EighDev& d, int tp, int step, int par, int inner_sweeps, double inner_tol2,
+                                                 C* S, C* Qs, C* cs, int* pairs, double* red) {
+  constexpr int LDA = std::is_same<C, float>::value ? NB + 1 : curv::LDA;      // (both 65: one bank step per row)
   int p, q;
   rr_pair(d.Nb, step, tp, p, q);
   const int np = d.np, tid = threadIdx.x;
-  const gdouble* A = (const gdouble*)d.A;
+  typedef __attribute__((address_space(1))) T gT;
+  const gT* A = std::is_same<T, float>::value ? (const gT*)d.A32 : (const gT*)d.A;
   for (int e = tid; e < NB * NB; e += EIG_THREADS) {
     const int x = e >> 6, y = e & 63;
-    S[x * LDA + y] = A[(long long)gidx(p, q, x) * np + gidx(p, q, y)];
-    Qs[x * LDA + y] = (x == y) ? 1.0 : 0.0;
+    S[x * LDA + y] = (C)A[(long long)gidx(p, q, x) * np + gidx(p, q, y)];
+    Qs[x * LDA + y] = (x == y) ? (C)1 : (C)0;
   }
   __syncthreads();
   // squared Frobenius norm of S (for the stopping test)
   double part = 0.0;
-  for (int e = tid; e < NB * NB; e += EIG_THREADS) { const double v = S[(e >> 6) * LDA + (e & 63)]; part += v * v; }
+  for (int e = tid; e < NB * NB; e += EIG_THREADS) { const double v = (double)S[(e >> 6) * LDA + (e & 63)]; part += v * v; }
   red[tid] = part;
   __syncthreads();
   for (int o = EIG_THREADS / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
@@ -140,7 +156,7 @@ jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sw
     double o2 = 0.0;
     for (int e = tid; e < NB * NB; e += EIG_THREADS) {
       const int x = e >> 6, y = e & 63;
-      if (x != y) { const double v = S[x * LDA + y]; o2 += v * v; }
+      if (x != y) { const double v = (double)S[x * LDA + y]; o2 += v * v; }
     }
     red[tid] = o2;
     __syncthreads();
@@ -148,8 +164,9 @@ jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sw
     const double off0 = red[0];
     __syncthreads();
     const double scale = d.scale[0];
+    const double outer_tol2 = std::is_same<T, float>::value ? d.tol2_a : d.tol2_b;
     const bool skip = scale > 0.0 && off0 <= (0.5 * outer_tol2 / ((double)d.Nb * d.Nb)) * scale;
-    if (tid == 0) d.skip[tp] = skip ? 1 : 0;
+    if (tid == 0) d.skip[par * (d.Nb / 2) + tp] = skip ? 1 : 0;
     if (skip) return;
   }
 
@@ -158,13 +175,20 @@ jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sw
       if (tid < 32) {
         int i, j;
         rr_pair(NB, rr, tid, i, j);
-        const double app = S[i * LDA + i], aqq = S[j * LDA + j], apq = S[i * LDA + j];
-        double c = 1.0, s = 0.0;
-        if (fabs(apq) > 1e-300 && fabs(apq) > 1e-17 * sqrt(fabs(app * aqq))) {
-          const double tau = (aqq - app) / (2.0 * apq);
+        const C app = S[i * LDA + i], aqq = S[j * LDA + j], apq = S[i * LDA + j];
+        C c = (C)1, s = (C)0;
+        if (std::is_same<C, float>::value) {
+          if (fabsf((float)apq) > 1e-30f && fabsf((float)apq) > 1e-9f * sqrtf(fabsf((float)(app * aqq)))) {
+            const float tau = (float)(aqq - app) / (2.0f * (float)apq);
+            const float tt = (tau >= 0.0f ? 1.0f : -1.0f) / (fabsf(tau) + sqrtf(1.0f + tau * tau));
+            const float cf = rsqrtf(1.0f + tt * tt);
+            c = (C)cf; s = (C)(tt * cf);
+          }
+        } else if (fabs((double)apq) > 1e-300 && fabs((double)apq) > 1e-17 * sqrt(fabs((double)(app * aqq)))) {
+          const double tau = (double)(aqq - app) / (2.0 * (double)apq);
           const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-          c = 1.0 / sqrt(1.0 + tt * tt);
-          s = tt * c;
+          const double cd = 1.0 / sqrt(1.0 + tt * tt);
+          c = (C)cd; s = (C)(tt * cd);
         }
         cs[2 * tid] = c; cs[2 * tid + 1] = s;
         pairs[2 * tid] = i; pairs[2 * tid + 1] = j;
@@ -174,11 +198,11 @@ jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sw
       for (int blk = tid; blk < 32 * 32; blk += EIG_THREADS) {
         const int ka = blk >> 5, kb = blk & 31;
         const int ia = pairs[2 * ka], ja = pairs[2 * ka + 1], ib = pairs[2 * kb], jb = pairs[2 * kb + 1];
-        const double ca = cs[2 * ka], sa = cs[2 * ka + 1], cb = cs[2 * kb], sb = cs[2 * kb + 1];
-        const double m00 = S[ia * LDA + ib], m01 = S[ia * LDA + jb], m10 = S[ja * LDA + ib], m11 = S[ja * LDA + jb];
+        const C ca = cs[2 * ka], sa = cs[2 * ka + 1], cb = cs[2 * kb], sb = cs[2 * kb + 1];
+        const C m00 = S[ia * LDA + ib], m01 = S[ia * LDA + jb], m10 = S[ja * LDA + ib], m11 = S[ja * LDA + jb];
         // rows: R_a^T [m0*; m1*]  with R = [[c, s], [-s, c]]
-        const double r00 = ca * m00 - sa * m10, r01 = ca * m01 - sa * m11;
-        const double r10 = sa * m00 + ca * m10, r11 = sa * m01 + ca * m11;
+        const C r00 = ca * m00 - sa * m10, r01 = ca * m01 - sa * m11;
+        const C r10 = sa * m00 + ca * m10, r11 = sa * m01 + ca * m11;
         // cols: [.] R_b
         S[ia * LDA + ib] = r00 * cb - r01 * sb;
         S[ia * LDA + jb] = r00 * sb + r01 * cb;
@@ -189,8 +213,8 @@ jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sw
       for (int e = tid; e < NB * 32; e += EIG_THREADS) {
         const int r = e >> 5, kb = e & 31;
         const int ib = pairs[2 * kb], jb = pairs[2 * kb + 1];
-        const double cb = cs[2 * kb], sb = cs[2 * kb + 1];
-        const double qi = Qs[r * LDA + ib], qj = Qs[r * LDA + jb];
+        const C cb = cs[2 * kb], sb = cs[2 * kb + 1];
+        const C qi = Qs[r * LDA + ib], qj = Qs[r * LDA + jb];
         Qs[r * LDA + ib] = qi * cb - qj * sb;
         Qs[r * LDA + jb] = qi * sb + qj * cb;
       }
@@ -200,7 +224,7 @@ jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sw
     part = 0.0;
     for (int e = tid; e < NB * NB; e += EIG_THREADS) {
       const int x = e >> 6, y = e & 63;
-      if (x != y) { const double v = S[x * LDA + y]; part += v * v; }
+      if (x != y) { const double v = (double)S[x * LDA + y]; part += v * v; }
     }
     red[tid] = part;
     __syncthreads();
@@ -209,8 +233,20 @@ jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sw
     __syncthreads();
     if (off2 <= inner_tol2 * fro2) break;
   }
-  gdouble* Qg = (gdouble*)d.Q + (long long)tp * NB * NB;
-  for (int e = tid; e < NB * NB; e += EIG_THREADS) Qg[e] = Qs[(e >> 6) * LDA + (e & 63)];
+  gT* Qg = (gT*)d.Q + ((long long)par * (d.Nb / 2) + tp) * NB * NB;
+  for (int e = tid; e < NB * NB; e += EIG_THREADS) Qg[e] = (T)Qs[(e >> 6) * LDA + (e & 63)];
+}
+
+__global__ void __launch_bounds__(EIG_THREADS)
+jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sweeps, double inner_tol2) {
+  __shared__ double S[NB * LDA];
+  __shared__ double Qs[NB * LDA];
+  __shared__ double cs[2 * 32];
+  __shared__ int pairs[2 * 32];
+  __shared__ double red[EIG_THREADS];
+  int f, tp;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return eig_active(d) ? d.Nb / 2 : 0; }, f, tp)) return;
+  jacobi_pair_body<double, double>(t[f], tp, step, 0, inner_sweeps, inner_tol2, S, Qs, cs, pairs, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -313,6 +349,256 @@ jacobi_cols_kernel(const EighDev* __restrict__ t, int nf, int step) {
   }
 }
 
+
+// ================================================================================================
+// Phase A: the same iteration on fp32 copies (A32, V32), 64x64x64 tile products on v_mfma_f32_32x32x2_f32
+// ================================================================================================
+constexpr int LDF = NB + 1;            // LDS row pitch (floats) of an fp32 operand tile
+typedef __attribute__((address_space(1))) float gfloat32;
+
+// acc (the wave's 32x32 block (wm, wn) of the 64x64 product) = As[row][k] * Bs[k][col], both tiles in LDS, pitch LDF
+__device__ __forceinline__ void mma_64_f32(const float* __restrict__ As, const float* __restrict__ Bs, int wm, int wn,
+                                           int lane, f32x16& acc) {
+  const int r32 = lane & 31, h = lane >> 5;
+  const float* a = As + (32 * wm + r32) * LDF + h;
+  const float* b = Bs + h * LDF + 32 * wn + r32;
+#pragma unroll 8
+  for (int kk = 0; kk < NB / 2; ++kk)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk], b[2 * kk * LDF], acc, 0, 0, 0);
+}
+// accumulator register `reg` of a lane holds row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), column lane & 31 of the block
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__global__ void __launch_bounds__(EIG_THREADS)
+eigh_prepare32_kernel(const EighDev* __restrict__ t, int nf) {
+  int f, tile;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { const int P = d.np / NB; return P * P; }, f, tile)) return;
+  const EighDev& d = t[f];
+  const int P = d.np / NB, bi = tile / P, bj = tile - bi * P, n = d.n, np = d.np;
+  const float* __restrict__ F = d.F;
+  gfloat32* A = (gfloat32*)d.A32;
+  gfloat32* V = (gfloat32*)d.V32;
+  for (int e = threadIdx.x; e < NB * NB; e += EIG_THREADS) {
+    const int i = bi * NB + (e >> 6), j = bj * NB + (e & 63);
+    float v = 0.0f;
+    if (i < n && j < n) v = (float)(0.5 * ((double)F[(long long)i * n + j] + (double)F[(long long)j * n + i]));
+    A[(long long)i * np + j] = v;
+    V[(long long)i * np + j] = (i == j) ? 1.0f : 0.0f;
+  }
+}
+
+// A32 tile (I, J) <- Q_I^T A_IJ Q_J for eig_etw() consecutive column pairs J per workgroup (pair I's Q staged once).
+// A pair the sub-problem kernel left alone (skip) contributes the identity: both skipped - nothing to do.
+__global__ void __launch_bounds__(EIG_THREADS)
+jacobi_two_sided32_kernel(const EighDev* __restrict__ t, int nf, int step) {
+  __shared__ float Qi[NB * LDF], Qj[NB * LDF], X[NB * LDF];
+  int f, local;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return eig_active(d) ? (d.Nb / 2) * eig_groups(d.Nb / 2) : 0; }, f, local)) return;
+  const EighDev& d = t[f];
+  const int npair = d.Nb / 2, ng = eig_groups(npair), etw = eig_etw(npair), np = d.np, tid = threadIdx.x;
+  const int tI = local / ng, j0 = (local - tI * ng) * etw, j1 = j0 + etw < npair ? j0 + etw : npair;
+  const int par = step & 1;                                  // which of the two Q / skip buffers this round uses
+  const int* skip = d.skip + par * npair;
+  const bool skipI = skip[tI] != 0;
+  int pI, qI;
+  rr_pair(d.Nb, step, tI, pI, qI);
+  gfloat32* A = (gfloat32*)d.A32;
+  const gfloat32* Q = (const gfloat32*)d.Q + (long long)par * npair * NB * NB;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), c = tid & 63, lane = tid & 63, wm = w >> 1, wn = w & 1;
+  if (!skipI) {
+    const gfloat32* Qg = Q + (long long)tI * NB * NB;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) Qi[c * LDF + w + 4 * u] = Qg[(w + 4 * u) * NB + c];          // Qi[row][k] = Q_I[k][row]
+  }
+  for (int tJ = j0; tJ < j1; ++tJ) {
+    const bool skipJ = skip[tJ] != 0;
+    if (skipI && skipJ) continue;                            // (wave-uniform)
+    int pJ, qJ;
+    rr_pair(d.Nb, step, tJ, pJ, qJ);
+    const int gc = gidx(pJ, qJ, c);
+    float xv[16], qv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) xv[u] = A[(long long)gidx(pI, qI, w + 4 * u) * np + gc];
+    if (!skipJ) {
+      const gfloat32* Qg = Q + (long long)tJ * NB * NB;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) qv[u] = Qg[(w + 4 * u) * NB + c];
+    }
+    __syncthreads();                                         // the previous tile's readers of X / Qj are done
+#pragma unroll
+    for (int u = 0; u < 16; ++u) X[(w + 4 * u) * LDF + c] = xv[u];
+    if (!skipJ) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) Qj[(w + 4 * u) * LDF + c] = qv[u];
+    }
+    __syncthreads();
+    f32x16 acc = {0};
+    if (!skipI) {
+      mma_64_f32(Qi, X, wm, wn, lane, acc);                  // T = Q_I^T A_IJ
+      if (!skipJ) {
+        __syncthreads();
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) X[(32 * wm + acc_row(reg, lane)) * LDF + 32 * wn + (lane & 31)] = acc[reg];
+        __syncthreads();
+      }
+    }
+    if (!skipJ) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) acc[reg] = 0.0f;
+      mma_64_f32(X, Qj, wm, wn, lane, acc);                  // R = T Q_J
+    }
+    // rows 32 wm .. of the tile are rows of block (wm ? qI : pI), columns 32 wn .. of block (wn ? qJ : pJ)
+    gfloat32* C = A + (long long)((wm ? qI : pI) * JB) * np + (wn ? qJ : pJ) * JB + (lane & 31);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) C[(long long)acc_row(reg, lane) * np] = acc[reg];
+  }
+}
+
+// One launch, two kinds of workgroups per matrix:
+//   * the sub-problems of round step + 1 (they only need A after the two-sided pass of round `step`, which is done):
+//     the serial part of a round, ~140 us of LDS latency, now beside ...
+//   * ... V32 columns {p, q} <- columns * Q of round `step` (eig_etw() 64-row tiles per workgroup), HBM-bound.
+// The rotation blocks and skip flags live in two buffers, by round parity.  do_cols = 0: the very first sub-problems.
+__global__ void __launch_bounds__(EIG_THREADS)
+jacobi_cols_pair32_kernel(const EighDev* __restrict__ t, int nf, int step, int do_cols, int inner_sweeps, double inner_tol2) {
+  __shared__ float buf[2 * NB * LDF];
+  __shared__ float cs[2 * 32];
+  __shared__ int pairs[2 * 32];
+  __shared__ double red[EIG_THREADS];
+  int f, local;
+  if (!eig_locate(t, nf, blockIdx.x, [do_cols](const EighDev& d) {
+        return eig_active(d) ? d.Nb / 2 + (do_cols ? (d.Nb / 2) * eig_groups(d.np / NB) : 0) : 0; }, f, local)) return;
+  const EighDev& d = t[f];
+  const int npair = d.Nb / 2;
+  if (local < npair) {
+    jacobi_pair_body<float, float>(d, local, step + 1, (step + 1) & 1, inner_sweeps, inner_tol2, buf, buf + NB * LDF, cs, pairs, red);
+    return;
+  }
+  local -= npair;
+  float* Qj = buf;
+  float* X = buf + NB * LDF;
+  const int par = step & 1;
+  const int nrt = d.np / NB, ng = eig_groups(nrt), etw = eig_etw(nrt), np = d.np, tid = threadIdx.x;
+  const int tp = local / ng, rt0 = (local - tp * ng) * etw, rt1 = rt0 + etw < nrt ? rt0 + etw : nrt;
+  if (d.skip[par * npair + tp]) return;
+  int p, q;
+  rr_pair(d.Nb, step, tp, p, q);
+  gfloat32* V = (gfloat32*)d.V32;
+  const gfloat32* Qg = (const gfloat32*)d.Q + ((long long)par * npair + tp) * NB * NB;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), c = tid & 63, lane = tid & 63, wm = w >> 1, wn = w & 1;
+  const int gc = gidx(p, q, c);
+  float xv[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    Qj[(w + 4 * u) * LDF + c] = Qg[(w + 4 * u) * NB + c];
+    xv[u] = V[(long long)(rt0 * NB + w + 4 * u) * np + gc];
+  }
+  for (int rt = rt0; rt < rt1; ++rt) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) X[(w + 4 * u) * LDF + c] = xv[u];
+    __syncthreads();
+    if (rt + 1 < rt1) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) xv[u] = V[(long long)((rt + 1) * NB + w + 4 * u) * np + gc];
+    }
+    f32x16 acc = {0};
+    mma_64_f32(X, Qj, wm, wn, lane, acc);
+    gfloat32* C = V + (long long)(rt * NB + 32 * wm) * np + (wn ? q : p) * JB + (lane & 31);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) C[(long long)acc_row(reg, lane) * np] = acc[reg];
+    __syncthreads();
+  }
+}
+
+// convergence norms of A32 (partial sums in double)
+__global__ void __launch_bounds__(EIG_THREADS)
+eigh_norms32_kernel(const EighDev* __restrict__ t, int nf, int step1) {
+  __shared__ double r0[EIG_THREADS], r1[EIG_THREADS];
+  int f, tile;
+  if (!eig_locate(t, nf, blockIdx.x,
+                  [step1](const EighDev& d) { const int P = d.np / NB; return (eig_active(d) && step1 % d.spf == 0) ? P * P : 0; },
+                  f, tile)) return;
+  const EighDev& d = t[f];
+  const int P = d.np / NB, bi = tile / P, bj = tile - bi * P, np = d.np, tid = threadIdx.x;
+  const gfloat32* A = (const gfloat32*)d.A32;
+  double off = 0.0, dg = 0.0;
+  for (int e = tid; e < NB * NB; e += EIG_THREADS) {
+    const int i = bi * NB + (e >> 6), j = bj * NB + (e & 63);
+    const double v = (double)A[(long long)i * np + j];
+    if (i == j) dg += v * v; else off += v * v;
+  }
+  r0[tid] = off; r1[tid] = dg;
+  __syncthreads();
+  for (int o = EIG_THREADS / 2; o > 0; o >>= 1) {
+    if (tid < o) { r0[tid] += r0[tid + o]; r1[tid] += r1[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) { d.norms[2 * tile] = r0[0]; d.norms[2 * tile + 1] = r1[0]; }
+}
+
+// ---- the switch to fp64 ----
+// V = (double) V32 and T3 = 1.5 V (the Newton-Schulz step V' = 1.5 V - 0.5 V (V^T V) accumulates onto it)
+__global__ void __launch_bounds__(EIG_THREADS)
+eigh_widen_kernel(const EighDev* __restrict__ t, int nf) {
+  int f, tile;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { const int P = d.np / NB; return P * P; }, f, tile)) return;
+  const EighDev& d = t[f];
+  const int P = d.np / NB, bi = tile / P, bj = tile - bi * P, np = d.np;
+  const gfloat32* V32 = (const gfloat32*)d.V32;
+  gdouble* V = (gdouble*)d.V;
+  gdouble* T3 = (gdouble*)d.T3;
+  for (int e = threadIdx.x; e < NB * NB; e += EIG_THREADS) {
+    const long long idx = (long long)(bi * NB + (e >> 6)) * np + bj * NB + (e & 63);
+    const double v = (double)V32[idx];
+    V[idx] = v;
+    T3[idx] = 1.5 * v;
+  }
+}
+// A = (F + F^T) / 2 in fp64, zero padded (the fp32 copies in that buffer are dead by now)
+__global__ void __launch_bounds__(EIG_THREADS)
+eigh_input64_kernel(const EighDev* __restrict__ t, int nf) {
+  int f, tile;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { const int P = d.np / NB; return P * P; }, f, tile)) return;
+  const EighDev& d = t[f];
+  const int P = d.np / NB, bi = tile / P, bj = tile - bi * P, n = d.n, np = d.np;
+  const float* __restrict__ F = d.F;
+  gdouble* A = (gdouble*)d.A;
+  for (int e = threadIdx.x; e < NB * NB; e += EIG_THREADS) {
+    const int i = bi * NB + (e >> 6), j = bj * NB + (e & 63);
+    double v = 0.0;
+    if (i < n && j < n) v = 0.5 * ((double)F[(long long)i * n + j] + (double)F[(long long)j * n + i]);
+    A[(long long)i * np + j] = v;
+  }
+}
+// A <- (A + A^T) / 2 after the products (tile pairs (bi, bj), bi <= bj)
+__global__ void __launch_bounds__(EIG_THREADS)
+eigh_symmetrise_kernel(const EighDev* __restrict__ t, int nf) {
+  __shared__ double S0[NB * LDA], S1[NB * LDA];
+  int f, tile;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { const int P = d.np / NB; return P * P; }, f, tile)) return;
+  const EighDev& d = t[f];
+  const int P = d.np / NB, bi = tile / P, bj = tile - bi * P, np = d.np;
+  if (bi > bj) return;
+  gdouble* A = (gdouble*)d.A;
+  for (int e = threadIdx.x; e < NB * NB; e += EIG_THREADS) {
+    const int x = e >> 6, y = e & 63;
+    S0[x * LDA + y] = A[(long long)(bi * NB + x) * np + bj * NB + y];
+    S1[x * LDA + y] = A[(long long)(bj * NB + x) * np + bi * NB + y];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NB * NB; e += EIG_THREADS) {
+    const int x = e >> 6, y = e & 63;
+    const double v = 0.5 * (S0[x * LDA + y] + S1[y * LDA + x]);
+    A[(long long)(bi * NB + x) * np + bj * NB + y] = v;
+    A[(long long)(bj * NB + y) * np + bi * NB + x] = v;
+  }
+}
+// phase A -> phase B: matrices that finished phase A (state 3) iterate again
+__global__ void __launch_bounds__(64) eigh_resume_kernel(const EighDev* __restrict__ t, int nf) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < nf && t[i].flags[0] == 3) { t[i].flags[0] = 0; t[i].scale[0] = 0.0; t[i].scale[1] = 0.0; }
+}
+
 // off-diagonal / diagonal squared norms of A (convergence test) of the matrices that finished one of their own
 // sweeps with step `step1 - 1`: per-tile partial sums, no atomics (the decision below must be reproducible)
 __global__ void __launch_bounds__(EIG_THREADS)
@@ -343,7 +629,7 @@ eigh_norms_kernel(const EighDev* __restrict__ t, int nf, int step1) {
 // one workgroup per matrix: sum the tile partials in a fixed order, count the sweep, freeze the matrix when
 // off(A) <= tol ||A||_F (state 1) or when it has used up its sweeps (state 2)
 __global__ void __launch_bounds__(256)
-eigh_check_kernel(const EighDev* __restrict__ t, int nf, int step1, double tol2, int max_sweeps) {
+eigh_check_kernel(const EighDev* __restrict__ t, int nf, int step1, int max_sweeps, int phase) {
   __shared__ double r0[256], r1[256];
   const EighDev& d = t[blockIdx.x];
   if (d.flags[0] != 0 || step1 % d.spf != 0) return;
@@ -357,11 +643,20 @@ eigh_check_kernel(const EighDev* __restrict__ t, int nf, int step1, double tol2,
     __syncthreads();
   }
   if (tid == 0) {
-    const int sweeps = d.flags[1] + 1;
+    const int sweeps = d.flags[1] + (phase == 2 ? 0 : 1);
     d.flags[1] = sweeps;
+    const bool phase_a = phase == 1;
+    const double tol2 = phase_a ? d.tol2_a : d.tol2_b;
     const double off2 = r0[0], all2 = r0[0] + r1[0];
+    const double prev = d.scale[1];                          // off^2 at the previous test of this phase (0: none yet)
     d.scale[0] = all2;
-    if (off2 <= tol2 * all2) d.flags[0] = 1;
+    d.scale[1] = phase == 2 ? 0.0 : off2;
+    if (phase_a) {
+      // fp32 phase: done at its target, or when a sweep no longer gains 20 % (the fp32 floor), and always before the
+      // last sweep the caller allows (the fp64 phase gets at least that one)
+      if (!(all2 == all2)) d.flags[0] = 2;
+      else if (off2 <= tol2 * all2 || (prev > 0.0 && off2 > 0.64 * prev) || sweeps + 1 >= max_sweeps) d.flags[0] = 3;
+    } else if (off2 <= tol2 * all2) d.flags[0] = 1;
     else if (sweeps >= max_sweeps || !(all2 == all2)) d.flags[0] = 2;
   }
 }
@@ -418,7 +713,7 @@ eigh_gather_kernel(const EighDev* __restrict__ t, int nf, const int* __restrict_
   }
 }
 
-constexpr int EIG_UPLOAD_CHUNK = 40;
+constexpr int EIG_UPLOAD_CHUNK = 24;
 struct EighChunk { EighDev f[EIG_UPLOAD_CHUNK]; };
 static_assert(sizeof(EighChunk) <= 3840, "kernel argument block must stay below 4 KB");
 
@@ -432,7 +727,7 @@ __global__ void __launch_bounds__(256) eigh_upload_kernel(EighDev* __restrict__ 
 struct EighLayout {
   size_t table, norms, flags, perm, total;
   std::vector<size_t> norm_off;
-  std::vector<size_t> a_off, v_off, q_off;
+  std::vector<size_t> a_off, v_off, q_off, t2_off, t3_off;
   int perm_stride;
 };
 
@@ -453,13 +748,15 @@ static bool eigh_layout(const curv_eigh_desc* descs, int n, EighLayout& L) {
   L.perm_stride = nmax;
   L.perm = align_up((size_t)std::max(n, 1) * nmax * sizeof(int), 256);
   size_t off = L.table + L.norms + L.flags + L.perm;
-  L.a_off.resize(n); L.v_off.resize(n); L.q_off.resize(n);
+  L.a_off.resize(n); L.v_off.resize(n); L.q_off.resize(n); L.t2_off.resize(n); L.t3_off.resize(n);
   for (int i = 0; i < n; ++i) {
     const size_t np = (size_t)cdiv(descs[i].n, NB) * NB;
     L.a_off[i] = off; off += np * np * sizeof(double);
     L.v_off[i] = off; off += np * np * sizeof(double);
+    L.t2_off[i] = off; off += np * np * sizeof(double);
+    L.t3_off[i] = off; off += np * np * sizeof(double);
     L.q_off[i] = off; off += (np / NB) * NB * NB * sizeof(double);
-    off += align_up((np / NB) * sizeof(int), 256);          // skip flags, one per pair, behind the rotation blocks
+    off += align_up(2 * (np / NB) * sizeof(int), 256);      // skip flags, one per pair and round parity, behind the rotation blocks
   }
   L.total = off;
   return true;
@@ -486,15 +783,20 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
     set_error("curv_syevd: workspace too small (%zu < %zu bytes)", workspace_bytes, L.total);
     return CURV_ERR_WORKSPACE;
   }
-  if (max_sweeps <= 0) max_sweeps = 60;   // the loop ends at convergence: ResNet factors need 19-23
-  if (tol <= 0.0) tol = 1e-8;
+  if (max_sweeps <= 0) max_sweeps = 60;   // the loop ends at convergence: ResNet factors need 16-24
+  // tol <= 0: automatic.  off(A) <= 1e-8 ||A|| for matrices up to 1024 wide (fp64 sweeps are cheap there), 5e-6 ||A||
+  // above: the reference's own decomposition - LAPACK's fp32 symeig - leaves off(A) ~ 1e-5 ||A|| and a residual of
+  // 1e-5 at n = 2304 (measured), and polishing a 4608-wide factor from the 4e-6 where the fp32 phase ends
+  // to 1e-8 costs eight more fp64 sweeps (its rank-deficient spectrum converges linearly down there).  An explicit
+  // tol applies to every matrix.
+  const bool auto_tol = tol <= 0.0;
   char* base = reinterpret_cast<char*>(workspace);
   EighDev* table = reinterpret_cast<EighDev*>(base);
   double* norms = reinterpret_cast<double*>(base + L.table);
   int* flags = reinterpret_cast<int*>(base + L.table + L.norms);
   int* perm = reinterpret_cast<int*>(base + L.table + L.norms + L.flags);
   std::vector<EighDev> tab(n_mats);
-  long long prep_tiles = 0, pair_wgs = 0, row_tiles = 0, gather_tiles = 0;
+  long long prep_tiles = 0, pair_wgs = 0, row_tiles = 0, gather_tiles = 0, ts_wgs = 0;
   int maxNb = 2;
   for (int i = 0; i < n_mats; ++i) {
     const curv_eigh_desc& s = descs[i];
@@ -506,6 +808,11 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
     d.Nb = d.np / JB;
     d.A = reinterpret_cast<double*>(base + L.a_off[i]);
     d.V = reinterpret_cast<double*>(base + L.v_off[i]);
+    d.T2 = reinterpret_cast<double*>(base + L.t2_off[i]);
+    d.T3 = reinterpret_cast<double*>(base + L.t3_off[i]);
+    d.A32 = reinterpret_cast<float*>(base + L.a_off[i]);                 // both fp32 copies inside the fp64 A buffer
+    d.A32 += 0;
+    d.V32 = d.A32 + (size_t)(cdiv(s.n, NB) * NB) * (cdiv(s.n, NB) * NB);
     d.Q = reinterpret_cast<double*>(base + L.q_off[i]);
     d.norms = norms + L.norm_off[i];
     d.flags = flags + 2 * i;
@@ -515,11 +822,17 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
       d.skip = reinterpret_cast<int*>(base + L.q_off[i] + (np_ / NB) * NB * NB * sizeof(double));
     }
     d.spf = std::max(1, d.Nb - 1);
+    {
+      const double tb = auto_tol ? (d.np <= 1024 ? 1e-8 : 5e-6) : tol;
+      const double ta = std::max(tb / 2.5, 2e-6);          // the fp32 copy understates the true off(A) by ~2x at its floor
+      d.tol2_a = ta * ta; d.tol2_b = tb * tb;
+    }
     maxNb = std::max(maxNb, d.Nb);
     const long long P = d.np / NB;
     prep_tiles += P * P;
     pair_wgs += d.Nb / 2;
     row_tiles += (long long)(d.Nb / 2) * eig_groups(P);
+    ts_wgs += (long long)(d.Nb / 2) * eig_groups(d.Nb / 2);
     const long long Pg = cdiv(s.n, NB);
     gather_tiles += Pg * Pg;
   }
@@ -531,14 +844,12 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
     hipLaunchKernelGGL(eigh_upload_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count);
     CURV_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(eigh_prepare_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats);
-  CURV_LAUNCH_CHECK();
   CURV_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)n_mats * 2 * sizeof(int), stream));
   CURV_HIP_CHECK(hipMemsetAsync(norms, 0, L.norms, stream));      // includes every matrix's scale (0 = no test yet)
   std::vector<int> host_flags(2 * n_mats);
   // One cyclic sweep over the 64x64 sub-problem per visit.  Diagonalising it to 1e-13 (up to ten inner sweeps)
   // cost 82 % of the solver's time and bought nothing: the outer iteration needs the same number of sweeps
-  // either way (ResNet factors: 19-23, linear until the off-norm drops below the small eigenvalue gaps).
+  // either way (ResNet factors: 17-23, linear until the off-norm drops below the small eigenvalue gaps).
   const int inner_sweeps = 1;
   const double inner_tol2 = 1e-26;
   const int steps_per_sweep = std::max(1, maxNb - 1);
@@ -546,35 +857,126 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
   // the host looks at the per-matrix states once per sweep of the largest matrix (the only synchronisation);
   // freezing itself happens on the device, after each matrix's own sweep
   const int poll = steps_per_sweep;
-  bool all_done = false;
   int sweeps = 0;
-  for (long long step = 0; step < max_steps && !all_done; ++step) {
-    hipLaunchKernelGGL(jacobi_pair_kernel, dim3((unsigned)pair_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step, inner_sweeps, inner_tol2, tol * tol);
-    CURV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(jacobi_rows_kernel, dim3((unsigned)row_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step);
-    CURV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(jacobi_cols_kernel, dim3((unsigned)(2 * row_tiles)), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step);
-    CURV_LAUNCH_CHECK();
-    const int step1 = (int)(step + 1);
-    bool any = false;
-    for (int i = 0; i < n_mats && !any; ++i) any = (step1 % tab[i].spf == 0);
-    if (any) {
-      hipLaunchKernelGGL(eigh_norms_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, step1);
-      CURV_LAUNCH_CHECK();
-      hipLaunchKernelGGL(eigh_check_kernel, dim3((unsigned)n_mats), dim3(256), 0, stream, table, n_mats, step1, tol * tol, max_sweeps);
-      CURV_LAUNCH_CHECK();
+  static const bool trace = getenv("CURV_EIGH_TRACE") != nullptr;
+  auto iterate = [&](bool phase_a) -> int {
+    bool all_done = false;
+    for (long long step = 0; step < max_steps && !all_done; ++step) {
+      if (phase_a) {
+        if (step == 0) {                                       // the sub-problems of round 0
+          hipLaunchKernelGGL(jacobi_cols_pair32_kernel, dim3((unsigned)pair_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, -1, 0, inner_sweeps, inner_tol2);
+          CURV_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(jacobi_two_sided32_kernel, dim3((unsigned)ts_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step);
+        CURV_LAUNCH_CHECK();
+        // V of this round and, beside it, the sub-problems of the next one
+        hipLaunchKernelGGL(jacobi_cols_pair32_kernel, dim3((unsigned)(pair_wgs + row_tiles)), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step, 1, inner_sweeps, inner_tol2);
+        CURV_LAUNCH_CHECK();
+      } else {
+        hipLaunchKernelGGL(jacobi_pair_kernel, dim3((unsigned)pair_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step, inner_sweeps, inner_tol2);
+        CURV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(jacobi_rows_kernel, dim3((unsigned)row_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step);
+        CURV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(jacobi_cols_kernel, dim3((unsigned)(2 * row_tiles)), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step);
+        CURV_LAUNCH_CHECK();
+      }
+      const int step1 = (int)(step + 1);
+      bool any = false;
+      for (int i = 0; i < n_mats && !any; ++i) any = (step1 % tab[i].spf == 0);
+      if (any) {
+        if (phase_a) hipLaunchKernelGGL(eigh_norms32_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, step1);
+        else hipLaunchKernelGGL(eigh_norms_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, step1);
+        CURV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(eigh_check_kernel, dim3((unsigned)n_mats), dim3(256), 0, stream, table, n_mats, step1, max_sweeps, phase_a ? 1 : 0);
+        CURV_LAUNCH_CHECK();
+      }
+      if (step1 % poll == 0 || step1 == max_steps) {
+        CURV_HIP_CHECK(hipMemcpyAsync(host_flags.data(), flags, (size_t)n_mats * 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        CURV_HIP_CHECK(hipStreamSynchronize(stream));
+        all_done = true;
+        for (int i = 0; i < n_mats; ++i) all_done = all_done && host_flags[2 * i] != 0;
+        if (trace) {
+          std::vector<double> nn(L.norms / sizeof(double));
+          (void)hipMemcpy(nn.data(), norms, L.norms, hipMemcpyDeviceToHost);
+          for (int i = 0; i < n_mats; ++i) {
+            if (tab[i].n < atoi(getenv("CURV_EIGH_TRACE"))) continue;
+            const size_t P = (size_t)cdiv(descs[i].n, NB);
+            const double* sc = nn.data() + L.norm_off[i] + 2 * P * P;
+            fprintf(stderr, "eigh trace: %s step %lld mat %d n=%d state=%d sweeps=%d off/all=%.3e\n", phase_a ? "fp32" : "fp64",
+                    step + 1, i, tab[i].n, host_flags[2 * i], host_flags[2 * i + 1], sc[0] > 0 ? sqrt(sc[1] / sc[0]) : -1.0);
+          }
+        }
+      }
     }
-    if (step1 % poll == 0 || step1 == max_steps) {
+    if (!all_done) {
       CURV_HIP_CHECK(hipMemcpyAsync(host_flags.data(), flags, (size_t)n_mats * 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
       CURV_HIP_CHECK(hipStreamSynchronize(stream));
-      all_done = true;
-      for (int i = 0; i < n_mats; ++i) all_done = all_done && host_flags[2 * i] != 0;
     }
+    return CURV_OK;
+  };
+
+  // ---- phase A: fp32 copies, until off(A) <= 4e-6 ||A|| (or the caller's tolerance if that is looser) or a stall
+  hipLaunchKernelGGL(eigh_prepare32_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats);
+  CURV_LAUNCH_CHECK();
+  int rc_it = iterate(true);
+  if (rc_it != CURV_OK) return rc_it;
+
+  // ---- the switch: V' = 1.5 V - 0.5 V (V^T V), A = V'^T sym(F) V' in fp64; V' becomes the basis of phase B
+  {
+    hipLaunchKernelGGL(eigh_widen_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats);
+    CURV_LAUNCH_CHECK();
+    std::vector<curv_gemm64_desc> g(n_mats);
+    auto gemm_all = [&](auto fill) -> int {
+      for (int i = 0; i < n_mats; ++i) { memset(&g[i], 0, sizeof(g[i])); fill(i, g[i]); }
+      return curv_gemm_f64_batched(stream, g.data(), n_mats);
+    };
+    auto dims = [&](int i, curv_gemm64_desc& q) { q.M = q.N = q.K = tab[i].np; q.c_rs = tab[i].np; q.c_cs = 1; };
+    // T2 = V^T V
+    int rcg = gemm_all([&](int i, curv_gemm64_desc& q) {
+      dims(i, q); q.A = tab[i].V; q.a_rs = 1; q.a_cs = tab[i].np; q.B = tab[i].V; q.b_rs = tab[i].np; q.b_cs = 1;
+      q.C = tab[i].T2; q.alpha = 1.0; q.beta = 0.0; });
+    if (rcg != CURV_OK) return rcg;
+    // T3 (= 1.5 V) -= 0.5 V T2
+    rcg = gemm_all([&](int i, curv_gemm64_desc& q) {
+      dims(i, q); q.A = tab[i].V; q.a_rs = tab[i].np; q.a_cs = 1; q.B = tab[i].T2; q.b_rs = tab[i].np; q.b_cs = 1;
+      q.C = tab[i].T3; q.alpha = -0.5; q.beta = 1.0; });
+    if (rcg != CURV_OK) return rcg;
+    hipLaunchKernelGGL(eigh_input64_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats);
+    CURV_LAUNCH_CHECK();
+    // V (scratch now) = sym(F) T3
+    rcg = gemm_all([&](int i, curv_gemm64_desc& q) {
+      dims(i, q); q.A = tab[i].A; q.a_rs = tab[i].np; q.a_cs = 1; q.B = tab[i].T3; q.b_rs = tab[i].np; q.b_cs = 1;
+      q.C = tab[i].V; q.alpha = 1.0; q.beta = 0.0; });
+    if (rcg != CURV_OK) return rcg;
+    // A = T3^T V
+    rcg = gemm_all([&](int i, curv_gemm64_desc& q) {
+      dims(i, q); q.A = tab[i].T3; q.a_rs = 1; q.a_cs = tab[i].np; q.B = tab[i].V; q.b_rs = tab[i].np; q.b_cs = 1;
+      q.C = tab[i].A; q.alpha = 1.0; q.beta = 0.0; });
+    if (rcg != CURV_OK) return rcg;
+    // the rotations of phase B accumulate onto V' (T3): swap the roles of the two buffers in the device table
+    for (int i = 0; i < n_mats; ++i) std::swap(tab[i].V, tab[i].T3);
+    for (int b = 0; b < n_mats; b += EIG_UPLOAD_CHUNK) {
+      EighChunk chunk;
+      const int count = std::min(EIG_UPLOAD_CHUNK, n_mats - b);
+      memset(&chunk, 0, sizeof(chunk));
+      memcpy(chunk.f, tab.data() + b, (size_t)count * sizeof(EighDev));
+      hipLaunchKernelGGL(eigh_upload_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count);
+      CURV_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(eigh_symmetrise_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats);
+    CURV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(eigh_resume_kernel, dim3((unsigned)cdiv(n_mats, 64)), dim3(64), 0, stream, table, n_mats);
+    CURV_LAUNCH_CHECK();
+    // where does the exact A = V'^T F V' stand?  (no sweep counted; matrices already within their tolerance are done)
+    hipLaunchKernelGGL(eigh_norms_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, 0);
+    CURV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(eigh_check_kernel, dim3((unsigned)n_mats), dim3(256), 0, stream, table, n_mats, 0, max_sweeps, 2);
+    CURV_LAUNCH_CHECK();
   }
-  if (!all_done) {
-    CURV_HIP_CHECK(hipMemcpyAsync(host_flags.data(), flags, (size_t)n_mats * 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
-    CURV_HIP_CHECK(hipStreamSynchronize(stream));
-  }
+
+  // ---- phase B: fp64, to the final tolerance
+  rc_it = iterate(false);
+  if (rc_it != CURV_OK) return rc_it;
   bool converged = true;
   int n_bad = 0, first_bad = -1;
   for (int i = 0; i < n_mats; ++i) {
@@ -589,7 +991,7 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
   if (!converged) {
     // the outputs hold the last iterate (sorted, gathered); the caller decides whether that is usable
     set_error("curv_syevd: not converged: %d of %d matrices (first: %d) still have off(A) > %.1e ||A||_F after %d sweeps",
-              n_bad, n_mats, first_bad, tol, max_sweeps);
+              n_bad, n_mats, first_bad, sqrt(tab[first_bad].tol2_b), max_sweeps);
     return CURV_ERR_NOT_CONVERGED;
   }
   return CURV_OK;
