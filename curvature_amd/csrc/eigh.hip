@@ -411,7 +411,8 @@ jacobi_two_sided32_kernel(const EighDev* __restrict__ t, int nf, int step) {
     for (int u = 0; u < 16; ++u) Qi[c * LDF + w + 4 * u] = Qg[(w + 4 * u) * NB + c];          // Qi[row][k] = Q_I[k][row]
   }
   for (int tJ = j0; tJ < j1; ++tJ) {
-    const bool skipJ = skip[tJ] != 0;
+    if (tJ < tI) continue;                                   // A32 is kept exactly symmetric: tile (J, I) is written as the
+    const bool skipJ = skip[tJ] != 0;                        // transpose of tile (I, J) by the workgroup of (I, J)
     if (skipI && skipJ) continue;                            // (wave-uniform)
     int pJ, qJ;
     rr_pair(d.Nb, step, tJ, pJ, qJ);
@@ -451,6 +452,16 @@ jacobi_two_sided32_kernel(const EighDev* __restrict__ t, int nf, int step) {
     gfloat32* C = A + (long long)((wm ? qI : pI) * JB) * np + (wn ? qJ : pJ) * JB + (lane & 31);
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) C[(long long)acc_row(reg, lane) * np] = acc[reg];
+    if (tJ != tI) {
+      // the mirror tile (J, I) = R^T, through LDS so that its rows go out as contiguous runs
+      __syncthreads();                                       // everybody is done reading X as an operand
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) X[(32 * wm + acc_row(reg, lane)) * LDF + 32 * wn + (lane & 31)] = acc[reg];
+      __syncthreads();
+      const int gci = gidx(pI, qI, c);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) A[(long long)gidx(pJ, qJ, w + 4 * u) * np + gci] = X[c * LDF + w + 4 * u];
+    }
   }
 }
 
