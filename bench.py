@@ -28,25 +28,11 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA = 157.3e12      # /opt/skills/guides/MI355X_MICROARCH.md: f32-input MFMA, dense
 
 
-def sharding_build_flops(n, m, K, layer, batch):
-    from curvature_amd import sharding
-    return sharding.conv_build_flops(n, m, K, layer, batch)
-
-
 def layer_dims(layers, record):
-    """(n, m, K, build flops) per layer from the recorded activations / gradients."""
-    dims = []
-    for layer in layers:
-        x, g = record[layer]
-        bias = int(layer.bias is not None)
-        if layer.__class__.__name__ == "Conv2d":
-            n = layer.in_channels * layer.kernel_size[0] * layer.kernel_size[1] + bias
-            K = g.shape[0] * g.shape[2] * g.shape[3]
-        else:
-            n = layer.in_features + bias
-            K = g.shape[0]
-        dims.append((n, g.shape[1], K, sharding_build_flops(n, g.shape[1], K, layer, g.shape[0])))
-    return dims
+    """(n, m, K, build flops) per layer from the recorded activations / gradients; the build flops come from the
+    library's launch plan (curv_kfac_plan_info), not from a copy of its rules."""
+    from curvature_amd import sharding
+    return sharding.layer_dims(layers, {l: (tuple(record[l][0].shape), tuple(record[l][1].shape)) for l in layers})
 
 
 def _cpu_model() -> str:

@@ -34,45 +34,112 @@ def lpt_partition(costs: Sequence[float], world: int) -> List[int]:
     return owner
 
 
-def rank_cost(dims: Sequence[Sequence[float]]) -> float:
-    """Estimated step time (s) of a rank that owns the layers `dims` = [(n, m, K) or (n, m, K, build_flops), ...].
+def rank_cost(dims: Sequence[Sequence[float]], estimator: str = "kfac", rank: int = 100) -> float:
+    """Estimated step time (s) of a rank that owns the layers `dims` = [(n, m, K, build_flops), ...] (`build_flops`:
+    what the factor build executes for the layer, from the library's own launch plan - `kfac_build_flops`; when it is
+    missing the symmetric products (n (n + 1) + m (m + 1)) K are assumed).
+
     Not additive: the factors of a rank are inverted in one batched sweep, so the serial chains of 64-column steps
-    overlap and only the longest one counts (calibrated on MI355X: single 4608^2 factor 3.9 ms = 72 steps x 54 us,
-    three of them 6.6 ms, all 108 ResNet-50 factors 9.6 ms; build 85 TFLOP/s executed, sampling GEMMs 95 TFLOP/s).
-    `build_flops`: what the factor build of the layer executes when that is not (n (n + 1) + m (m + 1)) K - a 3x3 /
-    stride 1 A factor assembled from shifted correlations costs a third of it (`conv_build_flops`)."""
+    overlap and only the longest one counts, and every phase pays a fixed price for its launches however little work
+    they carry (a rank with ten small layers is bound by that, not by flops).  Calibrated on one MI355X
+    (tools/emulate_sharding.py, profiles/r03_emulate_sharding.txt): single 4608^2 factor 3.5 ms = 72 steps x 48 us,
+    three of them 5.6 ms, all 108 ResNet-50 factors 8.4 ms; grouped factor build 95 TFLOP/s executed for a whole
+    model, ~60 for a rank's share; sampling GEMMs 95 TFLOP/s.
+
+    `estimator`: "kfac" prices update + invert + sample_and_replace of KFAC; "efb" adds the eigendecomposition of the
+    rank's factors (HBM-bound block-Jacobi: ~2.8e-12 s per n^3, and never faster than the serial chain of the
+    largest factor: ~16 sweeps x n / 32 rounds x 0.19 ms) and EFB's update; "inf" adds INF.invert on top of that:
+    fp64 factor-and-invert sweeps and triangular products of the (a b)^2 matrices, a b ~ 0.4 min(n, rank) min(m, rank)
+    (ResNet layers at rank 100: 3400-4200), ~7.5e-14 s per (a b)^3, again bounded below by the largest one's chain."""
     if not dims:
         return 0.0
-    build = sum(d[3] if len(d) > 3 else (d[0] * (d[0] + 1.0) + d[1] * (d[1] + 1.0)) * d[2] for d in dims) / 85e12
-    sample = sum(2.0 * (d[0] * d[0] * d[1] + d[0] * d[1] * d[1]) for d in dims) / 95e12
-    chain = max(max(d[0], d[1]) for d in dims) / 64.0 * 54e-6
-    invert = 0.7 * chain + sum((2.0 / 3.0) * (d[0] ** 3 + d[1] ** 3) for d in dims) / 42e12
-    return build + invert + sample + 1.0e-3
+    flops = sum(d[3] if len(d) > 3 else (d[0] * (d[0] + 1.0) + d[1] * (d[1] + 1.0)) * d[2] for d in dims)
+    build = 0.25e-3 + 0.035e-3 * min(len(dims), 10) + flops / 70e12
+    sample = 0.15e-3 + sum(2.0 * (d[0] * d[0] * d[1] + d[0] * d[1] * d[1]) for d in dims) / 95e12 + 6e-6 * len(dims)
+    chain = max(max(d[0], d[1]) for d in dims) / 64.0 * 48e-6
+    invert = 0.3e-3 + 0.7 * chain + sum((2.0 / 3.0) * (d[0] ** 3 + d[1] ** 3) for d in dims) / 42e12 + 6e-6 * len(dims)
+    total = build + invert + sample
+    if estimator in ("efb", "inf"):
+        n3 = sum(float(d[0]) ** 3 + float(d[1]) ** 3 for d in dims)
+        eig_chain = 16.0 * (max(max(d[0], d[1]) for d in dims) / 32.0) * 0.19e-3
+        total += max(2.8e-12 * n3, eig_chain)
+        total += 0.2e-3 + sum(2.0 * (d[1] * d[1] * d[0] + d[1] * d[0] * d[0]) for d in dims) / 60e12      # EFB.update
+    if estimator == "inf":
+        ab = [max(float(rank), 0.4 * min(d[0], rank) * min(d[1], rank)) for d in dims]
+        ab = [min(x, float(d[0]) * d[1]) for x, d in zip(ab, dims)]
+        total += max(7.5e-14 * sum(x ** 3 for x in ab), max(ab) / 64.0 * 2 * 48e-6)
+    return total
 
 
-def conv_build_flops(n: int, m: int, K: int, layer=None, batch: int = 0) -> float:
-    """Multiply-add flops the factor build executes for a layer (both factors).  The library assembles the A factor
-    of a 3x3 / stride 1 / padding 1 convolution without bias whose channel count is a multiple of 128 from 13 shifted
-    correlations + border strips (csrc/syrk_corr.hip; needs >= 8 samples): about 13 / 40.5 of the symmetric product,
-    more on small images because of the two zero columns per row (curv_kfac_plan_info gives the exact figure)."""
-    direct_a, direct_g = n * (n + 1.0) * K, m * (m + 1.0) * K
-    if layer is not None and layer.__class__.__name__ == "Conv2d" and tuple(layer.kernel_size) == (3, 3) and \
-            tuple(layer.stride) == (1, 1) and tuple(layer.padding) == (1, 1) and layer.bias is None and \
-            layer.in_channels % 128 == 0 and batch >= 8:
-        return direct_a * 0.36 + direct_g
-    return direct_a + direct_g
+def layer_geometry(layer, x_shape: Sequence[int], g_shape: Sequence[int]):
+    """The two factor geometries (A side, G side) of a Linear / Conv2d layer as dicts of curv_factor_desc fields, from
+    the shapes of its recorded input and grad_output."""
+    bias = int(layer.bias is not None)
+    if layer.__class__.__name__ == "Conv2d":
+        N, C, H, W = x_shape
+        (kh, kw), (sh, sw), (ph, pw) = layer.kernel_size, layer.stride, layer.padding
+        a = dict(N=N, C=C, H=H, W=W, kh=kh, kw=kw, sh=sh, sw=sw, ph=ph, pw=pw, has_bias=bias)
+        g = dict(N=g_shape[0], C=g_shape[1], H=g_shape[2], W=g_shape[3], kh=1, kw=1, sh=1, sw=1, ph=0, pw=0, has_bias=0)
+    else:
+        rows = 1
+        for v in x_shape[:-1]:
+            rows *= int(v)
+        a = dict(N=rows, C=x_shape[-1], H=1, W=1, kh=1, kw=1, sh=1, sw=1, ph=0, pw=0, has_bias=bias)
+        g = dict(N=rows, C=g_shape[-1], H=1, W=1, kh=1, kw=1, sh=1, sw=1, ph=0, pw=0, has_bias=0)
+    return a, g
 
 
-def partition_layers(dims: Sequence[Sequence[int]], world: int) -> List[int]:
+def kfac_build_flops(geometries: Sequence[dict]) -> List[int]:
+    """Multiply-add flops the library's launch plan executes for each factor geometry (curv_kfac_plan_info, host
+    only - no GPU needed): dim (dim + 1) K for a symmetric product, the sum over its 29 shifted correlations for a 3x3 /
+    stride 1 / padding 1 factor.  The partition asks the planner instead of re-stating its eligibility rules."""
+    import ctypes
+    from . import _lib
+    n = len(geometries)
+    if n == 0:
+        return []
+    arr = (_lib.curv_factor_desc * n)()
+    for d, a in zip(geometries, arr):
+        for k, v in d.items():
+            setattr(a, k, int(v))
+        a.scale = 1.0
+    fields = 25                                           # CURV_PLAN_INFO_FIELDS
+    out = (ctypes.c_longlong * (fields * n))()
+    _lib.check(_lib.lib().curv_kfac_plan_info(arr, n, out), "curv_kfac_plan_info")
+    return [int(out[fields * i + fields - 1]) for i in range(n)]
+
+
+def layer_dims(layers, shapes) -> List[tuple]:
+    """[(n, m, K, build flops)] per layer for `partition_layers` / `make_layer_shard`; `shapes[layer]` = (input
+    shape, grad_output shape) of one batch."""
+    geoms = []
+    for layer in layers:
+        a, g = layer_geometry(layer, *shapes[layer])
+        geoms += [a, g]
+    flops = kfac_build_flops(geoms)
+    dims = []
+    for i, layer in enumerate(layers):
+        a, g = geoms[2 * i], geoms[2 * i + 1]
+        n = a["C"] * a["kh"] * a["kw"] + a["has_bias"]
+        if layer.__class__.__name__ == "Conv2d":
+            (kh, kw), (sh, sw), (ph, pw) = layer.kernel_size, layer.stride, layer.padding
+            K = a["N"] * ((a["H"] + 2 * ph - kh) // sh + 1) * ((a["W"] + 2 * pw - kw) // sw + 1)
+        else:
+            K = a["N"]
+        dims.append((n, g["C"], K, float(flops[2 * i] + flops[2 * i + 1])))
+    return dims
+
+
+def partition_layers(dims: Sequence[Sequence[int]], world: int, estimator: str = "kfac", rank: int = 100) -> List[int]:
     """Greedy partition under `rank_cost`: layers in descending stand-alone cost, each to the rank whose
     estimated step time grows the least past the current maximum.  Deterministic on every rank."""
-    order = sorted(range(len(dims)), key=lambda i: (-rank_cost([dims[i]]), i))
+    order = sorted(range(len(dims)), key=lambda i: (-rank_cost([dims[i]], estimator, rank), i))
     groups: List[List[int]] = [[] for _ in range(world)]
     owner = [0] * len(dims)
     for idx in order:
         best, best_key = 0, None
         for r in range(world):
-            c = rank_cost([dims[i] for i in groups[r]] + [dims[idx]])
+            c = rank_cost([dims[i] for i in groups[r]] + [dims[idx]], estimator, rank)
             key = (c, r)
             if best_key is None or key < best_key:
                 best, best_key = r, key
@@ -172,10 +239,11 @@ def make_shard(costs: Sequence[float], rank: Optional[int] = None, world: Option
 
 
 def make_layer_shard(dims: Sequence[Sequence[int]], rank: Optional[int] = None, world: Optional[int] = None,
-                     group=None) -> Shard:
-    """Shard from the layer sizes [(n, m, K), ...] with the calibrated, non-additive rank cost model."""
+                     group=None, estimator: str = "kfac", inf_rank: int = 100) -> Shard:
+    """Shard from the layer sizes [(n, m, K, build flops), ...] (`layer_dims`) with the calibrated, non-additive rank
+    cost model; `estimator` = "kfac" | "efb" | "inf": which chain the step consists of."""
     if world is None:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
     if rank is None:
         rank = dist.get_rank(group) if dist.is_initialized() else 0
-    return Shard(partition_layers(dims, world), rank, world, group)
+    return Shard(partition_layers(dims, world, estimator, inf_rank), rank, world, group)

@@ -1,7 +1,11 @@
 #!/usr/bin/env python
-"""What layer sharding gives on N GPUs, measured on ONE: each rank's share of the ResNet-50 step (update +
-invert + sample of the layers the LPT partition assigns to it) is run in turn; the N-GPU step time is the
-slowest rank plus the all-gather (not included here)."""
+"""What layer sharding gives on N GPUs, measured on ONE: each rank's share of the ResNet-50 step is run in turn; the
+N-GPU step time is the slowest rank plus the all-gather (NOT included here: 102 MB of parameters).
+
+    python tools/emulate_sharding.py            KFAC step: update + invert(1, 1000) + sample_and_replace (config 4)
+    python tools/emulate_sharding.py --chain    config 5: EFB constructor (eigenvectors), efb.update, INF.update(100),
+                                                inf.invert(1, 1000), inf.sample_and_replace per rank
+"""
 import os
 import sys
 import time
@@ -10,63 +14,84 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from curvature_amd import models, sharding  # noqa: E402
-from curvature_amd.curvatures import KFAC  # noqa: E402
+from curvature_amd.curvatures import KFAC, EFB, INF  # noqa: E402
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
 
 
 def main():
+    chain = "--chain" in sys.argv
+    estimator = "inf" if chain else "kfac"
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model = models.resnet50().to(dev).train()
-    rows = models.layer_table(models.resnet50(), (3, 224, 224))
     x = torch.randn(32, 3, 224, 224, device=dev)
-    for world in (1, 2, 4, 8):
-        mods = dict(model.named_modules())
-        dims = [(r["n"], r["m"], 32 * r["L"], sharding.conv_build_flops(r["n"], r["m"], 32 * r["L"], mods[r["name"]], 32))
-                for r in rows]
-        costs = [sharding.rank_cost([d]) for d in dims]
-        owner = sharding.partition_layers(dims, world)
-        est = [sharding.rank_cost([d for d, o in zip(dims, owner) if o == r]) * 1e3 for r in range(world)]
+    probe = KFAC(model)
+    logits = model(x)
+    labels = torch.distributions.Categorical(logits=logits).sample()
+    torch.nn.functional.cross_entropy(logits, labels).backward()
+    layers = probe._layers()
+    dims = sharding.layer_dims(layers, {l: (tuple(probe.record[l][0].shape), tuple(probe.record[l][1].shape)) for l in layers})
+    for h in probe.hooks:
+        h.remove()
+    for world in ((1, 8) if chain else (1, 2, 4, 8)):
+        owner = sharding.partition_layers(dims, world, estimator)
+        est = [sharding.rank_cost([d for d, o in zip(dims, owner) if o == r], estimator) * 1e3 for r in range(world)]
         print("   model ms per rank:", " ".join(f"{e:.1f}" for e in est))
         times = []
         for rank in range(world):
-            kfac = KFAC(model)
-            kfac.shard = sharding.Shard(owner, rank, world)
+            shard = sharding.Shard(owner, rank, world)
+            kfac = KFAC(model, shard=shard)
             kfac._allgather_sampled = lambda: None
+            model.load_state_dict(kfac.model_state)
             logits = model(x)
             labels = torch.distributions.Categorical(logits=logits).sample()
             model.zero_grad()
             torch.nn.functional.cross_entropy(logits, labels).backward()
-
-            def step():
+            own = [i for i, o in enumerate(owner) if o == rank]
+            if not chain:
+                def step():
+                    kfac.update(32)
+                    kfac.invert(1.0, 1000.0)
+                    kfac.sample_and_replace()
+                step()
+                step()
+                times.append(timed(step, 4))
+                if world == 8:
+                    ph = [timed(lambda: kfac.update(32), 4), timed(lambda: kfac.invert(1.0, 1000.0), 4), timed(kfac.sample_and_replace, 4)]
+                    print(f"      rank {rank}: layers {own} dims {[tuple(dims[i][:2]) for i in own]}: update {ph[0]:.2f} invert {ph[1]:.2f} "
+                          f"sample {ph[2]:.2f} ms")
+            else:
                 kfac.update(32)
-                kfac.invert(1.0, 1000.0)
-                kfac.sample_and_replace()
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(4):
-                step()
-            torch.cuda.synchronize()
-            times.append((time.perf_counter() - t0) / 4 * 1e3)
-            if world == 8:
-                # per-phase times of this rank (each phase synchronised: an upper bound of its share of the step)
-                ph = []
-                for fn in (lambda: kfac.update(32), lambda: kfac.invert(1.0, 1000.0), kfac.sample_and_replace):
-                    fn()
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    for _ in range(4):
-                        fn()
-                    torch.cuda.synchronize()
-                    ph.append((time.perf_counter() - t1) / 4 * 1e3)
-                own = [i for i, o in enumerate(owner) if o == rank]
-                print(f"      rank {rank}: layers {own} dims {[tuple(dims[i][:2]) for i in own]}: update {ph[0]:.2f} invert {ph[1]:.2f} sample {ph[2]:.2f} ms")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                efb = EFB(model, kfac.state, shard=shard)
+                torch.cuda.synchronize()
+                t_eig = (time.perf_counter() - t0) * 1e3
+                efb._allgather_sampled = lambda: None
+                t_upd = timed(lambda: efb.update(32), 2)
+                inf = INF(model, efb.diags, kfac.state, efb.state, shard=shard, eigvecs=efb.eigvecs)
+                inf._allgather_sampled = lambda: None
+                t_iu = timed(lambda: inf.update(rank=100), 1)
+                t_ii = timed(lambda: inf.invert(1.0, 1000.0), 2)
+                t_is = timed(inf.sample_and_replace, 2)
+                times.append(t_eig + t_upd + t_iu + t_ii + t_is)
+                print(f"      rank {rank}: {len(own)} layers, largest factor {max(max(dims[i][:2]) for i in own)}: eigenvectors {t_eig:.0f}  "
+                      f"efb.update {t_upd:.1f}  inf.update {t_iu:.1f}  inf.invert {t_ii:.1f}  inf.sample_and_replace {t_is:.1f} ms")
+                del efb, inf
             for h in kfac.hooks:
                 h.remove()
+            del kfac
         mx = max(times)
-        print(f"world {world}: per-rank ms " + " ".join(f"{t:.1f}" for t in times) +
-              f" -> step {mx:.1f} ms (+ all-gather), model cost balance {max(sum(c for c, o in zip(costs, owner) if o == r) for r in range(world)) / (sum(costs) / world):.2f}")
+        print(f"world {world}: per-rank ms " + " ".join(f"{t:.1f}" for t in times) + f" -> step {mx:.1f} ms (+ all-gather)")
 
 
 if __name__ == "__main__":
