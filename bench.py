@@ -204,6 +204,24 @@ def other_configs_gpu(dev, model50, kfac50, batch):
     out["config2_lenet5_n100"] = {"workload": "LeNet-5 N=100: KFAC.update + invert(0.5, 1) + sample_and_replace, 5 layers",
                                   "ms_per_step": ms, "layers_per_s": 5 / ms * 1e3,
                                   "bound": "launch latency (0.6 GFLOP and 0.04 MB per sample: ~20 launches per step)"}
+    try:        # the same step captured once and replayed as a HIP graph (curvature_amd.graph; bit-identical to eager)
+        from curvature_amd.graph import KFACStepGraph
+        k2._fresh.update((layer, side) for layer in k2.state for side in (0, 1))         # start the accumulation again
+        k2.update(batch_size=100)
+        step_graph = KFACStepGraph(k2, add=0.5, multiply=1, batch_size=100)
+        for _ in range(5):
+            step_graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            step_graph.replay()
+        torch.cuda.synchronize()
+        gms = (time.perf_counter() - t0) / 100 * 1e3
+        step_graph.check()
+        out["config2_lenet5_n100"].update({"graph_replay_ms_per_step": gms, "graph_replay_layers_per_s": 5 / gms * 1e3})
+        del step_graph
+    except Exception as exc:
+        out["config2_lenet5_n100"]["graph_replay_error"] = f"{type(exc).__name__}: {exc}"
     del k2, lenet
 
     # ---- config 3: ImageNet ResNet-18, N = 32: KFAC step, then EFB (eigenvectors, update, invert, sample)

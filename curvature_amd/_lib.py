@@ -142,6 +142,7 @@ SIGNATURES = {
     "curv_gemm_workspace_bytes_for": (_sz, [ctypes.POINTER(curv_gemm_desc), _i]),
     "curv_gemm_batched": (_i, [_vp, ctypes.POINTER(curv_gemm_desc), _i, _vp, _sz]),
     "curv_randn": (_i, [_vp, _vp, _ll, ctypes.c_ulonglong, ctypes.c_ulonglong]),
+    "curv_randn_counter": (_i, [_vp, _vp, ctypes.c_longlong, ctypes.c_ulonglong, _vp]),
     "curv_rsqrt_affine": (_i, [_vp, _vp, _d, _d, _vp, _ll]),
     "curv_sq_accumulate": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _i]),
     "curv_sq_accumulate_batched": (_i, [_vp, ctypes.POINTER(curv_sq_desc), _i, _d]),

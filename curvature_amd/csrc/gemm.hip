@@ -578,7 +578,9 @@ __device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsi
 }
 
 __global__ void __launch_bounds__(256)
-randn_kernel(float* __restrict__ out, long long count, unsigned long long seed, unsigned long long offset) {
+randn_kernel(float* __restrict__ out, long long count, unsigned long long seed, unsigned long long offset,
+             const unsigned long long* __restrict__ counter) {
+  if (counter != nullptr) offset += *counter;           // device-side stream position (HIP-graph replays advance it)
   const long long nquad = (count + 3) >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += stride) {
@@ -607,6 +609,9 @@ randn_kernel(float* __restrict__ out, long long count, unsigned long long seed, 
       if (4 * q + e < count) out[4 * q + e] = z[e];
   }
 }
+
+// the draw is over: advance the device-side stream position (its own launch, ordered behind every reader of the value)
+__global__ void counter_add_kernel(unsigned long long* counter, unsigned long long inc) { *counter += inc; }
 
 }  // namespace curv
 
@@ -792,7 +797,22 @@ extern "C" int curv_randn(void* stream, float* out, long long count, unsigned lo
   long long blocks = cdivll(cdivll(count, 4), 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, count, seed,
-                     offset);
+                     offset, (const unsigned long long*)nullptr);
+  CURV_LAUNCH_CHECK();
+  return CURV_OK;
+}
+
+extern "C" int curv_randn_counter(void* stream, float* out, long long count, unsigned long long seed,
+                                  unsigned long long* counter) {
+  if (count <= 0) return CURV_OK;
+  CURV_REQUIRE(out != nullptr && counter != nullptr, "curv_randn_counter: null pointer");
+  long long blocks = cdivll(cdivll(count, 4), 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, count, seed,
+                     0ull, (const unsigned long long*)counter);
+  CURV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter,
+                     (unsigned long long)((count + 3) >> 2));
   CURV_LAUNCH_CHECK();
   return CURV_OK;
 }

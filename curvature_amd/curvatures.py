@@ -148,9 +148,26 @@ class Curvature(ABC):
         numel = 1
         for s in shape:
             numel *= int(s)
+        counter = getattr(self, "_noise_counter", None)
+        if counter is not None:
+            # stream position on the device (curvature_amd.graph): the same draws as with the host-side offset, but a
+            # captured replay advances it too
+            return ops.randn(shape, device, self._seed(), out=out, counter=counter)
         out = ops.randn(shape, device, self._seed(), self.noise_offset, out=out)
         self.noise_offset += (numel + 3) // 4
         return out
+
+    def use_device_noise_counter(self, enable: bool = True) -> None:
+        """Keep the position of the noise stream in a device word instead of `noise_offset` (needed inside a captured
+        HIP graph, where a host-side offset would be frozen).  Switching back reads the word once (a host sync)."""
+        counter = getattr(self, "_noise_counter", None)
+        if enable and counter is None:
+            dev = next(self.model.parameters()).device
+            self._seed()
+            self._noise_counter = torch.tensor([self.noise_offset], dtype=torch.int64, device=dev)
+        elif not enable and counter is not None:
+            self.noise_offset = int(counter.item())
+            self._noise_counter = None
 
     def _sample_plans(self) -> dict:
         """Launch plans of sample_and_replace, keyed by the addresses they were described for.  TWO are kept: the
@@ -581,7 +598,9 @@ class KFAC(Curvature):
             self._last_flops = sum(ops.kfac_plan_flops(jobs))
         ops.kfac_accumulate(jobs, events=getattr(self, "_timing_events", None))
 
-    def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
+    def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1., *, check: bool = True):
+        """`check=False` (keyword-only extension): skip the read-back of the status words - the call's only host
+        synchronisation - and leave them for `check_invert()`; a HIP-graph capture of the step needs that."""
         assert self.state, "State dict is empty. Did you call 'update' prior to this?"
         factors, adds, muls = [], [], []
         gindex = self._global_index()
@@ -596,9 +615,17 @@ class KFAC(Curvature):
         # outputs of the previous call are overwritten in place (stable addresses keep the cached launch
         # plan of sample_and_replace valid); RuntimeError if a damped factor is not positive definite
         prev = [t for layer in self.state.keys() for t in self.inv_state.get(layer, (None, None))]
-        chols = ops.chol_inv_lower(factors, adds, muls, outs=prev)
+        chols = ops.chol_inv_lower(factors, adds, muls, check=check, outs=prev)
+        self._invert_info = ops.chol_inv_lower.last_info
         for index, layer in enumerate(self.state.keys()):
             self.inv_state[layer] = (chols[2 * index], chols[2 * index + 1])
+
+    def check_invert(self) -> None:
+        """Raise ``RuntimeError`` if the last ``invert(check=False)`` (or the last replay of a graph that contains it)
+        met a damped factor that is not positive definite (curvatures.py:377-383 raises at that point)."""
+        info = getattr(self, "_invert_info", None)
+        if info is not None:
+            ops.check_chol_info(info)
 
     def sample(self, layer: Module, z: Optional[Tensor] = None) -> Tensor:
         """(L_A z L_G^T)^T -> (m, n) (curvatures.py:387-392); `z` (n, m) may be supplied for parity tests."""

@@ -217,13 +217,19 @@ def chol_inv_lower(factors: Sequence[torch.Tensor], adds: Sequence[float], multi
     ws = workspace(need, dev, "invert")
     _lib.check(L.curv_chol_inv_lower(_lib.stream_ptr(), arr, n, info.data_ptr(), ws.data_ptr(), ws.numel()),
                "curv_chol_inv_lower")
+    chol_inv_lower.last_info = info              # check=False: the caller reads it later (check_chol_info)
     if check:
-        host = info.cpu()                        # the one host synchronisation of invert()
-        bad = torch.nonzero(host).flatten().tolist()
-        if bad:
-            raise RuntimeError(f"cholesky: damped factor(s) {bad} are not positive-definite "
-                               f"(first failing pivot {int(host[bad[0]]) - 1})")
+        check_chol_info(info)                    # the one host synchronisation of invert()
     return outs
+
+
+def check_chol_info(info: torch.Tensor) -> None:
+    """Raise ``RuntimeError`` if a status word of a finished `chol_inv_lower` sweep reports a non-positive pivot."""
+    host = info.cpu()
+    bad = torch.nonzero(host).flatten().tolist()
+    if bad:
+        raise RuntimeError(f"cholesky: damped factor(s) {bad} are not positive-definite "
+                           f"(first failing pivot {int(host[bad[0]]) - 1})")
 
 
 EPI_NONE, EPI_SQUARE, EPI_MUL_E, EPI_ADD_E, EPI_MUL_E_ADD_F = 0, 1, 2, 3, 4
@@ -302,12 +308,21 @@ class GemmPlan:
                    "curv_gemm_batched")
 
 
-def randn(shape, device, seed: int, offset: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Standard normal noise from the library's Philox generator (counter `offset` in units of 4 values)."""
+def randn(shape, device, seed: int, offset: int = 0, out: Optional[torch.Tensor] = None,
+          counter: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Standard normal noise from the library's Philox generator (counter `offset` in units of 4 values).
+    `counter`: a one-element int64 GPU tensor that holds the stream position instead (read by the kernel, advanced by
+    a second launch): the form a captured HIP graph needs, see `curvature_amd.graph`."""
     if out is None:
         out = torch.empty(shape, dtype=torch.float32, device=device)
     else:
         _require_gpu(out)
+    if counter is not None:
+        if not counter.is_cuda or counter.dtype != torch.int64 or counter.numel() != 1:
+            raise RuntimeError("randn: the device counter must be a one-element int64 GPU tensor")
+        _lib.check(_lib.lib().curv_randn_counter(_lib.stream_ptr(), out.data_ptr(), out.numel(), int(seed) & (2 ** 64 - 1),
+                                                 counter.data_ptr()), "curv_randn_counter")
+        return out
     _lib.check(_lib.lib().curv_randn(_lib.stream_ptr(), out.data_ptr(), out.numel(), int(seed) & (2 ** 64 - 1),
                                      int(offset)), "curv_randn")
     return out

@@ -209,6 +209,10 @@ int curv_gemm_f64_batched(void* stream, const curv_gemm64_desc* descs, int n_des
 /* out[0..count) ~ N(0,1): Philox4x32-10 keyed by `seed`, counter starting at `offset` (in units of 4
  * values); the draw of torch.randn at curvatures.py:391, :457, :590 with a device-side generator. */
 int curv_randn(void* stream, float* out, long long count, unsigned long long seed, unsigned long long offset);
+/* The same stream with its position kept on the DEVICE: the draw starts at *counter (units of 4 values) and a second
+ * launch advances *counter by ceil(count / 4).  A captured HIP graph that contains the call therefore draws fresh
+ * noise at every replay (a host-side offset would be frozen into the kernel arguments). */
+int curv_randn_counter(void* stream, float* out, long long count, unsigned long long seed, unsigned long long* counter);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise pieces (Diagonal / EFB / INF)

@@ -1,0 +1,69 @@
+"""HIP-graph replay of the KFAC step (curvature_amd.graph): the captured update + invert(check=False) +
+sample_and_replace must be bit-identical to the eager calls (scripts/test.py:29-53 is the loop), draw fresh noise at
+every replay, and still report a non-positive-definite factor."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _setup(gpu):
+    from curvature_amd import models
+    from curvature_amd.curvatures import KFAC
+    g1 = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "g1_kfac_lenet.npz")).items()}
+    model = models.lenet5()
+    layers = [m for m in model.modules() if m.__class__.__name__ in ("Conv2d", "Linear")]
+    with torch.no_grad():
+        for li, layer in enumerate(layers):
+            layer.weight.copy_(g1[f"w_l{li}"])
+            layer.bias.copy_(g1[f"bias_l{li}"])
+    model = model.to(gpu).eval()
+    kfac = KFAC(model)
+    kfac.noise_seed = 4242
+    for li, layer in enumerate(layers):                     # recorded inputs / gradients of golden g1, batch 0
+        kfac.record[layer] = [g1[f"b0_l{li}_x"].to(gpu), g1[f"b0_l{li}_g"].to(gpu)]
+    return model, layers, kfac
+
+
+def test_replay_is_bit_identical_to_eager(gpu):
+    from curvature_amd.graph import KFACStepGraph
+    model_e, layers_e, eager = _setup(gpu)
+    weights_e = []
+    for step in range(6):
+        eager.update(8)
+        eager.invert(0.5, 1.0)
+        eager.sample_and_replace()
+        weights_e.append([l.weight.detach().clone() for l in layers_e] + [l.bias.detach().clone() for l in layers_e])
+    model_g, layers_g, kfac = _setup(gpu)
+    graph = KFACStepGraph(kfac, add=0.5, multiply=1.0, batch_size=8, warmup=3)      # three eager steps, then the capture
+    assert graph.record_is_static()
+    for step in range(3, 6):
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [l.weight.detach() for l in layers_g] + [l.bias.detach() for l in layers_g]
+        for a, b in zip(got, weights_e[step]):
+            assert torch.equal(a, b), step
+    graph.check()
+    for le, lg in zip(layers_e, layers_g):                  # accumulated factors and inverse factors too
+        for a, b in zip(eager.state[le] + list(eager.inv_state[le]), kfac.state[lg] + list(kfac.inv_state[lg])):
+            assert torch.equal(a, b)
+    # successive replays drew different noise (the stream position lives on the device)
+    assert not torch.equal(weights_e[4][0], weights_e[5][0])
+    kfac.use_device_noise_counter(False)
+    assert kfac.noise_offset == eager.noise_offset
+
+
+def test_replay_reports_a_failed_factorisation(gpu):
+    from curvature_amd.graph import KFACStepGraph
+    model, layers, kfac = _setup(gpu)
+    graph = KFACStepGraph(kfac, add=0.5, multiply=1.0, batch_size=8)
+    graph.replay()
+    graph.check()                                           # fine
+    kfac.state[layers[2]][0].fill_(float("nan"))            # poison a factor in place: the captured sweep reads it
+    graph.replay()
+    with pytest.raises(RuntimeError, match="positive-definite"):
+        graph.check()
