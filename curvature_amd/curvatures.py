@@ -766,23 +766,42 @@ class EFB(Curvature):
                                                int(grads[k][1] is not None)) for k in missing], dev, zero=True)
             for k, v in zip(missing, views):
                 self.state[layers[k]] = v
-        key = tuple(t.data_ptr() for gw, gb in grads for t in (gw, gb) if t is not None) + \
-            tuple(self.state[l].data_ptr() for l in layers) + tuple(t.data_ptr() for l in layers for t in self.eigvecs[l])
+        # The launch plan is keyed by what it writes and by the eigenvectors only.  The gradients are staged into an arena the
+        # plan owns with one batched copy per call: after zero_grad(set_to_none=True) every backward pass allocates new
+        # .grad tensors, so a plan keyed by their addresses would be rebuilt on every update() and would pin the old
+        # gradients (a second copy of all of them) through its descriptors.
+        key = tuple(self.state[l].data_ptr() for l in layers) + tuple(t.data_ptr() for l in layers for t in self.eigvecs[l])
         plan = getattr(self, "_update_plan", None)
         if plan is None or plan[0] != key:
-            stage1, stage2 = [], []
+            stage1, stage2, staged = [], [], []
             _, tmps = _arena([tuple(self.state[l].shape) for l in layers], dev)
-            for layer, (gw, gb), tmp in zip(layers, grads, tmps):
+            shapes = []
+            for layer, (gw, gb) in zip(layers, grads):
                 m = gw.shape[0]
-                gw2 = gw.view(m, -1)
-                n0 = gw2.shape[1]
-                U_A, U_G = self.eigvecs[layer]
-                stage1.append(ops.Gemm(U_G.t(), gw2, tmp[:, :n0]))                  # U_G^T [W.grad | b.grad]
+                shapes.append((m, gw.numel() // m))
                 if gb is not None:
-                    stage1.append(ops.Gemm(U_G.t(), gb.view(m, 1), tmp[:, n0:]))
+                    shapes.append((m, 1))
+            _, views = _arena(shapes, dev)
+            vi = 0
+            for layer, (gw, gb), tmp in zip(layers, grads, tmps):
+                n0 = gw.numel() // gw.shape[0]
+                U_A, U_G = self.eigvecs[layer]
+                stage1.append(ops.Gemm(U_G.t(), views[vi], tmp[:, :n0]))              # U_G^T [W.grad | b.grad]
+                staged.append(views[vi])
+                vi += 1
+                if gb is not None:
+                    stage1.append(ops.Gemm(U_G.t(), views[vi], tmp[:, n0:]))
+                    staged.append(views[vi])
+                    vi += 1
                 stage2.append(ops.Gemm(tmp, U_A, self.state[layer], beta=1.0, epilogue=ops.EPI_SQUARE))   # Lambda += (. U_A)**2
-            plan = (key, ops.GemmPlan(stage1), ops.GemmPlan(stage2))
+            plan = (key, ops.GemmPlan(stage1), ops.GemmPlan(stage2), staged)
             self._update_plan = plan
+        srcs = []
+        for gw, gb in grads:
+            srcs.append(gw.view(gw.shape[0], -1))
+            if gb is not None:
+                srcs.append(gb.contiguous().view(-1, 1))
+        ops.CopyPlan(plan[3], srcs).run()
         plan[1].run()
         plan[2].run()
         done = ops.sq_accumulate_many([(gw, gb.contiguous() if gb is not None else None, self.diags.get(layer), None)

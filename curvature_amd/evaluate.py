@@ -66,6 +66,33 @@ class _StateBufferSets:
                 d.copy_(s_)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device: torch.device) -> "torch.cuda.Stream":
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    stream = _SIDE_STREAMS.get(index)
+    if stream is None:
+        stream = _SIDE_STREAMS[index] = torch.cuda.Stream(device)
+    return stream
+
+
+def _drop_plans_for(estimator, tensors) -> None:
+    """Forget the estimator's (and its shard's) cached launch plans that mention any of `tensors` by address."""
+    ptrs = {t.data_ptr() for t in tensors if t.numel()}
+
+    def mentions(key) -> bool:
+        if isinstance(key, (tuple, list)):
+            return any(mentions(k) for k in key)
+        return isinstance(key, int) and key in ptrs
+    for owner, name in ((estimator, "_sample_plan_cache"), (estimator, "_reload_plans"),
+                        (getattr(estimator, "shard", None), "_plans")):
+        cache = getattr(owner, name, None) if owner is not None else None
+        if isinstance(cache, dict):
+            for key in [k for k in cache if mentions(k)]:
+                del cache[key]
+
+
 def eval_bnn(model: torch.nn.Module, dataset: Iterable, estimator, samples: int = 30, device=None,
              overlap: bool = None):
     """Mean predictive distribution over `samples` posterior weight samples (scripts/evaluate.py:121-152,
@@ -92,8 +119,8 @@ def eval_bnn(model: torch.nn.Module, dataset: Iterable, estimator, samples: int 
                 mean_predictions = predictions if mean_predictions is None else mean_predictions + predictions
         else:
             main = torch.cuda.current_stream(device)
-            side = torch.cuda.Stream(device)
-            sets = _StateBufferSets(model)
+            side = _side_stream(device)         # one per device for the life of the process: scratch workspaces are
+            sets = _StateBufferSets(model)      # cached per stream, a fresh stream per call would pin a new set each time
             written = [torch.cuda.Event(), torch.cuda.Event()]     # sample is complete in set i
             consumed = [torch.cuda.Event(), torch.cuda.Event()]    # the forward sweep has finished reading set i
             side.wait_stream(main)                                 # invert() etc. enqueued by the caller
@@ -119,5 +146,7 @@ def eval_bnn(model: torch.nn.Module, dataset: Iterable, estimator, samples: int 
                 sets.copy(0, 1)
                 sets.activate(0)
             main.wait_stream(side)
+            # the launch plans described for the temporary second buffer set keep a whole model copy alive: drop them
+            _drop_plans_for(estimator, sets.sets[1])
         mean_predictions = mean_predictions / samples
     return mean_predictions.cpu().numpy(), labels.numpy()

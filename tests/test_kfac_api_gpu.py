@@ -422,3 +422,71 @@ def test_gemm_nt_kernel(gpu, shape):
         ops.gemm_batched([ops.Gemm(A, Lt.t(), out3, tri=ops.TRI_B_UPPER)])
         want3 = A.double() @ Lt.double().t()
         assert float((out3.double() - want3).abs().max()) <= 2e-5 * float(want3.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(130, 200, 401), (256, 300, 2049), (129, 64, 7), (512, 1000, 4609)])
+def test_gemm_nt_kernel_unaligned_operands(gpu, shape):
+    """K % 4 != 0 (the last LDS-DMA step masks stale pixel groups) and operand rows that are only 4-byte aligned: the
+    operands are column slices of wider buffers whose row pitch is not a multiple of 4 floats - L_A of a biased layer
+    (2049 / 4609 wide) and EFB's `ua_t[:, :n0]` look like this."""
+    from curvature_amd import ops
+    M, N, K = shape
+    torch.manual_seed(K)
+    Abuf = torch.randn(M, K + 3, device=gpu)
+    Bbuf = torch.randn(N, K + 5, device=gpu)
+    A, Bt = Abuf[:, 1:K + 1], Bbuf[:, 2:K + 2]               # row pitches K + 3 / K + 5, first element at +1 / +2
+    assert A.stride() == (K + 3, 1) and Bt.stride() == (K + 5, 1)
+    E = torch.randn(M, N, device=gpu)
+    C = torch.full((M, N), float("nan"), device=gpu)
+    ops.gemm_batched([ops.Gemm(A, Bt.t(), C, alpha=0.5, epilogue=ops.EPI_ADD_E, E=E)])
+    want = 0.5 * (A.double() @ Bt.double().t()) + E.double()
+    assert float((C.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_gemm_nt_split_k_with_triangular_cut_and_beta(gpu):
+    """A launch with few tiles is K-sliced (partial slabs + a reduce launch that applies the epilogue): with a
+    triangular cut only the slices that intersect the tile's K range exist, and beta = 1 must add the old C once."""
+    from curvature_amd import ops
+    torch.manual_seed(11)
+    K = 2304
+    L = torch.tril(torch.randn(K, K, device=gpu))
+    Z = torch.randn(96, K, device=gpu)
+    C0 = torch.randn(K, 96, device=gpu)
+    out = C0.clone()
+    ops.gemm_batched([ops.Gemm(L, Z.t(), out, beta=1.0, tri=ops.TRI_A_LOWER)])          # 18 x 1 tiles: sliced
+    want = L.double() @ Z.double().t() + C0.double()
+    assert float((out.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    Lt = torch.tril(torch.randn(K, K, device=gpu))
+    A = torch.randn(100, K, device=gpu)
+    C1 = torch.randn(100, K, device=gpu)
+    out2 = C1.clone()
+    ops.gemm_batched([ops.Gemm(A, Lt.t(), out2, alpha=2.0, beta=1.0, tri=ops.TRI_B_UPPER)])
+    want2 = 2.0 * (A.double() @ Lt.double().t()) + C1.double()
+    assert float((out2.double() - want2).abs().max()) <= 2e-5 * float(want2.abs().max())
+    first = out2.clone()
+    out3 = C1.clone()
+    ops.gemm_batched([ops.Gemm(A, Lt.t(), out3, alpha=2.0, beta=1.0, tri=ops.TRI_B_UPPER)])
+    assert torch.equal(first, out3)                           # fixed-order slice sums: bit-reproducible
+
+
+@pytest.mark.gpu
+def test_gemv_path_for_one_column_products(gpu):
+    """N == 1 products with K-contiguous operands (the bias column of a sampled layer, INF's P_c x) run as row-wise
+    dot products; with every epilogue, against fp64."""
+    from curvature_amd import ops
+    torch.manual_seed(3)
+    M, K = 1000, 2049
+    A = torch.randn(M, K, device=gpu)
+    LA = torch.randn(K, K, device=gpu)
+    col = LA.t()[:, K - 1:]                                   # (K, 1) view with unit row stride: row K - 1 of LA
+    assert col.stride(0) == 1
+    E = torch.randn(M, 1, device=gpu)
+    F = torch.randn(M, 1, device=gpu)
+    ref = A.double() @ col.double()
+    for ep, e, f, alpha, want in ((ops.EPI_NONE, None, None, 1.0, ref), (ops.EPI_ADD_E, E, None, -1.0, -ref + E.double()),
+                                  (ops.EPI_MUL_E_ADD_F, E, F, 2.0, 2.0 * ref * E.double() + F.double())):
+        C = torch.full((M, 1), float("nan"), device=gpu)
+        ops.gemm_batched([ops.Gemm(A, col, C, alpha=alpha, epilogue=ep, E=e, F=f)])
+        assert float((C.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()), ep
