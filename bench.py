@@ -540,7 +540,7 @@ def main():
     # collected by tools/collect_profiles.sh (rocprofv3, separate FETCH_SIZE / WRITE_SIZE passes, gfx950
     # correction of MI355X_MICROARCH.md) on this same workload and committed under profiles/
     traffic, traffic_source = None, None
-    for name in ("r02_syrk_pmc.json", "r01_syrk_pmc.json"):
+    for name in ("r03_syrk_pmc.json", "r02_syrk_pmc.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if world == 1 and args.batch == 32 and os.path.exists(pmc_path):
             try:

@@ -29,6 +29,7 @@ def timed(fn, reps):
 
 def main():
     chain = "--chain" in sys.argv
+    nocheck = "--nocheck" in sys.argv      # invert(check=False): no host synchronisation inside the step (diagnostic)
     estimator = "inf" if chain else "kfac"
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -60,7 +61,7 @@ def main():
             if not chain:
                 def step():
                     kfac.update(32)
-                    kfac.invert(1.0, 1000.0)
+                    kfac.invert(1.0, 1000.0, check=not nocheck)
                     kfac.sample_and_replace()
                 step()
                 step()

@@ -12,7 +12,7 @@ import glob
 import json
 import sys
 
-DEFAULT = ["syrk_patch_kernel", "syrk_flat_kernel", "syrk_reduce_kernel", "outer_update_kernel", "outer_update_wide_kernel",
+DEFAULT = ["syrk_pre_kernel", "syrk_patch_kernel", "syrk_flat_kernel", "patch_prep_kernel", "syrk_reduce_kernel", "gemv_rows_kernel", "outer_update_kernel", "outer_update_wide_kernel",
            "inner_update_kernel", "panel_product_kernel", "panel_product_wide_kernel", "chol_diag_kernel", "chol_panel_kernel",
            "gemm_f32_kernel", "gemm_nt_kernel", "gemm_f64_kernel", "corr_prep_kernel", "corr_assemble_kernel", "jacobi_pair_kernel", "jacobi_rows_kernel", "jacobi_cols_kernel"]
 
@@ -83,7 +83,17 @@ def summarise(root, kernel):
 
 def main():
     root = sys.argv[1]
-    kernels = sys.argv[2:] or DEFAULT
+    args = sys.argv[2:]
+    if args and args[0] == "--factor-build":
+        # bench.py's `roofline.traffic`: HBM bytes of one update()'s MFMA kernels (the three SYRK kernels together)
+        parts = {k: summarise(root, k) for k in ("syrk_pre_kernel", "syrk_patch_kernel", "syrk_flat_kernel")}
+        parts = {k: v for k, v in parts.items() if v}
+        print(json.dumps({"kernel": " + ".join("curv::" + k for k in parts),
+                          "per": "update() (one launch of each), average over the profiled launches",
+                          "hbm_bytes_per_launch": sum(v.get("hbm_bytes_per_launch", 0.0) for v in parts.values()),
+                          "parts": parts}, indent=1))
+        return
+    kernels = args or DEFAULT
     out = [s for s in (summarise(root, k) for k in kernels) if s]
     print(json.dumps(out, indent=1))
 
