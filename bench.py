@@ -206,7 +206,7 @@ def other_configs_gpu(dev, model50, kfac50, batch):
                                   "bound": "launch latency (0.6 GFLOP and 0.04 MB per sample: ~20 launches per step)"}
     try:        # the same step captured once and replayed as a HIP graph (curvature_amd.graph; bit-identical to eager)
         from curvature_amd.graph import KFACStepGraph
-        k2._fresh.update((layer, side) for layer in k2.state for side in (0, 1))         # start the accumulation again
+        k2.restart_accumulation()
         k2.update(batch_size=100)
         step_graph = KFACStepGraph(k2, add=0.5, multiply=1, batch_size=100)
         for _ in range(5):
@@ -233,7 +233,7 @@ def other_configs_gpu(dev, model50, kfac50, batch):
                       "(eigenvectors of the 42 factors), update, invert(1, 1000), sample_and_replace"}
     k3.update(batch_size=32)
     c3["kfac_update_ms"] = _timed_gpu(lambda: k3.update(batch_size=32))
-    k3._fresh.update((layer, side) for layer in k3.state for side in (0, 1))        # back to one batch
+    k3.restart_accumulation()                                                         # back to one batch
     k3.update(batch_size=32)
     c3["kfac_invert_ms"] = _timed_gpu(lambda: k3.invert(1.0, 1000.0))
     c3["kfac_sample_and_replace_ms"] = _timed_gpu(k3.sample_and_replace)
@@ -483,7 +483,7 @@ def main():
 
     def step(e):
         if counter["steps"] % RESTART == 0 and counter["steps"] > 0:
-            kfac._fresh.update((layer, side) for layer in kfac.state for side in (0, 1))
+            kfac.restart_accumulation()
         counter["steps"] += 1
         if e is not None:
             e[0].record()

@@ -598,6 +598,15 @@ class KFAC(Curvature):
             self._last_flops = sum(ops.kfac_plan_flops(jobs))
         ops.kfac_accumulate(jobs, events=getattr(self, "_timing_events", None))
 
+    def restart_accumulation(self) -> None:
+        """The next `update()` overwrites the factors of every layer instead of adding to them (the tensors, their
+        addresses and the launch plans built on them stay).  Extension of the reference API: its only way to start
+        over is a new estimator."""
+        fresh = getattr(self, "_fresh", None)
+        if fresh is None:
+            fresh = self._fresh = set()
+        fresh.update((layer, side) for layer in self.state for side in (0, 1))
+
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1., *, check: bool = True):
         """`check=False` (keyword-only extension): skip the read-back of the status words - the call's only host
         synchronisation - and leave them for `check_invert()`; a HIP-graph capture of the step needs that."""
