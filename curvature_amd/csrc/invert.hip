@@ -886,6 +886,18 @@ static int stream_set(StreamSet** out) {
   return CURV_OK;
 }
 
+// The factor build (syrk.hip) runs its register-staged kernel on a side stream.  It borrows this set's `masked`
+// stream instead of creating one more: HIP maps streams onto a handful of hardware queues, and a sixth stream in the
+// process changed that mapping for the sweep's own streams (invert() of the ResNet-50 factors 8.3 -> 9.2 ms with an
+// extra stream created by the factor build).  The two uses never overlap: both are ordered on the caller's stream.
+int curv_internal_side_stream(hipStream_t* out) {
+  StreamSet* ss = nullptr;
+  const int rc = stream_set(&ss);
+  if (rc != CURV_OK) return rc;
+  *out = ss->masked;
+  return CURV_OK;
+}
+
 }  // namespace curv
 
 using namespace curv;

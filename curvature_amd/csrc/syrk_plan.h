@@ -87,6 +87,9 @@ __device__ __forceinline__ int xcd_item(int bid) {
   return ((j / XCD_GROUP) * 8 + xcd) * XCD_GROUP + (j % XCD_GROUP);
 }
 
+// invert.hip: one of the library's internal streams (per thread and device), lent to the factor build's side work
+int curv_internal_side_stream(hipStream_t* out);
+
 // syrk_flat.hip: host launcher of the LDS-DMA kernel over a device table of dma factors
 int launch_syrk_flat(hipStream_t stream, const FactorDev* table, int n_factors, int n_items, float* slabs);
 // host-side eligibility / stage count of the LDS-DMA kernel
