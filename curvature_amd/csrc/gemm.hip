@@ -219,11 +219,17 @@ gemm_f32_kernel(const GemmDev* __restrict__ table, int n_desc) {
 // Rows beyond M / N are clamped to the last row (their results are never stored); k beyond K is zeroed in the last
 // step; triangular operands cut the K range per tile (what lies beyond the cut inside the last step is stored zeros).
 // ------------------------------------------------------------------------------------------------
+#ifndef CURV_NT_KC
+#define CURV_NT_KC 32
+#endif
 namespace nt {
-constexpr int TM = 128, KC = 32, ROW_B = KC * 4, SLOTS = KC / 4, STEPS = KC / 8, RPP = 1024 / ROW_B;
+constexpr int TM = 128, KC = CURV_NT_KC, ROW_B = KC * 4, SLOTS = KC / 4, STEPS = KC / 8, RPP = 1024 / ROW_B;
 constexpr int PIECES = TM / RPP / 4, PANEL_B = TM * ROW_B, LDS_B = 4 * PANEL_B, NP = 2 * PIECES;
 constexpr int PPS = (NP + STEPS / 2 - 1) / (STEPS / 2);
 static_assert(PPS <= 4, "at most one DMA piece per MFMA group");
+constexpr int KEY_SHIFT = SLOTS == 8 ? 1 : 2, LANES_PER_ROW_SHIFT = SLOTS == 8 ? 3 : 2;   // see syrk_flat.hip
+constexpr int WGS = KC == 32 ? 2 : 4;       // workgroups per CU (64 / 32 KiB of LDS)
+static_assert(SLOTS == 8 || SLOTS == 4, "stage rows of 32 or 16 k values");
 }  // namespace nt
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(3))) char lds_char_t;
@@ -276,13 +282,13 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmDev& d, int local, lds_ch
   const int nv_last = (cut || inner) ? 8 : K - kb - 8 * (TS - 1);   // k values of the last step that exist (beyond a cut: stored zeros)
 
   // DMA lane geometry (see syrk_flat.hip): piece `slot` of this wave covers panel rows 32 slot + 8 wave + (lane >> 3)
-  const int rsub = RPP * wave + (lane >> 3);
-  const int g_lane = (lane & (SLOTS - 1)) ^ ((rsub >> 1) & 7);
+  const int rsub = RPP * wave + (lane >> LANES_PER_ROW_SHIFT);
+  const int g_lane = (lane & (SLOTS - 1)) ^ ((rsub >> KEY_SHIFT) & (SLOTS - 1));
   // per-piece row offsets: rows beyond the matrix are clamped to its last row
   int voff_a[PIECES], voff_b[PIECES];
 #pragma unroll
   for (int p = 0; p < PIECES; ++p) {
-    const int ra = min(i0 + 32 * p + rsub, M - 1), rb = min(j0 + 32 * p + rsub, N - 1);
+    const int ra = min(i0 + 4 * RPP * p + rsub, M - 1), rb = min(j0 + 4 * RPP * p + rsub, N - 1);
     voff_a[p] = (int)(((long long)ra * d.a_rs + 4 * g_lane) * 4);
     voff_b[p] = (int)(((long long)rb * d.b_cs + 4 * g_lane) * 4);
   }
@@ -294,7 +300,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmDev& d, int local, lds_ch
   for (int o = 0; o < 4; ++o) {
     const int R = ((o < 2) ? 64 * wm : 64 * wn) + (o & 1) * 32 + r32;
     const unsigned pbase = (o < 2) ? 0u : 2u * PANEL_B;
-    const int rkey = (R >> 1) & 7;
+    const int rkey = (R >> KEY_SHIFT) & (SLOTS - 1);
 #pragma unroll
     for (int j = 0; j < STEPS; ++j) addr[o][j] = pbase + R * ROW_B + (((2 * j + h) ^ rkey) << 4);
   }
@@ -400,7 +406,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmDev& d, int local, lds_ch
   store_block(c11, 1, 1);
 }
 
-__global__ void __launch_bounds__(GEMM_THREADS, 2)
+__global__ void __launch_bounds__(GEMM_THREADS, nt::WGS)
 gemm_nt_kernel(const GemmDev* __restrict__ table, int n_desc, float* __restrict__ slabs) {
   __shared__ __attribute__((aligned(1024))) char smem[nt::LDS_B];
   const int f = gemm_find(table, n_desc, blockIdx.x);

@@ -8,22 +8,31 @@
 //   * LDS-DMA staging: buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, straight from global memory into a
 //     double-buffered LDS image - no staging registers, no store pass, no vector-ALU work; the pieces of stage t + 1 are
 //     issued behind the first MFMA groups of stage t and have the rest of the stage to land;
-//   * the image is [128 rows][8 x 16 B] (32 pixels per stage) with the 16-byte slots XOR-swizzled by (row >> 1) & 7:
+//   * the image is [128 rows][4 x 16 B] (16 pixels per stage; round 2: 8 x 16 B) with the 16-byte slots XOR-swizzled by
+//     (row >> 2) & 3 (16 consecutive rows x one slot must cover 16 different 4-bank groups):
 //     the DMA writes lane-linear bytes, so the swizzle is applied to the per-lane SOURCE address, and operands are
 //     read back with conflict-free ds_read_b128 (one read = one operand row x 4 pixels = the A or B input of 4 MFMAs);
 //   * the k order inside a stage is whatever suits the reads (lane half h takes pixel group 2 j + h): a SYRK only
 //     needs both operands to agree on it;
 //   * every lane's four read addresses per operand are computed once per work item (16 registers); the steady state
 //     has no vector-ALU instructions besides the MFMAs;
-//   * 64 KiB of LDS and <= 128 registers: two workgroups per CU, each covering the other's barriers and DMA waits.
+//   * 32 KiB of LDS and <= 128 registers: FOUR workgroups per CU, each covering the others' barriers and DMA waits
+//     (round 3: 32-pixel stages, 64 KiB, two per CU -> 16-pixel stages, four per CU: the MFMA kernels of a ResNet-50
+//     update() 5.89 -> 5.75 ms on one box; the stand-alone prototype's trend - 64-pixel stages at one per CU 0.42-0.50
+//     of peak, 32 at two 0.57-0.60 - continues.  The same change made gemm_nt_kernel, whose tiles have short K ranges,
+//     slower: 1.45 -> 1.55 ms per sample, so that kernel keeps its 32-wide stages).
 // Work items, slabs and the wave roles on diagonal tiles are those of syrk.hip; syrk_reduce_kernel sums the slabs.
 #include "syrk_plan.h"
 
 namespace curv {
 
+#ifndef CURV_FLAT_KC
+#define CURV_FLAT_KC 16
+#endif
+
 namespace flat {
 constexpr int TM = 128;
-constexpr int KC = 32;                      // pixels per stage row
+constexpr int KC = CURV_FLAT_KC;            // pixels per stage row
 constexpr int ROW_B = KC * 4;               // 128 B
 constexpr int SLOTS = KC / 4;               // 16-byte slots per row
 constexpr int STEPS = KC / 8;               // MFMA steps (8 pixels: 4 per lane half) per full stage
@@ -34,6 +43,12 @@ constexpr int LDS_B = 4 * PANEL_B;          // [Pi buf0][Pi buf1][Pj buf0][Pj bu
 constexpr int NP = 2 * PIECES;              // pieces per stage per wave
 constexpr int PPS = (NP + STEPS / 2 - 1) / (STEPS / 2);   // pieces per step when issued during the first half of a stage
 static_assert(PPS <= 4, "at most one DMA piece per MFMA group");
+// 16-byte slots of 16 consecutive rows must fall into 16 different 4-bank groups: rows R .. R + 16 / SLOTS - 1 share
+// a key, the slot is XORed with it
+constexpr int KEY_SHIFT = SLOTS == 8 ? 1 : SLOTS == 4 ? 2 : 0;
+constexpr int LANES_PER_ROW_SHIFT = SLOTS == 8 ? 3 : 2;
+constexpr int WGS = KC == 32 ? 2 : 4;       // workgroups per CU (LDS: 64 / 32 KiB)
+static_assert(SLOTS == 8 || SLOTS == 4, "stage rows of 32 or 16 pixels");
 }  // namespace flat
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -97,8 +112,8 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
   // ---- DMA lane geometry: piece `slot` of this wave covers panel rows 32 slot + 8 wave + (lane >> 3); the lane's
   // physical 16-byte slot (lane & 7) holds logical pixel group g = slot ^ ((row >> 1) & 7), which does not depend on
   // the piece index (pieces of a wave are 32 rows apart)
-  const int rsub = RPP * wave + (lane >> 3);
-  const int g_lane = (lane & (SLOTS - 1)) ^ ((rsub >> 1) & 7);
+  const int rsub = RPP * wave + (lane >> LANES_PER_ROW_SHIFT);
+  const int g_lane = (lane & (SLOTS - 1)) ^ ((rsub >> KEY_SHIFT) & (SLOTS - 1));
   const int voff = (rsub * pitch + 4 * g_lane) * 4;
   const unsigned total_b = (unsigned)((long long)d.N * C * pitch * 4);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.src, 0, total_b, 0x00020000);
@@ -109,7 +124,7 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
   for (int o = 0; o < 4; ++o) {
     const int R = ((o < 2) ? 64 * wm : 64 * wn) + (o & 1) * 32 + r32;
     const unsigned pbase = (o < 2 || diag) ? 0u : 2u * PANEL_B;
-    const int rkey = (R >> 1) & 7;
+    const int rkey = (R >> KEY_SHIFT) & (SLOTS - 1);
 #pragma unroll
     for (int j = 0; j < STEPS; ++j) addr[o][j] = pbase + R * ROW_B + (((2 * j + h) ^ rkey) << 4);
   }
@@ -204,7 +219,7 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
   }
 }
 
-__global__ void __launch_bounds__(SYRK_THREADS, 2)
+__global__ void __launch_bounds__(SYRK_THREADS, flat::WGS)
 syrk_flat_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_items, float* __restrict__ slabs) {
   __shared__ __attribute__((aligned(1024))) char smem[flat::LDS_B];
   const int item = xcd_item(blockIdx.x);
