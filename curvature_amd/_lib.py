@@ -141,6 +141,7 @@ SIGNATURES = {
     "curv_gemm_workspace_bytes": (_sz, [_i]),
     "curv_gemm_workspace_bytes_for": (_sz, [ctypes.POINTER(curv_gemm_desc), _i]),
     "curv_gemm_batched": (_i, [_vp, ctypes.POINTER(curv_gemm_desc), _i, _vp, _sz]),
+    "curv_gemm_batched_ex": (_i, [_vp, ctypes.POINTER(curv_gemm_desc), _i, _vp, _sz, ctypes.c_uint]),
     "curv_randn": (_i, [_vp, _vp, _ll, ctypes.c_ulonglong, ctypes.c_ulonglong]),
     "curv_randn_counter": (_i, [_vp, _vp, ctypes.c_longlong, ctypes.c_ulonglong, _vp]),
     "curv_rsqrt_affine": (_i, [_vp, _vp, _d, _d, _vp, _ll]),
@@ -155,6 +156,7 @@ SIGNATURES = {
 
 ABI_VERSION = 4                     # CURV_ABI_VERSION of include/curv_hip.h
 KFAC_TABLE_RESIDENT = 1             # CURV_KFAC_TABLE_RESIDENT
+GEMM_TABLE_RESIDENT = 1             # CURV_GEMM_TABLE_RESIDENT
 ERR_NOT_PD, ERR_INVALID, ERR_WORKSPACE, ERR_HIP, ERR_NOT_CONVERGED = 1, 2, 3, 4, 5     # CURV_ERR_* of the header
 
 

@@ -686,8 +686,8 @@ extern "C" size_t curv_gemm_workspace_bytes_for(const curv_gemm_desc* descs, int
   return total;
 }
 
-extern "C" int curv_gemm_batched(void* stream_, const curv_gemm_desc* descs, int n_desc, void* workspace,
-                                 size_t workspace_bytes) {
+static int gemm_batched_impl(void* stream_, const curv_gemm_desc* descs, int n_desc, void* workspace,
+                             size_t workspace_bytes, unsigned flags) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_desc == 0) return CURV_OK;
   CURV_REQUIRE(descs != nullptr, "curv_gemm_batched: null descriptor array");
@@ -768,7 +768,9 @@ extern "C" int curv_gemm_batched(void* stream_, const curv_gemm_desc* descs, int
   std::vector<GemmDev> all(tab);
   all.insert(all.end(), tab_nt.begin(), tab_nt.end());
   all.insert(all.end(), tab_v.begin(), tab_v.end());
-  for (int b = 0; b < n + n_nt + n_v; b += GEMM_UPLOAD_CHUNK) {
+  // CURV_GEMM_TABLE_RESIDENT: the caller replays the very same descriptor array into a workspace nobody else has
+  // written since the previous call - the device table is still there
+  for (int b = 0; b < n + n_nt + n_v && !(flags & CURV_GEMM_TABLE_RESIDENT); b += GEMM_UPLOAD_CHUNK) {
     GemmChunk chunk;
     const int count = std::min(GEMM_UPLOAD_CHUNK, n + n_nt + n_v - b);
     memset(&chunk, 0, sizeof(chunk));
@@ -794,6 +796,16 @@ extern "C" int curv_gemm_batched(void* stream_, const curv_gemm_desc* descs, int
     CURV_LAUNCH_CHECK();
   }
   return CURV_OK;
+}
+
+extern "C" int curv_gemm_batched(void* stream, const curv_gemm_desc* descs, int n_desc, void* workspace,
+                                 size_t workspace_bytes) {
+  return gemm_batched_impl(stream, descs, n_desc, workspace, workspace_bytes, 0u);
+}
+
+extern "C" int curv_gemm_batched_ex(void* stream, const curv_gemm_desc* descs, int n_desc, void* workspace,
+                                    size_t workspace_bytes, unsigned flags) {
+  return gemm_batched_impl(stream, descs, n_desc, workspace, workspace_bytes, flags);
 }
 
 extern "C" int curv_randn(void* stream, float* out, long long count, unsigned long long seed,

@@ -301,11 +301,19 @@ class GemmPlan:
         if not self.n:
             return
         L = _lib.lib()
-        if getattr(self, "_ws_bytes", None) is None:        # table + slabs of K-sliced products (underfilled launches)
-            self._ws_bytes = L.curv_gemm_workspace_bytes_for(self.descs, self.n)
-        ws = workspace(self._ws_bytes, self.jobs[0].C.device, "gemm")
-        _lib.check(L.curv_gemm_batched(_lib.stream_ptr(), self.descs, self.n, ws.data_ptr(), ws.numel()),
-                   "curv_gemm_batched")
+        if getattr(self, "_ws", None) is None:
+            # table + slabs of K-sliced products (underfilled launches), owned by the plan: nobody else writes there, so
+            # the device copy of the descriptor table is uploaded by the first run only (a ResNet-50 sample was 6 upload
+            # launches per call otherwise).  Slab space is shared scratch in effect - only this plan's launches use it.
+            nbytes = int(L.curv_gemm_workspace_bytes_for(self.descs, self.n))
+            self._ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.jobs[0].C.device)
+            self._resident_on = None
+        stream = _lib.stream_ptr()
+        # (the table is written by launches on a stream: only replays on that same stream may rely on it)
+        flags = _lib.GEMM_TABLE_RESIDENT if self._resident_on == stream else 0
+        rc = L.curv_gemm_batched_ex(stream, self.descs, self.n, self._ws.data_ptr(), self._ws.numel(), flags)
+        self._resident_on = stream if rc == 0 else None
+        _lib.check(rc, "curv_gemm_batched")
 
 
 def randn(shape, device, seed: int, offset: int = 0, out: Optional[torch.Tensor] = None,

@@ -185,6 +185,12 @@ size_t curv_gemm_workspace_bytes(int n_desc);
 size_t curv_gemm_workspace_bytes_for(const curv_gemm_desc* descs, int n_desc);
 int curv_gemm_batched(void* stream, const curv_gemm_desc* descs, int n_desc, void* workspace,
                       size_t workspace_bytes);
+/* The same with flags.  CURV_GEMM_TABLE_RESIDENT: this exact descriptor array was the previous call's on this
+ * workspace and nobody else has written to the workspace since (a launch plan that owns its scratch and replays a fixed
+ * list of products): the device copy of the table is not uploaded again. */
+#define CURV_GEMM_TABLE_RESIDENT 1u
+int curv_gemm_batched_ex(void* stream, const curv_gemm_desc* descs, int n_desc, void* workspace,
+                         size_t workspace_bytes, unsigned flags);
 
 /* fp64 variant (alpha/beta only) for the ill-conditioned products of INF.pre_sampler.  `tri`: triangular operands -
  * entries outside the triangle are neither read nor multiplied (they must be zero in memory where a tile straddles the
