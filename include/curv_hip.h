@@ -74,7 +74,7 @@ size_t curv_kfac_workspace_bytes(const curv_factor_desc* descs, int n_factors);
  * float4 staging flag, log2 padded patch row length, 64x64 sub-tiles, k-run length, log2 row lanes
  * that walk patch rows while staging (the remaining row lanes split channels), 1 if the patch images are staged
  * by LDS-DMA from a pre-tiled copy of the source (full-width chunks of a kh x kw > 1 convolution), 1 if the factor is built by the LDS-DMA kernel for flattened per-pixel
- * factors (its own work list: item bases count from 0 per kernel; n_chunks = stages of <= 32 pixels), 2 if it is a
+ * factors (its own work list: item bases count from 0 per kernel; n_chunks = stages of <= 16 pixels), 2 if it is a
  * 3x3 / stride 1 / padding 1 factor assembled from 29 shifted correlations that run as virtual factors of the LDS-DMA
  * kernel (no items of its own), and last the multiply-add FLOPs (2 per multiply-add) the plan executes for the
  * factor: dim (dim + 1) K for a symmetric product over K = samples x output pixels, the sum over its correlations

@@ -66,10 +66,10 @@ def test_plan_respects_budgets(d):
     assert p["TM"] in (64, 128) and p["RL"] == 1
     if p["dma"]:
         # LDS-DMA kernel (syrk_flat.hip): flattened factor, whole 128-row tiles, no bias row; K in stages of at most
-        # 32 pixels of one sample, ceil(ceil(HW / 8) / 4) stages per sample
+        # 16 pixels of one sample, ceil(ceil(HW / 8) / 2) stages per sample
         assert flat and not d["has_bias"] and p["dim"] % 128 == 0 and p["TM"] == 128
         steps = -(-(Ho * Wo) // 8)
-        assert p["nchunks"] == d["N"] * -(-steps // 4)
+        assert p["nchunks"] == d["N"] * -(-steps // 2)
         P = p["dim"] // 128
         assert p["ntiles"] == P * (P + 1) // 2 and p["nitems"] == p["ntiles"] * p["nslices"]
         assert p["cpi"] * p["nslices"] >= p["nchunks"] and p["cpi"] * (p["nslices"] - 1) < p["nchunks"]

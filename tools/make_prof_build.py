@@ -31,10 +31,10 @@ def main():
             "    PROF(5)\n    __syncthreads();\n    PROF(6)\n")
     s = sub(s, "      if (part != 2) q[(32 + row) * 128 + 32 + r32] = acc11[reg];\n    }\n  }\n}\n",
             "      if (part != 2) q[(32 + row) * 128 + 32 + r32] = acc11[reg];\n    }\n  }\n  PROF(7)\n"
-            "  if (lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&g_prof[k], (unsigned long long)pacc[k]);"
+            "  if (PRE && lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&g_prof[k], (unsigned long long)pacc[k]);"
             " atomicAdd(&g_prof[10], (unsigned long long)nmf); atomicAdd(&g_prof[11], 1ull);"
             " atomicAdd(&g_prof[8], (unsigned long long)pacc8); atomicAdd(&g_prof[12], (unsigned long long)nchunk); }\n"
-            "  if (tid == 0 && blockIdx.x < 16384) { g_times[3 * blockIdx.x] = wall0; g_times[3 * blockIdx.x + 1] = wall_clock64();"
+            "  if (PRE && tid == 0 && blockIdx.x < 16384) { g_times[3 * blockIdx.x] = wall0; g_times[3 * blockIdx.x + 1] = wall_clock64();"
             " g_times[3 * blockIdx.x + 2] = ((unsigned long long)d.dim << 32) | (unsigned)(d.kh * 100 + d.TM); }\n}\n")
     s += '''
 extern "C" int curv_debug_syrk_times(unsigned long long* out) {
