@@ -20,6 +20,7 @@
 //                (S accumulates sum_{k'} C[i][k'] X[k'][j] in the storage of X[i][j])
 // Matrices are padded to a multiple of 64 with an identity tail, so no kernel needs bounds checks.
 // "Not positive definite" is reported through a per-factor device info word (0 = ok).
+#include <type_traits>
 #include "common.h"
 #include "mma64.h"
 
@@ -476,6 +477,14 @@ __device__ __forceinline__ double rsqrt_pos(double x) {
   return y;
 }
 
+// 1 / x for a positive finite double: hardware estimate (v_rcp_f64, ~2^-23) + one cubic step
+// y (1 + e + e^2), e = 1 - x y  (error e^3 ~ 2^-69): three dependent instructions behind the estimate.
+__device__ __forceinline__ double rcp_pos(double x) {
+  const double y = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, y, 1.0);
+  return fma(y, fma(e, e, e), y);
+}
+
 __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base) {
   __shared__ double Sc[4][16 * 17];
   __shared__ double dinv_s[NB];        // 1 / L_cc: the triangular inverse divides by the same pivots
@@ -554,42 +563,56 @@ __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* ba
       }
     }
     if (wave == 0) {
-      // The 16 columns of the panel as ONE straight-line block: no store, no branch and no exec-mask change between
-      // the columns (the failure flag and the pivots' reciprocals stay in registers until the panel is done), so that
-      // the scheduler can start column c + 1's pivot chain - broadcast, rsqrt, two Newton steps: the critical path -
-      // under the 14 remaining rank-1 updates of column c instead of after them.
-      double row[16], mine = 1.0;      // mine: lane c < 16 collects 1 / L_cc of its column (a VGPR, not 16 SGPR pairs)
-      int first_bad = 0;
+      // The 16 columns of the panel as ONE straight-line block (no store, no branch and no exec-mask change between
+      // the columns), in root-free form: the columns stay UNSCALED (u_c = L_c sqrt(d_c)) until the panel is done, so that
+      // the serial recurrence runs over the pivots alone,
+      //     d_{c+1} = (a_{c+1,c+1} - earlier columns) - u_c[c+1]^2 / d_c,
+      // i.e. per column one multiply-add on the pivot's lane, one broadcast, and a reciprocal (hardware estimate + one
+      // cubic correction step: 4 dependent instructions).  The rank-1 updates, the squares the next pivot needs and the
+      // bookkeeping hang off that chain and fill its latency; the pivots are tested and their 16 square roots taken at
+      // once at the end (lane c owns d_c), and the columns scaled by them.  The form with one rsqrt per column had 20 dependent instructions per
+      // column, six of them scalar (the pivot test selected the rsqrt's input): ~350 cycles per column.
+      double row[16];
+      int mine_lo = 0, mine_hi = 0x3ff00000;      // lane c < 16 collects the pivot d_c of its column
 #pragma unroll
       for (int c = 0; c < 16; ++c) row[c] = Ds[lane * LDA + c0 + c];
-      // software-pipelined by hand: column c + 1's pivot chain (broadcast, rsqrt, two Newton steps - the critical
-      // path) is started right after the one update it depends on, and the other updates of column c fill its latency;
-      // the scheduling barrier per column keeps the broadcasts (SGPR pairs) of one column from piling up over the next.
-      double dinv;
-      {
-        const double piv = readlane_f64(row[0], c0);
-        const bool ok = piv > 0.0 && piv < 1.0e300;               // also false for NaN
-        dinv = rsqrt_pos(ok ? piv : 1.0);                         // select the INPUT: a select of the result becomes a
-        first_bad = ok ? 0 : pivot_base + c0 + 1;                 // scalar branch that cuts the column into basic blocks
-      }
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        mine = (lane == c) ? dinv : mine;
-        row[c] *= dinv;
+      double d = readlane_f64(row[0], c0), rd = rcp_pos(d);
+      // one column; the column index is a compile-time constant (v_writelane takes its lane as an immediate)
+      auto column = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(mine_lo) : "s"(__double2loint(d)), "n"(c));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(mine_hi) : "s"(__double2hiint(d)), "n"(c));
         if (c + 1 < 16) {
-          row[c + 1] -= row[c] * readlane_f64(row[c], c0 + c + 1);
-          const double piv = readlane_f64(row[c + 1], c0 + c + 1);
-          const bool ok = piv > 0.0 && piv < 1.0e300;
-          dinv = rsqrt_pos(ok ? piv : 1.0);
-          first_bad = (!ok && first_bad == 0) ? pivot_base + c0 + c + 2 : first_bad;
+          // the chain: next pivot from this column's reciprocal (only lane c0 + c + 1 of pv is meaningful)
+          const double pv = fma(-(row[c] * row[c]), rd, row[c + 1 < 16 ? c + 1 : c]);
+          d = readlane_f64(pv, c0 + c + 1);
         }
+        const double t = row[c] * rd;                      // multipliers u_c[q] / d_c, lane q
+        if (c + 1 < 16) rd = rcp_pos(d);
+        // broadcasts issued one update ahead: two instructions between a v_readlane and the use of its SGPR
+        double m_next = c + 1 < 16 ? readlane_f64(t, c0 + c + 1) : 0.0;
 #pragma unroll
-        for (int q = c + 2; q < 16; ++q) row[q] -= row[c] * readlane_f64(row[c], c0 + q);
+        for (int q = c + 1; q < 16; ++q) {
+          const double m = m_next;
+          if (q + 1 < 16) m_next = readlane_f64(t, c0 + q + 1);
+          row[q] -= row[c] * m;
+        }
         __builtin_amdgcn_sched_barrier(0);
-      }
+      };
+#define CURV_COL(C) column(std::integral_constant<int, C>{});
+      CURV_COL(0) CURV_COL(1) CURV_COL(2) CURV_COL(3) CURV_COL(4) CURV_COL(5) CURV_COL(6) CURV_COL(7)
+      CURV_COL(8) CURV_COL(9) CURV_COL(10) CURV_COL(11) CURV_COL(12) CURV_COL(13) CURV_COL(14) CURV_COL(15)
+#undef CURV_COL
+      // pivot test, once per panel (false for NaN too; a failed factor turns into NaN / garbage and is reported)
+      const double mine = __hiloint2double(mine_hi, mine_lo);
+      const unsigned long long failed = __ballot(lane < 16 && !(mine > 0.0 && mine < 1.0e300));
+      const int first_bad = failed != 0 ? pivot_base + c0 + __ffsll((long long)failed) : 0;
+      // L_c = u_c / sqrt(d_c): the reciprocal roots of all 16 pivots at once, handed round through dinv_s
+      const double rs = rsqrt_pos(lane < 16 ? mine : 1.0);
+      if (lane < 16) dinv_s[c0 + lane] = rs;
+      wave_sync();
 #pragma unroll
-      for (int c = 0; c < 16; ++c) Ds[lane * LDA + c0 + c] = row[c];
-      if (lane < 16) dinv_s[c0 + lane] = mine;
+      for (int c = 0; c < 16; ++c) Ds[lane * LDA + c0 + c] = row[c] * dinv_s[c0 + c];
       if (first_bad != 0 && lane == 0 && *bad == 0) *bad = first_bad;
     }
     __syncthreads();
