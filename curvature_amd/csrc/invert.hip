@@ -32,6 +32,10 @@
 namespace curv {
 
 constexpr int INV_THREADS = MMA_THREADS;
+// flag words per factor of chol_square_kernel (zeroed by inv_prepare_kernel at the start of every sweep)
+constexpr int SQ_FLAGS = 32;
+constexpr int SQ_FD = 0, SQ_FLC = 4, SQ_FLROW = 8, SQ_FT = 12;
+constexpr int SQ_SPIN_LIMIT = 1 << 21;
 
 struct InvDev {
   const float* F;       // (n x n) fp32 factor
@@ -79,7 +83,7 @@ __device__ __forceinline__ bool locate(const InvDev* __restrict__ t, int nf, int
 //     identity tail on the padding; lower triangle only.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(INV_THREADS)
-inv_prepare_kernel(const InvDev* __restrict__ t, int nf) {
+inv_prepare_kernel(const InvDev* __restrict__ t, int nf, int* __restrict__ flags) {
   int f, tile;
   if (!locate(t, nf, blockIdx.x, [](const InvDev& d) { return d.P * (d.P + 1) / 2; }, f, tile)) return;
   const InvDev& d = t[f];
@@ -92,6 +96,7 @@ inv_prepare_kernel(const InvDev* __restrict__ t, int nf) {
   const gfloat* F = (const gfloat*)d.F;
   gdouble* W = (gdouble*)d.W;
   if (bi == 0 && bj == 0 && threadIdx.x == 0) *d.info = 0;
+  if (bi == 0 && bj == 0 && threadIdx.x < SQ_FLAGS) flags[(long long)f * SQ_FLAGS + threadIdx.x] = 0;
   if (d.f64_in) {
     // fp64 input (already symmetric by construction; symmetrised again at no cost): W = (M + M^T) / 2 + add * I
     const gdouble* M = (const gdouble*)d.F;
@@ -707,6 +712,278 @@ chol_panel_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int kend)
 }
 
 // ------------------------------------------------------------------------------------------------
+// The block square of an outer panel in ONE launch (few factors: the chain of a large factor, a layer-sharded
+// rank).  The per-step launches above put three kernel boundaries between two 64x64 factorisations
+// (panel solve, inner update + next factorisation); here the workgroups of a factor wait for each other
+// through flags in global memory instead:
+//   runner (row 0's workgroup) walks the diagonal: X_rr = factor-and-invert of A''_rr, then - with X_rr still in
+//     LDS - the one solve and the one update the next diagonal block is waiting for,
+//       L_{r+1,r} = T_{r+1,r} X_rr^T,    A'_{r+1,r+1} = A''_{r+1,r+1} - L_{r+1,r} L_{r+1,r}^T;
+//   helper r (rows 1..3) works left-looking and one step ahead of the runner: its row's other tiles
+//       L_{r,m} = (A_{r,m} - sum_{j<m} L_{r,j} L_{m,j}^T) X_mm^T  (m <= r - 2),   T_{r,r-1},   A''_rr,
+//     and COLUMN r - 1 of the square's inverse, X_{i,j} = -X_ii sum_{m=j}^{i-1} L_{i,m} X_{m,j}.
+// Tiles that cross workgroups are written and read with agent-coherent accesses (sc1: no cache maintenance); a
+// hand-off (store, flag, poll, load) takes ~5 us (tools/micro/wg_handoff.hip), which is why nothing on the runner's
+// path waits for one that was not posted a step earlier.  A workgroup only waits for workgroups with a lower
+// block index of the same launch (dispatched before it), and every wait is bounded: a lost flag ends in an
+// error code, not in a hung queue.
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void load_block_coh(const gdouble* __restrict__ g, int ld, double* __restrict__ s) {
+  const int tid = threadIdx.x, r0 = tid >> 6, c = tid & 63;
+  const long long step = 4ll * ld;
+  const double* base = (const double*)g + (long long)r0 * ld + c;
+  double v[NB * NB / MMA_THREADS];
+#pragma unroll
+  for (int u = 0; u < NB * NB / MMA_THREADS; ++u)
+    v[u] = __hip_atomic_load(base + u * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int u = 0; u < NB * NB / MMA_THREADS; ++u) s[(r0 + 4 * u) * LDA + c] = v[u];
+}
+__device__ __forceinline__ void store_block_coh(gdouble* __restrict__ g, int ld, const double* __restrict__ s) {
+  const int tid = threadIdx.x, r0 = tid >> 6, c = tid & 63;
+  const long long step = 4ll * ld;
+  double* base = (double*)g + (long long)r0 * ld + c;
+#pragma unroll
+  for (int u = 0; u < NB * NB / MMA_THREADS; ++u)
+    __hip_atomic_store(base + u * step, s[(r0 + 4 * u) * LDA + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// C = sign * acc, coherent
+__device__ __forceinline__ void store_acc_coh(gdouble* __restrict__ C, int ld, const f64x4 (&acc)[2][2], int wm, int wn,
+                                              int lane, double sign) {
+  const int c16 = lane & 15, rq = lane >> 4;
+  double* base = (double*)C + (long long)(32 * wm + rq) * ld + 32 * wn + c16;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        __hip_atomic_store(base + (long long)(16 * m + 4 * q) * ld + 16 * n, sign * acc[m][n][q], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+// LDS tile [row][col] -= acc (wave quadrant layout)
+__device__ __forceinline__ void lds_sub_acc(double* s, const f64x4 (&acc)[2][2], int wm, int wn, int lane) {
+  const int c16 = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[(32 * wm + 16 * m + rq + 4 * q) * LDA + 32 * wn + 16 * n + c16] -= acc[m][n][q];
+}
+// mma_64 (mma64.h) for a workgroup that is alone on its CU: every operand of the 64-deep product is read from LDS
+// first (a lane owns 16 consecutive k of its rows: k = 16 (lane >> 4) + ks, pairs of ds_read2_b64), then the 64 MFMAs
+// run back to back - 1.2 us instead of 2.8 for mma_64, whose four-step groups wait for their LDS reads one after the
+// other when no second wave hides them.
+template <bool BT>
+__device__ __forceinline__ void mma_64_pre(const double* __restrict__ As, const double* __restrict__ Bs, int wm, int wn, int lane,
+                                           f64x4 (&acc)[2][2]) {
+  const int r16 = lane & 15, kq = lane >> 4;
+  double a[2][16], b[2][16];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) a[m][ks] = As[(32 * wm + 16 * m + r16) * LDA + 16 * kq + ks];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      b[n][ks] = BT ? Bs[(32 * wn + 16 * n + r16) * LDA + 16 * kq + ks] : Bs[(16 * kq + ks) * LDA + 32 * wn + 16 * n + r16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][ks], b[n][ks], acc[m][n], 0, 0, 0);
+}
+__device__ __forceinline__ void zero_acc(f64x4 (&acc)[2][2]) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[m][n] = f64x4{0.0, 0.0, 0.0, 0.0};
+}
+// everything this workgroup stored is visible device-wide, then the flag
+__device__ __forceinline__ void sq_signal(int* flag, int stamp) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sq_wait(int* flag, int stamp, int* lost) {
+  if (threadIdx.x == 0) {
+    int n = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < stamp) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++n > SQ_SPIN_LIMIT || *lost) { *lost = 1; break; }
+    }
+  }
+  __syncthreads();
+}
+
+#ifdef CURV_SQ_TRACE
+// diagnostics build (tools/sq_trace.py): 100 MHz time stamps of one panel of factor 0
+__device__ long long g_sq_trace[256];
+#define SQT(slot) { if (threadIdx.x == 0 && f == 0 && stamp == CURV_SQ_TRACE) g_sq_trace[slot] = wall_clock64(); }
+#else
+#define SQT(slot)
+#endif
+__global__ void __launch_bounds__(INV_THREADS)
+chol_square_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int* __restrict__ flags, int stamp) {
+  __shared__ double Ds[NB * LDA], Is[NB * LDA], Bf[NB * LDA];
+  __shared__ int bad, lost;
+  int f, r;
+  if (!locate(t, nf, blockIdx.x, [k0, kend](const InvDev& d) { return d.P > k0 ? (kend < d.P ? kend : d.P) - k0 : 0; }, f, r))
+    return;
+  const InvDev& d = t[f];
+  const int np = d.np, tid = threadIdx.x;
+  const int nbf = (kend < d.P ? kend : d.P) - k0;
+  gdouble* W = (gdouble*)d.W;
+  gdouble* X = (gdouble*)d.X;
+  int* fl = flags + (long long)f * SQ_FLAGS;
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  auto Wt = [&](int i, int j) { return W + (long long)(k0 + i) * NB * np + (k0 + j) * NB; };   // tiles of the square
+  auto Xt = [&](int i, int j) { return X + (long long)(k0 + i) * NB * np + (k0 + j) * NB; };
+  if (tid == 0) { bad = 0; lost = 0; }
+  __syncthreads();
+  f64x4 acc[2][2];
+  if (r == 0) {
+    // ---------------- runner ----------------
+    SQT(0)
+    load_block(Wt(0, 0), np, Ds);
+    if (nbf > 1) load_block(Wt(1, 0), np, Bf);                    // T_{1,0} = A_{1,0}: fetched ahead of the first step
+    __syncthreads();
+    SQT(1)
+    factor_invert_64(Ds, Is, &bad, k0 * NB);
+    SQT(2)
+    store_block_coh(Xt(0, 0), np, Is);
+    sq_signal(fl + SQ_FD + 0, stamp);
+    SQT(3)
+    for (int q = 1; q < nbf; ++q) {
+      if (q >= 2) {
+        sq_wait(fl + SQ_FT + q, stamp, &lost);
+        SQT(8 * q + 0)
+        load_block_coh(Wt(q, q - 1), np, Bf);                     // T_{q,q-1}
+      }
+      load_block_coh(Wt(q, q), np, Ds);                           // A''_qq
+      __syncthreads();
+      SQT(8 * q + 1)
+      zero_acc(acc);
+      mma_64_pre<true>(Bf, Is, wm, wn, lane, acc);                    // L_{q,q-1} = T X_{q-1,q-1}^T
+      SQT(8 * q + 2)
+      store_acc_coh(Wt(q, q - 1), np, acc, wm, wn, lane, 1.0);
+      __syncthreads();                                            // every wave is done reading Bf
+      acc_to_lds(acc, wm, wn, lane, Bf);
+      __syncthreads();
+      zero_acc(acc);
+      mma_64_pre<true>(Bf, Bf, wm, wn, lane, acc);
+      lds_sub_acc(Ds, acc, wm, wn, lane);                         // A'_qq
+      SQT(8 * q + 3)
+      sq_signal(fl + SQ_FLC + q, stamp);                          // L_{q,q-1} is out (also the barrier the step needs)
+      SQT(8 * q + 4)
+      factor_invert_64(Ds, Is, &bad, (k0 + q) * NB);
+      SQT(8 * q + 5)
+      store_block_coh(Xt(q, q), np, Is);
+      sq_signal(fl + SQ_FD + q, stamp);
+      SQT(8 * q + 6)
+    }
+    if (tid == 0 && bad != 0) atomicCAS(d.info, 0, bad);
+    if (tid == 0 && lost != 0) atomicCAS(d.info, 0, -1);
+    return;
+  }
+  // ---------------- helper of row r ----------------
+  double* Af = Ds;                                                // two staging tiles
+  SQT(64 * r + 0)
+  // phase A: the tiles of this row, T_{r,r-1} and A''_rr (row 1 has none: T_{1,0} = A_{1,0}, A''_11 = A_11).  Every
+  // product is formed as soon as its operands exist ("right-looking" inside the row): behind the runner's flag FLC[r-1]
+  // - posted one factorisation before the runner wants T_{r,r-1} - only ONE product is left.
+  double* Cf = Is;                                                // third tile: this row's newest L_{r,m}
+  if (r >= 2) {
+    f64x4 accA[2][2], accT0[2][2], accT1[2][2];                   // A''_rr, T_{r,1}, T_{r,2}: running sums
+    zero_acc(accA); zero_acc(accT0); zero_acc(accT1);
+    auto push = [&](int mp, int m) {                              // accT[mp - 1] += L_{r,m} L_{mp,m}^T, L_{r,m} in Cf
+      load_block_coh(Wt(mp, m), np, Bf);
+      __syncthreads();
+      if (mp == 1) mma_64_pre<true>(Cf, Bf, wm, wn, lane, accT0);
+      else mma_64_pre<true>(Cf, Bf, wm, wn, lane, accT1);
+      __syncthreads();
+    };
+    for (int m = 0; m <= r - 2; ++m) {
+      SQT(64 * r + 8 + 4 * m)
+      load_block(Wt(r, m), np, Af);                               // A_{r,m}: written by an earlier launch
+      __syncthreads();
+      if (m == 1) lds_sub_acc(Af, accT0, wm, wn, lane);           // T_{r,m}  (m <= r - 2 <= 1)
+      sq_wait(fl + SQ_FD + m, stamp, &lost);
+      SQT(64 * r + 9 + 4 * m)
+      load_block_coh(Xt(m, m), np, Bf);
+      __syncthreads();
+      zero_acc(acc);
+      mma_64_pre<true>(Af, Bf, wm, wn, lane, acc);                // L_{r,m}
+      SQT(64 * r + 10 + 4 * m)
+      store_acc_coh(Wt(r, m), np, acc, wm, wn, lane, 1.0);
+      acc_to_lds(acc, wm, wn, lane, Cf);
+      if (m == r - 2) sq_signal(fl + SQ_FLROW + r, stamp);        // (also the barrier behind the LDS writes)
+      else __syncthreads();
+      mma_64_pre<true>(Cf, Cf, wm, wn, lane, accA);
+      __syncthreads();
+      for (int mp = m + 1; mp <= r - 1; ++mp) {
+        if (m == r - 2 && mp == r - 1) break;                     // needs the runner's L_{r-1,r-2}: last, below
+        sq_wait(fl + (mp == m + 1 ? SQ_FLC : SQ_FLROW) + mp, stamp, &lost);
+        push(mp, m);
+      }
+    }
+    load_block(Wt(r, r), np, Bf);
+    __syncthreads();
+    lds_sub_acc(Bf, accA, wm, wn, lane);
+    __syncthreads();
+    store_block_coh(Wt(r, r), np, Bf);                            // A''_rr, in place
+    load_block(Wt(r, r - 1), np, Af);                             // A_{r,r-1}
+    sq_wait(fl + SQ_FLC + r - 1, stamp, &lost);                   // (barrier: Bf is free again)
+    push(r - 1, r - 2);
+    if (r == 2) lds_sub_acc(Af, accT0, wm, wn, lane);
+    else lds_sub_acc(Af, accT1, wm, wn, lane);
+    __syncthreads();
+    store_block_coh(Wt(r, r - 1), np, Af);                        // T_{r,r-1}, in place
+    sq_signal(fl + SQ_FT + r, stamp);
+    SQT(64 * r + 1)
+  }
+  // phase C: COLUMN r - 1 of the square's inverse, top to bottom,
+  //     X_{i,j} = -X_ii S_i,   S_i = sum_{m=j}^{i-1} L_{i,m} X_{m,j}      (j = r - 1 < i < nbf),
+  // whose X_{m,j} are this workgroup's own earlier results: the columns need nothing from each other, and the three
+  // tiles of the square's last row are finished by three workgroups side by side once the runner posts X_33.
+  {
+    const int j = r - 1;
+    for (int i = r; i < nbf; ++i) {
+      f64x4 S[2][2];
+      zero_acc(S);
+      for (int m = j; m < i; ++m) {
+        // L_{i,m}: the runner's tile (m = i - 1) or helper i's (FLROW[i]: posted with the last of them)
+        if (m == i - 1) sq_wait(fl + SQ_FLC + i, stamp, &lost);
+        else sq_wait(fl + SQ_FLROW + i, stamp, &lost);
+        if (m == j) sq_wait(fl + SQ_FD + j, stamp, &lost);          // X_jj; the others are this workgroup's own
+        load_block_coh(Wt(i, m), np, Af);
+        load_block_coh(Xt(m, j), np, Bf);
+        __syncthreads();
+        mma_64_pre<false>(Af, Bf, wm, wn, lane, S);
+        __syncthreads();
+      }
+      SQT(64 * r + 2 + 16 * (i - r))
+      acc_to_lds(S, wm, wn, lane, Af);
+      sq_wait(fl + SQ_FD + i, stamp, &lost);                        // (also the barrier behind the LDS writes)
+      SQT(64 * r + 3 + 16 * (i - r))
+      load_block_coh(Xt(i, i), np, Bf);
+      __syncthreads();
+      zero_acc(acc);
+      mma_64_pre<false>(Bf, Af, wm, wn, lane, acc);
+      store_acc_coh(Xt(i, j), np, acc, wm, wn, lane, -1.0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // read back by this workgroup for the next row
+      __syncthreads();
+      SQT(64 * r + 4 + 16 * (i - r))
+    }
+  }
+  if (tid == 0 && lost != 0) atomicCAS(d.info, 0, -1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // After the chain of diagonal steps has factorised the nb x nb block square of outer panel [k0, kend)
 // (L_sq in W, X_sq = L_sq^-1 in X), everything else of the panel is two triangular products:
 //   (1c) rows below the square:   W[i][k0 + c] <- sum_{k <= c} W[i][k0 + k] X_sq[c][k]^T      i >= kend
@@ -819,6 +1096,7 @@ __global__ void __launch_bounds__(256) inv_upload_kernel(InvDev* __restrict__ ta
 }
 
 static size_t inv_table_bytes(int n) { return align_up((size_t)std::max(n, 1) * sizeof(InvDev), 256); }
+static size_t inv_flags_bytes(int n) { return align_up((size_t)std::max(n, 1) * SQ_FLAGS * sizeof(int), 256); }
 
 // Extra streams of a sweep, one set per device, created on first use:
 //   side[g]  far part of the outer updates of factor group g (runs beside the next panel's chain of
@@ -925,8 +1203,14 @@ int curv_internal_side_stream(hipStream_t* out) {
 
 using namespace curv;
 
+#ifdef CURV_SQ_TRACE
+extern "C" int curv_debug_sq_trace(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(curv::g_sq_trace), 256 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int n_factors) {
-  size_t total = 2 * inv_table_bytes(n_factors);
+  size_t total = 2 * inv_table_bytes(n_factors) + 2 * inv_flags_bytes(n_factors);
   for (int i = 0; i < n_factors; ++i) {
     if (descs[i].n <= 0) return 0;
     const size_t np = (size_t)cdiv(descs[i].n, NB) * NB;
@@ -937,7 +1221,7 @@ extern "C" size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int 
 
 // One batched sweep over the factors of `tab` (work matrices already assigned), everything enqueued on
 // `stream` except the far outer updates, which go to side->stream.
-static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vector<InvDev>& tab, InvDev* table,
+static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vector<InvDev>& tab, InvDev* table, int* flags,
                             hipEvent_t progress_event = nullptr, int progress_panel = -1) {
   const int n_factors = (int)tab.size();
   int Pmax = 0;
@@ -955,7 +1239,7 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
     hipLaunchKernelGGL(inv_upload_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count);
     CURV_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(inv_prepare_kernel, dim3((unsigned)prep_tiles), dim3(INV_THREADS), 0, stream, table, n_factors);
+  hipLaunchKernelGGL(inv_prepare_kernel, dim3((unsigned)prep_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, flags);
   CURV_LAUNCH_CHECK();
   constexpr int NBO = 4;                       // outer panel: 4 block columns = 256
   // Per panel: the chain of diagonal steps (small, latency-bound launches) runs on the caller's stream,
@@ -964,13 +1248,25 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
   // launches narrower than the GPU take the 1024-thread form of the tile kernels (see tile_product_k32)
   static const long long wide_near = getenv("CURV_WIDE_NEAR") ? atoll(getenv("CURV_WIDE_NEAR")) : 512;
   static const long long wide_prod = getenv("CURV_WIDE_PROD") ? atoll(getenv("CURV_WIDE_PROD")) : 256;
+  // few factors (the chain of a large factor, a layer-sharded rank): the block square of a panel in one launch whose
+  // workgroups hand tiles to each other (chol_square_kernel); many factors: one wide launch per step of the chain
+  static const int square_max = getenv("CURV_SQUARE_MAX") ? atoi(getenv("CURV_SQUARE_MAX")) : 16;
+  const bool use_square = n_factors <= square_max;
   bool far_pending = false;
   int panel = 0;
   for (int k0 = 0; k0 < Pmax; k0 += NBO, ++panel) {
     const int kend = k0 + NBO, row0 = kend + NBO;
     if (progress_event != nullptr && panel == progress_panel) CURV_HIP_CHECK(hipEventRecord(progress_event, stream));
     long long prod_tiles = 0;
-    for (int k = k0; k < std::min(kend, Pmax); ++k) {
+    if (use_square) {
+      long long sq_wgs = 0;
+      for (const InvDev& d : tab)
+        if (d.P > k0) sq_wgs += std::min(kend, d.P) - k0;
+      hipLaunchKernelGGL(chol_square_kernel, dim3((unsigned)sq_wgs), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend,
+                         flags, panel + 1);
+      CURV_LAUNCH_CHECK();
+    }
+    for (int k = k0; !use_square && k < std::min(kend, Pmax); ++k) {
       long long diag_tiles = 0, panel_tiles = 0, upd_tiles = 0;
       for (const InvDev& d : tab) {
         if (d.P > k) { ++diag_tiles; panel_tiles += std::min(kend, d.P) - k0 - 1; }
@@ -1050,13 +1346,16 @@ constexpr int SPLIT_P = 16;
 static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* workspace, size_t workspace_bytes,
                       const char* who) {
   const int n_factors = (int)tab.size();
-  size_t need = 2 * inv_table_bytes(n_factors);
+  size_t need = 2 * inv_table_bytes(n_factors) + 2 * inv_flags_bytes(n_factors);
   for (const InvDev& d : tab) need += 2 * (size_t)d.np * d.np * sizeof(double);
   if (workspace == nullptr || workspace_bytes < need) {
     set_error("%s: workspace too small (%zu < %zu bytes)", who, workspace_bytes, need);
     return CURV_ERR_WORKSPACE;
   }
   char* p = reinterpret_cast<char*>(workspace) + 2 * inv_table_bytes(n_factors);
+  int* flags0 = reinterpret_cast<int*>(p);
+  int* flags1 = reinterpret_cast<int*>(p + inv_flags_bytes(n_factors));
+  p += 2 * inv_flags_bytes(n_factors);
   std::vector<InvDev> big, small;
   int Pmax = 0;
   for (const InvDev& d : tab) Pmax = std::max(Pmax, d.P);
@@ -1078,7 +1377,7 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
     // caller's stream may be.
     CURV_HIP_CHECK(hipEventRecord(ss->ev_fork, stream));
     CURV_HIP_CHECK(hipStreamWaitEvent(ss->aux, ss->ev_fork, 0));
-    const int rc1 = chol_sweep_group(ss->aux, &ss->side[0], big.empty() ? small : big, table0);
+    const int rc1 = chol_sweep_group(ss->aux, &ss->side[0], big.empty() ? small : big, table0, flags0);
     if (rc1 != CURV_OK) return rc1;
     CURV_HIP_CHECK(hipEventRecord(ss->ev_join, ss->aux));
     CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->ev_join, 0));
@@ -1098,10 +1397,10 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   // only a far-bound large group has such a tail to fill (a chain step is ~54 us, a far tile ~0.04 us of the
   // whole GPU): with [2048 | 1024, 512, 256] the delay costs 8 %
   const int start_panel = far0 >= 5000 ? std::min(n_panels - 1, n_panels * start_frac / 100) : 0;
-  int rc = chol_sweep_group(ss->aux, &ss->side[0], big, table0, start_panel > 0 ? ss->ev_join2 : nullptr, start_panel);
+  int rc = chol_sweep_group(ss->aux, &ss->side[0], big, table0, flags0, start_panel > 0 ? ss->ev_join2 : nullptr, start_panel);
   if (rc != CURV_OK) return rc;
   if (start_panel > 0) CURV_HIP_CHECK(hipStreamWaitEvent(ss->masked, ss->ev_join2, 0));
-  rc = chol_sweep_group(ss->masked, &ss->side[1], small, table1);
+  rc = chol_sweep_group(ss->masked, &ss->side[1], small, table1, flags1);
   if (rc != CURV_OK) return rc;
   CURV_HIP_CHECK(hipEventRecord(ss->ev_join, ss->aux));
   CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->ev_join, 0));
@@ -1133,7 +1432,7 @@ extern "C" int curv_chol_inv_lower(void* stream_, const curv_inv_desc* descs, in
 }
 
 extern "C" size_t curv_chol_factor_inverse_workspace_bytes(const curv_cholinv_desc* descs, int n) {
-  size_t total = 2 * inv_table_bytes(n);
+  size_t total = 2 * inv_table_bytes(n) + 2 * inv_flags_bytes(n);
   for (int i = 0; i < n; ++i) {
     if (descs[i].n <= 0) return 0;
     const size_t np = (size_t)cdiv(descs[i].n, NB) * NB;

@@ -26,7 +26,7 @@ start = None
 cnt = 0
 for r in rows:
     n = r["Kernel_Name"].split("(")[0].replace("curv::", "")
-    if n == "chol_diag_kernel":
+    if n in ("chol_diag_kernel", "chol_square_kernel"):
         cnt += 1
     if cnt in (9, 10):
         st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
