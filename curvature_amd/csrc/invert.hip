@@ -366,6 +366,91 @@ __device__ __forceinline__ void tile_product_k32(const TileJob& o, double* __res
   else tile_product_impl<WV, 0>(o, As, Bs);
 }
 
+// Quarter form of the panel product for calls that are bound by their chain (chol_sweep_group): a
+// 64x64 tile job is cut into four workgroups of four waves, one 16x16 MFMA tile per wave - rows 16 q.. of the tile when
+// the operands are K-contiguous, columns 16 q.. when B is [k][col] (that job may overwrite a block row of B: a
+// workgroup touches only its own columns of it).  fp64 MFMAs are slow enough (~100 cycles each) that a lone 1024-thread
+// workgroup is bound by its CU's four matrix pipes (a K = 256 tile: 256 MFMAs per SIMD, 11 us); spread over four CUs
+// the same waves have a pipe each (4608^2: 2.78 -> 2.66 ms, 2304^2: 1.20 -> 1.08; the near update in the same form was
+// slower - 2.94 ms - beside the far update it shares the GPU with).  K advances in steps of 64 (one 16-deep group of loads per thread in flight beside
+// the MFMAs of the previous step); every output element sums its products in the same order as in the other forms.
+constexpr int QKS = 64;
+constexpr int QUARTER_LDS = 80 * LDA;             // one buffer: [16][LDA] + [64][LDA], or [64][LDA] + [64][17]  (41.6 KB)
+template <int MODE>
+__device__ __forceinline__ void tile_quarter_impl(const TileJob& o, int q, double* __restrict__ Qs, double* __restrict__) {
+  constexpr bool colsplit = MODE == 2;            // B as [k][col]: quarter = columns, the waves own rows
+  double* __restrict__ As = Qs;
+  double* __restrict__ Bs = Qs + (colsplit ? 64 : 16) * LDA;
+  const int np = o.np;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  constexpr int NA = colsplit ? 16 : 4, NBL = colsplit ? 4 : 16;   // loads per thread and step
+  double ra[NA], rb[NBL];
+  // [rows][64 k] operands: element (row = tid / 64 + 4 u, k = tid % 64)
+  const unsigned voff_k = (unsigned)(((long long)(tid >> 6) * np + (tid & 63)) * 8);
+  const long long step_k = 4ll * np * 8;
+  // [64 k][16 cols] operand: element (k = tid / 16 + 16 u, col = tid % 16)
+  const unsigned voff_c = (unsigned)(((long long)(tid >> 4) * np + (tid & 15)) * 8);
+  const long long step_c = 16ll * np * 8;
+  const gbyte* abase = colsplit ? o.a0 : o.a0 + (long long)(16 * q) * np * 8;
+  const gbyte* bbase = colsplit ? o.b0 + (long long)(16 * q) * 8 : o.b0;
+  auto fetch = [&](int ke) __attribute__((always_inline)) {
+    const gbyte* ga = abase + (long long)ke * 8;
+    const gbyte* gb = colsplit ? bbase + (long long)ke * np * 8 : bbase + (long long)ke * 8;
+#pragma unroll
+    for (int u = 0; u < NA; ++u) ra[u] = *(const gdouble*)(ga + u * step_k + voff_k);
+#pragma unroll
+    for (int u = 0; u < NBL; ++u) rb[u] = colsplit ? *(const gdouble*)(gb + u * step_c + voff_c) : *(const gdouble*)(gb + u * step_k + voff_k);
+  };
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  const int ke0 = o.ke0, ke1 = o.ke1;
+  fetch(ke0);
+  for (int ke = ke0; ke < ke1; ke += QKS) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) As[((tid >> 6) + 4 * u) * LDA + (tid & 63)] = ra[u];
+#pragma unroll
+    for (int u = 0; u < NBL; ++u) {
+      if (colsplit) Bs[((tid >> 4) + 16 * u) * 17 + (tid & 15)] = rb[u];
+      else Bs[((tid >> 6) + 4 * u) * LDA + (tid & 63)] = rb[u];
+    }
+    __syncthreads();
+    if (ke + QKS < ke1) fetch(ke + QKS);
+#pragma unroll
+    for (int ks = 0; ks < QKS / 4; ++ks) {
+      const int k = 4 * ks + kq;
+      const double a = colsplit ? As[(16 * wave + r16) * LDA + k] : As[r16 * LDA + k];
+      const double b = colsplit ? Bs[k * 17 + r16] : Bs[(16 * wave + r16) * LDA + k];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // 16x16 tile: rows 16 wm + rq + 4 qq, column 16 wn + c16, (wm, wn) = colsplit ? (wave, q) : (q, wave)
+  const int wm = colsplit ? wave : q, wn = colsplit ? q : wave;
+  const int c16 = lane & 15, rq = lane >> 4;
+  gbyte* base = (gbyte*)o.C;
+  const unsigned voff = (unsigned)(((long long)(16 * wm + rq) * np + 16 * wn + c16) * 8);
+  double old[4];
+  if (o.mode == 0 || o.mode == 2) {
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) old[qq] = *(const gdouble*)(base + (long long)(4 * qq) * np * 8 + voff);
+  }
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const double v = acc[qq];
+    const double out = o.mode == 0 ? old[qq] - v : o.mode == 1 ? v : o.mode == 2 ? old[qq] + v : -v;
+    *(gdouble*)(base + (long long)(4 * qq) * np * 8 + voff) = out;
+  }
+}
+__device__ __forceinline__ void tile_quarter(const TileJob& o, int q, double* __restrict__ As, double* __restrict__ Bs) {
+  if (!o.bt) tile_quarter_impl<2>(o, q, As, Bs);
+  else tile_quarter_impl<0>(o, q, As, Bs);          // a diagonal tile reads its A rows again as B
+}
+// block index -> (tile job, quarter): the four quarters of a job on one XCD (they share its operands in that L2)
+__device__ __forceinline__ void quarter_of_block(int bid, int& job, int& q) {
+  job = (bid >> 5) * 8 + (bid & 7);
+  q = (bid >> 3) & 3;
+}
+
 template <int WV>
 __device__ __forceinline__ void outer_update_body(const InvDev* __restrict__ t, int nf, int k0, int kend, int lo, int hi,
                                                   int strip, int n_items, double* __restrict__ As, double* __restrict__ Bs) {
@@ -997,7 +1082,9 @@ template <int WV>
 __device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t, int nf, int k0, int kend,
                                                    double* __restrict__ As, double* __restrict__ Bs) {
   int f, local;
-  if (!locate(t, nf, blockIdx.x,
+  int job = blockIdx.x, quarter = 0;
+  if constexpr (WV == 1) quarter_of_block(blockIdx.x, job, quarter);
+  if (!locate(t, nf, job,
               [k0, kend](const InvDev& d) { return d.P > k0 ? (d.P > kend ? d.P - kend : 0) + k0 : 0; }, f, local))
     return;
   const InvDev& d = t[f];
@@ -1019,8 +1106,14 @@ __device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t,
     o.b0 = below ? (const gbyte*)xsq : (const gbyte*)(X + (long long)k0 * NB * np + j * NB);
     o.C = below ? W + (long long)i * NB * np + (k0 + c) * NB : X + (long long)(k0 + c) * NB * np + j * NB;
     o.ke1 = (c + 1) * NB;
-    tile_product_k32<WV>(o, As, Bs);
+    if constexpr (WV == 1) tile_quarter(o, quarter, As, Bs);
+    else tile_product_k32<WV>(o, As, Bs);
   }
+}
+__global__ void __launch_bounds__(INV_THREADS)
+panel_product_quarter_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
+  __shared__ double Qs[QUARTER_LDS];
+  panel_product_body<1>(t, nf, k0, kend, Qs, Qs);
 }
 __global__ void __launch_bounds__(INV_THREADS, 3)
 panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
@@ -1222,7 +1315,7 @@ extern "C" size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int 
 // One batched sweep over the factors of `tab` (work matrices already assigned), everything enqueued on
 // `stream` except the far outer updates, which go to side->stream.
 static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vector<InvDev>& tab, InvDev* table, int* flags,
-                            hipEvent_t progress_event = nullptr, int progress_panel = -1) {
+                            bool latency_bound, hipEvent_t progress_event = nullptr, int progress_panel = -1) {
   const int n_factors = (int)tab.size();
   int Pmax = 0;
   long long prep_tiles = 0, fin_tiles = 0;
@@ -1248,10 +1341,16 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
   // launches narrower than the GPU take the 1024-thread form of the tile kernels (see tile_product_k32)
   static const long long wide_near = getenv("CURV_WIDE_NEAR") ? atoll(getenv("CURV_WIDE_NEAR")) : 512;
   static const long long wide_prod = getenv("CURV_WIDE_PROD") ? atoll(getenv("CURV_WIDE_PROD")) : 256;
-  // few factors (the chain of a large factor, a layer-sharded rank): the block square of a panel in one launch whose
-  // workgroups hand tiles to each other (chol_square_kernel); many factors: one wide launch per step of the chain
-  static const int square_max = getenv("CURV_SQUARE_MAX") ? atoi(getenv("CURV_SQUARE_MAX")) : 16;
-  const bool use_square = n_factors <= square_max;
+  // ... and below this many tile jobs the quarter form (four 256-thread workgroups per job, see tile_quarter_impl)
+  static const long long quarter_prod_env = getenv("CURV_QUARTER_PROD") ? atoll(getenv("CURV_QUARTER_PROD")) : 512;
+  const long long quarter_prod = latency_bound ? quarter_prod_env : 0;
+  // A call with few factors (a layer-sharded rank, a single large factor) is bound by the latency of its chain: the block
+  // square of a panel then goes into one launch whose workgroups hand tiles to each other (chol_square_kernel), and the
+  // panel product takes the quarter form.  A whole model on one GPU is bound by its far updates: there the workgroups
+  // of the square kernel (109 KB of LDS each, most of them waiting) only take CUs away - ResNet-50's 108 factors:
+  // 8.40 ms with the per-step launches, 8.55 with the square kernel for the large group, 8.66 with both; its shards
+  // over 2 / 4 / 8 ranks (tools/emulate_sharding.py): step 9.6 / 6.3 / 4.4 -> 9.2 / 5.6 / 3.8 ms.
+  const bool use_square = latency_bound;
   bool far_pending = false;
   int panel = 0;
   for (int k0 = 0; k0 < Pmax; k0 += NBO, ++panel) {
@@ -1288,7 +1387,10 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
     for (const InvDev& d : tab)
       if (d.P > k0) prod_tiles += std::max(0, d.P - kend) + k0;
     if (prod_tiles > 0) {   // rows below / columns left of the square: one triangular product each
-      if (prod_tiles <= wide_prod)
+      if (prod_tiles <= quarter_prod)
+        hipLaunchKernelGGL(panel_product_quarter_kernel, dim3((unsigned)(cdivll(prod_tiles, 8) * 32)), dim3(INV_THREADS), 0, stream,
+                           table, n_factors, k0, kend);
+      else if (prod_tiles <= wide_prod)
         hipLaunchKernelGGL(panel_product_wide_kernel, dim3((unsigned)prod_tiles), dim3(1024), 0, stream, table, n_factors, k0, kend);
       else
         hipLaunchKernelGGL(panel_product_kernel, dim3((unsigned)prod_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend);
@@ -1346,6 +1448,8 @@ constexpr int SPLIT_P = 16;
 static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* workspace, size_t workspace_bytes,
                       const char* who) {
   const int n_factors = (int)tab.size();
+  static const int latency_max = getenv("CURV_LATENCY_MAX") ? atoi(getenv("CURV_LATENCY_MAX")) : 64;
+  const bool latency_bound = n_factors <= latency_max;
   size_t need = 2 * inv_table_bytes(n_factors) + 2 * inv_flags_bytes(n_factors);
   for (const InvDev& d : tab) need += 2 * (size_t)d.np * d.np * sizeof(double);
   if (workspace == nullptr || workspace_bytes < need) {
@@ -1377,7 +1481,7 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
     // caller's stream may be.
     CURV_HIP_CHECK(hipEventRecord(ss->ev_fork, stream));
     CURV_HIP_CHECK(hipStreamWaitEvent(ss->aux, ss->ev_fork, 0));
-    const int rc1 = chol_sweep_group(ss->aux, &ss->side[0], big.empty() ? small : big, table0, flags0);
+    const int rc1 = chol_sweep_group(ss->aux, &ss->side[0], big.empty() ? small : big, table0, flags0, latency_bound);
     if (rc1 != CURV_OK) return rc1;
     CURV_HIP_CHECK(hipEventRecord(ss->ev_join, ss->aux));
     CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->ev_join, 0));
@@ -1397,10 +1501,10 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   // only a far-bound large group has such a tail to fill (a chain step is ~54 us, a far tile ~0.04 us of the
   // whole GPU): with [2048 | 1024, 512, 256] the delay costs 8 %
   const int start_panel = far0 >= 5000 ? std::min(n_panels - 1, n_panels * start_frac / 100) : 0;
-  int rc = chol_sweep_group(ss->aux, &ss->side[0], big, table0, flags0, start_panel > 0 ? ss->ev_join2 : nullptr, start_panel);
+  int rc = chol_sweep_group(ss->aux, &ss->side[0], big, table0, flags0, latency_bound, start_panel > 0 ? ss->ev_join2 : nullptr, start_panel);
   if (rc != CURV_OK) return rc;
   if (start_panel > 0) CURV_HIP_CHECK(hipStreamWaitEvent(ss->masked, ss->ev_join2, 0));
-  rc = chol_sweep_group(ss->masked, &ss->side[1], small, table1, flags1);
+  rc = chol_sweep_group(ss->masked, &ss->side[1], small, table1, flags1, latency_bound);
   if (rc != CURV_OK) return rc;
   CURV_HIP_CHECK(hipEventRecord(ss->ev_join, ss->aux));
   CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->ev_join, 0));

@@ -153,3 +153,46 @@ def test_same_result_without_cu_masks(gpu, tmp_path):
     there = torch.load(tmp_path / "out.pt")
     for a, b in zip(here, there):
         assert torch.equal(a, b)
+
+
+def test_chain_bound_and_throughput_forms_agree(gpu):
+    """A call with few factors sweeps a panel's block square in one launch whose workgroups hand tiles to each other
+    (chol_square_kernel, quarter-form panel products); the same factors inside a call with many factors take the
+    per-step launches.  Both forms must reproduce the fp64 oracle, for block counts that are not multiples of the
+    panel width (1, 2, 3 and 4 block rows in the last square) and for several factors advancing together."""
+    import oracle.curvature_oracle as o
+    from curvature_amd import ops
+    torch.manual_seed(11)
+    sizes = [64, 100, 190, 256, 321, 700, 1100]
+    Fs = []
+    for n in sizes:
+        X = torch.randn(n, n + 12, device=gpu)
+        F = X @ X.t() / X.shape[1]
+        Fs.append(((F + F.t()) / 2).contiguous())
+    adds, muls = [0.3] * len(Fs), [50.0] * len(Fs)
+    few = ops.chol_inv_lower(Fs, adds, muls)
+    filler = [torch.eye(8, device=gpu) * (i + 1.0) for i in range(70)]          # 77 factors: the throughput form
+    many = ops.chol_inv_lower(Fs + filler, adds + [0.0] * 70, muls + [1.0] * 70)
+    for F, L_few, L_many in zip(Fs, few, many):
+        exact = o.chol_of_inverse(damp32_then_64(F.cpu(), 0.3, 50.0))
+        assert rel_fro(L_few, exact) < 1e-6
+        assert rel_fro(L_many, exact) < 1e-6
+        assert rel_fro(L_few, L_many.cpu()) < 1e-6
+
+
+def test_chain_bound_form_reports_failed_pivots(gpu):
+    """A non-positive pivot in any block row of a square ends in the status word, not in a hang: the workgroups of the
+    square kernel keep posting their flags when a factorisation fails."""
+    from curvature_amd import ops
+    torch.manual_seed(12)
+    for n, bad_at in ((200, 130), (500, 20), (500, 470)):
+        X = torch.randn(n, n + 8, device=gpu)
+        F = (X @ X.t() / X.shape[1]).contiguous()
+        F[bad_at, bad_at] = -5.0
+        with pytest.raises(RuntimeError):
+            ops.chol_inv_lower([F], [0.0], [1.0])
+    # and the next call on the same workspace is clean again
+    X = torch.randn(300, 320, device=gpu)
+    F = (X @ X.t() / 320).contiguous()
+    out = ops.chol_inv_lower([F], [1.0], [1.0])[0]
+    assert torch.isfinite(out).all()
