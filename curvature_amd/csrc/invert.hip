@@ -366,91 +366,6 @@ __device__ __forceinline__ void tile_product_k32(const TileJob& o, double* __res
   else tile_product_impl<WV, 0>(o, As, Bs);
 }
 
-// Quarter form of the panel product for calls that are bound by their chain (chol_sweep_group): a
-// 64x64 tile job is cut into four workgroups of four waves, one 16x16 MFMA tile per wave - rows 16 q.. of the tile when
-// the operands are K-contiguous, columns 16 q.. when B is [k][col] (that job may overwrite a block row of B: a
-// workgroup touches only its own columns of it).  fp64 MFMAs are slow enough (~100 cycles each) that a lone 1024-thread
-// workgroup is bound by its CU's four matrix pipes (a K = 256 tile: 256 MFMAs per SIMD, 11 us); spread over four CUs
-// the same waves have a pipe each (4608^2: 2.78 -> 2.66 ms, 2304^2: 1.20 -> 1.08; the near update in the same form was
-// slower - 2.94 ms - beside the far update it shares the GPU with).  K advances in steps of 64 (one 16-deep group of loads per thread in flight beside
-// the MFMAs of the previous step); every output element sums its products in the same order as in the other forms.
-constexpr int QKS = 64;
-constexpr int QUARTER_LDS = 80 * LDA;             // one buffer: [16][LDA] + [64][LDA], or [64][LDA] + [64][17]  (41.6 KB)
-template <int MODE>
-__device__ __forceinline__ void tile_quarter_impl(const TileJob& o, int q, double* __restrict__ Qs, double* __restrict__) {
-  constexpr bool colsplit = MODE == 2;            // B as [k][col]: quarter = columns, the waves own rows
-  double* __restrict__ As = Qs;
-  double* __restrict__ Bs = Qs + (colsplit ? 64 : 16) * LDA;
-  const int np = o.np;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r16 = lane & 15, kq = lane >> 4;
-  constexpr int NA = colsplit ? 16 : 4, NBL = colsplit ? 4 : 16;   // loads per thread and step
-  double ra[NA], rb[NBL];
-  // [rows][64 k] operands: element (row = tid / 64 + 4 u, k = tid % 64)
-  const unsigned voff_k = (unsigned)(((long long)(tid >> 6) * np + (tid & 63)) * 8);
-  const long long step_k = 4ll * np * 8;
-  // [64 k][16 cols] operand: element (k = tid / 16 + 16 u, col = tid % 16)
-  const unsigned voff_c = (unsigned)(((long long)(tid >> 4) * np + (tid & 15)) * 8);
-  const long long step_c = 16ll * np * 8;
-  const gbyte* abase = colsplit ? o.a0 : o.a0 + (long long)(16 * q) * np * 8;
-  const gbyte* bbase = colsplit ? o.b0 + (long long)(16 * q) * 8 : o.b0;
-  auto fetch = [&](int ke) __attribute__((always_inline)) {
-    const gbyte* ga = abase + (long long)ke * 8;
-    const gbyte* gb = colsplit ? bbase + (long long)ke * np * 8 : bbase + (long long)ke * 8;
-#pragma unroll
-    for (int u = 0; u < NA; ++u) ra[u] = *(const gdouble*)(ga + u * step_k + voff_k);
-#pragma unroll
-    for (int u = 0; u < NBL; ++u) rb[u] = colsplit ? *(const gdouble*)(gb + u * step_c + voff_c) : *(const gdouble*)(gb + u * step_k + voff_k);
-  };
-  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-  const int ke0 = o.ke0, ke1 = o.ke1;
-  fetch(ke0);
-  for (int ke = ke0; ke < ke1; ke += QKS) {
-#pragma unroll
-    for (int u = 0; u < NA; ++u) As[((tid >> 6) + 4 * u) * LDA + (tid & 63)] = ra[u];
-#pragma unroll
-    for (int u = 0; u < NBL; ++u) {
-      if (colsplit) Bs[((tid >> 4) + 16 * u) * 17 + (tid & 15)] = rb[u];
-      else Bs[((tid >> 6) + 4 * u) * LDA + (tid & 63)] = rb[u];
-    }
-    __syncthreads();
-    if (ke + QKS < ke1) fetch(ke + QKS);
-#pragma unroll
-    for (int ks = 0; ks < QKS / 4; ++ks) {
-      const int k = 4 * ks + kq;
-      const double a = colsplit ? As[(16 * wave + r16) * LDA + k] : As[r16 * LDA + k];
-      const double b = colsplit ? Bs[k * 17 + r16] : Bs[(16 * wave + r16) * LDA + k];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  // 16x16 tile: rows 16 wm + rq + 4 qq, column 16 wn + c16, (wm, wn) = colsplit ? (wave, q) : (q, wave)
-  const int wm = colsplit ? wave : q, wn = colsplit ? q : wave;
-  const int c16 = lane & 15, rq = lane >> 4;
-  gbyte* base = (gbyte*)o.C;
-  const unsigned voff = (unsigned)(((long long)(16 * wm + rq) * np + 16 * wn + c16) * 8);
-  double old[4];
-  if (o.mode == 0 || o.mode == 2) {
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) old[qq] = *(const gdouble*)(base + (long long)(4 * qq) * np * 8 + voff);
-  }
-#pragma unroll
-  for (int qq = 0; qq < 4; ++qq) {
-    const double v = acc[qq];
-    const double out = o.mode == 0 ? old[qq] - v : o.mode == 1 ? v : o.mode == 2 ? old[qq] + v : -v;
-    *(gdouble*)(base + (long long)(4 * qq) * np * 8 + voff) = out;
-  }
-}
-__device__ __forceinline__ void tile_quarter(const TileJob& o, int q, double* __restrict__ As, double* __restrict__ Bs) {
-  if (!o.bt) tile_quarter_impl<2>(o, q, As, Bs);
-  else tile_quarter_impl<0>(o, q, As, Bs);          // a diagonal tile reads its A rows again as B
-}
-// block index -> (tile job, quarter): the four quarters of a job on one XCD (they share its operands in that L2)
-__device__ __forceinline__ void quarter_of_block(int bid, int& job, int& q) {
-  job = (bid >> 5) * 8 + (bid & 7);
-  q = (bid >> 3) & 3;
-}
-
 template <int WV>
 __device__ __forceinline__ void outer_update_body(const InvDev* __restrict__ t, int nf, int k0, int kend, int lo, int hi,
                                                   int strip, int n_items, double* __restrict__ As, double* __restrict__ Bs) {
@@ -912,6 +827,11 @@ __device__ long long g_sq_trace[256];
 #else
 #define SQT(slot)
 #endif
+#ifdef CURV_SQ_TRACE
+#define PQT(slot) { if (threadIdx.x == 0 && blockIdx.x == 0 && k0 == 4 * (CURV_SQ_TRACE - 1)) g_sq_trace[slot] = wall_clock64(); }
+#else
+#define PQT(slot)
+#endif
 __global__ void __launch_bounds__(INV_THREADS)
 chol_square_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int* __restrict__ flags, int stamp) {
   __shared__ double Ds[NB * LDA], Is[NB * LDA], Bf[NB * LDA];
@@ -1082,9 +1002,7 @@ template <int WV>
 __device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t, int nf, int k0, int kend,
                                                    double* __restrict__ As, double* __restrict__ Bs) {
   int f, local;
-  int job = blockIdx.x, quarter = 0;
-  if constexpr (WV == 1) quarter_of_block(blockIdx.x, job, quarter);
-  if (!locate(t, nf, job,
+  if (!locate(t, nf, blockIdx.x,
               [k0, kend](const InvDev& d) { return d.P > k0 ? (d.P > kend ? d.P - kend : 0) + k0 : 0; }, f, local))
     return;
   const InvDev& d = t[f];
@@ -1106,14 +1024,127 @@ __device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t,
     o.b0 = below ? (const gbyte*)xsq : (const gbyte*)(X + (long long)k0 * NB * np + j * NB);
     o.C = below ? W + (long long)i * NB * np + (k0 + c) * NB : X + (long long)(k0 + c) * NB * np + j * NB;
     o.ke1 = (c + 1) * NB;
-    if constexpr (WV == 1) tile_quarter(o, quarter, As, Bs);
-    else tile_product_k32<WV>(o, As, Bs);
+    tile_product_k32<WV>(o, As, Bs);
+  }
+}
+
+// Quarter form of the panel product, for calls that are bound by their chain (chol_sweep_group).  A job of
+// panel_product_body (one block row below the square, or one block column left of it) is cut into four workgroups of
+// four waves: rows 16 q.. of the block row (whose products are independent row by row), or columns 16 q.. of the block
+// column.  fp64 MFMAs are slow enough (~100 cycles each) that a lone 1024-thread workgroup is bound by its CU's four
+// matrix pipes (ten 64-deep products: 640 MFMAs per SIMD, 28 us); spread over four CUs the same waves have a pipe
+// each.  The workgroup's own operand - 16 rows x 256 of W, or 256 x 16 columns of S - is read ONCE into LDS, which also
+// removes the in-place ordering between the outputs; the ten tiles of X_sq stream through a second LDS tile, the next
+// ones in registers while the MFMAs of the current one run.
+constexpr int PQ_PITCH = 4 * NB + 1;                 // [16][257]: rows of the workgroup's slice of W
+constexpr int PQ_OWN = 16 * PQ_PITCH > 4 * NB * 17 ? 16 * PQ_PITCH : 4 * NB * 17;   // or [256][17]: columns of S
+// `below` is a template parameter: tested inside the K loop it put a scalar branch in front of every operand read
+template <bool below>
+__device__ __forceinline__ void panel_quarter_body(const InvDev& d, int k0, int nb, int i, int j, int q,
+                                                   double* __restrict__ Own, double* __restrict__ Ts) {
+  const int np = d.np;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+  PQT(240)
+  const gbyte* Wb = (const gbyte*)d.W;
+  const gbyte* Xb = (const gbyte*)d.X;
+  // the workgroup's own operand
+  if (below) {
+    // W[i*64 + 16 q + r][k0*64 + k], r < 16, k < 64 nb: element (r = tid / 64 + 4 u, k = tid % 64 + 64 v)
+    const gbyte* g = Wb + (((long long)i * NB + 16 * q) * np + (long long)k0 * NB) * 8;
+    for (int v = 0; v < nb; ++v) {
+      double x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = *(const gdouble*)(g + ((long long)((tid >> 6) + 4 * u) * np + (tid & 63) + 64 * v) * 8);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Own[((tid >> 6) + 4 * u) * PQ_PITCH + (tid & 63) + 64 * v] = x[u];
+    }
+  } else {
+    // S[k0*64 + k][j*64 + 16 q + c], k < 64 nb, c < 16: element (k = tid / 16 + 16 u, c = tid % 16)
+    const gbyte* g = Xb + ((long long)k0 * NB * np + (long long)j * NB + 16 * q) * 8;
+    for (int v = 0; v < nb; ++v) {
+      double x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = *(const gdouble*)(g + ((long long)((tid >> 4) + 16 * u + 64 * v) * np + (tid & 15)) * 8);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Own[((tid >> 4) + 16 * u + 64 * v) * 17 + (tid & 15)] = x[u];
+    }
+  }
+  // stream of X_sq tiles: (c, kb), c = nb - 1 .. 0, kb = 0 .. c; tile rows = block row c of X_sq, K-contiguous.
+  // Three tiles are in flight in registers: the square kernel has just written X_sq through to memory, every tile
+  // is a miss in this XCD's L2 (~2.5 us), and with one tile in flight the ten of them cost 29 us.
+  double rt0[16], rt1[16], rt2[16];
+  auto fetch = [&](int c, int kb, double (&rt)[16]) __attribute__((always_inline)) {
+    const gbyte* g = Xb + (((long long)(k0 + c) * NB) * np + (long long)(k0 + kb) * NB) * 8;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) rt[u] = *(const gdouble*)(g + ((long long)((tid >> 6) + 4 * u) * np + (tid & 63)) * 8);
+  };
+  auto next = [](int& c, int& kb) { if (++kb > c) { --c; kb = 0; } };
+  int c = nb - 1, kb = 0;                 // tile being multiplied
+  int cf = c, kf = kb;                    // next tile to fetch
+  fetch(cf, kf, rt0); next(cf, kf);
+  if (cf >= 0) { fetch(cf, kf, rt1); next(cf, kf); }
+  if (cf >= 0) { fetch(cf, kf, rt2); next(cf, kf); }
+  // four accumulators, every fourth group of four k each: back-to-back MFMAs into ONE accumulator wait for each other
+  // (a 64-deep product took 2.9 us that way, 16 dependent fp64 MFMAs), independent ones pipeline
+  f64x4 acc[4] = {};
+  PQT(241)
+  int pq_n = 0;
+  // one tile: registers -> LDS, refill the registers with the tile three ahead, multiply (no register rotation: a
+  // move would wait for the loads it copies)
+  auto step = [&](double (&rt)[16]) __attribute__((always_inline)) {
+    __syncthreads();                                   // the previous tile's readers are done (and Own is written)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) Ts[((tid >> 6) + 4 * u) * LDA + (tid & 63)] = rt[u];
+    __syncthreads();
+    if (cf >= 0) { fetch(cf, kf, rt); next(cf, kf); }
+#pragma unroll
+    for (int ks = 0; ks < NB / 4; ++ks) {
+      const int k = 4 * ks + kq;
+      // below: out[r][col] += W[r][kb 64 + k] X_sq[c][col][k]      left: out[row][cc] += X_sq[c][row][k] S[kb 64 + k][cc]
+      const double a = below ? Own[r16 * PQ_PITCH + 64 * kb + k] : Ts[(16 * wave + r16) * LDA + k];
+      const double b = below ? Ts[(16 * wave + r16) * LDA + k] : Own[(64 * kb + k) * 17 + r16];
+      acc[ks & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[ks & 3], 0, 0, 0);
+    }
+    if (kb == c) {
+      // 16x16 tile of output block c: rows 16 wm + rq + 4 qq, column 16 wn + c16
+      const int wm = below ? q : wave, wn = below ? wave : q;
+      const int c16 = lane & 15, rq = lane >> 4;
+      gbyte* base = below ? (gbyte*)d.W + (((long long)i * NB) * np + (long long)(k0 + c) * NB) * 8
+                          : (gbyte*)d.X + (((long long)(k0 + c) * NB) * np + (long long)j * NB) * 8;
+      const unsigned voff = (unsigned)(((long long)(16 * wm + rq) * np + 16 * wn + c16) * 8);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const double v = (acc[0][qq] + acc[1][qq]) + (acc[2][qq] + acc[3][qq]);
+        *(gdouble*)(base + (long long)(4 * qq) * np * 8 + voff) = below ? v : -v;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = f64x4{0.0, 0.0, 0.0, 0.0};
+    }
+    next(c, kb);
+    PQT(242 + pq_n)
+    ++pq_n;
+  };
+  while (c >= 0) {
+    step(rt0);
+    if (c < 0) break;
+    step(rt1);
+    if (c < 0) break;
+    step(rt2);
   }
 }
 __global__ void __launch_bounds__(INV_THREADS)
 panel_product_quarter_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
-  __shared__ double Qs[QUARTER_LDS];
-  panel_product_body<1>(t, nf, k0, kend, Qs, Qs);
+  __shared__ double Own[PQ_OWN], Ts[NB * LDA];
+  const int job = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7), q = (blockIdx.x >> 3) & 3;   // the four quarters of a job on one XCD
+  int f, local;
+  if (!locate(t, nf, job,
+              [k0, kend](const InvDev& d) { return d.P > k0 ? (d.P > kend ? d.P - kend : 0) + k0 : 0; }, f, local))
+    return;
+  const InvDev& d = t[f];
+  const int nb = (kend < d.P ? kend : d.P) - k0;
+  const int n_below = d.P > kend ? d.P - kend : 0;
+  if (local < n_below) panel_quarter_body<true>(d, k0, nb, kend + local, 0, q, Own, Ts);
+  else panel_quarter_body<false>(d, k0, nb, 0, local - n_below, q, Own, Ts);
 }
 __global__ void __launch_bounds__(INV_THREADS, 3)
 panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
@@ -1341,7 +1372,7 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
   // launches narrower than the GPU take the 1024-thread form of the tile kernels (see tile_product_k32)
   static const long long wide_near = getenv("CURV_WIDE_NEAR") ? atoll(getenv("CURV_WIDE_NEAR")) : 512;
   static const long long wide_prod = getenv("CURV_WIDE_PROD") ? atoll(getenv("CURV_WIDE_PROD")) : 256;
-  // ... and below this many tile jobs the quarter form (four 256-thread workgroups per job, see tile_quarter_impl)
+  // ... and below this many jobs the quarter form of the panel product (panel_product_quarter_kernel)
   static const long long quarter_prod_env = getenv("CURV_QUARTER_PROD") ? atoll(getenv("CURV_QUARTER_PROD")) : 512;
   const long long quarter_prod = latency_bound ? quarter_prod_env : 0;
   // A call with few factors (a layer-sharded rank, a single large factor) is bound by the latency of its chain: the block

@@ -53,6 +53,9 @@ def main():
         ms = " ".join("m%d: T %.1f X seen %.1f L %.1f |" % (m, us(t[b + 8 + 4 * m]), us(t[b + 9 + 4 * m]), us(t[b + 10 + 4 * m])) for m in range(max(r - 1, 0)))
         cols = " ".join("X[%d][%d]: S done %.1f, X_ii seen %.1f, stored %.1f |" % (i, r - 1, us(t[b + 2 + 16 * (i - r)]), us(t[b + 3 + 16 * (i - r)]), us(t[b + 4 + 16 * (i - r)])) for i in range(r, 4))
         print("helper %d: start %.1f | %s FT posted %.1f | %s" % (r, us(t[b]), ms, us(t[b + 1]), cols))
+    p0 = t[240]
+    print("panel product (block 0): body start 0 | own operand issued, first tiles requested %.1f | after tile k: %s"
+          % ((t[241] - p0) / 100.0, " ".join("%.1f" % ((t[242 + k] - p0) / 100.0) for k in range(10))))
 
 
 if __name__ == "__main__":
