@@ -42,8 +42,9 @@ def rank_cost(dims: Sequence[Sequence[float]], estimator: str = "kfac", rank: in
     Not additive: the factors of a rank are inverted in one batched sweep, so the serial chains of 64-column steps
     overlap and only the longest one counts, and every phase pays a fixed price for its launches however little work
     they carry (a rank with ten small layers is bound by that, not by flops).  Calibrated on one MI355X
-    (tools/emulate_sharding.py, profiles/r03_emulate_sharding.txt): single 4608^2 factor 3.5 ms = 72 steps x 48 us,
-    three of them 5.6 ms, all 108 ResNet-50 factors 8.4 ms; grouped factor build 95 TFLOP/s executed for a whole
+    (tools/emulate_sharding.py, profiles/r03_emulate_sharding.txt): single 4608^2 factor 2.65 ms = 72 steps x 37 us
+    when the call has at most 64 factors (the library then sweeps a panel's block square in one launch), 48 us per step
+    otherwise; three of them 5.2 ms, all 108 ResNet-50 factors 8.4 ms; grouped factor build 95 TFLOP/s executed for a whole
     model, ~60 for a rank's share; sampling GEMMs 95 TFLOP/s.
 
     `estimator`: "kfac" prices update + invert + sample_and_replace of KFAC; "efb" adds the eigendecomposition of the
@@ -56,7 +57,7 @@ def rank_cost(dims: Sequence[Sequence[float]], estimator: str = "kfac", rank: in
     flops = sum(d[3] if len(d) > 3 else (d[0] * (d[0] + 1.0) + d[1] * (d[1] + 1.0)) * d[2] for d in dims)
     build = 0.25e-3 + 0.035e-3 * min(len(dims), 10) + flops / 70e12
     sample = 0.15e-3 + sum(2.0 * (d[0] * d[0] * d[1] + d[0] * d[1] * d[1]) for d in dims) / 95e12 + 6e-6 * len(dims)
-    chain = max(max(d[0], d[1]) for d in dims) / 64.0 * 48e-6
+    chain = max(max(d[0], d[1]) for d in dims) / 64.0 * (37e-6 if 2 * len(dims) <= 64 else 48e-6)
     invert = 0.3e-3 + 0.7 * chain + sum((2.0 / 3.0) * (d[0] ** 3 + d[1] ** 3) for d in dims) / 42e12 + 6e-6 * len(dims)
     total = build + invert + sample
     if estimator in ("efb", "inf"):
