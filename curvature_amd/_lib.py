@@ -133,6 +133,8 @@ SIGNATURES = {
     "curv_inf_vtv_assemble": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "curv_inf_vtv_assemble_f64": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "curv_colpairs_f64": (_i, [_vp, _vp, _i, _i, _ll, _vp]),
+    "curv_colpairs_sym_f64": (_i, [_vp, _vp, _i, _i, _ll, _vp]),
+    "curv_inf_vtv_assemble_sym_f64": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "curv_square_f64": (_i, [_vp, _vp, _vp, _ll]),
     "curv_diag_scale": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i]),
     "curv_gather2d": (_i, [_vp, _vp, _ll, _ll, _vp, _vp, _vp, _i, _i]),

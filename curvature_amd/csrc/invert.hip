@@ -1365,7 +1365,8 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
   }
   hipLaunchKernelGGL(inv_prepare_kernel, dim3((unsigned)prep_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, flags);
   CURV_LAUNCH_CHECK();
-  constexpr int NBO = 4;                       // outer panel: 4 block columns = 256
+  static const int nbo_env = getenv("CURV_NBO") ? atoi(getenv("CURV_NBO")) : 0;
+  const int NBO = (nbo_env > 0 && !latency_bound) ? nbo_env : 4;      // outer panel: 4 block columns = 256
   // Per panel: the chain of diagonal steps (small, latency-bound launches) runs on the caller's stream,
   // then the near part of the outer update (the block columns / rows the NEXT chain touches); the rest of
   // the outer update goes to a second stream and overlaps the following chains (see below).

@@ -1028,7 +1028,7 @@ class INF(Curvature):
         # processed in groups of at most ~24 GB, far below the 288 GB of the device
         def scratch(reg):
             (n, a), (m, b) = reg[0].shape, reg[1].shape
-            return 8.0 * (n * a * a + m * b * b + n * m + a * a * m + 6.0 * (a * b) ** 2)
+            return 8.0 * (n * a * a / 2 + m * b * b / 2 + n * m + a * a * m / 2 + 6.0 * (a * b) ** 2)
         if len(regs) > 1:
             groups, cur, size = [], [], 0.0
             for k, reg in enumerate(regs):
@@ -1051,19 +1051,24 @@ class INF(Curvature):
         first, parts = [], []
         for ua, ug, sigma, r in regs:
             (n, a), (m, b) = ua.shape, ug.shape
-            PA, PG = ops.colpairs(ua, f64=True), ops.colpairs(ug, f64=True)      # (n, a*a), (m, b*b)
+            # distinct column pairs only (i <= k): (n, a (a + 1) / 2), (m, b (b + 1) / 2) - half the flops of the first
+            # product, a quarter of the second, the same values
+            PA, PG = ops.colpairs_sym(ua), ops.colpairs_sym(ug)
             r2 = ops.square_f64(r).view(n, m)
             first.append(ops.Gemm64(PA.t(), r2))
             parts.append((PG, sigma, a, b))
         Ms = ops.gemm_f64_batched(first)
         V4s = ops.gemm_f64_batched([ops.Gemm64(M, PG) for M, (PG, _, _, _) in zip(Ms, parts)])
-        vtvs = [ops.inf_vtv_assemble(V4.contiguous(), sigma, a, b) for V4, (_, sigma, a, b) in zip(V4s, parts)]
+        vtvs = [ops.inf_vtv_assemble_sym(V4.contiguous(), sigma, a, b) for V4, (_, sigma, a, b) in zip(V4s, parts)]
         del first, Ms, V4s, parts
         mats, adds = [], []
         for v in vtvs:
             mats += [v, v]
             adds += [0.0, 1.0]
-        inv = ops.chol_factor_inverse(mats, adds)                        # float64, lower triangular
+        # float64, lower triangular.  The status words are read at the END of this function: a read-back here would
+        # leave the GPU idle while the ~170 launches below are described and enqueued (14 of 115 ms on ResNet-50)
+        inv = ops.chol_factor_inverse(mats, adds, check=False)
+        info = ops.chol_factor_inverse.last_info
         # T = (I - B^-1) A^-1 = A^-1 - B^-1 A^-1 (accumulated onto a copy of A^-1); L_c = A^-T T
         Ts = [torch.empty_like(inv[2 * i]) for i in range(len(regs))]
         ops.CopyPlan(Ts, [inv[2 * i] for i in range(len(regs))]).run()
@@ -1077,17 +1082,18 @@ class INF(Curvature):
         for i, (_, _, sigma, _) in enumerate(regs):
             prev = outs[i] if outs is not None else None
             out.append(ops.diag_scale(L_cs[i], sigma, sigma, out=prev))
+        ops.check_factor_inverse_info(info)                              # RuntimeError where curvatures.py:566-567 raises: inside invert()
         return out
 
     @staticmethod
     def vtv(frst_eigvecs: Tensor, scnd_eigvecs: Tensor, reg_lambda: Tensor, reg_inv_correction: Tensor) -> Tensor:
         """V_s^T V_s, symmetrised, in closed form (no Kronecker matrix), evaluated in float64."""
         (n, a), (m, b) = frst_eigvecs.shape, scnd_eigvecs.shape
-        PA, PG = ops.colpairs(frst_eigvecs, f64=True), ops.colpairs(scnd_eigvecs, f64=True)
+        PA, PG = ops.colpairs_sym(frst_eigvecs), ops.colpairs_sym(scnd_eigvecs)
         r2 = ops.square_f64(reg_inv_correction).view(n, m)
         M = ops.gemm_f64(PA.t(), r2)
         V4 = ops.gemm_f64(M, PG)
-        return ops.inf_vtv_assemble(V4, reg_lambda, a, b)
+        return ops.inf_vtv_assemble_sym(V4.contiguous(), reg_lambda, a, b)
 
     @staticmethod
     def pre_sampler(frst_eigvecs: Tensor, scnd_eigvecs: Tensor, reg_lambda: Tensor,

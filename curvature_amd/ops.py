@@ -472,6 +472,29 @@ def colpairs(U: torch.Tensor, f64: bool = False) -> torch.Tensor:
     return out
 
 
+def colpairs_sym(U: torch.Tensor) -> torch.Tensor:
+    """(n, a) -> (n, a (a + 1) / 2) float64 with out[p, t(i, k)] = U[p,i] U[p,k] for i <= k, t(i, k) = i a - i (i - 1) / 2 + k - i:
+    the distinct columns of `colpairs`."""
+    _require_gpu(U)
+    n, a = U.shape
+    out = torch.empty(n, a * (a + 1) // 2, dtype=torch.float64, device=U.device)
+    _lib.check(_lib.lib().curv_colpairs_sym_f64(_lib.stream_ptr(), U.data_ptr(), n, a, U.stride(0), out.data_ptr()),
+               "curv_colpairs_sym_f64")
+    return out
+
+
+def inf_vtv_assemble_sym(V4p: torch.Tensor, sigma: torch.Tensor, a: int, b: int) -> torch.Tensor:
+    """vtv (ab x ab, float64) from the packed V4p (a (a + 1) / 2 x b (b + 1) / 2) of `colpairs_sym` operands."""
+    _require_gpu(sigma)
+    if not V4p.is_cuda or not V4p.is_contiguous() or V4p.dtype != torch.float64 \
+            or V4p.shape != (a * (a + 1) // 2, b * (b + 1) // 2):
+        raise RuntimeError("inf_vtv_assemble_sym: bad V4p")
+    out = torch.empty(a * b, a * b, dtype=torch.float64, device=V4p.device)
+    _lib.check(_lib.lib().curv_inf_vtv_assemble_sym_f64(_lib.stream_ptr(), V4p.data_ptr(), sigma.data_ptr(), a, b,
+                                                        out.data_ptr()), "curv_inf_vtv_assemble_sym_f64")
+    return out
+
+
 def square_f64(v: torch.Tensor) -> torch.Tensor:
     """float64 v**2 of a float32 tensor (same shape)."""
     _require_gpu(v)
@@ -506,8 +529,10 @@ def diag_scale(src: torch.Tensor, dl: torch.Tensor, dr: torch.Tensor, out: Optio
     return out
 
 
-def chol_factor_inverse(mats: Sequence[torch.Tensor], diag_adds: Sequence[float]) -> List[torch.Tensor]:
-    """[chol_lower(M + d I)^-1] in float64 for symmetric float32 or float64 matrices (batched)."""
+def chol_factor_inverse(mats: Sequence[torch.Tensor], diag_adds: Sequence[float], check: bool = True) -> List[torch.Tensor]:
+    """[chol_lower(M + d I)^-1] in float64 for symmetric float32 or float64 matrices (batched).  `check=False` leaves
+    the status words on the device (``chol_factor_inverse.last_info``) for `check_factor_inverse_info`: a caller with
+    more launches to enqueue does that first and synchronises once, at its end."""
     n = len(mats)
     arr = (curv_cholinv_desc * n)()
     outs = []
@@ -524,10 +549,17 @@ def chol_factor_inverse(mats: Sequence[torch.Tensor], diag_adds: Sequence[float]
     ws = workspace(L.curv_chol_factor_inverse_workspace_bytes(arr, n), dev, "invert")
     _lib.check(L.curv_chol_factor_inverse(_lib.stream_ptr(), arr, n, info.data_ptr(), ws.data_ptr(), ws.numel()),
                "curv_chol_factor_inverse")
+    chol_factor_inverse.last_info = info
+    if check:
+        check_factor_inverse_info(info)
+    return outs
+
+
+def check_factor_inverse_info(info: torch.Tensor) -> None:
+    """Raise like `chol_factor_inverse` does when a status word of the batch is non-zero (one host synchronisation)."""
     bad = torch.nonzero(info).flatten().tolist()
     if bad:
         raise RuntimeError(f"cholesky: matrix/matrices {bad} are not positive-definite")
-    return outs
 
 
 def eigh(mats: Sequence[torch.Tensor], with_values: bool = False, max_sweeps: int = 0, tol: float = 0.0,

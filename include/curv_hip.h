@@ -308,6 +308,12 @@ int curv_square_f64(void* stream, const float* v, double* out, long long count);
 /* vtv[(i,j),(k,l)] = (w + w^T)/2, w = sigma_ij sigma_kl V4[(i,k),(j,l)]   (:564-565) */
 int curv_inf_vtv_assemble(void* stream, const float* V4, const float* sigma, int a, int b, float* vtv);
 int curv_inf_vtv_assemble_f64(void* stream, const double* V4, const float* sigma, int a, int b, double* vtv);
+/* Packed forms: the column pairs are symmetric in (i, k), so out[p][t(i,k)] = U[p][i] U[p][k] for i <= k only,
+ * t(i,k) = i a - i (i - 1) / 2 + (k - i), a (a + 1) / 2 columns; V4p = PAp^T r^2 PGp is then
+ * (a (a + 1) / 2) x (b (b + 1) / 2) and vtv[(i,j),(k,l)] = sigma_ij sigma_kl V4p[t_a(i,k)][t_b(j,l)] - half / a quarter
+ * of the flops of the two products of the closed form, same values (the symmetrisation of :565 is exact here). */
+int curv_colpairs_sym_f64(void* stream, const float* U, int n, int a, long long u_row_stride, double* out);
+int curv_inf_vtv_assemble_sym_f64(void* stream, const double* V4p, const float* sigma, int a, int b, double* vtv);
 /* dst[i][j] = src[i][j] * dl[i] * dr[j] (src fp32 or fp64, dst fp32): P_c = diag(s) L_c diag(s) (:570) */
 int curv_diag_scale(void* stream, const void* src, int src_is_f64, float* dst, const float* dl, const float* dr,
                     int rows, int cols);

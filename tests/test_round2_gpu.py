@@ -546,3 +546,26 @@ def test_diagonal_fused_sample_and_replace(gpu):
             want_b = g1[f"bias_l{li}"].to(gpu) + s[:, -1]
             assert torch.allclose(layer.weight.data.view(m, n - 1), want_w, rtol=0, atol=1e-6), (call, li)
             assert torch.allclose(layer.bias.data, want_b, rtol=0, atol=1e-6), (call, li)
+
+
+def test_packed_column_pairs_reproduce_the_full_closed_form(gpu):
+    """INF's closed-form V_s^T V_s keeps only the distinct column pairs (i <= k) of the Khatri-Rao squares
+    (`colpairs_sym`, `inf_vtv_assemble_sym`): the result must equal the full a^2 x b^2 form - whose symmetrisation
+    (curvatures.py:565) is exact - and the oracle's dense V_s^T V_s."""
+    from curvature_amd import ops
+    torch.manual_seed(21)
+    n, m, a, b = 70, 33, 7, 5
+    ua, ug = torch.randn(n, a, device=gpu), torch.randn(m, b, device=gpu)
+    sigma = torch.rand(a * b, device=gpu) + 0.5
+    r = torch.rand(n * m, device=gpu) + 0.1
+    r2 = ops.square_f64(r).view(n, m)
+    full = ops.inf_vtv_assemble(ops.gemm_f64(ops.gemm_f64(ops.colpairs(ua, f64=True).t(), r2), ops.colpairs(ug, f64=True)).contiguous(),
+                                sigma, a, b)
+    PA, PG = ops.colpairs_sym(ua), ops.colpairs_sym(ug)
+    assert PA.shape == (n, a * (a + 1) // 2) and PG.shape == (m, b * (b + 1) // 2)
+    packed = ops.inf_vtv_assemble_sym(ops.gemm_f64(ops.gemm_f64(PA.t(), r2), PG).contiguous(), sigma, a, b)
+    assert torch.allclose(packed, full, rtol=1e-13, atol=1e-13)
+    assert torch.equal(packed, packed.t())
+    # dense restatement: V_s = diag(r) (U_A kron U_G) diag(sigma)
+    V = (r.double()[:, None] * torch.kron(ua.double(), ug.double())) * sigma.double()[None, :]
+    assert torch.allclose(packed, V.t() @ V, rtol=1e-11, atol=1e-11)
