@@ -30,5 +30,8 @@ def run(sizes, iters=5):
 
 
 if __name__ == "__main__":
+    # CURV_DUMMY_STREAMS=k: k unused streams created before the sweep's own (what RCCL / a data loader would add; the
+    # per-step launches of the sweep were sensitive to that: profiles/r03_stream_sensitivity.txt)
+    dummies = [torch.cuda.Stream() for _ in range(int(os.environ.get("CURV_DUMMY_STREAMS", "0")))]
     for sizes in ([4608], [4608, 512], [2304], [2304, 256], [1024], [4608, 4608, 4608], [2048, 512, 1024, 256]):
         run(sizes)
