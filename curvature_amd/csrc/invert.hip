@@ -1507,6 +1507,21 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   { const int rc = stream_set(&ss); if (rc != CURV_OK) return rc; }
   InvDev* table0 = reinterpret_cast<InvDev*>(workspace);
   InvDev* table1 = reinterpret_cast<InvDev*>(reinterpret_cast<char*>(workspace) + inv_table_bytes(n_factors));
+  // Under stream capture (curvature_amd/graph.py) the chains run on the caller's stream and only the far updates fork
+  // from it: hipStreamEndCapture of ROCm 7.2 crashed on every capture in which two forked streams depend on each other
+  // (the chain's internal stream and its far-update stream: every call with a factor wider than 512), while forks that
+  // only exchange events with the capturing stream itself are fine.  The two groups then run one after the other.
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  CURV_HIP_CHECK(hipStreamIsCapturing(stream, &capture));
+  if (capture != hipStreamCaptureStatusNone) {
+    if (!big.empty()) {
+      const int rc = chol_sweep_group(stream, &ss->side[0], big, table0, flags0, latency_bound);
+      if (rc != CURV_OK) return rc;
+    }
+    if (!small.empty()) return chol_sweep_group(stream, &ss->side[1], small, big.empty() ? table0 : table1,
+                                                big.empty() ? flags0 : flags1, latency_bound);
+    return CURV_OK;
+  }
   if (big.empty() || small.empty()) {
     // one group: still swept on an internal stream.  The CU-masked side streams are created by an API that
     // has no "non-blocking" flag, so they synchronise implicitly with the legacy default stream - which the

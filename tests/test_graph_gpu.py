@@ -67,3 +67,33 @@ def test_replay_reports_a_failed_factorisation(gpu):
     graph.replay()
     with pytest.raises(RuntimeError, match="positive-definite"):
         graph.check()
+
+
+def test_capture_of_an_inversion_with_far_updates(gpu):
+    """Factors wider than 512 have far updates on a second stream.  Captured, the sweep keeps its chain on the capturing
+    stream (two forked streams that depend on each other crashed hipStreamEndCapture): the replay must reproduce the
+    eager result bit for bit - every tile is written by one workgroup in a fixed order - for one factor group and for
+    two, on the chain-bound kernels and on the per-step launches (77 factors)."""
+    from curvature_amd import ops
+    for sizes in ([1100], [2304, 700, 64], [1100, 300] + [8] * 75):
+        Fs = []
+        for i, n in enumerate(sizes):
+            torch.manual_seed(100 + i)
+            X = torch.randn(n, n + 8, device=gpu)
+            Fs.append((X @ X.t() / (n + 8)).contiguous())
+        adds, muls = [0.7] * len(Fs), [20.0] * len(Fs)
+        eager = [t.clone() for t in ops.chol_inv_lower(Fs, adds, muls)]
+        outs = ops.chol_inv_lower(Fs, adds, muls, check=False)
+        torch.cuda.synchronize()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+            ops.chol_inv_lower(Fs, adds, muls, check=False, outs=outs)
+        for t in outs:
+            t.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        ops.check_chol_info(ops.chol_inv_lower.last_info)
+        for a, b in zip(outs, eager):
+            assert torch.equal(a, b), sizes

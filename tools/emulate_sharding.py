@@ -30,6 +30,7 @@ def timed(fn, reps):
 def main():
     chain = "--chain" in sys.argv
     nocheck = "--nocheck" in sys.argv      # invert(check=False): no host synchronisation inside the step (diagnostic)
+    graph = "--graph" in sys.argv          # the rank's step as a replayed HIP graph (curvature_amd.graph) + check()
     estimator = "inf" if chain else "kfac"
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -65,6 +66,14 @@ def main():
                     kfac.sample_and_replace()
                 step()
                 step()
+                if graph:
+                    from curvature_amd.graph import KFACStepGraph
+                    g = KFACStepGraph(kfac, add=1.0, multiply=1000.0, batch_size=32)
+
+                    def step():
+                        g.replay()
+                        g.check()
+                    step()
                 times.append(timed(step, 4))
                 if world == 8:
                     ph = [timed(lambda: kfac.update(32), 4), timed(lambda: kfac.invert(1.0, 1000.0), 4), timed(kfac.sample_and_replace, 4)]
