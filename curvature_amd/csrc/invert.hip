@@ -1498,10 +1498,15 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   // the large group holds the factors that share the longest chain (more than half of the largest block
   // count): measured on ResNet-50, {4608} vs the rest beats {2048, 2304, 4608} vs the rest by 4 %
   const int split = std::max(SPLIT_P, Pmax / 2);
+  // a chain-bound call is swept as ONE group: the square kernel gives every factor its own workgroups, so the small
+  // factors do not widen the large one's chain launches, and half the launches, events and waits remain (the host needs
+  // 0.5 ms to enqueue the two sweeps of an 18-factor shard whose kernels take 0.6 ms)
+  static const int one_group_env = getenv("CURV_ONE_GROUP") ? atoi(getenv("CURV_ONE_GROUP")) : 1;
+  const bool one_group = latency_bound && one_group_env != 0;
   for (InvDev& d : tab) {
     d.W = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double);
     d.X = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double);
-    (d.P > split ? big : small).push_back(d);
+    (d.P > split || one_group ? big : small).push_back(d);
   }
   StreamSet* ss = nullptr;
   { const int rc = stream_set(&ss); if (rc != CURV_OK) return rc; }
