@@ -36,6 +36,22 @@ constexpr int INV_THREADS = MMA_THREADS;
 constexpr int SQ_FLAGS = 32;
 constexpr int SQ_FD = 0, SQ_FLC = 4, SQ_FLROW = 8, SQ_FT = 12;
 constexpr int SQ_SPIN_LIMIT = 1 << 21;
+#ifdef CURV_SQ_TRACE
+// diagnostics build (tools/sq_trace.py): 100 MHz time stamps of one panel of factor 0
+__device__ long long g_sq_trace[256];
+#define KT_BEGIN(slot) { if (threadIdx.x == 0 && k0 == 4 * (CURV_SQ_TRACE - 1)) atomicMax((unsigned long long*)&g_sq_trace[slot], (1ull << 62) - (unsigned long long)wall_clock64()); }
+#define KT_END(slot) { if (threadIdx.x == 0 && k0 == 4 * (CURV_SQ_TRACE - 1)) atomicMax((unsigned long long*)&g_sq_trace[slot], (unsigned long long)wall_clock64()); }
+#define SQT(slot) { if (threadIdx.x == 0 && f == 0 && stamp == CURV_SQ_TRACE) g_sq_trace[slot] = wall_clock64(); }
+#else
+#define SQT(slot)
+#define KT_BEGIN(slot) {}
+#define KT_END(slot) {}
+#endif
+#ifdef CURV_SQ_TRACE
+#define PQT(slot) { if (threadIdx.x == 0 && blockIdx.x == 0 && k0 == 4 * (CURV_SQ_TRACE - 1)) g_sq_trace[slot] = wall_clock64(); }
+#else
+#define PQT(slot)
+#endif
 
 struct InvDev {
   const float* F;       // (n x n) fp32 factor
@@ -437,12 +453,16 @@ __device__ __forceinline__ void outer_update_body(const InvDev* __restrict__ t, 
 __global__ void __launch_bounds__(INV_THREADS, 3)
 outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int lo, int hi, int strip, int n_items) {
   __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
+  if (!strip) KT_BEGIN(254)
   outer_update_body<2>(t, nf, k0, kend, lo, hi, strip, n_items, As, Bs);
+  if (!strip) KT_END(255)
 }
 __global__ void __launch_bounds__(1024)
 outer_update_wide_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int lo, int hi, int strip, int n_items) {
   __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
+  KT_BEGIN(252)
   outer_update_body<4>(t, nf, k0, kend, lo, hi, strip, n_items, As, Bs);
+  KT_END(253)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -820,18 +840,6 @@ __device__ __forceinline__ void sq_wait(int* flag, int stamp, int* lost) {
   __syncthreads();
 }
 
-#ifdef CURV_SQ_TRACE
-// diagnostics build (tools/sq_trace.py): 100 MHz time stamps of one panel of factor 0
-__device__ long long g_sq_trace[256];
-#define SQT(slot) { if (threadIdx.x == 0 && f == 0 && stamp == CURV_SQ_TRACE) g_sq_trace[slot] = wall_clock64(); }
-#else
-#define SQT(slot)
-#endif
-#ifdef CURV_SQ_TRACE
-#define PQT(slot) { if (threadIdx.x == 0 && blockIdx.x == 0 && k0 == 4 * (CURV_SQ_TRACE - 1)) g_sq_trace[slot] = wall_clock64(); }
-#else
-#define PQT(slot)
-#endif
 __global__ void __launch_bounds__(INV_THREADS)
 chol_square_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int* __restrict__ flags, int stamp) {
   __shared__ double Ds[NB * LDA], Is[NB * LDA], Bf[NB * LDA];
@@ -854,6 +862,9 @@ chol_square_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int* 
   if (r == 0) {
     // ---------------- runner ----------------
     SQT(0)
+#ifdef CURV_SQ_TRACE
+    if (tid == 0 && f == 0 && stamp == CURV_SQ_TRACE + 1) g_sq_trace[238] = wall_clock64();
+#endif
     load_block(Wt(0, 0), np, Ds);
     if (nbf > 1) load_block(Wt(1, 0), np, Bf);                    // T_{1,0} = A_{1,0}: fetched ahead of the first step
     __syncthreads();
@@ -1088,7 +1099,7 @@ __device__ __forceinline__ void panel_quarter_body(const InvDev& d, int k0, int 
   // (a 64-deep product took 2.9 us that way, 16 dependent fp64 MFMAs), independent ones pipeline
   f64x4 acc[4] = {};
   PQT(241)
-  int pq_n = 0;
+  [[maybe_unused]] int pq_n = 0;
   // one tile: registers -> LDS, refill the registers with the tile three ahead, multiply (no register rotation: a
   // move would wait for the loads it copies)
   auto step = [&](double (&rt)[16]) __attribute__((always_inline)) {
@@ -1137,6 +1148,7 @@ panel_product_quarter_kernel(const InvDev* __restrict__ t, int nf, int k0, int k
   __shared__ double Own[PQ_OWN], Ts[NB * LDA];
   const int job = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7), q = (blockIdx.x >> 3) & 3;   // the four quarters of a job on one XCD
   int f, local;
+  KT_BEGIN(236)
   if (!locate(t, nf, job,
               [k0, kend](const InvDev& d) { return d.P > k0 ? (d.P > kend ? d.P - kend : 0) + k0 : 0; }, f, local))
     return;
@@ -1145,6 +1157,7 @@ panel_product_quarter_kernel(const InvDev* __restrict__ t, int nf, int k0, int k
   const int n_below = d.P > kend ? d.P - kend : 0;
   if (local < n_below) panel_quarter_body<true>(d, k0, nb, kend + local, 0, q, Own, Ts);
   else panel_quarter_body<false>(d, k0, nb, 0, local - n_below, q, Own, Ts);
+  KT_END(237)
 }
 __global__ void __launch_bounds__(INV_THREADS, 3)
 panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
@@ -1328,6 +1341,10 @@ int curv_internal_side_stream(hipStream_t* out) {
 using namespace curv;
 
 #ifdef CURV_SQ_TRACE
+extern "C" int curv_debug_sq_trace_reset() {
+  long long zeros[256] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(curv::g_sq_trace), zeros, sizeof(zeros)) == hipSuccess ? 0 : 1;
+}
 extern "C" int curv_debug_sq_trace(long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(curv::g_sq_trace), 256 * sizeof(long long)) == hipSuccess ? 0 : 1;
 }

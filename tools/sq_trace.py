@@ -34,11 +34,14 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4608
     X = torch.randn(n, 4096, device=dev)
     F = (X @ X.t() / 4096).contiguous()
+    lib = ctypes.CDLL(LIB)
     for _ in range(3):
         ops.chol_inv_lower([F], [1.0], [1000.0], check=False)
     torch.cuda.synchronize()
+    assert lib.curv_debug_sq_trace_reset() == 0
+    ops.chol_inv_lower([F], [1.0], [1000.0], check=False)
+    torch.cuda.synchronize()
     out = (ctypes.c_longlong * 256)()
-    lib = ctypes.CDLL(LIB)
     assert lib.curv_debug_sq_trace(out) == 0
     t = list(out)
     t0 = t[0]
@@ -56,6 +59,11 @@ def main():
     p0 = t[240]
     print("panel product (block 0): body start 0 | own operand issued, first tiles requested %.1f | after tile k: %s"
           % ((t[241] - p0) / 100.0, " ".join("%.1f" % ((t[242 + k] - p0) / 100.0) for k in range(10))))
+    big = 1 << 62
+    kt = lambda s_, e_: ((big - t[s_] - t0) / 100.0 if t[s_] else float("nan"), (t[e_] - t0) / 100.0 if t[e_] else float("nan"))
+    print("launches of this panel, first workgroup in -> last workgroup out (us after the square kernel's start): "
+          "panel product %.1f -> %.1f | near update %.1f -> %.1f | far update %.1f -> %.1f | next panel's square kernel starts %.1f"
+          % (kt(236, 237) + kt(252, 253) + kt(254, 255) + (us(t[238]),)))
 
 
 if __name__ == "__main__":
