@@ -861,6 +861,8 @@ chol_square_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int* 
   f64x4 acc[2][2];
   if (r == 0) {
     // ---------------- runner ----------------
+    // (ONE call site of factor_invert_64: inlined twice its 35 KB made this kernel 100 KB of code, and the first two
+    // factorisations of every launch ran 11 us instead of 8 - instruction-cache misses, 64 KB shared by two CUs)
     SQT(0)
 #ifdef CURV_SQ_TRACE
     if (tid == 0 && f == 0 && stamp == CURV_SQ_TRACE + 1) g_sq_trace[238] = wall_clock64();
@@ -869,38 +871,35 @@ chol_square_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int* 
     if (nbf > 1) load_block(Wt(1, 0), np, Bf);                    // T_{1,0} = A_{1,0}: fetched ahead of the first step
     __syncthreads();
     SQT(1)
-    factor_invert_64(Ds, Is, &bad, k0 * NB);
-    SQT(2)
-    store_block_coh(Xt(0, 0), np, Is);
-    sq_signal(fl + SQ_FD + 0, stamp);
-    SQT(3)
-    for (int q = 1; q < nbf; ++q) {
-      if (q >= 2) {
-        sq_wait(fl + SQ_FT + q, stamp, &lost);
-        SQT(8 * q + 0)
-        load_block_coh(Wt(q, q - 1), np, Bf);                     // T_{q,q-1}
+    for (int q = 0; q < nbf; ++q) {
+      if (q >= 1) {
+        if (q >= 2) {
+          sq_wait(fl + SQ_FT + q, stamp, &lost);
+          SQT(8 * q + 0)
+          load_block_coh(Wt(q, q - 1), np, Bf);                   // T_{q,q-1}
+        }
+        load_block_coh(Wt(q, q), np, Ds);                         // A''_qq
+        __syncthreads();
+        SQT(8 * q + 1)
+        zero_acc(acc);
+        mma_64_pre<true>(Bf, Is, wm, wn, lane, acc);              // L_{q,q-1} = T X_{q-1,q-1}^T
+        SQT(8 * q + 2)
+        store_acc_coh(Wt(q, q - 1), np, acc, wm, wn, lane, 1.0);
+        __syncthreads();                                          // every wave is done reading Bf
+        acc_to_lds(acc, wm, wn, lane, Bf);
+        __syncthreads();
+        zero_acc(acc);
+        mma_64_pre<true>(Bf, Bf, wm, wn, lane, acc);
+        lds_sub_acc(Ds, acc, wm, wn, lane);                       // A'_qq
+        SQT(8 * q + 3)
+        sq_signal(fl + SQ_FLC + q, stamp);                        // L_{q,q-1} is out (also the barrier the step needs)
+        SQT(8 * q + 4)
       }
-      load_block_coh(Wt(q, q), np, Ds);                           // A''_qq
-      __syncthreads();
-      SQT(8 * q + 1)
-      zero_acc(acc);
-      mma_64_pre<true>(Bf, Is, wm, wn, lane, acc);                    // L_{q,q-1} = T X_{q-1,q-1}^T
-      SQT(8 * q + 2)
-      store_acc_coh(Wt(q, q - 1), np, acc, wm, wn, lane, 1.0);
-      __syncthreads();                                            // every wave is done reading Bf
-      acc_to_lds(acc, wm, wn, lane, Bf);
-      __syncthreads();
-      zero_acc(acc);
-      mma_64_pre<true>(Bf, Bf, wm, wn, lane, acc);
-      lds_sub_acc(Ds, acc, wm, wn, lane);                         // A'_qq
-      SQT(8 * q + 3)
-      sq_signal(fl + SQ_FLC + q, stamp);                          // L_{q,q-1} is out (also the barrier the step needs)
-      SQT(8 * q + 4)
       factor_invert_64(Ds, Is, &bad, (k0 + q) * NB);
-      SQT(8 * q + 5)
+      SQT(q == 0 ? 2 : 8 * q + 5)
       store_block_coh(Xt(q, q), np, Is);
       sq_signal(fl + SQ_FD + q, stamp);
-      SQT(8 * q + 6)
+      SQT(q == 0 ? 3 : 8 * q + 6)
     }
     if (tid == 0 && bad != 0) atomicCAS(d.info, 0, bad);
     if (tid == 0 && lost != 0) atomicCAS(d.info, 0, -1);
