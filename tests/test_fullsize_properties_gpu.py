@@ -144,6 +144,33 @@ def test_invert_and_sample_properties(gpu, resnet50_kfac):
 
 
 @pytest.mark.gpu
+def test_a_rank_share_inverts_like_the_whole_model(gpu, resnet50_kfac):
+    """Layer sharding at full size: the factors of one rank's layers (here the largest layer alone, and a nine-layer
+    share) go through the chain-bound kernels of the inversion (at most 64 factors in a call: block squares swept by
+    one launch, quarter-form panel products), the whole model through the per-step launches.  Both must satisfy the
+    defining identity, and agree with each other to output rounding."""
+    from curvature_amd import ops
+    model, kfac = resnet50_kfac
+    kfac.invert(add=1.0, multiply=1000.0)
+    layers = kfac._layers()
+    largest = max(layers, key=lambda l: kfac.state[l][0].shape[0])
+    share = [layers[i] for i in (2, 5, 15, 23, 25, 27, 33, 40, 49)]
+    for group in ([largest], share):
+        factors = [F for layer in group for F in kfac.state[layer]]
+        outs = ops.chol_inv_lower(factors, [1.0] * len(factors), [1000.0] * len(factors))
+        whole = [L for layer in group for L in kfac.inv_state[layer]]
+        for F, L_rank, L_whole in zip(factors, outs, whole):
+            n = F.shape[0]
+            assert torch.equal(L_rank, torch.tril(L_rank))
+            assert rel_fro(L_rank, L_whole.cpu()) < 1e-6
+            if n >= 1024:
+                M = (1000.0 ** 0.5) * F.double() + torch.eye(n, device=gpu, dtype=torch.float64)
+                M = (M + M.t()) / 2
+                R = (L_rank.double() @ L_rank.double().t()) @ M - torch.eye(n, device=gpu, dtype=torch.float64)
+                assert float(torch.linalg.norm(R)) / n ** 0.5 < 1e-4
+
+
+@pytest.mark.gpu
 def test_resnet18_full_estimator_chain(gpu):
     """SURVEY 8(d) config 3 at full size: Diagonal -> KFAC -> EFB -> INF(rank = 100) -> invert -> sample on an
     ImageNet ResNet-18 (random init, N = 32 as SURVEY 8(d) prescribes).  No oracle at this size; checked through
