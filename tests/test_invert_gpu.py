@@ -196,3 +196,29 @@ def test_chain_bound_form_reports_failed_pivots(gpu):
     F = (X @ X.t() / 320).contiguous()
     out = ops.chol_inv_lower([F], [1.0], [1.0])[0]
     assert torch.isfinite(out).all()
+
+
+def test_chain_bound_form_is_reproducible_beside_other_work(gpu):
+    """The square kernel's workgroups wait for each other through flags; whatever order the hardware runs them in -
+    alone, or squeezed between the GEMMs of another stream - every tile is produced by one workgroup from the same
+    operands in the same order: repeated calls must agree bit for bit, and no wait may run into its bound."""
+    from curvature_amd import ops
+    for sizes in ([2304, 700, 64], [1024] * 6 + [333] * 10):
+        Fs = []
+        for i, n in enumerate(sizes):
+            torch.manual_seed(40 + i)
+            X = torch.randn(n, n + 8, device=gpu)
+            Fs.append((X @ X.t() / (n + 8)).contiguous())
+        adds, muls = [0.5] * len(Fs), [30.0] * len(Fs)
+        ref = [t.clone() for t in ops.chol_inv_lower(Fs, adds, muls)]
+        side = torch.cuda.Stream()
+        A = torch.randn(2048, 2048, device=gpu)
+        for it in range(12):
+            if it % 2:
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        A @ A
+            outs = ops.chol_inv_lower(Fs, adds, muls)
+            for a, b in zip(outs, ref):
+                assert torch.equal(a, b)
+        torch.cuda.synchronize()
