@@ -7,6 +7,10 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from curvature_amd import _lib  # noqa: E402
+
+if os.environ.get("CURV_ALT_LIB"):                       # A/B of an alternative build on one box
+    _lib.LIB_PATH = os.path.abspath(os.environ["CURV_ALT_LIB"])
 from curvature_amd import models, ops  # noqa: E402
 
 
