@@ -540,7 +540,7 @@ def main():
     # collected by tools/collect_profiles.sh (rocprofv3, separate FETCH_SIZE / WRITE_SIZE passes, gfx950
     # correction of MI355X_MICROARCH.md) on this same workload and committed under profiles/
     traffic, traffic_source = None, None
-    for name in ("r03_syrk_pmc.json", "r02_syrk_pmc.json"):
+    for name in ("r04_syrk_pmc.json",):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if world == 1 and args.batch == 32 and os.path.exists(pmc_path):
             try:
@@ -569,13 +569,13 @@ def main():
                                    "KFAC.update + invert(1.0, 1000.0) + sample_and_replace, 54 layers",
                        "batch": args.batch, "layers": n_layers, "accumulation_restarts_every": 16,
                        "parallelism": f"layer-sharded x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "curv::syrk_flat_kernel + curv::syrk_pre_kernel + curv::syrk_patch_kernel: the "
-                                                       "MFMA kernels of the factor build (LDS-DMA kernel for flattened factors and "
-                                                       "the shifted correlations of 3x3 factors; implicit-im2col kernel with LDS-DMA "
-                                                       "staging from pre-tiled copies; its register-staged variant on a side stream), "
-                                                       "HIP events from the padding / pre-tiling passes in front of them to the end of "
-                                                       "the last one.  NOT inside: the k-slice reduction and assembly passes behind "
-                                                       "them (build_ms_with_reduce has them)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "the whole factor build of update(): curv::syrk_flat_kernel + curv::syrk_pre_kernel + "
+                                                       "curv::syrk_patch_kernel (LDS-DMA kernel for flattened factors and the shifted "
+                                                       "correlations of 3x3 factors; implicit-im2col kernel with LDS-DMA staging from "
+                                                       "pre-tiled copies; its register-staged variant on a side stream) WITH the padding / "
+                                                       "pre-tiling passes in front of them and the k-slice reduction and 3x3 assembly "
+                                                       "passes behind them: HIP events on the launch stream around everything "
+                                                       "curv_kfac_accumulate_ex enqueues", "achieved": achieved,
                          "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_F32_MFMA / 1e12),
                          "traffic": traffic, "traffic_source": traffic_source,
                          "flops_counted": "what the launch plan executes (curv_kfac_plan_info): n(n+1)K per symmetric "
@@ -585,8 +585,8 @@ def main():
                          "direct_symmetric_tflops": direct_flops / syrk_s / 1e12,
                          "dense_equivalent_tflops": dense_flops / syrk_s / 1e12,
                          "kernel_ms": syrk_s * 1e3,
-                         "build_ms_with_reduce": phase[0] / args.steps,
-                         "frac_with_reduce": plan_flops / (phase[0] / args.steps * 1e-3) / PEAK_F32_MFMA},
+                         "update_call_ms": phase[0] / args.steps,
+                         "frac_of_update_call": plan_flops / (phase[0] / args.steps * 1e-3) / PEAK_F32_MFMA},
             "phases_ms": {"update": phase[0] / args.steps, "invert": phase[1] / args.steps,
                           "sample_and_replace": phase[2] / args.steps},
         }

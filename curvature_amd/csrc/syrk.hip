@@ -38,6 +38,12 @@
 #include <cstdlib>
 #include <vector>
 
+#ifndef CURV_SINGLE_MAX
+#define CURV_SINGLE_MAX 5.0            // a 128x128 tile whose K range costs at most this many target item lengths stays unsliced
+#endif
+#ifndef CURV_MAX_CHAIN_PX
+#define CURV_MAX_CHAIN_PX 3072         // longest fp32 accumulation chain, in k values (pixels x samples)
+#endif
 #ifndef CURV_PRE_PANEL_WORDS
 #define CURV_PRE_PANEL_WORDS 6528
 #define CURV_PRE_WGS 3
@@ -45,6 +51,7 @@
 
 namespace curv {
 
+constexpr double MAX_CHAIN_PX = CURV_MAX_CHAIN_PX;
 constexpr int GU = 2;                  // k steps (MFMA groups) per operand fetch: one address per operand row serves GU steps
 constexpr int PANEL_WORDS = 8704;      // LDS words per panel patch
 constexpr int PATCH_WORDS = 2 * PANEL_WORDS;   // >= 4 x (64x64) cross-wave reduce scratch
@@ -570,8 +577,12 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
     }
   };
 
-  const int ch_begin = slice * d.cpi;
-  const int ch_end = min(ch_begin + d.cpi, n_chunks);
+  // sliced factor: chunks [slice cpi, + cpi) into a slab; unsliced (direct, 128x128 tiles only) factor: all chunks, the
+  // accumulators flushed into the factor behind every cpi of them (d.direct segments, see syrk_plan.h)
+  const int nseg = (TMv == 128) ? d.direct : 0;
+  const int ch_begin = nseg ? 0 : slice * d.cpi;
+  const int ch_end = nseg ? n_chunks : min(ch_begin + d.cpi, n_chunks);
+  int seg = 0, seg_end = nseg ? min(d.cpi, ch_end) : ch_end + 1;
 
   __syncthreads();                       // ZERO/ONE visible
   Chunk cur = decode_chunk(min(ch_begin, n_chunks - 1));
@@ -611,7 +622,19 @@ __device__ __forceinline__ void syrk_body(const FactorDev& d, const int local, f
       else mfma_chunk(std::integral_constant<int, 0>{}, work, by_sample);     // strides > 2: step offsets at run time
     }
     __syncthreads();
+    if constexpr (TMv == 128) {
+      if (ch + 1 == seg_end) {
+        // end of a segment of an unsliced item: the wave's quadrant goes straight into the factor (scaled, added) and,
+        // behind the last segment, into its mirror image; the next chunk's loads are in flight meanwhile
+        direct_store_quadrant(d, part, i0 + 64 * wm, j0 + 64 * wn, r32, h, acc00, acc01, acc10, acc11, seg == 0,
+                              ch + 1 == ch_end);
+        acc00 = 0.0f; acc01 = 0.0f; acc10 = 0.0f; acc11 = 0.0f;
+        ++seg;
+        seg_end = min(seg_end + d.cpi, ch_end);
+      }
+    }
   }
+  if (nseg) return;
 
   gfloat* slab = (gfloat*)slabs + d.slab_base + (long long)local * (TMv * TMv);
   if (TMv == 64 && PRE) {
@@ -976,6 +999,7 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
   plan.corr.clear();
   plan.area_floats = 0;
   std::vector<double> chunk_cost(n);   // MFMA CU-cycles of one (tile, chunk)
+  std::vector<double> chunk_px(n, 1.0); // k values (samples x output pixels) of one chunk
   double total_cost = 0.0;
   for (int i = 0; i < n; ++i) {
     const curv_factor_desc& s = descs[i];
@@ -1024,8 +1048,8 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
       f.n_tiles = f.P * (f.P + 1) / 2;
       const int sps = syrk_flat_stages(f.W);
       f.n_chunks = f.N * sps;
-      f.RL = 1;
       chunk_cost[i] = (double)f.W / sps * 32.0 * 4.0 + 800.0;     // 128x128xk = 128 k CU-cycles; + barrier / DMA wait
+      chunk_px[i] = (double)f.W / sps;
       total_cost += chunk_cost[i] * f.n_tiles * f.n_chunks;
       continue;
     }
@@ -1035,8 +1059,6 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     f.nch = std::min(f.C, (f.khkw + f.TM - 2) / f.khkw + 1);
     f.flat = (flattened && (f.nch & (f.nch - 1)) == 0) ? 1 : 0;
     f.vec4 = (f.flat && f.W % 4 == 0 && f.W >= 4 && (reinterpret_cast<uintptr_t>(s.src) & 15) == 0) ? 1 : 0;
-
-    f.RL = 1;
 
     // chunk extent: full-width rows if they fit, then as many rows, then as many samples
     ChunkGeom g;
@@ -1083,6 +1105,7 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     const double kc = (double)NS * R * (Wc + (Wc & 1));
     const double q = f.TM / 64.0;
     chunk_cost[i] = kc * 32.0 * q * q + 1500.0;   // 64x64xk = 32 k CU-cycles; + staging / barriers
+    chunk_px[i] = std::max(1.0, (double)NS * R * Wc);
     total_cost += chunk_cost[i] * f.n_tiles * f.n_chunks;
   }
   for (int i = 0; i < n; ++i) {
@@ -1095,6 +1118,7 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
       const int sps = syrk_flat_stages(v.W);
       const double cost = (double)v.W / sps * 32.0 * 4.0 + 800.0;
       chunk_cost.push_back(cost);
+      chunk_px.push_back((double)v.W / sps);
       total_cost += cost * v.n_tiles * v.n_chunks;
     }
   }
@@ -1109,10 +1133,33 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     if (f.dma == 2) continue;
     int cpi = (int)(target / chunk_cost[i] + 0.5);
     cpi = std::max(1, std::min(cpi, f.n_chunks));
+    // 128x128 tiles whose whole K range is a few target lengths are NOT sliced: the item then owns its tile, and its
+    // epilogue scales, adds into the factor and writes the mirror tile itself (FactorDev::direct) - no slab, no
+    // reduce pass over it.  These items are the longest of their list and are dispatched first (longest-first list
+    // scheduling), so they cost no balance; slicing stays for what it is needed for, the few-tile / huge-K factors.
+    const bool unsliced = f.TM == 128 && (long long)f.dim * f.dim * 4 < (1LL << 31) &&     // (31-bit offsets of the direct epilogue)
+                          (cpi >= f.n_chunks || chunk_cost[i] * f.n_chunks <= CURV_SINGLE_MAX * target);
+    // Bounded accumulation chains: the fp32 MFMA accumulates with a small systematic (truncation-like) bias that grows
+    // with the number of steps a sum runs through (measured on ResNet-50 gradients: -1.0e-5 of a diagonal entry after
+    // 3136 steps of two pixels).  No k-slice, and no serial segment of an unsliced item, sums more than MAX_CHAIN_PX
+    // pixels in one chain (a 64x64 tile's four waves split its K range: four chains), whatever the batch size.
+    const int chain_cap = std::max(1, (int)((f.TM == 64 ? 4.0 : 1.0) * MAX_CHAIN_PX / chunk_px[i]));
+    if (unsliced) {
+      const int nseg = cdiv(f.n_chunks, chain_cap);
+      f.cpi = cdiv(f.n_chunks, nseg);              // chunks per serial segment
+      f.direct = cdiv(f.n_chunks, f.cpi);
+      f.n_slices = 1;
+      f.n_items = f.n_tiles;
+      f.n_sub = 0;
+      item_cost[i] = chunk_cost[i] * f.n_chunks;
+      continue;
+    }
+    cpi = std::min(cpi, chain_cap);
     f.n_slices = cdiv(f.n_chunks, cpi);
     f.cpi = cdiv(f.n_chunks, f.n_slices);          // even out the slices
     f.n_slices = cdiv(f.n_chunks, f.cpi);
     f.n_items = f.n_slices * f.n_tiles;
+    f.direct = 0;
     f.n_sub = f.n_tiles * (f.TM / 64) * (f.TM / 64);
     item_cost[i] = chunk_cost[i] * f.cpi;
   }
@@ -1128,8 +1175,10 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
       FactorDev& f = plan.f[j];
       f.cpi = plan.f[lead].cpi;
       f.n_slices = plan.f[lead].n_slices;
+      f.direct = plan.f[lead].direct;
+      f.n_sub = f.direct ? 0 : f.n_tiles * (f.TM / 64) * (f.TM / 64);
       f.n_items = j == i ? gn * f.n_slices * f.n_tiles : 0;       // the range belongs to the first member
-      cost = std::max(cost, chunk_cost[j] * f.cpi);
+      cost = std::max(cost, chunk_cost[j] * (f.direct ? f.n_chunks : f.cpi));
     }
     for (int j = i; j < i + gn; ++j) item_cost[j] = cost;         // equal keys: the stable sort keeps them together
   }
@@ -1158,7 +1207,7 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
           const double mine = chunk_cost[idx] * f.n_tiles * f.n_chunks;
           const double start = seen / list_cost;
           seen += mine;
-          if (f.group_n > 0 || start < 0.7) continue;  // (groups share one slicing: left alone)
+          if (f.group_n > 0 || f.direct || start < 0.7) continue;  // (groups share one slicing, unsliced items own their tiles: left alone)
           const double t = start < 0.9 ? target * 0.5 : target * 0.25;
           int cpi = (int)(t / chunk_cost[idx] + 0.5);
           cpi = std::max(1, std::min(cpi, f.n_chunks));
@@ -1181,7 +1230,7 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
       f.slab_base = slab;
       items += f.n_items;
       subs += f.n_sub;
-      slab += (long long)f.n_slices * f.n_tiles * f.TM * f.TM;
+      if (!f.direct) slab += (long long)f.n_slices * f.n_tiles * f.TM * f.TM;
       CURV_REQUIRE(items < (1LL << 30) && subs < (1LL << 30), "curv_kfac: too many work items");
     }
     plan.n_items[k] = (int)items;
@@ -1227,7 +1276,7 @@ extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors,
     o[0] = f.dim; o[1] = f.Ho; o[2] = f.Wo; o[3] = f.NS; o[4] = f.R; o[5] = f.Wc;
     o[6] = f.n_chunks; o[7] = f.RS; o[8] = f.PS; o[9] = f.SS; o[10] = f.nch;
     o[11] = f.n_tiles; o[12] = f.cpi; o[13] = f.n_slices; o[14] = f.n_items; o[15] = f.item_base;
-    o[16] = f.TM; o[17] = f.vec4; o[18] = f.cshift; o[19] = f.n_sub; o[20] = f.RL; o[21] = f.rshift; o[22] = f.pre;
+    o[16] = f.TM; o[17] = f.vec4; o[18] = f.cshift; o[19] = f.n_sub; o[20] = f.direct; o[21] = f.rshift; o[22] = f.pre;
     o[23] = f.dma;
     auto flops_of = [](const FactorDev& v) {
       const double K = (double)v.N * v.Ho * v.Wo;
@@ -1299,7 +1348,10 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
   const bool resident = (flags & CURV_KFAC_TABLE_RESIDENT) && shadow.ws == workspace;
   if (!resident) shadow.rows.clear();
   shadow.ws = workspace;
-  if ((int)shadow.rows.size() < n_table) {
+  {
+    // the shadow describes exactly this call's table: everything behind table_bytes(n_table) is scratch of this call
+    // (zero pad, slabs, correlation area), so rows a LONGER previous table left there are gone - forget them, or the
+    // next long table would match them and skip their upload
     FactorDev none;
     memset(&none, 0xff, sizeof(none));
     shadow.rows.resize(n_table, none);
@@ -1371,12 +1423,14 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
     if (rc1 != CURV_OK) return rc1;
   }
   if (fork) CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->join, 0));           // the register-staged MFMA kernel is done
-  if (ev_stop) CURV_HIP_CHECK(hipEventRecord((hipEvent_t)ev_stop, stream));
   if (fork) CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->join_r, 0));
   if (!fork && (rc = reduce(stream, 0, 0, n0)) != CURV_OK) return rc;
   if ((rc = reduce(stream, 1, n0, n1)) != CURV_OK) return rc;
   if ((rc = reduce(stream, 2, n0 + n1, n2)) != CURV_OK) return rc;
-  if (!plan.corr.empty()) return launch_corr_assemble(stream, plan.corr, plan.f, area);
+  if (!plan.corr.empty() && (rc = launch_corr_assemble(stream, plan.corr, plan.f, area)) != CURV_OK) return rc;
+  // the timed window (bench.py's roofline) spans the WHOLE build: padding / pre-tiling passes, the MFMA kernels, the
+  // k-slice reduction of the sliced factors and the assembly of the 3x3 factors
+  if (ev_stop) CURV_HIP_CHECK(hipEventRecord((hipEvent_t)ev_stop, stream));
   return CURV_OK;
 }
 

@@ -209,7 +209,6 @@ void syrk_corr_expand(const curv_factor_desc& s, int user, std::vector<FactorDev
     v.P = s.C / 128;
     v.n_tiles = nonsym ? v.P * v.P : v.P * (v.P + 1) / 2;
     v.n_chunks = samples * syrk_flat_stages(K);
-    v.RL = 1;
     // src / dst: offsets into the correlation area for now (syrk_corr_bind turns them into pointers)
     v.src = reinterpret_cast<const float*>(src_off);
     v.dst = reinterpret_cast<float*>(L.comp_off + (long long)comp * s.C * s.C);

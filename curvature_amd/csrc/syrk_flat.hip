@@ -130,7 +130,11 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
   }
 
   f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
-  const int t0 = slice * d.cpi, t1 = min(t0 + d.cpi, d.n_chunks);
+  // sliced factor: stages [slice cpi, + cpi) into a slab; unsliced (direct) factor: all stages, the accumulators
+  // flushed into the factor behind every cpi of them (d.direct segments: bounded fp32 accumulation chains)
+  const int nseg = d.direct;
+  const int t0 = nseg ? 0 : slice * d.cpi, t1 = nseg ? d.n_chunks : min(t0 + d.cpi, d.n_chunks);
+  int seg = 0, seg_end = nseg ? min(d.cpi, t1) : t1 + 1;
   const int n_panels = diag ? 1 : 2;
 
   auto stage_geo = [&](int t, int& s, int& px0, int& nsteps, bool& last) {
@@ -205,8 +209,16 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
 #pragma unroll
       for (int i = 0; i < NP; ++i) if (i >= next_piece) piece(i);      // short stages: the rest
     }
+    if (t + 1 == seg_end) {
+      // end of a segment of an unsliced item: scale, add into the factor, (last segment) write the mirror tile; the
+      // DMA of the next stage is in flight meanwhile
+      direct_store_quadrant(d, PART, i0 + 64 * wm, j0 + 64 * wn, r32, h, c00, c01, c10, c11, seg == 0, t + 1 == t1);
+      c00 = 0.0f; c01 = 0.0f; c10 = 0.0f; c11 = 0.0f;
+      ++seg;
+      seg_end = min(seg_end + d.cpi, t1);
+    }
   }
-
+  if (nseg) return;
   gfloat_t* slab = (gfloat_t*)slabs + d.slab_base + (long long)local * (TM * TM);
   gfloat_t* q = slab + (64 * wm) * 128 + 64 * wn;
 #pragma unroll

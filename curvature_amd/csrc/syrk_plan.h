@@ -26,7 +26,11 @@ struct FactorDev {
   int n_chunks;
   int RS, PS, SS, nch;     // LDS strides in words, channels per panel
   int cshift;              // log2 of the padded patch row length (lanes along x)
-  int RL;                  // (reserved; the k loop no longer works with table-driven runs)
+  int direct;              // > 0: unsliced 128x128 items whose epilogue scales, adds into dst and writes the mirror tile
+                           // itself (direct_store_block below): no slab, no sub-tiles in the reduce pass.  The value
+                           // is the number of SERIAL segments (of cpi chunks each) the item cuts its K range into:
+                           // the accumulators are flushed into dst behind every segment, which bounds the length of
+                           // an fp32 accumulation chain (see MAX_CHAIN_PX in syrk.hip)
   int P, n_tiles;
   int cpi, n_slices;       // chunks per item, k-slices
   int item_base, n_items;
@@ -85,6 +89,113 @@ __device__ __forceinline__ void decode_tile(int t, int P, int& ti, int& tj) {
 __device__ __forceinline__ int xcd_item(int bid) {
   const int xcd = bid & 7, j = bid >> 3;
   return ((j / XCD_GROUP) * 8 + xcd) * XCD_GROUP + (j % XCD_GROUP);
+}
+
+// Direct epilogue of an unsliced work item (FactorDev::direct): one 32x32 MFMA block of the wave's quadrant, whose
+// lane (r32, h) holds acc[reg] = element (row(reg, h), r32) with row = (reg & 3) + 8 (reg >> 2) + 4 h, goes straight to
+//   dst[gi][gj] (+)= scale * acc      and, for a symmetric factor, the same VALUE to dst[gj][gi]
+// (exactly symmetric by construction; the old value is read from the upper position only).  Only one work item touches
+// a tile and its mirror image, so there is nothing to order.  A block on the factor's diagonal writes its upper
+// triangle and mirrors that (both triangles of an MFMA block are computed, only one is used - as the reduce pass does).
+// Same arithmetic as syrk_reduce_kernel with one slice: (acc * scale) rounded, then dst + that.
+// All accesses are raw buffer operations on a descriptor of the factor: address = base + scalar offset (the row of a
+// register, SALU) + per-lane offset (ONE vector register for the upper position, one for the mirror), so the epilogue
+// needs no 64-bit per-register addresses (an earlier form with pointers spilled 250-800 bytes per lane inside the
+// MFMA kernels); masked elements (ragged edge, wrong triangle of a diagonal block) carry an out-of-range lane offset
+// and are dropped by the hardware.  Upper stores: 2 rows x 32 consecutive floats per instruction.  Mirror stores: four
+// consecutive rows of a lane are four consecutive floats of a mirror row -> 16-byte stores when the factor's rows are
+// 16-byte granular (the four stores of a block complete 128-byte lines in L2).  Eight registers are in flight at a time.
+struct DirectDst {
+  __amdgpu_buffer_rsrc_t rs;
+  int dim;
+  float scale;
+  bool vec_ok;
+};
+__device__ __forceinline__ DirectDst direct_dst(const FactorDev& d) {
+  DirectDst t;
+  t.dim = d.dim;
+  t.scale = d.scale;
+  // the planner keeps dim^2 * 4 < 2^31 for direct factors: every byte offset fits 31 bits, 0x80000000 is out of range
+  t.rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.dst, 0, (unsigned)d.dim * (unsigned)d.dim * 4u, 0x00020000);
+  t.vec_ok = (((unsigned)d.dim & 3u) | (unsigned)(reinterpret_cast<uintptr_t>(d.dst) & 15)) == 0;
+  return t;
+}
+
+__device__ __forceinline__ void direct_store_block(const DirectDst& t, const f32x16& acc, int gi0, int gj0, int r32,
+                                                   int h, bool diag_block, bool first, bool mirror) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int OOB = (int)0x80000000;
+  const int dim = t.dim;
+  const float scale = t.scale;
+  const int gj = gj0 + r32;
+  const bool plain = gi0 + 32 <= dim && gj0 + 32 <= dim && !diag_block;     // no element of the block is masked
+  const int vu = (gj < dim) ? ((4 * h) * dim + gj) * 4 : OOB;                // + row offset (scalar)
+  const int vm = (gj < dim) ? (gj * dim + 4 * h) * 4 : OOB;                  // + column offset (scalar)
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    float out[8];
+    int vo[8], so[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row0 = (k & 3) + 8 * (2 * b + (k >> 2));           // register 8 b + k: row = row0 + 4 h
+      so[k] = (gi0 + row0) * dim * 4;
+      vo[k] = vu;
+      if (!plain) {
+        const int row = row0 + 4 * h;
+        if (gi0 + row >= dim || (diag_block && row > r32)) vo[k] = OOB;
+      }
+      out[k] = first ? 0.0f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.rs, vo[k], so[k], 0));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float v = __fmul_rn(acc[8 * b + k], scale);            // no fma: the reduce pass rounds the product too
+      out[k] = first ? v : __fadd_rn(out[k], v);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, out[k]), t.rs, vo[k], so[k], 0);
+    }
+    if (mirror) {
+      if (plain && t.vec_ok) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const u32x4 v = {__builtin_bit_cast(unsigned, out[4 * g]), __builtin_bit_cast(unsigned, out[4 * g + 1]),
+                           __builtin_bit_cast(unsigned, out[4 * g + 2]), __builtin_bit_cast(unsigned, out[4 * g + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, t.rs, vm, (gi0 + 8 * (2 * b + g)) * 4, 0);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int row0 = (k & 3) + 8 * (2 * b + (k >> 2));
+          int v = vm;
+          if (!plain) {
+            const int row = row0 + 4 * h;
+            if (gi0 + row >= dim || (diag_block && row >= r32)) v = OOB;
+          }
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, out[k]), t.rs, v, (gi0 + row0) * 4, 0);
+        }
+      }
+    }
+  }
+}
+
+// the wave's 64x64 quadrant at (qi0, qj0) of a 128x128 tile: parts as in syrk.hip / syrk_flat.hip
+//   0: all four blocks   1: diagonal quadrant (upper three blocks)   2: left block column   3: right block column
+// first_seg / last_seg: position of the flushed segment in the item's serial segments: the first one honours the
+// factor's `first` flag (overwrite), the others add; only the last one - whose upper tile then holds the final values -
+// writes the mirror
+__device__ __forceinline__ void direct_store_quadrant(const FactorDev& d, int part, int qi0, int qj0, int r32, int h,
+                                                      const f32x16& c00, const f32x16& c01, const f32x16& c10,
+                                                      const f32x16& c11, bool first_seg, bool last_seg) {
+  // the flush sits inside the K loop and everything it computes is loop-invariant: without these barriers the
+  // compiler hoists the per-register lane offsets and masks out of the loop and spills them (100-250 bytes per lane)
+  asm volatile("" : "+v"(r32), "+v"(h));
+  asm volatile("" : "+s"(qi0), "+s"(qj0));
+  const bool first = d.first != 0 && first_seg;
+  const bool mirror = !d.nonsym && last_seg;
+  const bool dq = part == 1;
+  const DirectDst t = direct_dst(d);
+  if (part != 3) direct_store_block(t, c00, qi0, qj0, r32, h, dq, first, mirror);
+  if (part != 2) direct_store_block(t, c01, qi0, qj0 + 32, r32, h, false, first, mirror);
+  if (part == 0 || part == 2) direct_store_block(t, c10, qi0 + 32, qj0, r32, h, false, first, mirror);
+  if (part != 2) direct_store_block(t, c11, qi0 + 32, qj0 + 32, r32, h, dq, first, mirror);
 }
 
 // invert.hip: one of the library's internal streams (per thread and device), lent to the factor build's side work

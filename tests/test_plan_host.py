@@ -8,7 +8,7 @@ import pytest
 from curvature_amd import _lib
 
 NF = 25
-NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub RL rshift pre dma flops".split()
+NAMES = "dim Ho Wo NS R Wc nchunks RS PS SS nch ntiles cpi nslices nitems base TM vec4 cshift nsub direct rshift pre dma flops".split()
 PANEL_WORDS, PRE_PANEL_WORDS, KTAB_MAX, SLOTS, THREADS = 8704, 6528, 1024, 32, 256
 
 
@@ -63,7 +63,10 @@ def test_plan_respects_budgets(d):
         assert p["flops"] < 0.4 * p["dim"] * (p["dim"] + 1) * K          # the point of it
         return
     assert p["flops"] == p["dim"] * (p["dim"] + 1) * K
-    assert p["TM"] in (64, 128) and p["RL"] == 1
+    assert p["TM"] in (64, 128)
+    # an unsliced 128x128-tile factor writes its tiles itself (direct epilogue): no sub-tiles for the reduce pass
+    assert p["direct"] == int(p["TM"] == 128 and p["nslices"] == 1)
+    assert p["nsub"] == (0 if p["direct"] else p["ntiles"] * (p["TM"] // 64) ** 2)
     if p["dma"]:
         # LDS-DMA kernel (syrk_flat.hip): flattened factor, whole 128-row tiles, no bias row; K in stages of at most
         # 16 pixels of one sample, ceil(ceil(HW / 8) / 2) stages per sample

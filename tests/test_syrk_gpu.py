@@ -202,3 +202,53 @@ def test_more_assembled_factors_than_one_argument_block(gpu):
     ops.kfac_accumulate(jobs)
     for j, ref in zip(jobs, refs):
         assert rel_fro(j.dst, ref) < TOL and torch.equal(j.dst, j.dst.t())
+
+
+def _linear_jobs(ops, gpu, count, seed):
+    torch.manual_seed(seed)
+    jobs = []
+    for i in range(count):
+        C = 24 + 8 * (i % 7)
+        x = torch.randn(6, C, device=gpu)
+        jobs.append(ops.FactorJob(x, torch.empty(C + 1, C + 1, device=gpu), has_bias=True, scale=1.0 / 6, first=True))
+    return jobs
+
+
+def test_resident_table_survives_a_shorter_table_in_between(gpu):
+    """Round-3 advisor: the library's host shadow of the resident descriptor table only ever grew, so a call with a
+    SHORTER table (whose zero pad / slabs overwrite the tail rows of the longer one on the device) left stale shadow
+    rows behind and the next long call skipped their upload.  40 factors (three 15-row argument blocks), a 6-factor call
+    on the same workspace in between, then the 40 again: bit-identical to the first result."""
+    from curvature_amd import ops
+    jobs = _linear_jobs(ops, gpu, 40, 11)
+    ops.kfac_accumulate(jobs)
+    torch.cuda.synchronize()
+    want = [j.dst.clone() for j in jobs]
+    ops.kfac_accumulate(jobs)                    # same buffer again: resident, every block matches
+    for _ in range(3):                           # steady-state alternation, as compute_factors(share_inputs=True) does
+        ops.kfac_accumulate(jobs[:6])
+        for j in jobs:
+            j.dst.fill_(float("nan"))
+        ops.kfac_accumulate(jobs)
+        torch.cuda.synchronize()
+        for j, w in zip(jobs, want):
+            assert torch.equal(j.dst, w)
+
+
+def test_two_estimators_of_different_size_share_a_workspace(gpu):
+    """The same hazard with two callers: a 35-factor and a 17-factor job list alternate on one stream (one "kfac"
+    workspace); each keeps producing its own first result."""
+    from curvature_amd import ops
+    big, small = _linear_jobs(ops, gpu, 35, 12), _linear_jobs(ops, gpu, 17, 13)
+    ops.kfac_accumulate(big)
+    ops.kfac_accumulate(small)
+    torch.cuda.synchronize()
+    want_big, want_small = [j.dst.clone() for j in big], [j.dst.clone() for j in small]
+    for _ in range(3):
+        for jobs, want in ((big, want_big), (small, want_small)):
+            for j in jobs:
+                j.dst.fill_(float("nan"))
+            ops.kfac_accumulate(jobs)
+            torch.cuda.synchronize()
+            for j, w in zip(jobs, want):
+                assert torch.equal(j.dst, w)
