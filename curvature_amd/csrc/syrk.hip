@@ -800,7 +800,7 @@ syrk_reduce_kernel(const FactorDev* __restrict__ descs, int n_factors, const flo
 
 // The descriptor table travels as kernel arguments (copied by the runtime at launch time), so the
 // call is fully asynchronous and needs neither pinned staging memory nor a stream synchronisation.
-constexpr int UPLOAD_CHUNK = 15;
+constexpr int UPLOAD_CHUNK = 14;
 constexpr int ZERO_PAD_FLOATS = 64;    // dummy load target of masked staging slots
 struct TableChunk { FactorDev f[UPLOAD_CHUNK]; };
 static_assert(sizeof(TableChunk) <= 3840, "kernel argument block must stay below 4 KB");
@@ -1113,7 +1113,7 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     CorrLayer layer;
     syrk_corr_expand(descs[i], i, plan.f, layer, plan.area_floats);
     plan.corr.push_back(layer);
-    for (int k = 0; k < CORR_COMPONENTS; ++k) {
+    for (int k = 0; k < layer.n_vf; ++k) {
       const FactorDev& v = plan.f[layer.vf0 + k];
       const int sps = syrk_flat_stages(v.W);
       const double cost = (double)v.W / sps * 32.0 * 4.0 + 800.0;
@@ -1286,7 +1286,7 @@ extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors,
     if (f.dma == 2) {
       for (const CorrLayer& layer : plan.corr)
         if (layer.user == i)
-          for (int k = 0; k < CORR_COMPONENTS; ++k) fl += flops_of(plan.f[layer.vf0 + k]);
+          for (int k = 0; k < layer.n_vf; ++k) fl += flops_of(plan.f[layer.vf0 + k]);
     } else {
       fl = flops_of(f);
     }

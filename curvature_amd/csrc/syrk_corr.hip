@@ -37,6 +37,7 @@ namespace corr {
 constexpr int CT = 8;                        // channels per assembly tile edge: a (9 CT) x (9 CT) output tile
 constexpr int OUT = 9 * CT;
 constexpr int LEAD = 4;                      // zero floats in front of every gathered row (negative shifts of sample 0)
+constexpr int XP_LEAD = 4;                   // 64 channels: zero floats in front of the padded copy (offset -1 of its first row)
 
 // component index of F[dh, dw]: dh = 0: dw = 0, -1, -2 -> 0..2; dh = -1: dw = -2..2 -> 3..7; dh = -2 -> 8..12
 __host__ __device__ __forceinline__ int f_index(int dh, int dw) { return dh == 0 ? -dw : 3 + 5 * (-dh - 1) + (dw + 2); }
@@ -51,13 +52,16 @@ struct CorrDev {
   const float* comp;
   int N, C, H, W, Wp, Hq;
   int row_pitch, col_pitch, pt_pitch;
+  int xp_pitch, xp_lead;     // floats per (sample, channel) row of Xp (>= H Wp: zero tail) and zero floats in front of Xp
+  int comp_pitch;            // row pitch of the component matrices; component k starts at comp + comp_at[k]
+  int comp_at[CORR_COMPONENTS];
   int first;
   float scale;
   long long prep_base;       // first workgroup of this layer in the prep grid
   int tile_base;             // first workgroup of this layer in the assembly grid
   unsigned wp_magic, h_magic, c_magic;      // ceil(2^32 / d) for W + 2, H, C
 };
-constexpr int CORR_CHUNK = 16;
+constexpr int CORR_CHUNK = 14;
 struct CorrChunk { CorrDev l[CORR_CHUNK]; };
 static_assert(sizeof(CorrChunk) <= 3840, "kernel argument block must stay below 4 KB");
 
@@ -81,7 +85,8 @@ __global__ void __launch_bounds__(256) corr_prep_kernel(CorrChunk chunk, int cou
   const int v0 = (int)(e0 - (long long)row0 * Wp);
   const int cnt = (int)min((long long)PREP_SEG, words - e0);
   const unsigned wp_magic = d.wp_magic, h_magic = d.h_magic, c_magic = d.c_magic;
-  gfl* xp = (gfl*)d.xp + e0;
+  gfl* xp = (gfl*)d.xp;
+  const int plane = H * Wp, tail = d.xp_pitch - plane;
   for (int t = threadIdx.x; t < cnt; t += 256) {
     const int off = v0 + t;                                 // < PREP_SEG + Wp
     const int drow = (int)__umulhi((unsigned)off, wp_magic);
@@ -92,7 +97,13 @@ __global__ void __launch_bounds__(256) corr_prep_kernel(CorrChunk chunk, int cou
     const int n = corr_divu(sc, C, c_magic);
     const int c = sc - n * C;
     const float val = v < W ? d.src[(long long)r * W + v] : 0.0f;
-    xp[t] = val;
+    xp[(long long)sc * d.xp_pitch + u * Wp + v] = val;
+    if (tail > 0 && v >= W) {
+      // packed pair tiles read every row up to two image rows past its end: zero tail, written by the 2 H threads
+      // that hold the row's padding columns
+      for (int q = 2 * u + (v - W); q < tail; q += 2 * H) xp[(long long)sc * d.xp_pitch + plane + q] = 0.0f;
+      if (sc == 0 && u == 0) for (int q = v - W; q < d.xp_lead; q += 2) xp[q - d.xp_lead] = 0.0f;
+    }
     if (u == H - 1) d.rowb[(long long)c * d.row_pitch + corr::LEAD + n * Wp + v] = val;
     if (u == 0) d.rowt[(long long)c * d.row_pitch + corr::LEAD + n * Wp + v] = val;
     if (v == W - 1 || v == 0) {
@@ -125,12 +136,11 @@ __global__ void __launch_bounds__(256) corr_assemble_kernel(CorrChunk chunk, int
   const int C = d.C, nct = C / CT;
   const int t = blockIdx.x - d.tile_base;
   const int cb = t / nct, cb2 = t - cb * nct;
-  const long long C2 = (long long)C * C;
   for (int e = threadIdx.x; e < 29 * CT * CT; e += 256) {
     const int k = e / (CT * CT), rc = e - k * (CT * CT), r = rc / CT, c = rc - r * CT;
-    const float* m = d.comp + k * C2;
-    ta[k][r][c] = m[(long long)(cb * CT + r) * C + cb2 * CT + c];
-    tb[k][r][c] = m[(long long)(cb2 * CT + r) * C + cb * CT + c];
+    const float* m = d.comp + d.comp_at[k];
+    ta[k][r][c] = m[(long long)(cb * CT + r) * d.comp_pitch + cb2 * CT + c];
+    tb[k][r][c] = m[(long long)(cb2 * CT + r) * d.comp_pitch + cb * CT + c];
   }
   __syncthreads();
   const int dim = 9 * C;
@@ -166,11 +176,95 @@ static long long round_up4(long long v) { return (v + 3) & ~3LL; }
 
 bool syrk_corr_eligible(const curv_factor_desc& s) {
   if (!(s.kh == 3 && s.kw == 3 && s.sh == 1 && s.sw == 1 && s.ph == 1 && s.pw == 1) || s.has_bias) return false;
-  if (s.C < 128 || s.C % 128 != 0 || s.N < 8 || s.H < 3 || s.W < 3) return false;
+  // whole 128-row tiles of channels, or exactly 64 channels (packed pair tiles)
+  if (!(s.C == 64 || (s.C >= 128 && s.C % 128 == 0)) || s.N < 8 || s.H < 3 || s.W < 3) return false;
   // every operand array addressable by one buffer descriptor of the LDS-DMA kernel
-  if ((long long)s.N * s.C * s.H * (s.W + 2) * 4 >= (1LL << 32) - 4096) return false;
+  if ((long long)s.N * s.C * ((long long)s.H * (s.W + 2) + 2 * (s.W + 2) + 16) * 4 >= (1LL << 32) - 4096) return false;
   if ((long long)s.N * s.C * s.H * std::max(s.H, s.C) >= (1LL << 32)) return false;     // row numbers are divided by multiply-high
   return true;
+}
+
+// 64 channels: a 128x128 tile of the LDS-DMA kernel holds FOUR shifted correlations.  Panel j is the image twice, at
+// offsets (0, -1); panel i the image at two offsets (a1, a2): block (hi, hj) = sum_p X[c][p + a_hi] X[c'][p + b_hj] is
+// the correlation with relative offset a_hi - b_hj, i.e. a row offset a covers the offsets {a, a + 1}.  The 13 offsets
+// 0..2, Wp-2..Wp+2, 2Wp-2..2Wp+2 take 8 row offsets = 4 tiles (16 blocks, 3 of them duplicates) instead of the 45
+// blocks of the factor computed one by one; the border strips one tile per strip array, the corner products two
+// symmetric 128-row tiles over [corner k; corner k + 1].  Every row of Xp ends in a zero tail and the array starts
+// behind XP_LEAD zeros, so all four blocks of a tile sum over the same K = H Wp positions.
+static void syrk_corr_expand_half(const curv_factor_desc& s, std::vector<FactorDev>& f, CorrLayer& L, long long& area_floats) {
+  using namespace corr;
+  auto take = [&](long long n) { const long long o = area_floats; area_floats += round_up4(n) + 64; return o; };
+  const int Wp = L.Wp, plane = s.H * Wp;
+  L.xp_pitch = (int)round_up4((long long)plane + 2 * Wp + 12);
+  L.comp_pitch = 128;
+  L.n_vf = 10;
+  L.comp_off = take(10LL * 128 * 128);
+  for (int k = 0; k < CORR_COMPONENTS; ++k) L.comp_at[k] = -1;
+  int tile = 0;
+  auto pair_tile = [&](long long src_off, int samples, int pitch, int K, int lead, int a1, int a2) {
+    FactorDev v;
+    memset(&v, 0, sizeof(v));
+    v.N = samples; v.C = 64; v.H = 1; v.W = K;
+    v.kh = v.kw = v.sh = v.sw = 1;
+    v.Ho = 1; v.Wo = K; v.khkw = 1;
+    v.rows = v.dim = 128;
+    v.compact = 1;
+    v.first = 1; v.scale = 1.0f;
+    v.dma = 1;
+    v.pitch = pitch; v.nonsym = 1; v.half = 1;
+    v.off_i = lead + a1; v.off_i2 = lead + a2; v.off_j = lead; v.off_j2 = lead - 1;
+    v.TM = 128; v.P = 1; v.n_tiles = 1;
+    v.n_chunks = samples * syrk_flat_stages(K);
+    v.src = reinterpret_cast<const float*>(src_off);
+    v.dst = reinterpret_cast<float*>(L.comp_off + (long long)tile * 128 * 128);
+    f.push_back(v);
+    return tile++;
+  };
+  auto block_at = [&](int t, int hi, int hj) { return t * 128 * 128 + hi * 64 * 128 + hj * 64; };
+  // whole-image correlations
+  const int rows8[4][2] = {{0, 1}, {Wp - 2, Wp}, {Wp + 1, 2 * Wp - 2}, {2 * Wp, 2 * Wp + 1}};
+  for (int t4 = 0; t4 < 4; ++t4) {
+    const int t = pair_tile(L.xp_off, s.N, L.xp_pitch, plane, XP_LEAD, rows8[t4][0], rows8[t4][1]);
+    f.back().group_n = 4; f.back().group_pos = t4;
+    for (int hi = 0; hi < 2; ++hi)
+      for (int hj = 0; hj < 2; ++hj) {
+        const int delta = rows8[t4][hi] + hj;                  // = -(dh Wp + dw)
+        const int m = (delta + Wp / 2) / Wp, dh = -m, dw = -(delta - m * Wp);
+        if (dw < -2 || dw > 2 || m > 2 || (m == 0 && dw > 0)) continue;
+        L.comp_at[f_index(dh, dw)] = block_at(t, hi, hj);
+      }
+  }
+  // border strips: offsets 0, 1, 2 from the row offsets (0, 1)
+  const long long strip_src[4] = {L.rowb_off, L.rowt_off, L.colr_off, L.coll_off};
+  const int strip_comp[4] = {RB0, RT0, CR0, CL0};
+  for (int k = 0; k < 4; ++k) {
+    const bool rows = k < 2;
+    const int t = pair_tile(strip_src[k], 1, rows ? L.row_pitch : L.col_pitch, rows ? s.N * Wp : s.N * L.Hq, LEAD, 0, 1);
+    L.comp_at[strip_comp[k] + 0] = block_at(t, 0, 0);
+    L.comp_at[strip_comp[k] + 1] = block_at(t, 0, 1);
+    L.comp_at[strip_comp[k] + 2] = block_at(t, 1, 1);
+  }
+  // corner products: [corner k; corner k + 1] as one symmetric 128-row factor, the products on its diagonal blocks
+  for (int k = 0; k < 4; k += 2) {
+    FactorDev v;
+    memset(&v, 0, sizeof(v));
+    v.N = 1; v.C = 128; v.H = 1; v.W = s.N;
+    v.kh = v.kw = v.sh = v.sw = 1;
+    v.Ho = 1; v.Wo = s.N; v.khkw = 1;
+    v.rows = v.dim = 128;
+    v.compact = 1;
+    v.first = 1; v.scale = 1.0f;
+    v.dma = 1;
+    v.pitch = L.pt_pitch;
+    v.TM = 128; v.P = 1; v.n_tiles = 1;
+    v.n_chunks = syrk_flat_stages(s.N);
+    v.src = reinterpret_cast<const float*>(L.pt_off + (long long)k * 64 * L.pt_pitch);
+    v.dst = reinterpret_cast<float*>(L.comp_off + (long long)tile * 128 * 128);
+    f.push_back(v);
+    L.comp_at[PT0 + k] = block_at(tile, 0, 0);
+    L.comp_at[PT0 + k + 1] = block_at(tile, 1, 1);
+    ++tile;
+  }
 }
 
 // Append the 29 virtual factors of one eligible user factor to `f` (pointers are filled in by syrk_corr_bind) and
@@ -186,12 +280,19 @@ void syrk_corr_expand(const curv_factor_desc& s, int user, std::vector<FactorDev
   L.col_pitch = (int)round_up4(LEAD + (long long)s.N * L.Hq) + 4;
   L.pt_pitch = (int)round_up4(s.N) + 4;
   auto take = [&](long long n) { const long long o = area_floats; area_floats += round_up4(n) + 64; return o; };
-  L.xp_off = take((long long)s.N * s.C * s.H * L.Wp);
+  // 64 channels: rows with a zero tail of two image rows (+ DMA slack) and XP_LEAD zeros in front of the array
+  const int xp_pitch = s.C == 64 ? (int)round_up4((long long)s.H * L.Wp + 2 * L.Wp + 12) : s.H * L.Wp;
+  L.xp_off = take((long long)s.N * s.C * xp_pitch + (s.C == 64 ? XP_LEAD : 0));
   L.rowb_off = take((long long)s.C * L.row_pitch);
   L.rowt_off = take((long long)s.C * L.row_pitch);
   L.colr_off = take((long long)s.C * L.col_pitch);
   L.coll_off = take((long long)s.C * L.col_pitch);
   L.pt_off = take(4LL * s.C * L.pt_pitch);
+  if (s.C == 64) { syrk_corr_expand_half(s, f, L, area_floats); return; }
+  L.n_vf = CORR_COMPONENTS;
+  L.xp_pitch = s.H * L.Wp;
+  L.comp_pitch = s.C;
+  for (int k = 0; k < CORR_COMPONENTS; ++k) L.comp_at[k] = k * s.C * s.C;
   L.comp_off = take((long long)CORR_COMPONENTS * s.C * s.C);
 
   auto add = [&](int comp, long long src_off, int samples, int pitch, int K, int off_i, int off_j, bool nonsym) {
@@ -232,7 +333,7 @@ void syrk_corr_expand(const curv_factor_desc& s, int user, std::vector<FactorDev
 
 // area-relative offsets of a layer's virtual factors -> device pointers
 void syrk_corr_bind(const CorrLayer& L, std::vector<FactorDev>& f, float* area) {
-  for (int k = 0; k < CORR_COMPONENTS; ++k) {
+  for (int k = 0; k < L.n_vf; ++k) {
     FactorDev& v = f[L.vf0 + k];
     v.src = area + reinterpret_cast<intptr_t>(v.src);
     v.dst = area + reinterpret_cast<intptr_t>(v.dst);
@@ -242,7 +343,11 @@ void syrk_corr_bind(const CorrLayer& L, std::vector<FactorDev>& f, float* area) 
 static void fill_dev(const CorrLayer& L, const FactorDev& user, float* area, CorrDev& d) {
   memset(&d, 0, sizeof(d));
   d.src = user.src; d.dst = user.dst;
-  d.xp = area + L.xp_off;
+  d.xp_lead = L.C == 64 ? corr::XP_LEAD : 0;
+  d.xp = area + L.xp_off + d.xp_lead;
+  d.xp_pitch = L.xp_pitch;
+  d.comp_pitch = L.comp_pitch;
+  for (int k = 0; k < CORR_COMPONENTS; ++k) d.comp_at[k] = L.comp_at[k];
   d.rowb = area + L.rowb_off; d.rowt = area + L.rowt_off;
   d.colr = area + L.colr_off; d.coll = area + L.coll_off;
   d.pt = area + L.pt_off;

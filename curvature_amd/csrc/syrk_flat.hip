@@ -146,6 +146,8 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
   };
   // next stage's DMA geometry (scalars) and the issue of one piece: piece i = (panel i / PIECES, row group i % PIECES)
   int n_soff[2] = {0, 0};
+  // packed pair tile (d.half): rows 64 .. 127 of a panel are the 64 channel rows again, at the panel's second offset
+  const int hadj[2] = {d.half ? (d.off_i2 - d.off_i - 64 * pitch) * 4 : 0, d.half ? (d.off_j2 - d.off_j - 64 * pitch) * 4 : 0};
   int n_gmax = 0;
   unsigned n_buf = 0;
   auto plan_next = [&](int t) {
@@ -160,7 +162,8 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
     const int p = i / PIECES, slot = i % PIECES;
     if (p < n_panels && g_lane < n_gmax) {
       const unsigned lbase = (p ? 2u * PANEL_B : 0u) + n_buf + (unsigned)(RPP * wave + 4 * RPP * slot) * ROW_B;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lbase), 16, voff, n_soff[p] + slot * 4 * RPP * pitch * 4, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lbase), 16, voff,
+                                               n_soff[p] + slot * 4 * RPP * pitch * 4 + (slot * 4 * RPP >= 64 ? hadj[p] : 0), 0, 0);
     }
   };
 

@@ -52,6 +52,10 @@ struct FactorDev {
   // offsets 0.  nonsym: a correlation X_i X_j^T between differently shifted rows - every (ti, tj) tile is computed
   // and nothing is mirrored.
   int pitch, off_i, off_j, nonsym;
+  // half: a PACKED pair tile for 64-channel sources (syrk_corr.hip): the 128 rows of a panel are the source's 64
+  // channel rows twice, rows 64 .. 127 at the second offset (off_i2 / off_j2), so the tile's four 64x64 blocks are four
+  // different shifted correlations of one 64-channel image
+  int half, off_i2, off_j2, pad1;
   // group: group_n consecutive table entries (this one is number group_pos) with equal n_tiles / cpi / n_slices share
   // one item range, enumerated (k-slice, member, tile): the workgroups that stream the same slice of one source - the
   // shifted correlations of a layer - are then neighbours in launch order and meet in an XCD's L2.  The range starts
@@ -220,7 +224,11 @@ int launch_patch_prep(hipStream_t stream, const std::vector<FactorDev>& f, const
 constexpr int CORR_COMPONENTS = 29;
 struct CorrLayer {
   int user;                  // index of the user factor in Plan::f
-  int vf0;                   // its CORR_COMPONENTS virtual factors are Plan::f[vf0 ...]
+  int vf0, n_vf;             // its virtual factors are Plan::f[vf0 .. vf0 + n_vf): the 29 components one by one, or
+                             // (64 channels) 10 packed pair tiles that hold them as 64x64 blocks
+  int xp_pitch;              // floats between consecutive (sample, channel) rows of the padded copy
+  int comp_pitch;            // row pitch of a component matrix, and where each of the 29 starts (floats from comp_off)
+  int comp_at[CORR_COMPONENTS];
   int N, C, H, W, Wp, Hq;
   int row_pitch, col_pitch, pt_pitch;
   long long xp_off, rowb_off, rowt_off, colr_off, coll_off, pt_off, comp_off;    // floats from the area base

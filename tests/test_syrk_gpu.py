@@ -38,6 +38,11 @@ CONV_CASES = [
     (8, 256, 7, 7, 3, 1, 1, False),     # layer4-like: odd size, border strips are half of the image
     (9, 128, 12, 21, 3, 1, 1, False),   # non-square, odd width, odd sample count
     (8, 128, 3, 3, 3, 1, 1, False),     # smallest image: every pixel is a border pixel
+    # the same with exactly 64 channels: packed pair tiles (four shifted correlations per 128x128 tile)
+    (8, 64, 14, 14, 3, 1, 1, False),    # ResNet layer1-like
+    (9, 64, 12, 21, 3, 1, 1, False),    # non-square, odd width, odd sample count
+    (8, 64, 3, 3, 3, 1, 1, False),      # smallest image
+    (8, 64, 56, 56, 3, 1, 1, False),    # ResNet-50 layer1 geometry (K = 26 k positions per sample: many k-slices)
 ]
 
 
@@ -186,8 +191,8 @@ def test_more_pretiled_factors_than_one_argument_block(gpu):
 
 
 def test_more_assembled_factors_than_one_argument_block(gpu):
-    """The padding / assembly passes carry 16 layer descriptors per kernel-argument block: 19 assembled factors in one
-    call take two launches of each (a ResNet-34 has 23 such layers)."""
+    """The padding / assembly passes carry 14 layer descriptors per kernel-argument block: 19 assembled factors in one
+    call take two launches of each (a ResNet-34 has 16 such layers, a ResNet-50 13)."""
     from curvature_amd import ops
     o = _oracle()
     torch.manual_seed(5)
@@ -217,7 +222,7 @@ def _linear_jobs(ops, gpu, count, seed):
 def test_resident_table_survives_a_shorter_table_in_between(gpu):
     """Round-3 advisor: the library's host shadow of the resident descriptor table only ever grew, so a call with a
     SHORTER table (whose zero pad / slabs overwrite the tail rows of the longer one on the device) left stale shadow
-    rows behind and the next long call skipped their upload.  40 factors (three 15-row argument blocks), a 6-factor call
+    rows behind and the next long call skipped their upload.  40 factors (three 14-row argument blocks), a 6-factor call
     on the same workspace in between, then the 40 again: bit-identical to the first result."""
     from curvature_amd import ops
     jobs = _linear_jobs(ops, gpu, 40, 11)
