@@ -383,6 +383,59 @@ def other_configs_cpu_subprocess(timeout_s=240):
         return {"note": f"CPU leg did not finish within {timeout_s} s on this host and was stopped"}
 
 
+def stream_probe(mode: str, batch: int):
+    """Child process of `stream_probe_subprocess`: invert(1, 1000) of the headline workload's factors in a process that
+    holds three unrelated HIP streams (hipStreamCreateWithFlags, what RCCL or a data loader would add), created
+    "before" or "after" the estimator - whose constructor creates the library's own stream set (curv_init_streams) -
+    or not at all ("none").  The whole-model sweep is sensitive to streams created BEFORE its own."""
+    import ctypes
+    import statistics
+    from curvature_amd import models
+    from curvature_amd.curvatures import KFAC
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = models.resnet50().to(dev).train()
+    hip = ctypes.CDLL("libamdhip64.so")
+    keep = []
+
+    def extra():
+        for _ in range(3):
+            h = ctypes.c_void_p()
+            if hip.hipStreamCreateWithFlags(ctypes.byref(h), 1) != 0:
+                raise RuntimeError("hipStreamCreateWithFlags failed")
+            keep.append(h)
+    if mode == "before":
+        extra()
+    kfac = KFAC(model)
+    if mode == "after":
+        extra()
+    _backward_once(model, torch.randn(batch, 3, 224, 224, device=dev))
+    kfac.update(batch_size=batch)
+    for _ in range(3):
+        kfac.invert(add=1.0, multiply=1000.0)
+    ts = []
+    for _ in range(10):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kfac.invert(add=1.0, multiply=1000.0)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    print(json.dumps({"invert_ms": statistics.median(ts)}))
+
+
+def stream_probe_subprocess(mode: str, batch: int, timeout_s=180):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--stream-probe", mode, "--batch", str(batch)]
+    try:
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+        for line in reversed(proc.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)["invert_ms"]
+        return f"failed (rc {proc.returncode}): {proc.stderr.strip()[-200:]}"
+    except subprocess.TimeoutExpired:
+        return f"did not finish within {timeout_s} s"
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` without a torchrun environment: start N fresh rank processes (one per GPU) with
     torch.distributed.run and return its exit code.  Called before this process has made any HIP call (torch is
@@ -418,7 +471,11 @@ def main():
                     help="skip the untimed-region legs for BASELINE.json's configs 2, 3 and 5 (`other_configs`)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-other-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--stream-probe", default=None, choices=["none", "before", "after"], help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.stream_probe is not None:               # child of stream_probe_subprocess
+        stream_probe(args.stream_probe, args.batch)
+        return
     if args.cpu_baseline_only:                      # child of cpu_baseline_subprocess: CPU only, no GPU call
         print(json.dumps(cpu_baseline(args.batch, 0)))
         return
@@ -598,6 +655,14 @@ def main():
                 other = other_configs_gpu(dev, model, kfac, args.batch)
             except Exception as exc:                         # the headline line must survive a failure here
                 other = {"error": f"{type(exc).__name__}: {exc}"}
+            # invert() of this workload in fresh processes that hold three unrelated streams
+            other["stream_population"] = {
+                "what": "KFAC.invert(1, 1000) of the headline workload, median of 10, in a fresh process with three "
+                        "unrelated HIP streams created before / after the estimator (whose constructor creates the "
+                        "library's stream set), and without them",
+                "invert_ms_no_extra_streams": stream_probe_subprocess("none", args.batch),
+                "invert_ms_with_3_extra_streams": stream_probe_subprocess("after", args.batch),
+                "invert_ms_with_3_extra_streams_created_before_the_estimator": stream_probe_subprocess("before", args.batch)}
             if not args.no_cpu_baseline:
                 other["cpu_oracle"] = other_configs_cpu_subprocess()
             out["other_configs"] = other

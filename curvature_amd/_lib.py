@@ -113,6 +113,7 @@ _vp, _i, _ll, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes
 SIGNATURES = {
     "curv_version": (_i, []),
     "curv_last_error": (ctypes.c_char_p, []),
+    "curv_init_streams": (_i, []),
     "curv_kfac_workspace_bytes": (_sz, [ctypes.POINTER(curv_factor_desc), _i]),
     "curv_kfac_plan_info": (_i, [ctypes.POINTER(curv_factor_desc), _i, ctypes.POINTER(ctypes.c_longlong)]),
     "curv_kfac_accumulate": (_i, [_vp, ctypes.POINTER(curv_factor_desc), _i, _vp, _sz]),
@@ -156,7 +157,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 4                     # CURV_ABI_VERSION of include/curv_hip.h
+ABI_VERSION = 5                     # CURV_ABI_VERSION of include/curv_hip.h
 KFAC_TABLE_RESIDENT = 1             # CURV_KFAC_TABLE_RESIDENT
 GEMM_TABLE_RESIDENT = 1             # CURV_GEMM_TABLE_RESIDENT
 ERR_NOT_PD, ERR_INVALID, ERR_WORKSPACE, ERR_HIP, ERR_NOT_CONVERGED = 1, 2, 3, 4, 5     # CURV_ERR_* of the header
@@ -191,6 +192,18 @@ def check(status: int, what: str = "") -> None:
     if status != 0:
         msg = lib().curv_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"libcurv_hip {what} failed with status {status}: {msg}")
+
+
+def init_streams(device) -> None:
+    """Create the library's internal streams for `device` now (curv_init_streams): the mapping of streams onto hardware
+    queues depends on creation order, and the inversion sweep is fastest when its streams exist before any unrelated
+    ones.  Called by the estimator constructors; a no-op for CPU devices and after the first call."""
+    import torch
+    device = torch.device(device)
+    if device.type != "cuda":
+        return
+    with torch.cuda.device(device):
+        check(lib().curv_init_streams(), "curv_init_streams")
 
 
 def stream_ptr() -> int:

@@ -1349,6 +1349,11 @@ extern "C" int curv_debug_sq_trace(long long* out) {
 }
 #endif
 
+extern "C" int curv_init_streams(void) {
+  StreamSet* ss = nullptr;
+  return stream_set(&ss);
+}
+
 extern "C" size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int n_factors) {
   size_t total = 2 * inv_table_bytes(n_factors) + 2 * inv_flags_bytes(n_factors);
   for (int i = 0; i < n_factors; ++i) {

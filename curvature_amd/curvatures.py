@@ -24,7 +24,7 @@ import torch
 from torch import Tensor
 from torch.nn import Module, Sequential
 
-from . import ops
+from . import _lib, ops
 
 SUPPORTED_LAYERS = ['Linear', 'Conv2d', 'MultiheadAttention']
 
@@ -71,6 +71,11 @@ class Curvature(ABC):
         # torch.manual_seed() before sampling is honoured); assign `noise_seed` to pin it.
         self.noise_seed = None
         self.noise_offset = 0
+        # the library's internal streams should exist before unrelated ones (RCCL's, a data loader's, eval_bnn's): the
+        # estimator constructor is the earliest point at which the device is known (include/curv_hip.h: curv_init_streams)
+        first = next(iter(model.parameters()), None)
+        if first is not None and first.is_cuda:
+            _lib.init_streams(first.device)
 
     # ------------------------------------------------------------------ helpers
     def _layers(self) -> List[Module]:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CURV_ABI_VERSION 4
+#define CURV_ABI_VERSION 5
 
 #define CURV_OK 0
 #define CURV_ERR_NOT_PD 1
@@ -36,6 +36,14 @@ extern "C" {
 
 int curv_version(void);
 const char* curv_last_error(void);
+
+/* Create the library's internal streams (per calling thread and current device) NOW instead of at the first
+ * curv_chol_inv_lower / curv_kfac_accumulate call.  Whole-model inversions run their factor groups on four internal
+ * streams, and how the HIP runtime maps those onto hardware queues depends on which streams the process created BEFORE
+ * them: unrelated streams created first (RCCL's, a data loader's) made invert() of the ResNet-50 factors 8.4 -> 12.6 ms,
+ * the same streams created afterwards change nothing (profiles/r04_stream_sensitivity.txt).  Call this once, early -
+ * the Python estimators do it in their constructor.  Idempotent. */
+int curv_init_streams(void);
 
 /* ------------------------------------------------------------------------------------------------
  * KFAC factor build:  dst (+)= scale * X X^T           (curvature/curvatures.py:312-352)
