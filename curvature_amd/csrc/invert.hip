@@ -744,9 +744,13 @@ chol_panel_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int kend)
 //     and COLUMN r - 1 of the square's inverse, X_{i,j} = -X_ii sum_{m=j}^{i-1} L_{i,m} X_{m,j}.
 // Tiles that cross workgroups are written and read with agent-coherent accesses (sc1: no cache maintenance); a
 // hand-off (store, flag, poll, load) takes ~5 us (tools/micro/wg_handoff.hip), which is why nothing on the runner's
-// path waits for one that was not posted a step earlier.  A workgroup only waits for workgroups with a lower
-// block index of the same launch (dispatched before it), and every wait is bounded: a lost flag ends in an
-// error code, not in a hung queue.
+// path waits for one that was not posted a step earlier.  The helpers wait for workgroups with a lower block index of
+// the launch (dispatched before them); the RUNNER (the lowest index of its factor) also waits for flags its helpers
+// post (SQ_FT), i.e. for workgroups with a HIGHER index: forward progress needs all workgroups of a factor (at most 4,
+// 109 KB of LDS each: one per CU) resident at the same time, which a whole MI355X always grants but a CU-masked stream,
+// a partitioned device or heavy contention from other streams may not.  Every wait is therefore bounded: a lost flag
+// ends in status word -1 ("inter-workgroup hand-off timed out", ops.check_chol_info), not in a hung queue, and
+// CURV_LATENCY_MAX=0 selects the per-step launches that need no co-residency.
 // ------------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ void load_block_coh(const gdouble* __restrict__ g, int ld, double* __restrict__ s) {

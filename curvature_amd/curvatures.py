@@ -642,7 +642,7 @@ class KFAC(Curvature):
         # plan of sample_and_replace valid); RuntimeError if a damped factor is not positive definite
         prev = [t for layer in self.state.keys() for t in self.inv_state.get(layer, (None, None))]
         chols = ops.chol_inv_lower(factors, adds, muls, check=check, outs=prev)
-        self._invert_info = ops.chol_inv_lower.last_info
+        self._invert_info = chols.info
         for index, layer in enumerate(self.state.keys()):
             self.inv_state[layer] = (chols[2 * index], chols[2 * index + 1])
 

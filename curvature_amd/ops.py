@@ -217,10 +217,17 @@ def chol_inv_lower(factors: Sequence[torch.Tensor], adds: Sequence[float], multi
     ws = workspace(need, dev, "invert")
     _lib.check(L.curv_chol_inv_lower(_lib.stream_ptr(), arr, n, info.data_ptr(), ws.data_ptr(), ws.numel()),
                "curv_chol_inv_lower")
-    chol_inv_lower.last_info = info              # check=False: the caller reads it later (check_chol_info)
+    chol_inv_lower.last_info = info              # (kept for older callers; process-global: use the attribute below)
+    outs = _ListWithInfo(outs)
+    outs.info = info                             # check=False: the caller reads it later (check_chol_info)
     if check:
         check_chol_info(info)                    # the one host synchronisation of invert()
     return outs
+
+
+class _ListWithInfo(list):
+    """The list of inverse factors of one `chol_inv_lower` call, carrying that call's status words (`.info`)."""
+    info = None
 
 
 def check_chol_info(info: torch.Tensor) -> None:
@@ -228,6 +235,13 @@ def check_chol_info(info: torch.Tensor) -> None:
     host = info.cpu()
     bad = torch.nonzero(host).flatten().tolist()
     if bad:
+        lost = [i for i in bad if int(host[i]) < 0]
+        if lost:
+            # status -1: a workgroup of chol_square_kernel gave up waiting for a tile from another workgroup of its
+            # launch (bounded spin: all workgroups of a factor must be resident at once) - not a property of the matrix
+            raise RuntimeError(f"cholesky: inter-workgroup hand-off timed out for factor(s) {lost} (the GPU could not keep "
+                               "the sweep's workgroups resident: CU-masked / partitioned device or heavy contention); "
+                               "set CURV_LATENCY_MAX=0 to use the per-step launches")
         raise RuntimeError(f"cholesky: damped factor(s) {bad} are not positive-definite "
                            f"(first failing pivot {int(host[bad[0]]) - 1})")
 
@@ -566,8 +580,9 @@ def eigh(mats: Sequence[torch.Tensor], with_values: bool = False, max_sweeps: in
          allow_unconverged: bool = False):
     """Eigenvectors (columns, ascending eigenvalues) of symmetric float32 matrices, batched block-Jacobi.
 
-    Raises ``RuntimeError`` when the iteration has not converged to `tol` within `max_sweeps` sweeps (defaults
-    1e-8 / 60; the loop ends at convergence, Kronecker factors of ResNets need 19-23) unless
+    Raises ``RuntimeError`` when the iteration has not converged to `tol` within `max_sweeps` sweeps (default 60 sweeps;
+    default tolerance off(A) <= 1e-8 ||A|| for matrices up to 1024 wide and 5e-6 ||A|| above - where the reference's
+    fp32 LAPACK delivers 1e-5; an explicit `tol` applies to every matrix; the loop ends at convergence) unless
     `allow_unconverged` is set, in which case the last iterate is returned and ``eigh.converged`` is False."""
     from ._lib import curv_eigh_desc
     n = len(mats)

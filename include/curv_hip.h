@@ -273,7 +273,9 @@ int curv_copy_batched(void* stream, const curv_copy_desc* descs, int n);
  * optional) the eigenvalues of F (the reference decomposes F + F^T: same vectors, doubled values, and it
  * discards the values).  Signs / bases of degenerate clusters are arbitrary, as with LAPACK.
  * The call synchronises the stream once per sweep to test convergence (off(A) <= tol * ||A||_F);
- * max_sweeps <= 0 and tol <= 0 select the defaults (60, 1e-8).  n <= 8192.  If the iteration has not
+ * max_sweeps <= 0 selects 60; tol <= 0 selects the size-dependent default: 1e-8 for n <= 1024, 5e-6 above (an fp32 phase
+ * followed by one fp64 re-orthogonalisation; the reference's fp32 LAPACK reaches 1e-5 on such factors); a positive tol
+ * applies to every matrix of the call.  n <= 8192.  If the iteration has not
  * converged after max_sweeps sweeps the outputs hold the last iterate and the call returns
  * CURV_ERR_NOT_CONVERGED (curv_last_error() carries the final off-norm ratio); *sweeps_done is the
  * number of sweeps executed either way.

@@ -39,9 +39,13 @@ def test_replay_is_bit_identical_to_eager(gpu):
         eager.sample_and_replace()
         weights_e.append([l.weight.detach().clone() for l in layers_e] + [l.bias.detach().clone() for l in layers_e])
     model_g, layers_g, kfac = _setup(gpu)
-    graph = KFACStepGraph(kfac, add=0.5, multiply=1.0, batch_size=8, warmup=3)      # three eager steps, then the capture
+    # construction warms up (three real steps) and captures, then puts factors and noise position back: the replays are
+    # steps 0, 1, 2, ... of the eager loop (round-3 advisor: the warm-up used to stay accumulated in the factors)
+    graph = KFACStepGraph(kfac, add=0.5, multiply=1.0, batch_size=8, warmup=3)
     assert graph.record_is_static()
-    for step in range(3, 6):
+    for layer in layers_g:
+        assert all(float(t.abs().max()) == 0.0 for t in kfac.state[layer])
+    for step in range(6):
         graph.replay()
         torch.cuda.synchronize()
         got = [l.weight.detach() for l in layers_g] + [l.bias.detach() for l in layers_g]
@@ -97,3 +101,28 @@ def test_capture_of_an_inversion_with_far_updates(gpu):
         ops.check_chol_info(ops.chol_inv_lower.last_info)
         for a, b in zip(outs, eager):
             assert torch.equal(a, b), sizes
+
+
+def test_construction_leaves_accumulated_factors_alone_and_replay_guards_its_addresses(gpu):
+    """An estimator that already holds factors: building the graph must not add the warm-up batches to them, and a replay
+    after the factors were re-allocated (the graph holds the old addresses) is refused."""
+    from curvature_amd.graph import KFACStepGraph
+    model, layers, kfac = _setup(gpu)
+    kfac.update(8)
+    kfac.update(8)
+    before = {l: [t.clone() for t in kfac.state[l]] for l in layers}
+    graph = KFACStepGraph(kfac, add=0.5, multiply=1.0, batch_size=8)
+    for l in layers:
+        for a, b in zip(kfac.state[l], before[l]):
+            assert torch.equal(a, b)
+    graph.replay()
+    torch.cuda.synchronize()
+    for l in layers:                                        # exactly one more batch
+        assert torch.allclose(kfac.state[l][0], before[l][0] * 1.5, rtol=1e-5, atol=0)
+    from curvature_amd import ops
+    ops.release_workspaces()                                # the graph keeps what it addresses alive
+    graph.replay()
+    graph.check()
+    kfac.state[layers[0]] = [t.clone() for t in kfac.state[layers[0]]]
+    with pytest.raises(RuntimeError, match="re-allocated"):
+        graph.replay()
