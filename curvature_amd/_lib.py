@@ -13,9 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(CSRC, "libcurv_hip.so")
-SOURCES = ["api.cpp", "elementwise.hip", "syrk.hip", "syrk_flat.hip", "syrk_corr.hip", "syrk_pre.hip", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
+SOURCES = ["api.cpp", "collective.cpp", "elementwise.hip", "syrk.hip", "syrk_flat.hip", "syrk_corr.hip", "syrk_pre.hip", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-function"]
+               "-Wno-unused-function", "-ldl"]
 
 _lock = threading.Lock()
 _lib = None
@@ -114,6 +114,10 @@ SIGNATURES = {
     "curv_version": (_i, []),
     "curv_last_error": (ctypes.c_char_p, []),
     "curv_init_streams": (_i, []),
+    "curv_allgather_weights": (_i, [_vp, _vp, _vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
+    "curv_comm_unique_id": (_i, [_vp]),
+    "curv_comm_init": (_i, [ctypes.POINTER(_vp), _i, _vp, _i]),
+    "curv_comm_destroy": (_i, [_vp]),
     "curv_kfac_workspace_bytes": (_sz, [ctypes.POINTER(curv_factor_desc), _i]),
     "curv_kfac_plan_info": (_i, [ctypes.POINTER(curv_factor_desc), _i, ctypes.POINTER(ctypes.c_longlong)]),
     "curv_kfac_accumulate": (_i, [_vp, ctypes.POINTER(curv_factor_desc), _i, _vp, _sz]),

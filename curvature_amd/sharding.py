@@ -178,28 +178,29 @@ class Shard:
         plans = self.__dict__.setdefault("_plans", {})       # two kept: evaluate.eval_bnn alternates two buffer sets
         cache = plans.get(key)
         if cache is None:
+            # one flat vector, grouped by owning rank: rank r's parameters are flat[displs[r] : displs[r] + sizes[r]]
             sizes = [0] * self.world
             for i, ps in enumerate(params_per_layer):
                 sizes[owner[i]] += sum(p.numel() for p in ps)
-            cap = max(max(sizes), 1)
-            mine = torch.zeros(cap, dtype=ref.dtype, device=ref.device)
-            gathered = torch.empty(self.world * cap, dtype=ref.dtype, device=ref.device)
+            displs = [0] * self.world
+            for r in range(1, self.world):
+                displs[r] = displs[r - 1] + sizes[r - 1]
+            flat = torch.zeros(max(sum(sizes), 1), dtype=ref.dtype, device=ref.device)
             pack, unpack = [], []
-            cursor = [r * cap for r in range(self.world)]
-            pos = 0
+            cursor = list(displs)
             for i, ps in enumerate(params_per_layer):
                 r = owner[i]
                 for p in ps:
                     if not p.is_contiguous():
                         raise RuntimeError("sharded parameters must be contiguous")
                     n = p.numel()
+                    seg = flat[cursor[r]:cursor[r] + n]
                     if r == self.rank:
-                        pack.append((mine[pos:pos + n], p.detach().reshape(-1)))
-                        pos += n
+                        pack.append((seg, p.detach().reshape(-1)))
                     else:
-                        unpack.append((p.detach().reshape(-1), gathered[cursor[r]:cursor[r] + n]))
+                        unpack.append((p.detach().reshape(-1), seg))
                     cursor[r] += n
-            cache = {"key": key, "cap": cap, "mine": mine, "gathered": gathered, "pack": pack, "unpack": unpack,
+            cache = {"key": key, "sizes": sizes, "displs": displs, "flat": flat, "pack": pack, "unpack": unpack,
                      "pack_plan": None, "unpack_plan": None}
             if ref.is_cuda:
                 from . import ops
@@ -208,27 +209,75 @@ class Shard:
             while len(plans) >= 2:
                 plans.pop(next(iter(plans)))
             plans[key] = cache
-        mine, gathered = cache["mine"], cache["gathered"]
+        flat, sizes, displs = cache["flat"], cache["sizes"], cache["displs"]
         if cache["pack_plan"] is not None:
             cache["pack_plan"].run()
         else:
             for d, s_ in cache["pack"]:
                 d.copy_(s_)
         backend = dist.get_backend(self.group)
-        if mine.is_cuda and backend == "gloo":
-            # test configurations only (several ranks sharing one GPU over gloo): stage through the host
-            host = torch.empty(self.world * cache["cap"], dtype=ref.dtype)
-            dist.all_gather(list(host.chunk(self.world)), mine.cpu(), group=self.group)
-            gathered.copy_(host)
-        elif backend == "nccl":
-            dist.all_gather_into_tensor(gathered, mine, group=self.group)               # the one collective
+        if flat.is_cuda and backend == "nccl" and flat.dtype == torch.float32:
+            # the one collective: variable-count all-gather in place over RCCL (curv_allgather_weights), each segment
+            # travelling once - the shards differ several-fold in size, nothing is padded to the largest
+            self._allgather_rccl(flat, sizes, displs)
         else:
-            dist.all_gather(list(gathered.chunk(self.world)), mine, group=self.group)
+            # gloo (the CPU tests, and test configurations with several ranks on one GPU): equal-sized staging buffers
+            cap = max(max(sizes), 1)
+            mine = torch.zeros(cap, dtype=ref.dtype)
+            mine[:sizes[self.rank]] = flat[displs[self.rank]:displs[self.rank] + sizes[self.rank]].cpu()
+            parts = [torch.empty(cap, dtype=ref.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, mine, group=self.group)
+            for r in range(self.world):
+                if r != self.rank and sizes[r]:
+                    flat[displs[r]:displs[r] + sizes[r]].copy_(parts[r][:sizes[r]])
         if cache["unpack_plan"] is not None:
             cache["unpack_plan"].run()
         else:
             for d, s_ in cache["unpack"]:
                 d.copy_(s_)
+
+    # ------------------------------------------------------------------ RCCL communicator of this shard
+    def _rccl_comm(self, device: torch.device):
+        """An RCCL communicator of this shard's ranks for `curv_allgather_weights` (torch.distributed does not hand out
+        its own ncclComm_t): rank 0 draws the id, one torch.distributed broadcast ships its 128 bytes."""
+        comm = self.__dict__.get("_comm")
+        if comm is None:
+            import ctypes
+            from . import _lib
+            L = _lib.lib()
+            ident = (ctypes.c_ubyte * 128)()
+            if self.rank == 0:
+                _lib.check(L.curv_comm_unique_id(ident), "curv_comm_unique_id")
+            box = torch.tensor(list(ident), dtype=torch.uint8, device=device)
+            src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.broadcast(box, src=src, group=self.group)
+            ident = (ctypes.c_ubyte * 128)(*box.cpu().tolist())
+            handle = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(L.curv_comm_init(ctypes.byref(handle), self.world, ident, self.rank), "curv_comm_init")
+            comm = self.__dict__["_comm"] = handle
+        return comm
+
+    def _allgather_rccl(self, flat: torch.Tensor, sizes: Sequence[int], displs: Sequence[int]) -> None:
+        import ctypes
+        from . import _lib
+        comm = self._rccl_comm(flat.device)
+        counts = (ctypes.c_longlong * self.world)(*sizes)
+        offs = (ctypes.c_longlong * self.world)(*displs)
+        with torch.cuda.device(flat.device):
+            _lib.check(_lib.lib().curv_allgather_weights(comm, _lib.stream_ptr(), flat.data_ptr(), counts, offs),
+                       "curv_allgather_weights")
+
+    def rccl_ranks(self) -> int:
+        """Ranks of the RCCL communicator the all-gather runs on (0 before its first use / with another backend)."""
+        return self.world if self.__dict__.get("_comm") is not None else 0
+
+    def close(self) -> None:
+        """Destroy the RCCL communicator (optional; collective: call it on every rank)."""
+        comm = self.__dict__.pop("_comm", None)
+        if comm is not None:
+            from . import _lib
+            _lib.check(_lib.lib().curv_comm_destroy(comm), "curv_comm_destroy")
 
 
 def make_shard(costs: Sequence[float], rank: Optional[int] = None, world: Optional[int] = None, group=None) -> Shard:

@@ -340,6 +340,23 @@ int curv_kron(void* stream, const float* a, int ar, int ac, const float* b, int 
 int curv_mul2d(void* stream, const float* A, long long a_rs, long long a_cs, const float* B, long long b_rs,
                long long b_cs, float* out, int rows, int cols);
 
+/* ------------------------------------------------------------------------------------------------
+ * The one collective of the layer-sharded estimators (reference: per-layer independence,
+ * curvature/curvatures.py:20-21, sample_and_replace :117-129): every rank has written the sampled parameters of its
+ * own layers into `flat` (the parameters of all layers in one vector, grouped by owning rank: rank k's segment is
+ * [displs[k], displs[k] + counts[k]) in floats); after the call every rank holds every segment.  Variable counts,
+ * nothing padded to the largest shard: one ncclBroadcast per rank in one RCCL group call on `stream`.
+ * `comm` is an ncclComm_t (RCCL) of the caller; counts / displs have ncclCommCount(comm) entries and must agree on all
+ * ranks.  RCCL is bound at run time (dlopen): the library has no link-time dependency on it.
+ * curv_comm_unique_id / curv_comm_init / curv_comm_destroy: thin wrappers of ncclGetUniqueId / ncclCommInitRank /
+ * ncclCommDestroy for callers without RCCL bindings (`id` is the 128-byte ncclUniqueId drawn on rank 0 and shipped to
+ * the other ranks by the caller; the calling thread's current device is the rank's device).
+ * ---------------------------------------------------------------------------------------------- */
+int curv_allgather_weights(void* comm, void* stream, float* flat, const long long* counts, const long long* displs);
+int curv_comm_unique_id(void* id_out_128_bytes);
+int curv_comm_init(void** comm_out, int n_ranks, const void* id_128_bytes, int rank);
+int curv_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,7 +93,9 @@ def test_sharded_chain_world2_equals_unsharded(tmp_path):
 
 def _rccl_world1(rank, port, out_dir):
     """backend "nccl" (= RCCL) with a one-rank group on the box's single GPU: process-group init with a bound
-    device, then KFAC.sample_and_replace through Shard.allgather_params' all_gather_into_tensor branch."""
+    device, then KFAC.sample_and_replace through Shard.allgather_params' RCCL branch: the library's own export
+    curv_allgather_weights (variable-count all-gather in place on the flat parameter vector) on a communicator built by
+    curv_comm_unique_id / curv_comm_init."""
     from curvature_amd import models, sharding
     from curvature_amd.curvatures import KFAC
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -125,7 +127,16 @@ def _rccl_world1(rank, port, out_dir):
     cache = next(iter(shard._plans.values()))
     packed = torch.cat([t.reshape(-1) for t in want])
     ok = all(torch.equal(a, b) for a, b in zip(got, want))
-    ok_gather = torch.equal(cache["gathered"][:packed.numel()], packed) and cache["gathered"].numel() == cache["cap"]
+    ok_gather = torch.equal(cache["flat"], packed) and cache["flat"].numel() == sum(cache["sizes"]) and shard.rccl_ranks() == 1
+    # the export on its own: a three-segment vector of which this (only) rank owns everything, counts / displs honoured
+    import ctypes
+    from curvature_amd import _lib
+    vec = torch.arange(1000, dtype=torch.float32, device=dev)
+    counts, offs = (ctypes.c_longlong * 1)(1000), (ctypes.c_longlong * 1)(0)
+    _lib.check(_lib.lib().curv_allgather_weights(shard._rccl_comm(dev), _lib.stream_ptr(), vec.data_ptr(), counts, offs), "allgather")
+    torch.cuda.synchronize()
+    ok_gather = ok_gather and torch.equal(vec, torch.arange(1000, dtype=torch.float32, device=dev))
+    shard.close()
     # and the collective on its own, with a payload the ranks did not already hold in place
     src = torch.arange(1 << 20, dtype=torch.float32, device=dev)
     dst = torch.zeros_like(src)
@@ -142,7 +153,8 @@ def _rccl_world1(rank, port, out_dir):
 def test_rccl_backend_runs_the_allgather_branch(tmp_path):
     """the one collective of the path is an RCCL all-gather.  The box has one GPU (RCCL refuses two
     ranks on one device), so the nccl backend is initialised with world_size 1 and `force_collective` sends
-    sample_and_replace through pack -> all_gather_into_tensor -> unpack instead of the world == 1 early return."""
+    sample_and_replace through pack -> curv_allgather_weights (RCCL group of broadcasts) -> unpack instead of the
+    world == 1 early return.  No run with more than one RCCL rank exists: 8-GPU nodes are the driver's."""
     mp.spawn(_rccl_world1, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
     res = torch.load(os.path.join(tmp_path, "rccl.pt"))
     assert res == {"ok": True, "ok_gather": True, "copy": True, "max": 3.0}, res

@@ -1,6 +1,10 @@
 #!/usr/bin/env python
 """What layer sharding gives on N GPUs, measured on ONE: each rank's share of the ResNet-50 step is run in turn; the
-N-GPU step time is the slowest rank plus the all-gather (NOT included here: 102 MB of parameters).
+N-GPU step time is the slowest rank plus the all-gather of the sampled parameters, which one GPU cannot run: it is
+MODELLED (printed separately and labelled as such): every rank receives the other ranks' segments, (W - 1) / W of the
+102 MB flat vector, at the all-gather bus bandwidth RCCL reaches over xGMI for messages of this size (7 links x 153 GB/s
+peak per GPU; 300 GB/s assumed = 0.28 of link peak, the usual large-message figure) + 20 us per rank's broadcast of the
+group call.  No scaling curve has been measured on hardware.
 
     python tools/emulate_sharding.py            KFAC step: update + invert(1, 1000) + sample_and_replace (config 4)
     python tools/emulate_sharding.py --chain    config 5: EFB constructor (eigenvectors), efb.update, INF.update(100),
@@ -101,7 +105,10 @@ def main():
                 h.remove()
             del kfac
         mx = max(times)
-        print(f"world {world}: per-rank ms " + " ".join(f"{t:.1f}" for t in times) + f" -> step {mx:.1f} ms (+ all-gather)")
+        n_params = sum(n * m for n, m, *_ in dims)
+        gather_ms = 0.0 if world == 1 else (4.0 * n_params * (world - 1) / world / 300e9 + 20e-6 * world) * 1e3
+        print(f"world {world}: per-rank ms " + " ".join(f"{t:.1f}" for t in times) + f" -> slowest rank {mx:.1f} ms + MODELLED "
+              f"all-gather {gather_ms:.2f} ms ({4.0 * n_params / 1e6:.0f} MB vector, variable counts, unpadded) = {mx + gather_ms:.1f} ms")
 
 
 if __name__ == "__main__":
