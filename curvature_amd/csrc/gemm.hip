@@ -407,11 +407,14 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmDev& d, int local, lds_ch
 }
 
 __global__ void __launch_bounds__(GEMM_THREADS, nt::WGS)
-gemm_nt_kernel(const GemmDev* __restrict__ table, int n_desc, float* __restrict__ slabs) {
+gemm_nt_kernel(const GemmDev* __restrict__ table, int n_desc, float* __restrict__ slabs, const int* __restrict__ order) {
   __shared__ __attribute__((aligned(1024))) char smem[nt::LDS_B];
-  const int f = gemm_find(table, n_desc, blockIdx.x);
+  // `order`: the launch's tiles by descending K (host-sorted): workgroups are dispatched in index order, so the launch
+  // ends with its shortest tiles whatever product they belong to
+  const int id = order != nullptr ? order[blockIdx.x] : (int)blockIdx.x;
+  const int f = gemm_find(table, n_desc, id);
   const GemmDev& d = table[f];
-  gemm_nt_tile(d, blockIdx.x - d.tile_base, (lds_char_t*)smem, slabs);
+  gemm_nt_tile(d, id - d.tile_base, (lds_char_t*)smem, slabs);
 }
 
 // Split products: one workgroup per output tile sums the tile's partial slabs in slice order (deterministic) and
@@ -559,6 +562,12 @@ gemm_f64_kernel(Gemm64Dev d0, Gemm64Dev d1, Gemm64Dev d2, Gemm64Dev d3, int n_de
       }
 }
 
+constexpr int ORDER_UPLOAD_CHUNK = 944;
+struct OrderChunk { int v[ORDER_UPLOAD_CHUNK]; };
+__global__ void __launch_bounds__(256) order_upload_kernel(int* __restrict__ dst, OrderChunk chunk, int count) {
+  for (int w = threadIdx.x; w < count; w += blockDim.x) dst[w] = chunk.v[w];
+}
+
 constexpr int GEMM_UPLOAD_CHUNK = 17;
 struct GemmChunk { GemmDev f[GEMM_UPLOAD_CHUNK]; };
 static_assert(sizeof(GemmChunk) <= 3840, "kernel argument block must stay below 4 KB");
@@ -674,9 +683,14 @@ static int nt_slices(const curv_gemm_desc& s, bool underfilled) {
   return (underfilled && nt_eligible(s) && s.K >= 2 * NT_KSLICE) ? cdiv(s.K, NT_KSLICE) : 1;
 }
 
+static size_t nt_order_bytes(const curv_gemm_desc* descs, int n_desc) {       // the K-sorted tile list of an unsplit NT launch
+  return align_up((size_t)nt_tiles_of(descs, n_desc) * sizeof(int), 256);
+}
+
 extern "C" size_t curv_gemm_workspace_bytes_for(const curv_gemm_desc* descs, int n_desc) {
   size_t total = curv_gemm_workspace_bytes(n_desc);
   const bool underfilled = nt_tiles_of(descs, n_desc) < NT_SPLIT_BELOW_TILES;
+  if (!underfilled) return total + nt_order_bytes(descs, n_desc);
   for (int i = 0; i < n_desc; ++i) {
     const curv_gemm_desc& s = descs[i];
     if (s.M <= 0 || s.N <= 0) continue;
@@ -779,8 +793,39 @@ static int gemm_batched_impl(void* stream_, const curv_gemm_desc* descs, int n_d
     CURV_LAUNCH_CHECK();
   }
   float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + curv_gemm_workspace_bytes(n_desc));
+  // a full launch (several tiles per workgroup slot, no K slicing): its tiles in descending K order, in the space the
+  // slabs of an underfilled launch would take
+  const int* order = nullptr;
+  if (n_nt > 1 && !underfilled && workspace_bytes >= curv_gemm_workspace_bytes_for(descs, n_desc)) {
+    int* dev_order = reinterpret_cast<int*>(slabs);
+    order = dev_order;
+    if (!(flags & CURV_GEMM_TABLE_RESIDENT)) {
+      std::vector<std::pair<int, int>> keyed;               // (K of the tile, global tile id)
+      keyed.reserve((size_t)tiles_nt);
+      for (const GemmDev& d : tab_nt) {
+        const int tiles_m = cdiv(d.M, 128);
+        for (int local = 0; local < tiles_m * d.tiles_n; ++local) {
+          int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
+          if (d.tri == CURV_TRI_A_LOWER) tm = tiles_m - 1 - tm;
+          else if (d.tri == CURV_TRI_B_UPPER) tn = d.tiles_n - 1 - tn;
+          int K = d.K;
+          if (d.tri == CURV_TRI_A_LOWER) K = std::min(K, tm * 128 + 128);
+          else if (d.tri == CURV_TRI_B_UPPER) K = std::min(K, tn * 128 + 128);
+          keyed.emplace_back(K, d.tile_base + local);
+        }
+      }
+      std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
+      for (size_t b = 0; b < keyed.size(); b += ORDER_UPLOAD_CHUNK) {
+        OrderChunk chunk;
+        const int count = (int)std::min<size_t>(ORDER_UPLOAD_CHUNK, keyed.size() - b);
+        for (int k = 0; k < count; ++k) chunk.v[k] = keyed[b + k].second;
+        hipLaunchKernelGGL(order_upload_kernel, dim3(1), dim3(256), 0, stream, dev_order + b, chunk, count);
+        CURV_LAUNCH_CHECK();
+      }
+    }
+  }
   if (n_nt > 0) {
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)tiles_nt), dim3(GEMM_THREADS), 0, stream, table + n, n_nt, slabs);
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)tiles_nt), dim3(GEMM_THREADS), 0, stream, table + n, n_nt, slabs, order);
     CURV_LAUNCH_CHECK();
     if (red_tiles > 0) {
       hipLaunchKernelGGL(gemm_nt_reduce_kernel, dim3((unsigned)red_tiles), dim3(256), 0, stream, table + n, n_nt, slabs);
