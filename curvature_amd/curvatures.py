@@ -256,6 +256,51 @@ class Curvature(ABC):
     def sample(self, layer: Module) -> Tensor:
         raise NotImplementedError
 
+    def sample_many(self, count: int) -> "SampleBank":
+        """`count` sampled parameter sets of the estimator's own layers as a `SampleBank` (see `KFAC.sample_many`, which
+        produces them in two launches; this generic form runs `sample_and_replace` `count` times and files the
+        parameters away, so that `evaluate.eval_bnn(samples_per_launch=...)` works with every estimator)."""
+        S = int(count)
+        assert S >= 1
+        owned = [l for _, l in self._owned() if getattr(l, "weight", None) is not None]
+        weights = {l: torch.empty(S, *l.weight.shape, dtype=l.weight.dtype, device=l.weight.device) for l in owned}
+        biases = {l: (torch.empty(S, *l.bias.shape, dtype=l.bias.dtype, device=l.bias.device) if l.bias is not None else None)
+                  for l in owned}
+        gather, self._allgather_sampled = self._allgather_sampled, (lambda: None)     # the sets travel when they are loaded
+        try:
+            for k in range(S):
+                self.sample_and_replace()
+                for l in owned:
+                    weights[l][k].copy_(l.weight.data)
+                    if biases[l] is not None:
+                        biases[l][k].copy_(l.bias.data)
+        finally:
+            self._allgather_sampled = gather
+        return SampleBank(S, weights, biases)
+
+    def replace_from(self, bank: "SampleBank", index: int) -> None:
+        """Load parameter set `index` of a `sample_many` bank into the model (the other state tensors go back to their
+        means; under a layer shard the sets of all ranks are all-gathered as in `sample_and_replace`)."""
+        if not 0 <= index < bank.count:
+            raise IndexError("replace_from: sample index out of range")
+        plans = bank.__dict__.setdefault("_copy_plans", {})
+        layers = list(bank.weights.keys())
+        params = [p for l in layers for p in (l._parameters['weight'], l._parameters['bias']) if p is not None]
+        key = (index, tuple(map(Tensor.data_ptr, params)))
+        plan = plans.get(key)
+        if plan is None:
+            dsts, srcs = [], []
+            for layer in layers:
+                dsts.append(layer.weight.data)
+                srcs.append(bank.weights[layer][index].view(layer.weight.shape))
+                if layer.bias is not None:
+                    dsts.append(layer.bias.data)
+                    srcs.append(bank.biases[layer][index])
+            plan = plans[key] = ops.CopyPlan(dsts, srcs)
+        plan.run()
+        self._reload_mean(skip=params)
+        self._allgather_sampled()
+
     def sample_and_replace(self):
         """Reset to the mean weights, then add one posterior sample per selected layer (curvatures.py:117-129)."""
         self._reload_mean()
@@ -720,6 +765,80 @@ class KFAC(Curvature):
         # a step that has just synchronised in invert() gets its long kernels queued ~0.1 ms earlier this way
         self._reload_mean(skip=params)
         self._allgather_sampled()
+
+    # ------------------------------------------------------------------ batched multi-sample generation
+    def sample_many(self, count: int, noise: Optional[Dict[Module, Tensor]] = None) -> "SampleBank":
+        """`count` posterior samples of every owned layer in two launches (scripts/evaluate.py:134-139 draws one sample
+        per forward sweep; a BNN evaluation needs 10-100 of them).
+
+        With z_s (n x m) the noise of sample s, W_s = (L_A z_s L_G^T)^T = L_G (L_A z_s)^T (curvatures.py:387-392).
+        Stage A forms V = L_A [z_1 | ... | z_S] as ONE product per layer with S m columns - the n x n triangular factor
+        (80 % of a ResNet-50 sample's flops) is streamed once for all S samples instead of once per sample - and stage
+        B the S products W_s = L_G V_s^T with ``mean +`` fused, written into a bank of parameter sets
+        (`SampleBank.weights[layer]`: (S, m, n0), `.biases[layer]`: (S, m)).  `replace_from(bank, s)` loads set s into
+        the model.  `noise[layer]`: (S, n, m) caller-supplied z_s (parity tests); otherwise one generator launch."""
+        assert self.inv_state, "Inverse state dict is empty. Did you call 'invert' prior to this?"
+        S = int(count)
+        assert S >= 1
+        owned = self._owned()
+        ptr = Tensor.data_ptr
+        key = ("many", S, noise is None, tuple(map(ptr, [t for _, l in owned for t in self.inv_state[l]])),
+               tuple(map(ptr, noise.values())) if noise is not None else ())
+        cache = self.__dict__.setdefault("_many_plans", {})
+        plan = cache.get(key)
+        if plan is None:
+            cache.clear()                                    # one bank's worth of buffers at a time
+            dev = self.inv_state[owned[0][1]][0].device
+            total = sum(self.inv_state[l][0].size(0) * self.inv_state[l][1].size(0) for _, l in owned)
+            flat = torch.empty(S * total, dtype=torch.float32, device=dev) if noise is None else None
+            stage_a, stage_b, weights, biases, keep = [], [], {}, {}, []
+            pos = 0
+            for _, layer in owned:
+                first, second = self.inv_state[layer]
+                n, m = first.size(0), second.size(0)
+                if noise is not None:
+                    z = noise[layer]
+                    if tuple(z.shape) != (S, n, m):
+                        raise RuntimeError(f"sample_many: noise of a layer must be ({S}, {n}, {m})")
+                    zt = z.transpose(1, 2).contiguous().view(S * m, n)          # rows (s, j): z_s^T
+                else:
+                    zt = flat[pos:pos + S * n * m].view(S * m, n)                 # iid: drawn directly as z_s^T
+                    pos += S * n * m
+                V = torch.empty(n, S * m, dtype=torch.float32, device=dev)
+                stage_a.append(ops.Gemm(first, zt.t(), V, tri=ops.TRI_A_LOWER))     # V = L_A [z_1 | ... | z_S]
+                has_bias = layer.bias is not None
+                n0 = n - int(has_bias)
+                wb = torch.empty(S, m, n0, dtype=torch.float32, device=dev)
+                bb = torch.empty(S, m, dtype=torch.float32, device=dev) if has_bias else None
+                w_mean = self.model_state_of(layer, 'weight').view(m, n0)
+                b_mean = self.model_state_of(layer, 'bias').view(m, 1) if has_bias else None
+                for k in range(S):
+                    Vs_t = V[:, k * m:(k + 1) * m].t()                            # (m, n) view of V_s^T: K-contiguous columns
+                    stage_b.append(ops.Gemm(second, Vs_t[:, :n0], wb[k], epilogue=ops.EPI_ADD_E, E=w_mean, tri=ops.TRI_A_LOWER))
+                    if has_bias:
+                        stage_b.append(ops.Gemm(second, Vs_t[:, n0:], bb[k].view(m, 1), epilogue=ops.EPI_ADD_E, E=b_mean,
+                                                tri=ops.TRI_A_LOWER))
+                weights[layer], biases[layer] = wb, bb
+                keep += [zt, V]
+            stage_a.sort(key=lambda j: -(j.A.shape[0] * j.A.shape[1] * j.B.shape[1]))
+            stage_b.sort(key=lambda j: -(j.A.shape[0] * j.A.shape[1] * j.B.shape[1]))
+            plan = (flat, ops.GemmPlan(stage_a), ops.GemmPlan(stage_b), SampleBank(S, weights, biases), keep)
+            cache[key] = plan
+        if plan[0] is not None:
+            self._randn(plan[0].numel(), device=plan[0].device, out=plan[0])
+        plan[1].run()
+        plan[2].run()
+        return plan[3]
+
+
+class SampleBank:
+    """`count` sampled parameter sets of an estimator's own layers (`KFAC.sample_many`): ``weights[layer]`` is
+    (count, out, in[*kh*kw]) and ``biases[layer]`` (count, out) or None, each entry ``mean + sample``.  The buffers belong
+    to the estimator's launch plan: the next `sample_many` call of the same size overwrites them."""
+
+    def __init__(self, count: int, weights: Dict[Module, Tensor], biases: Dict[Module, Optional[Tensor]]):
+        self.count, self.weights, self.biases = count, weights, biases
+
 
 def _arena(shapes: Sequence[Sequence[int]], device, zero: bool = False):
     """One flat fp32 buffer and one view per shape, laid out back to back: whole-model elementwise steps

@@ -94,14 +94,18 @@ def _drop_plans_for(estimator, tensors) -> None:
 
 
 def eval_bnn(model: torch.nn.Module, dataset: Iterable, estimator, samples: int = 30, device=None,
-             overlap: bool = None):
+             overlap: bool = None, samples_per_launch: int = 1):
     """Mean predictive distribution over `samples` posterior weight samples (scripts/evaluate.py:121-152,
     ``stats=False`` path).  Returns ``(mean_predictions, labels)`` as numpy arrays like the reference.
     The model is left at the last sampled weights, as in the reference, in its original storage.
 
     `overlap`: produce sample k + 1 on a second stream while the forward sweep of sample k runs (see the module
     docstring for what that does and does not buy); default: only for a layer-sharded estimator on the GPU.
-    ``overlap=False`` is the reference's serial loop."""
+    ``overlap=False`` is the reference's serial loop.
+
+    `samples_per_launch` = S > 1: the weight samples are produced S at a time (`sample_many`: for KFAC two GEMM launches
+    for S parameter sets, the triangular factors streamed once per S samples; the other estimators file S ordinary samples
+    away) and loaded into the model one by one (`replace_from`); serial loop only."""
     if device is None:
         device = next(model.parameters()).device
     device = torch.device(device)
@@ -112,7 +116,17 @@ def eval_bnn(model: torch.nn.Module, dataset: Iterable, estimator, samples: int 
     mean_predictions = None
     labels = None
     with torch.no_grad():
-        if not overlap or samples < 2:
+        if samples_per_launch > 1:
+            done = 0
+            while done < samples:
+                group = min(int(samples_per_launch), samples - done)
+                bank = estimator.sample_many(group)
+                for k in range(group):
+                    estimator.replace_from(bank, k)
+                    predictions, labels = eval_nn(model, dataset, device)
+                    mean_predictions = predictions if mean_predictions is None else mean_predictions + predictions
+                done += group
+        elif not overlap or samples < 2:
             for _ in range(samples):
                 estimator.sample_and_replace()
                 predictions, labels = eval_nn(model, dataset, device)

@@ -32,6 +32,32 @@ def run(name, model, shape, batch, n_batches, samples=20):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / samples * 1e3
         print(f"{name}: batch {batch} x {n_batches} sweeps per sample, overlap={overlap}: {ms:.2f} ms per Monte-Carlo sample")
+    # weight samples alone: one at a time vs S per launch (sample_many + replace_from), ms per sample
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    one = timed(kfac.sample_and_replace, 20)
+    line = f"{name}: weight samples only: sample_and_replace {one:.3f} ms"
+    for S in (2, 4, 8, 16):
+        def many():
+            bank = kfac.sample_many(S)
+            for k in range(S):
+                kfac.replace_from(bank, k)
+        gen = timed(lambda: kfac.sample_many(S), 5) / S
+        line += f" | S={S}: {timed(many, 5) / S:.3f} ms per sample (generation alone {gen:.3f})"
+    print(line)
+    for S in (8,):
+        eval_bnn(model, data, kfac, samples=S, device=dev, samples_per_launch=S)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eval_bnn(model, data, kfac, samples=2 * S, device=dev, samples_per_launch=S)
+        torch.cuda.synchronize()
+        print(f"{name}: batch {batch} x {n_batches}, samples_per_launch={S}: {(time.perf_counter() - t0) / (2 * S) * 1e3:.2f} ms per Monte-Carlo sample")
 
 
 if __name__ == "__main__":
