@@ -41,6 +41,9 @@
 #ifndef CURV_SINGLE_MAX
 #define CURV_SINGLE_MAX 5.0            // a 128x128 tile whose K range costs at most this many target item lengths stays unsliced
 #endif
+#ifndef CURV_ITEM_FLOOR
+#define CURV_ITEM_FLOOR 40000          // shortest work item (MFMA CU-cycles) a small launch is cut into
+#endif
 #ifndef CURV_MAX_CHAIN_PX
 #define CURV_MAX_CHAIN_PX 3072         // longest fp32 accumulation chain, in k values (pixels x samples)
 #endif
@@ -1126,7 +1129,7 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
   // k-slicing: aim at ~16 items per workgroup slot (2 per CU) so that the tail of the launch is
   // a few percent, while keeping the slab traffic negligible.
   // (floor: a launch that is small as a whole must not be cut into items whose slab traffic exceeds their work)
-  const double target = std::max(total_cost / (512.0 * 16.0), 40000.0);
+  const double target = std::max(total_cost / (512.0 * 16.0), (double)CURV_ITEM_FLOOR);
   std::vector<double> item_cost(n_all, 0.0);
   for (int i = 0; i < n_all; ++i) {
     FactorDev& f = plan.f[i];

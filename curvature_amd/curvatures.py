@@ -34,6 +34,95 @@ def _is_scalar(x) -> bool:
     return isinstance(x, numbers.Real) or (hasattr(x, "ndim") and getattr(x, "ndim") == 0)
 
 
+class AttentionProjection:
+    """One of the two linear maps of an ``nn.MultiheadAttention`` module seen as a Linear layer: ``'attn_in'`` = the packed
+    input projection (in_proj_weight (3E, E), in_proj_bias), ``'attn_out'`` = out_proj (E, E).  KFAC / EFB / INF treat
+    each as a layer of its own (the reference raises NotImplementedError for these modules, curvatures.py:303-304,
+    351-352, 435-436; SURVEY 8f-4 asks for them): state dicts are keyed by these objects, which are created once per
+    module (`of`), so that every estimator of a model uses the same keys.  Self-attention only (query, key and value are
+    one tensor: the packed projection is then exactly a Linear(E, 3E) applied to every token)."""
+
+    def __init__(self, module: Module, kind: str):
+        self.module, self.kind = module, kind
+
+    @staticmethod
+    def of(module: Module):
+        cached = module.__dict__.get("_curv_projections")
+        if cached is None:
+            if not getattr(module, "_qkv_same_embed_dim", True) or module.in_proj_weight is None:
+                raise NotImplementedError("MultiheadAttention with kdim / vdim different from embed_dim is not supported")
+            cached = (AttentionProjection(module, 'attn_in'), AttentionProjection(module, 'attn_out'))
+            module.__dict__["_curv_projections"] = cached
+        return cached
+
+    @property
+    def weight(self):
+        return self.module.in_proj_weight if self.kind == 'attn_in' else self.module.out_proj.weight
+
+    @property
+    def bias(self):
+        return self.module.in_proj_bias if self.kind == 'attn_in' else self.module.out_proj.bias
+
+    @property
+    def _parameters(self):
+        return {'weight': self.weight, 'bias': self.bias}
+
+    @property
+    def in_features(self) -> int:
+        return self.weight.shape[1]
+
+    @property
+    def out_features(self) -> int:
+        return self.weight.shape[0]
+
+    def state_key(self, prefix: str, name: str) -> str:
+        """Key of `name` ('weight' / 'bias') in the model's state_dict, `prefix` = qualified name of the module."""
+        dot = prefix + "." if prefix else ""
+        return dot + ("in_proj_" + name if self.kind == 'attn_in' else "out_proj." + name)
+
+    def __repr__(self):
+        return f"AttentionProjection({self.kind}, {self.in_features} -> {self.out_features})"
+
+
+class _LinearTap:
+    """While an ``nn.MultiheadAttention`` forward runs, the module-level name ``torch.nn.functional.linear`` is replaced
+    by a wrapper that records, for the module's two projections, the input of the product and (through a tensor hook)
+    the gradient of its output - what the forward / backward hooks of an ordinary Linear layer record
+    (curvatures.py:306-310).  The attention forward calls F.linear directly (also for out_proj, whose own module hooks
+    therefore never fire).  Installed by a forward pre-hook, removed by an always-called forward hook."""
+
+    def __init__(self, estimator, module: Module):
+        self.estimator, self.module = estimator, module
+        self.original = None
+
+    def install(self, *_):
+        import torch.nn.functional as F
+        if self.original is not None:
+            return
+        self.original = F.linear
+        proj_in, proj_out = AttentionProjection.of(self.module)
+        record, original = self.estimator.record, self.original
+
+        def tapped(input, weight, bias=None):
+            out = original(input, weight, bias)
+            target = proj_in if weight is proj_in.weight else proj_out if weight is proj_out.weight else None
+            if target is None and weight.data_ptr() == proj_in.weight.data_ptr() and weight.shape != proj_in.weight.shape:
+                raise NotImplementedError("KFAC / EFB / INF support MultiheadAttention for self-attention only (query, key "
+                                          "and value must be the same tensor)")
+            if target is not None:
+                record[target][0] = input
+                if out.requires_grad:
+                    out.register_hook(lambda grad, t=target: record[t].__setitem__(1, grad))
+            return out
+        F.linear = tapped
+
+    def remove(self, *_):
+        import torch.nn.functional as F
+        if self.original is not None:
+            F.linear = self.original
+            self.original = None
+
+
 class Curvature(ABC):
     """Base class: layer selection, mean weights, `_replace`, `sample_and_replace`.
 
@@ -43,6 +132,9 @@ class Curvature(ABC):
     # estimators whose reference implementation handles nn.MultiheadAttention (Diagonal only here; the
     # reference's KFAC / EFB raise NotImplementedError for it, curvatures.py:303-304, 435-436)
     _supports_mha = False
+    # KFAC / EFB / INF: every selected MultiheadAttention module contributes its two projections as layers of their own
+    # (`AttentionProjection`), an extension of the reference (which raises for them)
+    _mha_as_projections = False
 
     def __init__(self, model: Union[Module, Sequential], layer_types: Union[List[str], str] = None, *,
                  shard=None):
@@ -92,6 +184,8 @@ class Curvature(ABC):
             if name in self.layer_types:
                 if name in ('Linear', 'Conv2d'):
                     out.append(layer)
+                elif name == 'MultiheadAttention' and self._mha_as_projections:
+                    out.extend(AttentionProjection.of(layer))
                 elif name == 'MultiheadAttention' and not self._supports_mha:
                     raise NotImplementedError
         self.__dict__["_layers_cache"] = (self.model, tuple(self.layer_types), tuple(out))
@@ -123,6 +217,8 @@ class Curvature(ABC):
                 continue
             if name in ('Linear', 'Conv2d'):
                 order.append(layer)
+            elif name == 'MultiheadAttention' and self._mha_as_projections:
+                order.extend(AttentionProjection.of(layer))
             elif name == 'MultiheadAttention' and self._supports_mha:
                 order.extend(k for k in ('attn_in', 'attn_out') if k not in order)
         return {k: i for i, k in enumerate(order)}
@@ -232,6 +328,10 @@ class Curvature(ABC):
             for prefix, mod in self.model.named_modules():
                 for pname, _ in mod.named_parameters(recurse=False):
                     self._state_keys[(mod, pname)] = (prefix + "." if prefix else "") + pname
+                if mod.__class__.__name__ == 'MultiheadAttention' and "_curv_projections" in mod.__dict__:
+                    for proj in mod.__dict__["_curv_projections"]:
+                        for pname in ('weight', 'bias'):
+                            self._state_keys[(proj, pname)] = proj.state_key(prefix, pname)
         return self.model_state[self._state_keys[(layer, name)]]
 
     @staticmethod
@@ -563,6 +663,8 @@ class KFAC(Curvature):
     reference the recorded grad_output is NOT pre-multiplied by the batch size (curvatures.py:310); the
     factor N is folded into the scale of the G-side SYRK, which saves one pass over every gradient."""
 
+    _mha_as_projections = True
+
     def __init__(self, model: Union[Module, Sequential], layer_types: Union[List[str], str] = None, *, shard=None):
         super().__init__(model, layer_types, shard=shard)
         self.hooks = list()
@@ -580,7 +682,13 @@ class KFAC(Curvature):
                     self.hooks.append(layer.register_forward_pre_hook(self._save_input))
                     self.hooks.append(layer.register_forward_hook(self._hook_output))
                 elif name == 'MultiheadAttention':
-                    raise NotImplementedError
+                    # the two projections as Linear-like layers (extension: curvatures.py:303-304 raises here); their
+                    # inputs / output gradients are tapped off the F.linear calls of the attention forward
+                    tap = _LinearTap(self, layer)
+                    for proj in AttentionProjection.of(layer):
+                        self.record[proj] = [None, None]
+                    self.hooks.append(layer.register_forward_pre_hook(tap.install))
+                    self.hooks.append(layer.register_forward_hook(tap.remove, always_call=True))
 
     def _save_input(self, module, input):
         self.record[module][0] = input[0]            # by reference, like curvatures.py:307
@@ -880,6 +988,8 @@ class EFB(Curvature):
     samples only the layers it owns; with a layer-sharded KFAC `factors` already holds just those) and
     `eigvecs` (a precomputed ``{layer: (U_A, U_G)}``, e.g. another estimator's, instead of decomposing)."""
 
+    _mha_as_projections = True
+
     def __init__(self, model: Union[Module, Sequential], factors: Dict[Module, Tensor],
                  layer_types: Union[List[str], str] = None, *, shard=None, eigvecs=None):
         super().__init__(model, layer_types, shard=shard)
@@ -1066,6 +1176,8 @@ class INF(Curvature):
     Keyword-only extensions of the reference constructor: `shard` (only this rank's layers are decomposed,
     reduced, inverted and sampled; dicts coming from sharded estimators already hold just those) and `eigvecs`
     (reuse e.g. ``efb.eigvecs`` instead of decomposing the same factors again, curvatures.py:403 vs :473)."""
+
+    _mha_as_projections = True
 
     def __init__(self, model: Union[Module, Sequential], diags: Dict[Module, Tensor],
                  factors: Dict[Module, Tensor], lambdas: Dict[Module, Tensor],

@@ -19,7 +19,12 @@ def _selected(est) -> Dict[torch.nn.Module, str]:
     names = {}
     for name, mod in est.model.named_modules():
         if mod.__class__.__name__ in est.layer_types:
-            names[mod] = name
+            if mod.__class__.__name__ == 'MultiheadAttention' and getattr(est, "_mha_as_projections", False):
+                from .curvatures import AttentionProjection       # KFAC / EFB / INF: the two projections are the layers
+                for proj in AttentionProjection.of(mod):
+                    names[proj] = (name + "." if name else "") + proj.kind
+            else:
+                names[mod] = name
     return names
 
 

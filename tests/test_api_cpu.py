@@ -42,12 +42,32 @@ def test_hyper_indexing():
         h([1, 2], [3, 4], 0, 3)                                        # wrong length
 
 
-def test_mha_is_rejected_like_the_reference():
+def test_mha_projections_are_layers_of_kfac_efb_inf():
+    """The reference raises NotImplementedError for MultiheadAttention in KFAC / EFB / INF (curvatures.py:303-304); here
+    its two projections are Linear-like layers, tapped off the attention forward's F.linear calls."""
+    import torch.nn.functional as F
+    from curvature_amd.curvatures import AttentionProjection, BlockDiagonal
     m = torch.nn.Sequential(torch.nn.Linear(4, 4))
     m.add_module("attn", torch.nn.MultiheadAttention(4, 2))
+    k = KFAC(m)
+    layers = k._layers()
+    assert [type(l).__name__ for l in layers] == ["Linear", "AttentionProjection", "AttentionProjection"]
+    assert layers[1:] == list(AttentionProjection.of(m.attn)) and layers[1].kind == "attn_in"
+    assert (layers[1].in_features, layers[1].out_features, layers[2].out_features) == (4, 12, 4)
+    assert k._global_index() == {layers[0]: 0, layers[1]: 1, layers[2]: 2}
+    original = F.linear
+    x = torch.randn(5, 3, 4)
+    y, _ = m.attn(x, x, x)
+    y.sum().backward()
+    assert F.linear is original                                       # the tap lives for the attention forward only
+    assert tuple(k.record[layers[1]][0].shape) == (5, 3, 4) and tuple(k.record[layers[1]][1].shape) == (5, 3, 12)
+    assert tuple(k.record[layers[2]][1].shape) == (15, 4)
+    assert len(KFAC(m, 'Linear')._layers()) == 1                      # not selected: untouched
     with pytest.raises(NotImplementedError):
-        KFAC(m)
-    KFAC(m, 'Linear')                                                 # fine when not selected
+        BlockDiagonal(m)._layers()                                    # (BlockDiagonal: as in the reference)
+    kdim = torch.nn.MultiheadAttention(4, 2, kdim=6, vdim=6)
+    with pytest.raises(NotImplementedError):
+        KFAC(kdim)
 
 
 def test_dilated_conv_rejected():
