@@ -184,9 +184,12 @@ __device__ __host__ __forceinline__ long long inner_tiles(int P, int k, int k0, 
   const long long sr = (ke - k - 1 > 0) ? (long long)(ke - k - 1) * (k - k0 + 1) : 0;
   return tr + sr;
 }
-// Outer tile lists are enumerated in 8x8 super-blocks (64 consecutive work items = one super-block, mapped
-// to one XCD): the 16 operand panels of a super-block (2 MB) stay in that XCD's L2 for its 64 tiles.
-constexpr int SB = 8;
+// Outer tile lists are enumerated in SB x SB super-blocks (consecutive work items = one super-block, mapped to one
+// XCD, whose L2 then holds the super-block's 2 SB operand panels).  Round 4, same-box A/B on the ResNet-50 factors:
+// SB = 16 8.7 ms, 8 (rounds 1-3) 8.32, 4 8.12, 3 8.08, 2 8.12 - the kernel does not live on L2 locality (75 % hit rate
+// either way); what the smaller super-blocks save are the workgroups that find their tile beyond the matrix edge or
+// above the diagonal and exit.
+constexpr int SB = 4;
 // far part of an outer update: rows/cols from row0 on (trailing) and rows from row0 on x cols < kend (S)
 __device__ __host__ __forceinline__ long long outer_tiles(int P, int kend, int row0) {
   const long long r = P - row0;

@@ -34,7 +34,7 @@ for d in ("gpurun_out/pi1", "gpurun_out/pi2", "gpurun_out/pi3", "gpurun_out/pi4"
         if "curv::" not in r["Kernel_Name"]:
             continue
         if name == "outer_update_kernel":
-            name += "_far" if int(r["Grid_Size_X"]) > 256 * 1200 else "_small"
+            name += "_far" if int(r.get("Grid_Size_X") or r["Grid_Size"]) > 256 * 1200 else "_small"
         acc.setdefault(name, {})
         acc[name][r["Counter_Name"]] = acc[name].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         if (name, r["Dispatch_Id"]) not in seen:
