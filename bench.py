@@ -153,7 +153,7 @@ def cpu_baseline_subprocess(batch_full, timeout_s=300):
 # call with the GPU idle before and after (torch.cuda.synchronize on both sides), median of a few repeats.
 # ------------------------------------------------------------------------------------------------------------------
 PEAK_HBM = 8.0e12             # MI355X_MICROARCH.md: HBM3E spec (6.3e12 achievable)
-PEAK_F64_MFMA = 48.0e12       # measured (tools/micro/mfma_f64_peak.hip); AMD's datasheet figure is 78.6e12
+PEAK_F64_MFMA = 78.6e12       # datasheet; reachable: profiles/r04_micro_mfma_f64.txt (rounds 2-3 priced against a mis-measured 48e12)
 
 
 def _timed_gpu(fn, reps=3, warm=1):
@@ -175,6 +175,17 @@ def _backward_once(model, x):
     labels = torch.distributions.Categorical(logits=logits.detach()).sample()
     model.zero_grad()
     torch.nn.functional.cross_entropy(logits, labels).backward()
+
+
+def _inf_anchor_layer(n=147, m=64, seed=0):
+    """One synthetic layer of ResNet-50's stem size (n = 147, m = 64) for the INF.invert anchor: random orthonormal
+    eigenvector matrices, a decaying positive Lambda, a positive diagonal (CPU tensors)."""
+    g = torch.Generator().manual_seed(seed)
+    U_A = torch.linalg.qr(torch.randn(n, n, generator=g))[0].contiguous()
+    U_G = torch.linalg.qr(torch.randn(m, m, generator=g))[0].contiguous()
+    lam = (torch.rand(m, n, generator=g) ** 8).contiguous()        # heavy-tailed, unstructured: rank 100 -> a b of a few thousand
+    diag = (lam.mean() * (0.5 + torch.rand(m, n, generator=g))).contiguous()
+    return U_A, U_G, lam, diag
 
 
 def other_configs_gpu(dev, model50, kfac50, batch):
@@ -274,6 +285,17 @@ def other_configs_gpu(dev, model50, kfac50, batch):
     c5["efb_invert_ms"] = _timed_gpu(lambda: e5.invert(1.0, 1000.0))
     c5["efb_sample_and_replace_ms"] = _timed_gpu(e5.sample_and_replace)
     out["config5_resnet50_efb_inf_chain"] = c5
+    # the same INF.invert on ONE synthetic layer of the stem's size, the only size at which the reference's explicit
+    # (n m) x (a b) Kronecker chain can be timed on the host (cpu_oracle.inf_invert_anchor_ms)
+    import oracle.curvature_oracle as o
+    U_A, U_G, lam, diag = _inf_anchor_layer()
+    ua, ug, lam_lr, corr, _, _ = o.inf_update(U_A, U_G, lam, diag, 100)
+    sigma = (1000.0 * lam_lr).sqrt().to(dev)
+    r = torch.reciprocal(1000.0 * corr.clamp(min=0) + 1.0).sqrt().to(dev)
+    from curvature_amd.curvatures import INF
+    ua_d, ug_d = ua.to(dev).contiguous(), ug.to(dev).contiguous()
+    out["inf_invert_anchor"] = {"layer": "synthetic n=147, m=64 (ResNet-50 stem size), rank 100: a x b = %d x %d" % (ua.shape[1], ug.shape[1]),
+                                "gpu_ms": _timed_gpu(lambda: INF.pre_sampler(ua_d, ug_d, sigma, r), reps=5)}
     return out
 
 
@@ -363,9 +385,19 @@ def other_configs_cpu(budget_s=100.0):
     else:
         res["config5_resnet50_eigenvectors_note"] = (f"skipped: torch.linalg.eigh of the 108 factors predicted at {est:.0f} s on this "
                                                      f"host, {left():.0f} s of the leg's budget left")
-    res["config5_inf_note"] = ("INF.invert / sample: no CPU figure - the reference's pre_sampler materialises a (n m) x (a b) matrix "
-                               "per layer (SURVEY 3.3: 18-46 s and 1.2-4 GB per layer on 8 cores; fp32 Cholesky fails on some "
-                               "layers), far beyond the 60 s bound of this leg")
+    res["config5_inf_note"] = ("INF.invert / sample at ResNet-50 size: no CPU figure - the reference's pre_sampler materialises a "
+                               "(n m) x (a b) matrix per layer (SURVEY 3.3: 18-46 s and 1.2-4 GB per layer on 8 cores; fp32 Cholesky "
+                               "fails on some layers), far beyond the 60 s bound of this leg; inf_invert_anchor_ms is the one layer "
+                               "size at which it can be timed")
+    if left() > 20:
+        # one synthetic layer of the stem's size through the oracle's literal INF.invert (explicit Kronecker matrix);
+        # other_configs.inf_invert_anchor.gpu_ms is the HIP path on the same layer
+        U_A, U_G, lam, diag = _inf_anchor_layer()
+        ua, ug, lam_lr, corr, _, _ = o.inf_update(U_A, U_G, lam, diag, 100)
+        o.inf_invert(ua, ug, lam_lr, corr, 1.0, 1000.0)
+        t0 = time.perf_counter()
+        o.inf_invert(ua, ug, lam_lr, corr, 1.0, 1000.0)
+        res["inf_invert_anchor_ms"] = (time.perf_counter() - t0) * 1e3
     res["seconds_used"] = time.perf_counter() - t_start
     return res
 

@@ -85,12 +85,24 @@ def main():
     root = sys.argv[1]
     args = sys.argv[2:]
     if args and args[0] == "--factor-build":
-        # bench.py's `roofline.traffic`: HBM bytes of one update()'s MFMA kernels (the three SYRK kernels together)
-        parts = {k: summarise(root, k) for k in ("syrk_pre_kernel", "syrk_patch_kernel", "syrk_flat_kernel")}
+        # bench.py's `roofline.traffic`: HBM bytes of ONE update(), everything inside the timed window: the padding /
+        # pre-tiling passes, the three MFMA kernels, the k-slice reductions and the 3x3 assembly.  Per kernel: average
+        # bytes per launch x launches per update (= its launches / the launches of syrk_flat_kernel, one per update)
+        names = ("corr_prep_kernel", "patch_prep_kernel", "syrk_pre_kernel", "syrk_patch_kernel", "syrk_flat_kernel",
+                 "syrk_reduce_kernel", "corr_assemble_kernel")
+        parts = {k: summarise(root, k) for k in names}
         parts = {k: v for k, v in parts.items() if v}
+        updates = max(parts.get("syrk_flat_kernel", {}).get("launches_profiled", 1), 1)
+        total, slab = 0.0, 0.0
+        for k, v in parts.items():
+            v["launches_per_update"] = v.get("launches_profiled", 0) / updates
+            v["hbm_bytes_per_update"] = v.get("hbm_bytes_per_launch", 0.0) * v["launches_per_update"]
+            total += v["hbm_bytes_per_update"]
         print(json.dumps({"kernel": " + ".join("curv::" + k for k in parts),
-                          "per": "update() (one launch of each), average over the profiled launches",
-                          "hbm_bytes_per_launch": sum(v.get("hbm_bytes_per_launch", 0.0) for v in parts.values()),
+                          "per": "update() (everything curv_kfac_accumulate_ex enqueues), average over the profiled updates",
+                          "hbm_bytes_per_launch": total,
+                          "mfma_kernels_bytes_per_update": sum(parts[k]["hbm_bytes_per_update"] for k in ("syrk_pre_kernel", "syrk_patch_kernel", "syrk_flat_kernel") if k in parts),
+                          "reduce_pass_bytes_per_update": parts.get("syrk_reduce_kernel", {}).get("hbm_bytes_per_update", 0.0),
                           "parts": parts}, indent=1))
         return
     kernels = args or DEFAULT
