@@ -303,7 +303,7 @@ def test_get_eigenvalues(gpu):
 def test_diagonal_multihead_attention(gpu):
     """Diagonal on a model with nn.MultiheadAttention (curvatures.py:159-174, 125-129): 'attn_in' / 'attn_out'
     keys, per-entry hyper-parameter lists indexed in the reference's state order, sample_and_replace touching
-    the projection parameters; KFAC still raises NotImplementedError for the same model."""
+    the projection parameters.  (KFAC / EFB / INF take the same model since round 4: tests/test_mha_gpu.py.)"""
     import oracle.curvature_oracle as o
     from curvature_amd.curvatures import Diagonal, KFAC
 
@@ -321,8 +321,7 @@ def test_diagonal_multihead_attention(gpu):
 
     torch.manual_seed(0)
     model = Net().to(gpu)
-    with pytest.raises(NotImplementedError):
-        KFAC(model)
+    assert len(KFAC(model)._layers()) == 4                    # two Linear layers + the two attention projections
     diag = Diagonal(model)
     x = torch.randn(5, 4, 6, device=gpu)
     labels = torch.tensor([0, 1, 2, 1], device=gpu)
