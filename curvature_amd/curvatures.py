@@ -89,38 +89,48 @@ class _LinearTap:
     by a wrapper that records, for the module's two projections, the input of the product and (through a tensor hook)
     the gradient of its output - what the forward / backward hooks of an ordinary Linear layer record
     (curvatures.py:306-310).  The attention forward calls F.linear directly (also for out_proj, whose own module hooks
-    therefore never fire).  Installed by a forward pre-hook, removed by an always-called forward hook."""
+    therefore never fire).  Installed by a forward pre-hook, removed by an always-called forward hook.  Several taps may
+    be active at once (two estimators on one model, nested modules): ONE wrapper serves all of them and F.linear is
+    restored when the last one leaves."""
+
+    _active: List["_LinearTap"] = []
+    _original = None
 
     def __init__(self, estimator, module: Module):
         self.estimator, self.module = estimator, module
-        self.original = None
 
-    def install(self, *_):
-        import torch.nn.functional as F
-        if self.original is not None:
-            return
-        self.original = F.linear
-        proj_in, proj_out = AttentionProjection.of(self.module)
-        record, original = self.estimator.record, self.original
-
-        def tapped(input, weight, bias=None):
-            out = original(input, weight, bias)
+    @staticmethod
+    def _dispatch(input, weight, bias=None):
+        out = _LinearTap._original(input, weight, bias)
+        for tap in list(_LinearTap._active):
+            proj_in, proj_out = AttentionProjection.of(tap.module)
             target = proj_in if weight is proj_in.weight else proj_out if weight is proj_out.weight else None
             if target is None and weight.data_ptr() == proj_in.weight.data_ptr() and weight.shape != proj_in.weight.shape:
                 raise NotImplementedError("KFAC / EFB / INF support MultiheadAttention for self-attention only (query, key "
                                           "and value must be the same tensor)")
             if target is not None:
+                record = tap.estimator.record
                 record[target][0] = input
                 if out.requires_grad:
-                    out.register_hook(lambda grad, t=target: record[t].__setitem__(1, grad))
-            return out
-        F.linear = tapped
+                    out.register_hook(lambda grad, r=record, t=target: r[t].__setitem__(1, grad))
+        return out
+
+    def install(self, *_):
+        import torch.nn.functional as F
+        if self in _LinearTap._active:
+            return
+        if not _LinearTap._active:
+            _LinearTap._original = F.linear
+            F.linear = _LinearTap._dispatch
+        _LinearTap._active.append(self)
 
     def remove(self, *_):
         import torch.nn.functional as F
-        if self.original is not None:
-            F.linear = self.original
-            self.original = None
+        if self in _LinearTap._active:
+            _LinearTap._active.remove(self)
+            if not _LinearTap._active:
+                F.linear = _LinearTap._original
+                _LinearTap._original = None
 
 
 class Curvature(ABC):

@@ -220,3 +220,18 @@ def test_layer_list_is_walked_once_and_survives_layer_type_changes():
     assert len(k._layers()) == 5 and not calls                # no further walk
     k.layer_types = ['Linear']
     assert len(k._layers()) == 3 and calls                    # a changed selection is a new walk
+
+
+def test_two_estimators_tapping_one_attention_module_leave_f_linear_alone():
+    """Both estimators record the projections' inputs / gradients, and F.linear is the original function again after
+    the forward (a per-estimator patch restored in registration order would leave the first tap's wrapper behind)."""
+    import torch.nn.functional as F
+    attn = torch.nn.MultiheadAttention(8, 2, batch_first=True)
+    original = F.linear
+    k1, k2 = KFAC(attn), KFAC(attn)
+    x = torch.randn(3, 5, 8)
+    attn(x, x, x, need_weights=False)[0].sum().backward()
+    assert F.linear is original
+    for k in (k1, k2):
+        for layer in k._layers():
+            assert k.record[layer][0] is not None and k.record[layer][1] is not None
