@@ -79,12 +79,15 @@ size_t curv_kfac_workspace_bytes(const curv_factor_desc* descs, int n_factors);
 /* Host-only introspection of the launch plan (tests, tuning): writes CURV_PLAN_INFO_FIELDS values per
  * factor: dim, Ho, Wo, chunk samples, chunk rows, chunk cols, n_chunks, LDS row stride, plane stride,
  * sample stride, channels per panel, n_tiles, chunks per item, k-slices, n_items, item_base, tile edge,
- * float4 staging flag, log2 padded patch row length, 64x64 sub-tiles, k-run length, log2 row lanes
+ * float4 staging flag, log2 padded patch row length, 64x64 sub-tiles of the reduce pass (0 for an unsliced factor), the number
+ * of serial segments an UNSLICED 128x128-tile factor cuts its K range into (0: k-sliced through slabs; > 0: its items scale,
+ * add into dst and write the mirror tile themselves, flushing their accumulators behind every segment), log2 row lanes
  * that walk patch rows while staging (the remaining row lanes split channels), 1 if the patch images are staged
  * by LDS-DMA from a pre-tiled copy of the source (full-width chunks of a kh x kw > 1 convolution), 1 if the factor is built by the LDS-DMA kernel for flattened per-pixel
  * factors (its own work list: item bases count from 0 per kernel; n_chunks = stages of <= 16 pixels), 2 if it is a
  * 3x3 / stride 1 / padding 1 factor assembled from 29 shifted correlations that run as virtual factors of the LDS-DMA
- * kernel (no items of its own), and last the multiply-add FLOPs (2 per multiply-add) the plan executes for the
+ * kernel (no items of its own; C a multiple of 128: one virtual factor per correlation, C = 64: ten packed pair tiles that
+ * hold four correlations each), and last the multiply-add FLOPs (2 per multiply-add) the plan executes for the
  * factor: dim (dim + 1) K for a symmetric product over K = samples x output pixels, the sum over its correlations
  * (C (C + 1) K' for the symmetric ones, 2 C^2 K' for the others) for an assembled factor. */
 #define CURV_PLAN_INFO_FIELDS 25
@@ -97,8 +100,9 @@ int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors, long long*
 int curv_kfac_accumulate(void* stream, const curv_factor_desc* descs, int n_factors, void* workspace,
                          size_t workspace_bytes);
 
-/* Same, recording HIP events (from curv_event_create) on `stream` immediately before and after the
- * SYRK kernel, so that a benchmark can time exactly that kernel without a profiler. */
+/* Same, recording HIP events (from curv_event_create) on `stream` around EVERYTHING the call enqueues behind the
+ * descriptor-table uploads (padding / pre-tiling passes, the MFMA kernels, the k-slice reductions, the 3x3 assembly), so
+ * that a benchmark can time the whole build without a profiler. */
 int curv_kfac_accumulate_timed(void* stream, const curv_factor_desc* descs, int n_factors, void* workspace,
                                size_t workspace_bytes, void* ev_start, void* ev_stop);
 
