@@ -216,10 +216,24 @@ class Shard:
             for d, s_ in cache["pack"]:
                 d.copy_(s_)
         backend = dist.get_backend(self.group)
-        if flat.is_cuda and backend == "nccl" and flat.dtype == torch.float32:
+        if flat.is_cuda and backend == "nccl" and flat.dtype == torch.float32 and self._rccl_ready(flat.device):
             # the one collective: variable-count all-gather in place over RCCL (curv_allgather_weights), each segment
             # travelling once - the shards differ several-fold in size, nothing is padded to the largest
             self._allgather_rccl(flat, sizes, displs)
+        elif flat.is_cuda and backend == "nccl":
+            # the library's own communicator could not be built on every rank (decided collectively, once): torch's
+            # all_gather_into_tensor on equal-sized, padded shards
+            cap = max(max(sizes), 1)
+            pad = cache.get("pad")
+            if pad is None:
+                pad = cache["pad"] = (torch.zeros(cap, dtype=flat.dtype, device=flat.device),
+                                      torch.empty(self.world * cap, dtype=flat.dtype, device=flat.device))
+            mine, gathered = pad
+            mine[:sizes[self.rank]].copy_(flat[displs[self.rank]:displs[self.rank] + sizes[self.rank]])
+            dist.all_gather_into_tensor(gathered, mine, group=self.group)
+            for r in range(self.world):
+                if r != self.rank and sizes[r]:
+                    flat[displs[r]:displs[r] + sizes[r]].copy_(gathered[r * cap:r * cap + sizes[r]])
         else:
             # gloo (the CPU tests, and test configurations with several ranks on one GPU): equal-sized staging buffers
             cap = max(max(sizes), 1)
@@ -237,6 +251,36 @@ class Shard:
                 d.copy_(s_)
 
     # ------------------------------------------------------------------ RCCL communicator of this shard
+    def _rccl_ready(self, device: torch.device) -> bool:
+        """True when every rank of the shard has the library's RCCL communicator (built at the first call).  The decision
+        is collective - one all-reduce(MIN) of a success flag - so that all ranks take the same branch; CURV_TORCH_ALLGATHER=1
+        forces torch's all_gather_into_tensor instead."""
+        ready = self.__dict__.get("_rccl_ok")
+        if ready is None:
+            import os
+            ok = 0 if os.environ.get("CURV_TORCH_ALLGATHER") else 1
+            if ok:
+                # can THIS rank reach RCCL through the library at all (dlopen, symbols)?  A local, communication-free probe:
+                # the collective steps below must not start unless every rank can take part in them
+                import ctypes
+                from . import _lib
+                try:
+                    probe = (ctypes.c_ubyte * 128)()
+                    ok = int(_lib.lib().curv_comm_unique_id(probe) == 0)
+                except Exception:                                         # noqa: BLE001
+                    ok = 0
+                if not ok:
+                    import warnings
+                    warnings.warn("curv_allgather_weights is not available on this rank (RCCL could not be bound); using "
+                                  "torch.distributed.all_gather_into_tensor")
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            ready = bool(int(flag.item()))
+            if ready:
+                self._rccl_comm(device)                                   # collective: id broadcast + ncclCommInitRank
+            self.__dict__["_rccl_ok"] = ready
+        return ready
+
     def _rccl_comm(self, device: torch.device):
         """An RCCL communicator of this shard's ranks for `curv_allgather_weights` (torch.distributed does not hand out
         its own ncclComm_t): rank 0 draws the id, one torch.distributed broadcast ships its 128 bytes."""

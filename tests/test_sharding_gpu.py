@@ -91,7 +91,7 @@ def test_sharded_chain_world2_equals_unsharded(tmp_path):
                 assert torch.equal(w, wf) and torch.equal(b, bf), name
 
 
-def _rccl_world1(rank, port, out_dir):
+def _rccl_world1(rank, port, out_dir, fallback=False):
     """backend "nccl" (= RCCL) with a one-rank group on the box's single GPU: process-group init with a bound
     device, then KFAC.sample_and_replace through Shard.allgather_params' RCCL branch: the library's own export
     curv_allgather_weights (variable-count all-gather in place on the flat parameter vector) on a communicator built by
@@ -100,6 +100,8 @@ def _rccl_world1(rank, port, out_dir):
     from curvature_amd.curvatures import KFAC
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if fallback:
+        os.environ["CURV_TORCH_ALLGATHER"] = "1"                  # torch's all_gather_into_tensor on padded shards
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)          # as bench.py does for N > 1
@@ -127,7 +129,11 @@ def _rccl_world1(rank, port, out_dir):
     cache = next(iter(shard._plans.values()))
     packed = torch.cat([t.reshape(-1) for t in want])
     ok = all(torch.equal(a, b) for a, b in zip(got, want))
-    ok_gather = torch.equal(cache["flat"], packed) and cache["flat"].numel() == sum(cache["sizes"]) and shard.rccl_ranks() == 1
+    ok_gather = torch.equal(cache["flat"], packed) and cache["flat"].numel() == sum(cache["sizes"]) and shard.rccl_ranks() == (0 if fallback else 1)
+    if fallback:
+        torch.save({"ok": ok, "ok_gather": bool(ok_gather), "copy": True, "max": 3.0}, os.path.join(out_dir, "rccl.pt"))
+        dist.destroy_process_group()
+        return
     # the export on its own: a three-segment vector of which this (only) rank owns everything, counts / displs honoured
     import ctypes
     from curvature_amd import _lib
@@ -150,12 +156,15 @@ def _rccl_world1(rank, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_rccl_backend_runs_the_allgather_branch(tmp_path):
+@pytest.mark.parametrize("fallback", [False, True])
+def test_rccl_backend_runs_the_allgather_branch(tmp_path, fallback):
     """the one collective of the path is an RCCL all-gather.  The box has one GPU (RCCL refuses two
     ranks on one device), so the nccl backend is initialised with world_size 1 and `force_collective` sends
     sample_and_replace through pack -> curv_allgather_weights (RCCL group of broadcasts) -> unpack instead of the
-    world == 1 early return.  No run with more than one RCCL rank exists: 8-GPU nodes are the driver's."""
-    mp.spawn(_rccl_world1, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    world == 1 early return.  No run with more than one RCCL rank exists: 8-GPU nodes are the driver's.
+    `fallback`: CURV_TORCH_ALLGATHER=1 - the path taken when a rank cannot bind RCCL through the library (decided
+    collectively): torch's all_gather_into_tensor on padded shards, same parameters."""
+    mp.spawn(_rccl_world1, args=(_free_port(), str(tmp_path), fallback), nprocs=1, join=True)
     res = torch.load(os.path.join(tmp_path, "rccl.pt"))
     assert res == {"ok": True, "ok_gather": True, "copy": True, "max": 3.0}, res
 
