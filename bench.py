@@ -528,6 +528,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # the library's internal streams before anything else creates streams on this device (RCCL's communicator streams
+    # below; DESIGN 3 K2 / INTEGRATION.md): the estimator constructor would do it, but only after init_process_group
+    from curvature_amd import _lib as _curv_lib
+    _curv_lib.init_streams(dev)
     if world > 1:
         backend = os.environ.get("BENCH_BACKEND", "nccl")
         if backend == "nccl":
