@@ -207,6 +207,11 @@ def init_streams(device) -> None:
     if device.type != "cuda":
         return
     with torch.cuda.device(device):
+        # torch's own stream of this device must have been USED before the set is created: measured with the set created
+        # first thing after set_device (before any torch kernel), invert() of the ResNet-50 factors takes 13.2 ms instead
+        # of 8.3 - the runtime gives hardware queues out lazily, in order of first use
+        torch.zeros(1, device=device).add_(1)
+        torch.cuda.current_stream(device).synchronize()
         check(lib().curv_init_streams(), "curv_init_streams")
 
 

@@ -42,7 +42,10 @@ const char* curv_last_error(void);
  * streams, and how the HIP runtime maps those onto hardware queues depends on which streams the process created BEFORE
  * them: unrelated streams created first (RCCL's, a data loader's) made invert() of the ResNet-50 factors 8.4 -> 12.6 ms,
  * the same streams created afterwards change nothing (profiles/r04_stream_sensitivity.txt).  Call this once, early -
- * the Python estimators do it in their constructor.  Idempotent. */
+ * but AFTER the caller's own stream has launched something: hardware queues are given out lazily, in order of first use,
+ * and with the set created before the caller's stream was ever used the same inversion takes 13.2 ms.  The Python
+ * estimators do it in their constructor (curvature_amd._lib.init_streams runs a one-element torch kernel first).
+ * Idempotent. */
 int curv_init_streams(void);
 
 /* ------------------------------------------------------------------------------------------------
