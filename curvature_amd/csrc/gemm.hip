@@ -455,6 +455,87 @@ gemm_nt_reduce_kernel(const GemmDev* __restrict__ table, int n_desc, const float
 }
 
 // ------------------------------------------------------------------------------------------------
+// NT products of a SMALL launch (LeNet-scale models: every matrix at most a few hundred wide).  A 128-wide tile of such
+// a product runs on ONE CU at 1/256 of the chip's MFMA rate and pays a memory round trip per 32-k stage: 27 + 50 us
+// for the two sampler launches of LeNet-5 (profiles/r04_lenet_trace.txt).  Here a workgroup owns one 32 x 32 output
+// block and its four waves split the K range in four contiguous quarters; each lane reads its operand rows straight
+// from global memory, 16 bytes (4 k values = the inputs of 4 MFMA steps) per load, up to 16 loads per operand in
+// flight at once - no LDS staging, no per-stage barrier: one memory round trip per 128 k of a wave.  The four partial
+// blocks meet in LDS and are summed in wave order (bit-reproducible); wave w finishes registers 4w .. 4w+3.
+// Rows beyond M / N are clamped to the last row (never stored); k beyond K is zeroed; a triangular operand cuts K.
+// ------------------------------------------------------------------------------------------------
+namespace sm {
+constexpr int T = 32;            // output block edge
+constexpr int CHUNKS = 16;       // 8-k chunks per wave and pass (16 B per lane and operand each)
+constexpr int MAX_K = 4 * 8 * CHUNKS;   // K range one pass covers
+}  // namespace sm
+
+__global__ void __launch_bounds__(GEMM_THREADS)
+gemm_nt_small_kernel(const GemmDev* __restrict__ table, int n_desc) {
+  using namespace sm;
+  __shared__ float part[4][16][64];
+  const int f = gemm_find(table, n_desc, blockIdx.x);
+  const GemmDev& d = table[f];
+  const int local = blockIdx.x - d.tile_base;
+  const int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
+  const int i0 = tm * T, j0 = tn * T, M = d.M, N = d.N;
+  int K = d.K;
+  if (d.tri == CURV_TRI_A_LOWER) K = min(K, i0 + T);
+  else if (d.tri == CURV_TRI_B_UPPER) K = min(K, j0 + T);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+  const gfl* arow = (const gfl*)d.A + (long long)min(i0 + r32, M - 1) * d.a_rs;
+  const gfl* brow = (const gfl*)d.B + (long long)min(j0 + r32, N - 1) * d.b_cs;
+  f32x16 acc = {0};
+  for (int p0 = 0; p0 < K; p0 += MAX_K) {
+    const int Kp = min(K - p0, MAX_K);                       // this pass
+    const int Kq = (((Kp + 3) >> 2) + 7) & ~7;               // a wave's quarter, whole chunks
+    const int kb = p0 + wave * Kq, ke = min(p0 + Kp, kb + Kq);
+    const int nch = __builtin_amdgcn_readfirstlane(ke > kb ? (ke - kb + 7) >> 3 : 0);
+    f32x4 a[CHUNKS], b[CHUNKS];
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      if (c < nch) {
+        const int k = kb + 8 * c + 4 * h;
+        if (kb + 8 * c + 8 <= ke) {                           // whole chunk (wave-uniform): 16-byte loads
+          a[c] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(arow + k);
+          b[c] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(brow + k);
+        } else {                                              // the chunk that holds the end of K
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = k + e < ke;
+            const int kk = ok ? k + e : kb;
+            const float va = arow[kk], vb = brow[kk];
+            a[c][e] = ok ? va : 0.0f;
+            b[c][e] = ok ? vb : 0.0f;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][e], b[c][e], acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) part[wave][reg][lane] = acc[reg];
+  __syncthreads();
+  // C/D map of the 32x32 block: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  const int j = j0 + r32;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int reg = 4 * wave + q;
+    const float v = ((part[0][reg][lane] + part[1][reg][lane]) + part[2][reg][lane]) + part[3][reg][lane];
+    const int i = i0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (i < M && j < N) nt_epilogue(d, i, j, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The same batched strided GEMM in fp64 (v_mfma_f64_16x16x4_f64) for the ill-conditioned products of
 // INF.pre_sampler (L_c = A^-T (I - B^-1) A^-1).  alpha/beta only, no fused epilogue.
 // ------------------------------------------------------------------------------------------------
@@ -683,6 +764,22 @@ static int nt_slices(const curv_gemm_desc& s, bool underfilled) {
   return (underfilled && nt_eligible(s) && s.K >= 2 * NT_KSLICE) ? cdiv(s.K, NT_KSLICE) : 1;
 }
 
+// A small launch (see gemm_nt_small_kernel): every product in NT layout and short, and so few 128-wide tiles that most
+// of the chip would idle behind them
+constexpr long long SMALL_MAX_BLOCKS = 2048;      // 32 x 32 blocks: 8 workgroups per CU
+constexpr long long SMALL_MAX_TILES128 = 64;
+static bool small_launch(const curv_gemm_desc* descs, int n_desc) {
+  long long blocks = 0, tiles128 = 0;
+  for (int i = 0; i < n_desc; ++i) {
+    const curv_gemm_desc& s = descs[i];
+    if (s.M <= 0 || s.N <= 0) continue;
+    if (s.a_cs != 1 || s.b_rs != 1 || s.K > 2 * sm::MAX_K || s.a_rs < 0 || s.b_cs < 0) return false;
+    blocks += (long long)cdiv(s.M, sm::T) * cdiv(s.N, sm::T);
+    tiles128 += (long long)cdiv(s.M, 128) * cdiv(s.N, 128);
+  }
+  return blocks > 0 && blocks <= SMALL_MAX_BLOCKS && tiles128 <= SMALL_MAX_TILES128;
+}
+
 static size_t nt_order_bytes(const curv_gemm_desc* descs, int n_desc) {       // the K-sorted tile list of an unsplit NT launch
   return align_up((size_t)nt_tiles_of(descs, n_desc) * sizeof(int), 256);
 }
@@ -712,6 +809,7 @@ static int gemm_batched_impl(void* stream_, const curv_gemm_desc* descs, int n_d
   std::vector<GemmDev> tab, tab_nt, tab_v;      // work lists: the general kernel, the NT / LDS-DMA kernel, thin products
   tab.reserve(n_desc);
   long long tiles = 0, tiles_nt = 0, red_tiles = 0, slab_floats = 0, gemv_wgs = 0;
+  const bool small = small_launch(descs, n_desc);      // everything goes to gemm_nt_small_kernel (work list `tab`)
   // K slicing needs the slab area behind the table: only with a workspace sized by curv_gemm_workspace_bytes_for
   const bool underfilled = nt_tiles_of(descs, n_desc) < NT_SPLIT_BELOW_TILES;
   const bool may_split = underfilled && workspace_bytes >= curv_gemm_workspace_bytes_for(descs, n_desc);
@@ -744,6 +842,14 @@ static int gemm_batched_impl(void* stream_, const curv_gemm_desc* descs, int n_d
     // NT products with K-contiguous rows on both sides and at least one full-width tile edge go to the LDS-DMA
     // kernel; their operand extents must fit a buffer descriptor (32-bit byte offsets)
     const long long a_ext = ((long long)(s.M - 1) * s.a_rs + s.K) * 4, b_ext = ((long long)(s.N - 1) * s.b_cs + s.K) * 4;
+    if (small) {
+      d.tm = sm::T;
+      d.tiles_n = cdiv(s.N, sm::T);
+      d.tile_base = (int)tiles;
+      tiles += (long long)cdiv(s.M, sm::T) * d.tiles_n;
+      tab.push_back(d);
+      continue;
+    }
     if (gemv_eligible(s)) {
       gemv_wgs += (s.M + 3) / 4;
       tab_v.push_back(d);
@@ -832,7 +938,10 @@ static int gemm_batched_impl(void* stream_, const curv_gemm_desc* descs, int n_d
       CURV_LAUNCH_CHECK();
     }
   }
-  if (n > 0) {
+  if (n > 0 && small) {
+    hipLaunchKernelGGL(gemm_nt_small_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, stream, table, n);
+    CURV_LAUNCH_CHECK();
+  } else if (n > 0) {
     hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, stream, table, n);
     CURV_LAUNCH_CHECK();
   }

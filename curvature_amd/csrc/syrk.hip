@@ -758,25 +758,54 @@ syrk_reduce_kernel(const FactorDev* __restrict__ descs, int n_factors, const flo
 
   const float* s0 = slabs + d.slab_base + (long long)t * (TMv * TMv) + (qi * 64) * TMv + qj * 64;
   const long long slice_stride = (long long)n_tiles * (TMv * TMv);
-  for (int e = tid; e < 64 * 64 / 4; e += SYRK_THREADS) {
-    const int r = e >> 4, c = (e & 15) << 2;
-    const float* p = s0 + r * TMv + c;
-    f32x4 v = *reinterpret_cast<const f32x4*>(p);
-    // the slices are added in slice order (bit-reproducible), but eight loads are in flight at a time: one at a
-    // time, a tile with 30-40 slices paid a memory round trip per slice (48 us for LeNet's conv factors)
+  // The slices are added in slice order per element (bit-reproducible) with the loads of a thread's four elements x
+  // eight slices in flight together: a tile with 30-40 slices paid a memory round trip per slice and element
+  // otherwise (48 us for LeNet's conv factors).  Rows / columns beyond the factor's edge are neither read nor summed
+  // (a 26-wide factor uses a sixth of its 64 x 64 block).
+  {
+    const float* p[4];
+    f32x4 v[4];
+    bool live[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + u * SYRK_THREADS;
+      const int r = e >> 4, c = (e & 15) << 2;
+      live[u] = i0 + r < dim && j0 + c < dim;            // (the mirror pass reads the same elements, transposed)
+      p[u] = s0 + r * TMv + c;
+      v[u] = live[u] ? *reinterpret_cast<const f32x4*>(p[u]) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
     int s = 1;
     for (; s + 8 <= n_slices; s += 8) {
-      f32x4 w[8];
+      f32x4 w[4][8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const f32x4*>(p + (long long)(s + u) * slice_stride);
+      for (int u = 0; u < 4; ++u)
+        if (live[u]) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v += w[u];
+          for (int q = 0; q < 8; ++q) w[u][q] = *reinterpret_cast<const f32x4*>(p[u] + (long long)(s + q) * slice_stride);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (live[u]) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[u] += w[u][q];
+        }
     }
-    for (; s < n_slices; ++s) v += *reinterpret_cast<const f32x4*>(p + s * slice_stride);
-    tile[r][c + 0] = v.x * scale;
-    tile[r][c + 1] = v.y * scale;
-    tile[r][c + 2] = v.z * scale;
-    tile[r][c + 3] = v.w * scale;
+    for (; s < n_slices; ++s) {
+      f32x4 w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (live[u]) w[u] = *reinterpret_cast<const f32x4*>(p[u] + (long long)s * slice_stride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (live[u]) v[u] += w[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + u * SYRK_THREADS;
+      const int r = e >> 4, c = (e & 15) << 2;
+      tile[r][c + 0] = v[u].x * scale;
+      tile[r][c + 1] = v[u].y * scale;
+      tile[r][c + 2] = v[u].z * scale;
+      tile[r][c + 3] = v[u].w * scale;
+    }
   }
   __syncthreads();
   for (int e = tid; e < 64 * 64; e += SYRK_THREADS) {

@@ -490,3 +490,54 @@ def test_gemv_path_for_one_column_products(gpu):
         C = torch.full((M, 1), float("nan"), device=gpu)
         ops.gemm_batched([ops.Gemm(A, col, C, alpha=alpha, epilogue=ep, E=e, F=f)])
         assert float((C.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()), ep
+
+
+@pytest.mark.gpu
+def test_gemm_small_launch_kernel(gpu):
+    """A launch whose products are all short and in NT layout (a LeNet-scale sampler) runs as 32 x 32 blocks with the K
+    range split over the four waves of a workgroup (gemm_nt_small_kernel): ragged M / N / K down to 1, K beyond one
+    pass (512), one-column products, triangular cuts, every epilogue, several products per launch; against fp64, and
+    bit-reproducible."""
+    from curvature_amd import ops
+    torch.manual_seed(17)
+    jobs, wants = [], []
+    shapes = [(120, 401, 401), (84, 121, 121), (16, 151, 151), (6, 26, 26), (10, 85, 85), (33, 1, 401), (1, 1, 1),
+              (5, 70, 3), (40, 40, 777), (31, 65, 1024), (64, 64, 513)]
+    eps = [ops.EPI_NONE, ops.EPI_SQUARE, ops.EPI_MUL_E, ops.EPI_ADD_E, ops.EPI_MUL_E_ADD_F]
+    for idx, (M, N, K) in enumerate(shapes):
+        Abuf = torch.randn(M, K + 3, device=gpu)
+        Bbuf = torch.randn(N, K + 1, device=gpu)
+        A, Bt = Abuf[:, 2:K + 2], Bbuf[:, 1:K + 1]           # rows only 4-byte aligned
+        E, F = torch.randn(M, N, device=gpu), torch.randn(M, N, device=gpu)
+        ep = eps[idx % len(eps)]
+        C0 = torch.randn(M, N, device=gpu)
+        C = C0.clone()
+        beta = 1.0 if idx % 3 == 0 else 0.0
+        if beta == 0.0:
+            C.fill_(float("nan"))
+        jobs.append(ops.Gemm(A, Bt.t(), C, alpha=0.75, beta=beta, epilogue=ep,
+                             E=E if ep >= ops.EPI_MUL_E else None, F=F if ep == ops.EPI_MUL_E_ADD_F else None))
+        r = A.double() @ Bt.double().t()
+        want = {ops.EPI_NONE: 0.75 * r, ops.EPI_SQUARE: 0.75 * r * r, ops.EPI_MUL_E: 0.75 * r * E.double(),
+                ops.EPI_ADD_E: 0.75 * r + E.double(), ops.EPI_MUL_E_ADD_F: 0.75 * r * E.double() + F.double()}[ep]
+        wants.append(want + beta * C0.double())
+    # the sampler's triangular products: L_G z^T (A lower, K = M) and (.) L_A^T (B upper, K = N)
+    for n in (120, 401, 37):
+        L = torch.tril(torch.randn(n, n, device=gpu))
+        Z = torch.randn(90, n, device=gpu)
+        out = torch.full((n, 90), float("nan"), device=gpu)
+        jobs.append(ops.Gemm(L, Z.t(), out, tri=ops.TRI_A_LOWER))
+        wants.append(L.double() @ Z.double().t())
+        out2 = torch.full((90, n), float("nan"), device=gpu)
+        jobs.append(ops.Gemm(Z, L.t(), out2, tri=ops.TRI_B_UPPER))
+        wants.append(Z.double() @ L.double().t())
+    starts = [j.C.clone() for j in jobs]
+    ops.gemm_batched(jobs)
+    for j, want in zip(jobs, wants):
+        assert float((j.C.double() - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1.0), (j.A.shape, j.B.shape)
+    first = [j.C.clone() for j in jobs]
+    for j, s in zip(jobs, starts):
+        j.C.copy_(s)
+    ops.gemm_batched(jobs)
+    for a, j in zip(first, jobs):
+        assert torch.equal(a, j.C)

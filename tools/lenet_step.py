@@ -21,3 +21,10 @@ for name, fn in (("update", lambda: k.update(100)), ("invert", lambda: k.invert(
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(50): fn()
     torch.cuda.synchronize(); print(name, (time.perf_counter() - t0) / 50 * 1e3)
+from curvature_amd.graph import KFACStepGraph
+g = KFACStepGraph(k, add=0.5, multiply=1, batch_size=100)
+for _ in range(10): g.replay()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(200): g.replay()
+torch.cuda.synchronize(); print("graph replay ms/step", (time.perf_counter() - t0) / 200 * 1e3)
+g.check()
