@@ -35,6 +35,7 @@
 
 #include <algorithm>
 #include <type_traits>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -917,6 +918,14 @@ static void pick_strides(const FactorDev& f, int rows_in, int cols_in, int& RS, 
   PS = best_ps[m];
 }
 
+// A launch that is small as a whole (LeNet: 10 factors, 0.1 GFLOP) is bound by its longest work item, and an item is
+// at least one chunk: such launches cap the chunk at SMALL_CHUNK_PX k values instead of filling the LDS panel
+// (conv1 of LeNet-5: 5 samples x 28 x 28 = 3920 px per chunk, 20 items of 64 us -> 1 sample, 50 items of 2 chunks).
+#ifndef CURV_SMALL_CHUNK_PX
+#define CURV_SMALL_CHUNK_PX 1024
+#endif
+static thread_local int g_chunk_px_cap = 4096;
+
 static bool chunk_fits(const FactorDev& f, int NS, int R, int Wc, ChunkGeom& g) {
   g.rows_in = f.compact ? R : (R - 1) * f.sh + f.kh;
   g.cols_in = f.compact ? Wc : (Wc - 1) * f.sw + f.kw;
@@ -933,6 +942,7 @@ static bool chunk_fits(const FactorDev& f, int NS, int R, int Wc, ChunkGeom& g) 
   if (pre) g.SS = (g.SS + 3) & ~3;                                  // DMA pieces are whole 16-byte lanes
   if ((long long)NS * g.SS + 16 > (pre ? PRE_PANEL_WORDS : PANEL_WORDS)) return false;   // + slack for padded run elements
   if ((long long)NS * R * Wc > 4096) return false;
+  if ((long long)NS * R * Wc > g_chunk_px_cap && NS > 1) return false;      // (small launches: fewer samples per chunk)
   if (NS > 127 || g.rows_in > 0xffff) return false;
   if ((long long)NS * f.C * f.H * f.W * 4 > 0x7fff0000ll) return false;   // buffer offsets of a chunk: 31 bits
   const long long prow = (long long)NS * f.nch * g.rows_in;
@@ -1033,6 +1043,19 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
   std::vector<double> chunk_cost(n);   // MFMA CU-cycles of one (tile, chunk)
   std::vector<double> chunk_px(n, 1.0); // k values (samples x output pixels) of one chunk
   double total_cost = 0.0;
+  {
+    // size of the launch in MFMA CU-cycles (64 x 64 x k = 32 k), before any chunk is planned
+    double estimate = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const curv_factor_desc& s = descs[i];
+      if (s.N <= 0 || s.C <= 0 || s.kh <= 0 || s.kw <= 0 || s.sh <= 0 || s.sw <= 0) continue;   // rejected below
+      const double dim = (double)s.C * s.kh * s.kw + (s.has_bias ? 1 : 0);
+      const double blocks = std::ceil(dim / 64.0);
+      const double ho = (s.H + 2.0 * s.ph - s.kh) / s.sh + 1, wo = (s.W + 2.0 * s.pw - s.kw) / s.sw + 1;
+      estimate += 32.0 * blocks * (blocks + 1) / 2 * s.N * std::max(ho, 1.0) * std::max(wo, 1.0);
+    }
+    g_chunk_px_cap = estimate < 512.0 * 16.0 * CURV_ITEM_FLOOR ? CURV_SMALL_CHUNK_PX : 4096;
+  }
   for (int i = 0; i < n; ++i) {
     const curv_factor_desc& s = descs[i];
     FactorDev& f = plan.f[i];
@@ -1454,12 +1477,15 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
     const int rc1 = launch_syrk_flat(stream, table + n0, n1, plan.n_items[1], slabs);
     if (rc1 != CURV_OK) return rc1;
   }
-  if (fork) CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->join, 0));           // the register-staged MFMA kernel is done
-  if (fork) CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->join_r, 0));
   if (!fork && (rc = reduce(stream, 0, 0, n0)) != CURV_OK) return rc;
   if ((rc = reduce(stream, 1, n0, n1)) != CURV_OK) return rc;
   if ((rc = reduce(stream, 2, n0 + n1, n2)) != CURV_OK) return rc;
   if (!plan.corr.empty() && (rc = launch_corr_assemble(stream, plan.corr, plan.f, area)) != CURV_OK) return rc;
+  // the side stream (register-staged MFMA kernel + its reduce pass) joins behind everything the caller's stream had to
+  // do itself: none of the passes above reads what the side stream writes (LeNet-5: the two chains are 60 us each, and
+  // ran one after the other when the join came first)
+  if (fork) CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->join, 0));
+  if (fork) CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->join_r, 0));
   // the timed window (bench.py's roofline) spans the WHOLE build: padding / pre-tiling passes, the MFMA kernels, the
   // k-slice reduction of the sliced factors and the assembly of the 3x3 factors
   if (ev_stop) CURV_HIP_CHECK(hipEventRecord((hipEvent_t)ev_stop, stream));

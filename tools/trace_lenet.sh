@@ -7,13 +7,18 @@ python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/lenet/trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-# last step: find the last upload / first kernel of update: take the last 40 kernels
-rows = rows[-45:]
-t0 = int(rows[0]["Start_Timestamp"])
+# one steady-state step of the eager loop: from the 30th noise draw back to the previous one
+idx = [i for i, r in enumerate(rows) if "randn" in r["Kernel_Name"]]
+seg = rows[idx[29] + 1:idx[30] + 1]
+seg = seg[-6:] and rows[idx[29]:idx[30]]
+t0 = int(seg[0]["Start_Timestamp"])
 prev_end = t0
-for r in rows:
+total = 0
+for r in seg:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:7.1f}  gap {(s - prev_end) / 1e3:6.1f}  {r['Kernel_Name'][:70]}  grid {r.get('Grid_Size')}")
+    total += e - s
+    print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:7.1f}  gap {(s - prev_end) / 1e3:6.1f}  {r['Kernel_Name'][:64]}  wgs {int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])}")
     prev_end = max(prev_end, e)
+print(f"kernel time of the step (sum of durations; the two MFMA kernels of update() overlap): {total / 1e3:.1f} us")
 PY
 tail -3 gpurun_out/lenet/run.txt
