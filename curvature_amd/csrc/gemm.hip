@@ -551,20 +551,39 @@ struct Gemm64Dev {
 
 typedef __attribute__((address_space(1))) double gdbl;
 
+// descriptors travel as kernel arguments, G64_BATCH per launch: a ResNet-scale INF.invert hands over 54 products of
+// 500-1100 tiles each, and four per launch (the first form) ended every launch with a partly filled round of its
+// longest tiles - 14 tails per call
+constexpr int G64_BATCH = 32;
+struct Gemm64Table { Gemm64Dev d[G64_BATCH]; };
+static_assert(sizeof(Gemm64Table) <= 3840, "kernel argument block must stay below 4 KB");
+
+// workgroup -> (descriptor, tile): tile_base is ascending; lane l looks at descriptor l
+__device__ __forceinline__ int gemm64_find(const Gemm64Table& tab, int n_desc, int bid) {
+  const int lane = threadIdx.x & 63;
+  const bool le = lane < n_desc && tab.d[lane < G64_BATCH ? lane : 0].tile_base <= bid;
+  return __builtin_amdgcn_readfirstlane(__popcll(__ballot(le)) - 1);
+}
+// tile order inside a product: longest K range first (triangular operands cut it per tile), so that a launch ends
+// with short tiles
+__device__ __forceinline__ void gemm64_tile(const Gemm64Dev& d, int local, int T, int& tm, int& tn) {
+  tm = local / d.tiles_n;
+  tn = local - tm * d.tiles_n;
+  if (d.tri & 1) tm = (d.M + T - 1) / T - 1 - tm;       // A lower: K ends at i0 + T
+  if (d.tri & 8) tn = d.tiles_n - 1 - tn;               // B upper: K ends at j0 + T
+}
+
 __global__ void __launch_bounds__(GEMM_THREADS)
-gemm_f64_kernel(Gemm64Dev d0, Gemm64Dev d1, Gemm64Dev d2, Gemm64Dev d3, int n_desc) {
+gemm_f64_kernel(const Gemm64Table tab, int n_desc) {
   __shared__ double As[GK * GP];     // [k][row]
   __shared__ double Bs[GK * GP];     // [k][col]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r16 = lane & 15, kq = lane >> 4;
-  int f = 0;
-  if (n_desc > 1 && (int)blockIdx.x >= d1.tile_base) f = 1;
-  if (n_desc > 2 && (int)blockIdx.x >= d2.tile_base) f = 2;
-  if (n_desc > 3 && (int)blockIdx.x >= d3.tile_base) f = 3;
-  const Gemm64Dev d = f == 0 ? d0 : f == 1 ? d1 : f == 2 ? d2 : d3;
+  const Gemm64Dev& d = tab.d[gemm64_find(tab, n_desc, blockIdx.x)];
   const int local = blockIdx.x - d.tile_base;
-  const int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
+  int tm, tn;
+  gemm64_tile(d, local, GT, tm, tn);
   const int i0 = tm * GT, j0 = tn * GT;
   const int M = d.M, N = d.N, K = d.K;
   const gdbl* A = (const gdbl*)d.A;
@@ -638,6 +657,109 @@ gemm_f64_kernel(Gemm64Dev d0, Gemm64Dev d1, Gemm64Dev d2, Gemm64Dev d3, int n_de
           const long long ci = i * d.c_rs + j * d.c_cs;
           double v = d.alpha * acc[m][n][r];
           if (d.beta != 0.0) v += d.beta * C[ci];
+          C[ci] = v;
+        }
+      }
+}
+
+// The macro-tile form of gemm_f64_kernel for large products (INF.pre_sampler on ResNet-scale layers: ab = 3400-4284):
+// 128 x 128 output tile, four waves of 64 x 64 = 4 x 4 MFMA tiles each, K steps of 16 with the next step's 16 loads per
+// thread in flight during the 64 MFMAs of the current one, two workgroups per CU.  16 flops per operand byte instead
+// of 8: the 64 x 64 tile loop is bound by where its operands come from (47 TFLOP/s from HBM, 66 from L2), this one
+// is not (61-65 either way, profiles/r04_micro_mfma_f64.txt).  Same descriptors, strides, triangular K cuts and
+// alpha / beta epilogue as gemm_f64_kernel.
+constexpr int G64M_T = 128, G64M_P = G64M_T + 1;
+__global__ void __launch_bounds__(GEMM_THREADS, 2)
+gemm_f64_macro_kernel(const Gemm64Table tab, int n_desc) {
+  __shared__ double As[GK * G64M_P];     // [k][row]
+  __shared__ double Bs[GK * G64M_P];     // [k][col]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const Gemm64Dev& d = tab.d[gemm64_find(tab, n_desc, blockIdx.x)];
+  const int local = blockIdx.x - d.tile_base;
+  int tm, tn;
+  gemm64_tile(d, local, G64M_T, tm, tn);
+  const int i0 = tm * G64M_T, j0 = tn * G64M_T;
+  const int M = d.M, N = d.N, K = d.K;
+  const gdbl* A = (const gdbl*)d.A;
+  const gdbl* B = (const gdbl*)d.B;
+  // staging maps: element u of a thread is (row ar0 + u a_dr, k ak0 + u a_dk); lanes run along the operand's unit stride
+  const bool a_kfast = (d.a_cs == 1), b_kfast = (d.b_rs == 1);
+  const int ar0 = a_kfast ? tid >> 4 : tid & 127, ak0 = a_kfast ? tid & 15 : tid >> 7;
+  const int a_dr = a_kfast ? 16 : 0, a_dk = a_kfast ? 0 : 2;
+  const int bc0 = b_kfast ? tid >> 4 : tid & 127, bk0 = b_kfast ? tid & 15 : tid >> 7;
+  const int b_dc = b_kfast ? 16 : 0, b_dk = b_kfast ? 0 : 2;
+  const long long oa0 = (long long)(i0 + ar0) * d.a_rs + (long long)ak0 * d.a_cs;
+  const long long ob0 = (long long)bk0 * d.b_rs + (long long)(j0 + bc0) * d.b_cs;
+  const long long sa = (long long)a_dr * d.a_rs + (long long)a_dk * d.a_cs;
+  const long long sb = (long long)b_dk * d.b_rs + (long long)b_dc * d.b_cs;
+  unsigned va = 0, vb = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    if (i0 + ar0 + u * a_dr < M) va |= 1u << u;
+    if (j0 + bc0 + u * b_dc < N) vb |= 1u << u;
+  }
+  int k_lo = 0, k_hi = K;
+  if (d.tri & 1) k_hi = min(k_hi, i0 + G64M_T);      // A lower: a[i][k] = 0 for k > i
+  if (d.tri & 2) k_lo = max(k_lo, i0);               // A upper: a[i][k] = 0 for k < i
+  if (d.tri & 4) k_lo = max(k_lo, j0);               // B lower: b[k][j] = 0 for k < j
+  if (d.tri & 8) k_hi = min(k_hi, j0 + G64M_T);      // B upper: b[k][j] = 0 for k > j
+  k_lo &= ~(GK - 1);
+  if (k_lo >= k_hi && d.beta == 1.0) return;         // nothing to add
+  double ra[8], rb[8];
+  auto fetch = [&](int k0) __attribute__((always_inline)) {
+    const gdbl* Ak = A + (long long)k0 * d.a_cs;
+    const gdbl* Bk = B + (long long)k0 * d.b_rs;
+    if (va == 0xffu && vb == 0xffu && k0 + GK <= k_hi) {        // interior step (wave-uniform in practice: plain loads)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { ra[u] = Ak[oa0 + u * sa]; rb[u] = Bk[ob0 + u * sb]; }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        ra[u] = (((va >> u) & 1) && k0 + ak0 + u * a_dk < k_hi) ? Ak[oa0 + u * sa] : 0.0;
+        rb[u] = (((vb >> u) & 1) && k0 + bk0 + u * b_dk < k_hi) ? Bk[ob0 + u * sb] : 0.0;
+      }
+    }
+  };
+  f64x4 acc[4][4] = {};
+  if (k_lo < k_hi) fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += GK) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      As[(ak0 + u * a_dk) * G64M_P + ar0 + u * a_dr] = ra[u];
+      Bs[(bk0 + u * b_dk) * G64M_P + bc0 + u * b_dc] = rb[u];
+    }
+    __syncthreads();
+    if (k0 + GK < k_hi) fetch(k0 + GK);
+#pragma unroll
+    for (int ks = 0; ks < GK / 4; ++ks) {
+      const int k = 4 * ks + kq;
+      double a[4], b[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) a[m] = As[k * G64M_P + 64 * wm + 16 * m + r16];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b[n] = Bs[k * G64M_P + 64 * wn + 16 * n + r16];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  gdbl* C = (gdbl*)d.C;
+  const double alpha = d.alpha, beta = d.beta;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 64 * wm + 16 * m + kq + 4 * r, j = j0 + 64 * wn + 16 * n + r16;
+        if (i < M && j < N) {
+          const long long ci = i * d.c_rs + j * d.c_cs;
+          double v = alpha * acc[m][n][r];
+          if (beta != 0.0) v += beta * C[ci];
           C[ci] = v;
         }
       }
@@ -989,28 +1111,52 @@ extern "C" int curv_randn_counter(void* stream, float* out, long long count, uns
   return CURV_OK;
 }
 
+// products with both output edges >= G64_MACRO_MIN go to the 128 x 128 macro-tile kernel
+#ifndef CURV_G64_MACRO_MIN
+#define CURV_G64_MACRO_MIN 1024
+#endif
+constexpr int G64_MACRO_MIN = CURV_G64_MACRO_MIN;
 extern "C" int curv_gemm_f64_batched(void* stream_, const curv_gemm64_desc* descs, int n_desc) {
   hipStream_t stream = (hipStream_t)stream_;
   CURV_REQUIRE(n_desc >= 0 && (n_desc == 0 || descs), "curv_gemm_f64_batched: bad arguments");
-  for (int base = 0; base < n_desc; base += 4) {
-    Gemm64Dev d[4];
-    memset(d, 0, sizeof(d));
-    const int cnt = std::min(4, n_desc - base);
+  for (int i = 0; i < n_desc; ++i) {
+    const curv_gemm64_desc& s = descs[i];
+    CURV_REQUIRE(s.M > 0 && s.N > 0 && s.K >= 0 && s.A && s.B && s.C, "curv_gemm_f64_batched: desc %d invalid", i);
+    CURV_REQUIRE((s.tri & ~15) == 0 && (s.tri & 3) != 3 && (s.tri & 12) != 12, "curv_gemm_f64_batched: desc %d: bad tri flags", i);
+  }
+  // launches of up to G64_BATCH descriptors (they travel as kernel arguments), per tile size, in the caller's order
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool macro = pass == 1;
+    const int T = macro ? G64M_T : GT;
+    Gemm64Table tab;
+    Gemm64Dev* d = tab.d;
+    int cnt = 0;
     long long tiles = 0;
-    for (int i = 0; i < cnt; ++i) {
-      const curv_gemm64_desc& s = descs[base + i];
-      CURV_REQUIRE(s.M > 0 && s.N > 0 && s.K >= 0 && s.A && s.B && s.C, "curv_gemm_f64_batched: desc %d invalid", base + i);
-      d[i].A = s.A; d[i].B = s.B; d[i].C = s.C;
-      d[i].a_rs = s.a_rs; d[i].a_cs = s.a_cs; d[i].b_rs = s.b_rs; d[i].b_cs = s.b_cs; d[i].c_rs = s.c_rs; d[i].c_cs = s.c_cs;
-      d[i].M = s.M; d[i].N = s.N; d[i].K = s.K; d[i].alpha = s.alpha; d[i].beta = s.beta;
-      CURV_REQUIRE((s.tri & ~15) == 0 && (s.tri & 3) != 3 && (s.tri & 12) != 12, "curv_gemm_f64_batched: desc %d: bad tri flags", base + i);
-      d[i].tri = s.tri;
-      d[i].tiles_n = cdiv(s.N, GT);
-      d[i].tile_base = (int)tiles;
-      tiles += (long long)cdiv(s.M, GT) * d[i].tiles_n;
+    auto flush = [&]() -> int {
+      if (cnt == 0) return CURV_OK;
+      if (macro) hipLaunchKernelGGL(gemm_f64_macro_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, stream, tab, cnt);
+      else hipLaunchKernelGGL(gemm_f64_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, stream, tab, cnt);
+      CURV_LAUNCH_CHECK();
+      cnt = 0; tiles = 0;
+      return CURV_OK;
+    };
+    memset(&tab, 0, sizeof(tab));
+    for (int i = 0; i < n_desc; ++i) {
+      const curv_gemm64_desc& s = descs[i];
+      if ((s.M >= G64_MACRO_MIN && s.N >= G64_MACRO_MIN) != macro) continue;
+      Gemm64Dev& o = d[cnt];
+      o.A = s.A; o.B = s.B; o.C = s.C;
+      o.a_rs = s.a_rs; o.a_cs = s.a_cs; o.b_rs = s.b_rs; o.b_cs = s.b_cs; o.c_rs = s.c_rs; o.c_cs = s.c_cs;
+      o.M = s.M; o.N = s.N; o.K = s.K; o.alpha = s.alpha; o.beta = s.beta;
+      o.tri = s.tri;
+      o.tiles_n = cdiv(s.N, T);
+      o.tile_base = (int)tiles;
+      tiles += (long long)cdiv(s.M, T) * o.tiles_n;
+      CURV_REQUIRE(tiles < (1LL << 30), "curv_gemm_f64_batched: too many tiles");
+      if (++cnt == G64_BATCH || tiles > (1LL << 24)) { const int rc = flush(); if (rc != CURV_OK) return rc; memset(&tab, 0, sizeof(tab)); }
     }
-    hipLaunchKernelGGL(gemm_f64_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, stream, d[0], d[1], d[2], d[3], cnt);
-    CURV_LAUNCH_CHECK();
+    const int rc = flush();
+    if (rc != CURV_OK) return rc;
   }
   return CURV_OK;
 }

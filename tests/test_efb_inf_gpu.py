@@ -186,7 +186,7 @@ def test_inf_invert_and_sample(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [64, 130, 333])
+@pytest.mark.parametrize("n", [64, 130, 333, 1024, 1100])      # >= 1024: the 128 x 128 macro-tile kernel
 def test_gemm_f64_triangular_operands(gpu, n):
     """curv_gemm_f64_batched with CURV_TRI64_* flags (the two products of INF.pre_sampler's triangular inverses):
     same result as the dense product when the operands really are triangular, all flag combinations, with the
@@ -213,3 +213,32 @@ def test_gemm_f64_triangular_operands(gpu, n):
     want = lower[1] - lower[0] @ lower[1]
     assert float((T - want).abs().max()) <= 1e-12 * float(want.abs().max())
     assert float(torch.triu(T, 1).abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_gemm_f64_macro_tiles_all_layouts(gpu):
+    """Products with both output edges >= 1024 run on 128 x 128 macro tiles (gemm_f64_macro_kernel): every operand
+    layout (row-major, transposed views, column slices of wider buffers), ragged M / N / K, alpha / beta, and a call
+    that mixes macro-tile and 64-tile products; against torch's fp64 product."""
+    from curvature_amd import ops
+    torch.manual_seed(5)
+    M, N, K = 1150, 1030, 333
+    A = torch.randn(M, K + 3, dtype=torch.float64, device=gpu)[:, 1:K + 1]
+    At = torch.randn(K, M, dtype=torch.float64, device=gpu).t()
+    B = torch.randn(K, N + 2, dtype=torch.float64, device=gpu)[:, 2:]
+    Bt = torch.randn(N, K, dtype=torch.float64, device=gpu).t()
+    small_a = torch.randn(70, 90, dtype=torch.float64, device=gpu)
+    small_b = torch.randn(90, 600, dtype=torch.float64, device=gpu)
+    jobs, wants = [], []
+    for a in (A, At):
+        for b in (B, Bt):
+            C0 = torch.randn(M, N, dtype=torch.float64, device=gpu)
+            jobs.append(ops.Gemm64(a, b, C0.clone(), alpha=0.5, beta=-2.0))
+            wants.append(0.5 * (a @ b) - 2.0 * C0)
+            jobs.append(ops.Gemm64(a, b))
+            wants.append(a @ b)
+    jobs.insert(3, ops.Gemm64(small_a, small_b))
+    wants.insert(3, small_a @ small_b)
+    outs = ops.gemm_f64_batched(jobs)
+    for c, want in zip(outs, wants):
+        assert float((c - want).abs().max()) <= 1e-12 * float(want.abs().max())
