@@ -654,7 +654,8 @@ class Gemm64:
 
 
 def gemm_f64_batched(jobs: Sequence[Gemm64]) -> List[torch.Tensor]:
-    """All products through one call of curv_gemm_f64_batched (it launches four descriptors at a time)."""
+    """All products through one call of curv_gemm_f64_batched (up to 32 descriptors per launch; the products must be
+    independent of each other: large ones run in a launch of their own behind the small ones)."""
     n = len(jobs)
     if n == 0:
         return []

@@ -211,7 +211,9 @@ int curv_gemm_batched_ex(void* stream, const curv_gemm_desc* descs, int n_desc, 
  * entries outside the triangle are neither read nor multiplied (they must be zero in memory where a tile straddles the
  * diagonal): the products of the two triangular inverses of pre_sampler (curvatures.py:566-572) are 2/3 of INF.invert's
  * flops when done densely.  A lower x B lower leaves the tiles above the diagonal of C untouched for beta = 1 and
- * zero for beta = 0. */
+ * zero for beta = 0.  The products of one call are INDEPENDENT (no C of one may be an operand of another): they run
+ * up to 32 to a launch, products with both output edges >= 1024 on 128 x 128 tiles in a launch of their own behind the
+ * others - not in the caller's order. */
 #define CURV_TRI64_A_LOWER 1
 #define CURV_TRI64_A_UPPER 2
 #define CURV_TRI64_B_LOWER 4
