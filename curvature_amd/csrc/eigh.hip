@@ -99,6 +99,12 @@ __device__ __host__ __forceinline__ void rr_pair(int N, int r, int t, int& p, in
 }
 
 __device__ __forceinline__ int gidx(int p, int q, int x) { return x < JB ? p * JB + x : q * JB + x - JB; }
+// Phase A keeps its fp32 matrices (A32, V32) in COLUMN BLOCKS of JB: element (row, col) lives at
+//   ((col / JB) np + row) JB + col % JB,
+// so the JB x JB sub-blocks a round touches - rows of blocks {p, q} times columns of blocks {p', q'} - are contiguous
+// 4 KB runs (a 64-row tile of V's column pair: two runs of 8 KB) instead of 128-byte segments one matrix row (4 np
+// bytes) apart; every kernel of the phase streamed at 2.3 TB/s with the row-major form.
+__device__ __forceinline__ long long b32(int row, int col, int np) { return ((long long)(col / JB) * np + row) * JB + (col % JB); }
 
 __global__ void __launch_bounds__(EIG_THREADS)
 eigh_prepare_kernel(const EighDev* __restrict__ t, int nf) {
@@ -135,7 +141,8 @@ __device__ __forceinline__ void jacobi_pair_body(const EighDev& d, int tp, int s
   const gT* A = std::is_same<T, float>::value ? (const gT*)d.A32 : (const gT*)d.A;
   for (int e = tid; e < NB * NB; e += EIG_THREADS) {
     const int x = e >> 6, y = e & 63;
-    S[x * LDA + y] = (C)A[(long long)gidx(p, q, x) * np + gidx(p, q, y)];
+    S[x * LDA + y] = (C)A[std::is_same<T, float>::value ? b32(gidx(p, q, x), gidx(p, q, y), np)
+                                                         : (long long)gidx(p, q, x) * np + gidx(p, q, y)];
     Qs[x * LDA + y] = (x == y) ? (C)1 : (C)0;
   }
   __syncthreads();
@@ -170,11 +177,22 @@ __device__ __forceinline__ void jacobi_pair_body(const EighDev& d, int tp, int s
     if (skip) return;
   }
 
+  // Which index pairs the visit rotates.  The first round of each of the matrix's own sweeps pairs every block with
+  // exactly one partner: there the whole 64x64 sub-problem gets one cyclic sweep (all 2016 pairs, 63 rounds), which covers
+  // the pairs INSIDE the two blocks once per sweep.  Every other visit rotates only the 32 x 32 CROSS pairs (i in p, j in
+  // q: 32 rounds) - the pairs inside a block were being rotated Nb - 1 times per sweep, and the sub-problem solve is the
+  // serial part of a round.
+#ifndef CURV_EIG_CROSS
+#define CURV_EIG_CROSS 1
+#endif
+  const bool cross_only = CURV_EIG_CROSS && d.Nb > 2 && (step % d.spf) != 0;
+  const int n_rounds = cross_only ? JB : NB - 1;
   for (int sweep = 0; sweep < inner_sweeps; ++sweep) {
-    for (int rr = 0; rr < NB - 1; ++rr) {
+    for (int rr = 0; rr < n_rounds; ++rr) {
       if (tid < 32) {
         int i, j;
-        rr_pair(NB, rr, tid, i, j);
+        if (cross_only) { i = tid; j = JB + ((tid + rr) & (JB - 1)); }
+        else rr_pair(NB, rr, tid, i, j);
         const C app = S[i * LDA + i], aqq = S[j * LDA + j], apq = S[i * LDA + j];
         C c = (C)1, s = (C)0;
         if (std::is_same<C, float>::value) {
@@ -382,8 +400,8 @@ eigh_prepare32_kernel(const EighDev* __restrict__ t, int nf) {
     const int i = bi * NB + (e >> 6), j = bj * NB + (e & 63);
     float v = 0.0f;
     if (i < n && j < n) v = (float)(0.5 * ((double)F[(long long)i * n + j] + (double)F[(long long)j * n + i]));
-    A[(long long)i * np + j] = v;
-    V[(long long)i * np + j] = (i == j) ? 1.0f : 0.0f;
+    A[b32(i, j, np)] = v;
+    V[b32(i, j, np)] = (i == j) ? 1.0f : 0.0f;
   }
 }
 
@@ -410,6 +428,8 @@ jacobi_two_sided32_kernel(const EighDev* __restrict__ t, int nf, int step) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) Qi[c * LDF + w + 4 * u] = Qg[(w + 4 * u) * NB + c];          // Qi[row][k] = Q_I[k][row]
   }
+  // (fetching the next tile of the walk into registers behind the LDS stores of the current one was measured: 193 ->
+  // 220 us per launch - the extra 32 live registers cost more occupancy than the overlap returns)
   for (int tJ = j0; tJ < j1; ++tJ) {
     if (tJ < tI) continue;                                   // A32 is kept exactly symmetric: tile (J, I) is written as the
     const bool skipJ = skip[tJ] != 0;                        // transpose of tile (I, J) by the workgroup of (I, J)
@@ -419,7 +439,7 @@ jacobi_two_sided32_kernel(const EighDev* __restrict__ t, int nf, int step) {
     const int gc = gidx(pJ, qJ, c);
     float xv[16], qv[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) xv[u] = A[(long long)gidx(pI, qI, w + 4 * u) * np + gc];
+    for (int u = 0; u < 16; ++u) xv[u] = A[b32(gidx(pI, qI, w + 4 * u), gc, np)];
     if (!skipJ) {
       const gfloat32* Qg = Q + (long long)tJ * NB * NB;
 #pragma unroll
@@ -449,9 +469,9 @@ jacobi_two_sided32_kernel(const EighDev* __restrict__ t, int nf, int step) {
       mma_64_f32(X, Qj, wm, wn, lane, acc);                  // R = T Q_J
     }
     // rows 32 wm .. of the tile are rows of block (wm ? qI : pI), columns 32 wn .. of block (wn ? qJ : pJ)
-    gfloat32* C = A + (long long)((wm ? qI : pI) * JB) * np + (wn ? qJ : pJ) * JB + (lane & 31);
+    gfloat32* C = A + b32((wm ? qI : pI) * JB, (wn ? qJ : pJ) * JB + (lane & 31), np);
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) C[(long long)acc_row(reg, lane) * np] = acc[reg];
+    for (int reg = 0; reg < 16; ++reg) C[acc_row(reg, lane) * JB] = acc[reg];
     if (tJ != tI) {
       // the mirror tile (J, I) = R^T, through LDS so that its rows go out as contiguous runs
       __syncthreads();                                       // everybody is done reading X as an operand
@@ -460,7 +480,7 @@ jacobi_two_sided32_kernel(const EighDev* __restrict__ t, int nf, int step) {
       __syncthreads();
       const int gci = gidx(pI, qI, c);
 #pragma unroll
-      for (int u = 0; u < 16; ++u) A[(long long)gidx(pJ, qJ, w + 4 * u) * np + gci] = X[c * LDF + w + 4 * u];
+      for (int u = 0; u < 16; ++u) A[b32(gidx(pJ, qJ, w + 4 * u), gci, np)] = X[c * LDF + w + 4 * u];
     }
   }
 }
@@ -469,23 +489,26 @@ jacobi_two_sided32_kernel(const EighDev* __restrict__ t, int nf, int step) {
 //   * the sub-problems of round step + 1 (they only need A after the two-sided pass of round `step`, which is done):
 //     the serial part of a round, ~140 us of LDS latency, now beside ...
 //   * ... V32 columns {p, q} <- columns * Q of round `step` (eig_etw() 64-row tiles per workgroup), HBM-bound.
-// The rotation blocks and skip flags live in two buffers, by round parity.  do_cols = 0: the very first sub-problems.
+// The rotation blocks and skip flags live in two buffers, by round parity.  A grid of pair_wgs workgroups: sub-problems only (round 0).
 __global__ void __launch_bounds__(EIG_THREADS)
-jacobi_cols_pair32_kernel(const EighDev* __restrict__ t, int nf, int step, int do_cols, int inner_sweeps, double inner_tol2) {
+jacobi_cols_pair32_kernel(const EighDev* __restrict__ t, int nf, int step, int pair_wgs, int inner_sweeps, double inner_tol2) {
   __shared__ float buf[2 * NB * LDF];
   __shared__ float cs[2 * 32];
   __shared__ int pairs[2 * 32];
   __shared__ double red[EIG_THREADS];
   int f, local;
-  if (!eig_locate(t, nf, blockIdx.x, [do_cols](const EighDev& d) {
-        return eig_active(d) ? d.Nb / 2 + (do_cols ? (d.Nb / 2) * eig_groups(d.np / NB) : 0) : 0; }, f, local)) return;
-  const EighDev& d = t[f];
-  const int npair = d.Nb / 2;
-  if (local < npair) {
-    jacobi_pair_body<float, float>(d, local, step + 1, (step + 1) & 1, inner_sweeps, inner_tol2, buf, buf + NB * LDF, cs, pairs, red);
+  // the sub-problems of ALL matrices come first in the grid (`pair_wgs` = their count over the whole batch, frozen
+  // matrices included: the surplus exits): they are the serial part of the round, and with one range per matrix the last
+  // matrices' sub-problems started behind the earlier matrices' column tiles
+  if ((int)blockIdx.x < pair_wgs) {
+    if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return eig_active(d) ? d.Nb / 2 : 0; }, f, local)) return;
+    jacobi_pair_body<float, float>(t[f], local, step + 1, (step + 1) & 1, inner_sweeps, inner_tol2, buf, buf + NB * LDF, cs, pairs, red);
     return;
   }
-  local -= npair;
+  if (!eig_locate(t, nf, (int)blockIdx.x - pair_wgs, [](const EighDev& d) {
+        return eig_active(d) ? (d.Nb / 2) * eig_groups(d.np / NB) : 0; }, f, local)) return;
+  const EighDev& d = t[f];
+  const int npair = d.Nb / 2;
   float* Qj = buf;
   float* X = buf + NB * LDF;
   const int par = step & 1;
@@ -502,7 +525,7 @@ jacobi_cols_pair32_kernel(const EighDev* __restrict__ t, int nf, int step, int d
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     Qj[(w + 4 * u) * LDF + c] = Qg[(w + 4 * u) * NB + c];
-    xv[u] = V[(long long)(rt0 * NB + w + 4 * u) * np + gc];
+    xv[u] = V[b32(rt0 * NB + w + 4 * u, gc, np)];
   }
   for (int rt = rt0; rt < rt1; ++rt) {
 #pragma unroll
@@ -510,13 +533,13 @@ jacobi_cols_pair32_kernel(const EighDev* __restrict__ t, int nf, int step, int d
     __syncthreads();
     if (rt + 1 < rt1) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) xv[u] = V[(long long)((rt + 1) * NB + w + 4 * u) * np + gc];
+      for (int u = 0; u < 16; ++u) xv[u] = V[b32((rt + 1) * NB + w + 4 * u, gc, np)];
     }
     f32x16 acc = {0};
     mma_64_f32(X, Qj, wm, wn, lane, acc);
-    gfloat32* C = V + (long long)(rt * NB + 32 * wm) * np + (wn ? q : p) * JB + (lane & 31);
+    gfloat32* C = V + b32(rt * NB + 32 * wm, (wn ? q : p) * JB + (lane & 31), np);
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) C[(long long)acc_row(reg, lane) * np] = acc[reg];
+    for (int reg = 0; reg < 16; ++reg) C[acc_row(reg, lane) * JB] = acc[reg];
     __syncthreads();
   }
 }
@@ -535,7 +558,7 @@ eigh_norms32_kernel(const EighDev* __restrict__ t, int nf, int step1) {
   double off = 0.0, dg = 0.0;
   for (int e = tid; e < NB * NB; e += EIG_THREADS) {
     const int i = bi * NB + (e >> 6), j = bj * NB + (e & 63);
-    const double v = (double)A[(long long)i * np + j];
+    const double v = (double)A[b32(i, j, np)];
     if (i == j) dg += v * v; else off += v * v;
   }
   r0[tid] = off; r1[tid] = dg;
@@ -560,7 +583,7 @@ eigh_widen_kernel(const EighDev* __restrict__ t, int nf) {
   gdouble* T3 = (gdouble*)d.T3;
   for (int e = threadIdx.x; e < NB * NB; e += EIG_THREADS) {
     const long long idx = (long long)(bi * NB + (e >> 6)) * np + bj * NB + (e & 63);
-    const double v = (double)V32[idx];
+    const double v = (double)V32[b32(bi * NB + (e >> 6), bj * NB + (e & 63), np)];
     V[idx] = v;
     T3[idx] = 1.5 * v;
   }
@@ -875,13 +898,13 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
     for (long long step = 0; step < max_steps && !all_done; ++step) {
       if (phase_a) {
         if (step == 0) {                                       // the sub-problems of round 0
-          hipLaunchKernelGGL(jacobi_cols_pair32_kernel, dim3((unsigned)pair_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, -1, 0, inner_sweeps, inner_tol2);
+          hipLaunchKernelGGL(jacobi_cols_pair32_kernel, dim3((unsigned)pair_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, -1, (int)pair_wgs, inner_sweeps, inner_tol2);
           CURV_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(jacobi_two_sided32_kernel, dim3((unsigned)ts_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step);
         CURV_LAUNCH_CHECK();
         // V of this round and, beside it, the sub-problems of the next one
-        hipLaunchKernelGGL(jacobi_cols_pair32_kernel, dim3((unsigned)(pair_wgs + row_tiles)), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step, 1, inner_sweeps, inner_tol2);
+        hipLaunchKernelGGL(jacobi_cols_pair32_kernel, dim3((unsigned)(pair_wgs + row_tiles)), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step, (int)pair_wgs, inner_sweeps, inner_tol2);
         CURV_LAUNCH_CHECK();
       } else {
         hipLaunchKernelGGL(jacobi_pair_kernel, dim3((unsigned)pair_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step, inner_sweeps, inner_tol2);
@@ -892,11 +915,15 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
         CURV_LAUNCH_CHECK();
       }
       const int step1 = (int)(step + 1);
-      bool any = false;
-      for (int i = 0; i < n_mats && !any; ++i) any = (step1 % tab[i].spf == 0);
+      // the matrices that finish one of their own sweeps with this step: only their tiles are launched (with ~100 sizes
+      // in a batch some matrix does at nearly every step; the whole batch's tile count was 34 us of empty workgroups)
+      long long norm_tiles = 0;
+      for (int i = 0; i < n_mats; ++i)
+        if (step1 % tab[i].spf == 0) norm_tiles += (long long)(tab[i].np / NB) * (tab[i].np / NB);
+      const bool any = norm_tiles > 0;
       if (any) {
-        if (phase_a) hipLaunchKernelGGL(eigh_norms32_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, step1);
-        else hipLaunchKernelGGL(eigh_norms_kernel, dim3((unsigned)prep_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, step1);
+        if (phase_a) hipLaunchKernelGGL(eigh_norms32_kernel, dim3((unsigned)norm_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, step1);
+        else hipLaunchKernelGGL(eigh_norms_kernel, dim3((unsigned)norm_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, step1);
         CURV_LAUNCH_CHECK();
         hipLaunchKernelGGL(eigh_check_kernel, dim3((unsigned)n_mats), dim3(256), 0, stream, table, n_mats, step1, max_sweeps, phase_a ? 1 : 0);
         CURV_LAUNCH_CHECK();
