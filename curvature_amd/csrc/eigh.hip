@@ -185,7 +185,7 @@ __device__ __forceinline__ void jacobi_pair_body(const EighDev& d, int tp, int s
 #ifndef CURV_EIG_CROSS
 #define CURV_EIG_CROSS 1
 #endif
-  const bool cross_only = CURV_EIG_CROSS && d.Nb > 2 && (step % d.spf) != 0;
+  const bool cross_only = CURV_EIG_CROSS && std::is_same<T, float>::value && d.Nb > 2 && (step % d.spf) != 0;
   const int n_rounds = cross_only ? JB : NB - 1;
   for (int sweep = 0; sweep < inner_sweeps; ++sweep) {
     for (int rr = 0; rr < n_rounds; ++rr) {
