@@ -273,7 +273,10 @@ jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sw
 // Both update kernels walk eig_etw() consecutive 64-wide tiles of their block pair per workgroup: the pair's Q is staged
 // once, and the next tile is in flight (registers) while the MFMAs of the current one run.
 // (four for matrices of 2048 and more, fewer below: small matrices need the workgroups more than the reuse)
-__device__ __host__ __forceinline__ int eig_etw(int tiles) { return tiles >= 32 ? 4 : tiles >= 16 ? 2 : 1; }
+#ifndef CURV_ETW_BIG
+#define CURV_ETW_BIG 4
+#endif
+__device__ __host__ __forceinline__ int eig_etw(int tiles) { return tiles >= 32 ? CURV_ETW_BIG : tiles >= 16 ? 2 : 1; }
 __device__ __host__ __forceinline__ int eig_groups(int tiles) { const int e = eig_etw(tiles); return (tiles + e - 1) / e; }
 
 __global__ void __launch_bounds__(EIG_THREADS)
