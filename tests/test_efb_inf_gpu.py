@@ -242,3 +242,27 @@ def test_gemm_f64_macro_tiles_all_layouts(gpu):
     outs = ops.gemm_f64_batched(jobs)
     for c, want in zip(outs, wants):
         assert float((c - want).abs().max()) <= 1e-12 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_gemm_f64_many_products_per_call(gpu):
+    """More products than one launch carries (32 descriptors travel as kernel arguments): 70 small ones and three
+    macro-tile ones in one call, with triangular flags on some - every product against torch's fp64 result."""
+    from curvature_amd import ops
+    torch.manual_seed(9)
+    jobs, wants = [], []
+    for k in range(70):
+        m, n, kk = 5 + 3 * k, 200 - 2 * k, 17 + k
+        a = torch.randn(m, kk, dtype=torch.float64, device=gpu)
+        b = torch.randn(kk, n, dtype=torch.float64, device=gpu)
+        jobs.append(ops.Gemm64(a, b))
+        wants.append(a @ b)
+    for n in (1024, 1100, 1300):
+        lo = torch.tril(torch.randn(n, n, dtype=torch.float64, device=gpu))
+        up = torch.triu(torch.randn(n, n, dtype=torch.float64, device=gpu))
+        jobs.insert(7 * (n % 9), ops.Gemm64(up, lo, tri=ops.TRI64_A_UPPER | ops.TRI64_B_LOWER))
+        wants.insert(7 * (n % 9), up @ lo)
+    outs = ops.gemm_f64_batched(jobs)
+    for c, want in zip(outs, wants):
+        assert c.shape == want.shape
+        assert float((c - want).abs().max()) <= 1e-12 * max(float(want.abs().max()), 1.0)
