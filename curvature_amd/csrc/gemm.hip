@@ -463,6 +463,8 @@ gemm_nt_reduce_kernel(const GemmDev* __restrict__ table, int n_desc, const float
 // flight at once - no LDS staging, no per-stage barrier: one memory round trip per 128 k of a wave.  The four partial
 // blocks meet in LDS and are summed in wave order (bit-reproducible); wave w finishes registers 4w .. 4w+3.
 // Rows beyond M / N are clamped to the last row (never stored); k beyond K is zeroed; a triangular operand cuts K.
+// Operand rows need only 4-byte alignment (a 401-wide factor, a column slice of a wider buffer): the 16-byte loads are
+// dword-aligned global loads, which gfx950 serves (as do the buffer loads of gemm_nt_kernel on the same operands).
 // ------------------------------------------------------------------------------------------------
 namespace sm {
 constexpr int T = 32;            // output block edge

@@ -924,7 +924,7 @@ static void pick_strides(const FactorDev& f, int rows_in, int cols_in, int& RS, 
 #ifndef CURV_SMALL_CHUNK_PX
 #define CURV_SMALL_CHUNK_PX 1024
 #endif
-static thread_local int g_chunk_px_cap = 4096;
+static thread_local int g_chunk_px_cap = 4096;      // set by build_plan for the plan it builds (chunk_fits has no other caller)
 
 static bool chunk_fits(const FactorDev& f, int NS, int R, int Wc, ChunkGeom& g) {
   g.rows_in = f.compact ? R : (R - 1) * f.sh + f.kh;
