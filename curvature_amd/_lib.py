@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(CSRC, "libcurv_hip.so")
-SOURCES = ["api.cpp", "collective.cpp", "elementwise.hip", "syrk.hip", "syrk_flat.hip", "syrk_corr.hip", "syrk_pre.hip", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
+SOURCES = ["api.cpp", "collective.cpp", "elementwise.hip", "syrk.hip", "syrk_flat.hip", "syrk_corr.hip", "syrk_pre.hip", "syrk_small.hip", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall",
                "-Wno-unused-function", "-ldl"]
 

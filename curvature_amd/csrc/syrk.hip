@@ -1318,7 +1318,8 @@ static size_t slab_bytes(const Plan& plan) { return align_up((size_t)plan.slab_f
 extern "C" size_t curv_kfac_workspace_bytes(const curv_factor_desc* descs, int n_factors) {
   Plan plan;
   if (plan_without_pointers(descs, n_factors, plan) != CURV_OK) return 0;
-  return table_bytes((int)plan.f.size()) + slab_bytes(plan) + (size_t)plan.area_floats * sizeof(float);
+  const size_t grouped = table_bytes((int)plan.f.size()) + slab_bytes(plan) + (size_t)plan.area_floats * sizeof(float);
+  return std::max(grouped, kfac_small_workspace_bytes(descs, n_factors));      // (either path may take the call)
 }
 
 extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors, long long* out) {
@@ -1400,6 +1401,12 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
   all.insert(all.end(), plan.order[2].begin(), plan.order[2].end());
   const int n_table = (int)all.size();
   static thread_local TableShadow shadow;
+  {
+    // a small launch (LeNet scale) is built by the two launches of syrk_small.hip instead; they use the head of the
+    // workspace for their slabs, so whatever table the shadow remembers there is gone
+    const int rcs = kfac_accumulate_small(stream, descs, n_factors, workspace, workspace_bytes, ev_start, ev_stop);
+    if (rcs != CURV_ERR_WORKSPACE) { shadow.ws = nullptr; shadow.rows.clear(); return rcs; }
+  }
   const bool resident = (flags & CURV_KFAC_TABLE_RESIDENT) && shadow.ws == workspace;
   if (!resident) shadow.rows.clear();
   shadow.ws = workspace;

@@ -202,6 +202,13 @@ __device__ __forceinline__ void direct_store_quadrant(const FactorDev& d, int pa
   if (part != 2) direct_store_block(t, c11, qi0 + 32, qj0 + 32, r32, h, dq, first, mirror);
 }
 
+// syrk_small.hip: the two-launch build of a small launch (LeNet scale).  kfac_small_workspace_bytes: 0 if the launch is
+// not a small one; kfac_accumulate_small: CURV_ERR_WORKSPACE (no error text) if it is not, or if the workspace does not
+// hold its slabs - the caller then takes the grouped path.
+size_t kfac_small_workspace_bytes(const curv_factor_desc* descs, int n);
+int kfac_accumulate_small(hipStream_t stream, const curv_factor_desc* descs, int n, void* workspace, size_t workspace_bytes,
+                          void* ev_start, void* ev_stop);
+
 // invert.hip: one of the library's internal streams (per thread and device), lent to the factor build's side work
 int curv_internal_side_stream(hipStream_t* out);
 

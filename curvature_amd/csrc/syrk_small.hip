@@ -1,0 +1,327 @@
+// KFAC factor build of a SMALL launch (LeNet-scale: ten factors, 0.6 GFLOP) on gfx950: two launches.
+//
+// The grouped build of syrk.hip is made for models whose factors fill the chip: LDS-staged patch images, k-slices of tens
+// of thousands of pixels, three MFMA kernels that are big straight-line programs.  On a launch this small every
+// workgroup runs one short item, pays for fetching that program cold and for filling and staging 70 KB of LDS, and the
+// launch lasts as long as its slowest item: 35-50 us per factor CLASS whatever its size (a 121-wide Linear factor with
+// K = 100: 45 us; profiles/r04_lenet_trace.txt), five launches and two streams per update().
+//
+// Here a workgroup owns one 32 x 32 block (bi <= bj) of one factor and one slice of its K range (samples x output
+// pixels); its four waves split the slice.  A lane gathers its two operand values of a step straight from the source
+// tensor - row i = (channel, kh, kw) of the unfolded matrix at pixel k = (sample, y, x) is
+// src[sample][channel][y sh + kh - ph][x sw + kw - pw], zero outside, 1 for the bias row (curvatures.py:329-343) -
+// eight steps of loads in flight behind eight MFMAs; no LDS staging, no chunk planning.  The partial
+// blocks go to slabs; syrk_small_reduce_kernel sums a block's slices in a fixed order (bit-reproducible), scales, adds
+// into the factor and writes the mirror block.  The slicing aims at ~4 workgroups per CU for the launch as a whole.
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "syrk_plan.h"
+
+namespace curv {
+
+struct SmallDev {
+  const float* src;
+  float* dst;
+  int N, C, H, W, kh, kw, sh, sw, ph, pw, Ho, Wo;
+  int rows, dim, has_bias, first;
+  float scale;
+  int nb, n_pairs, n_slices, kslice, K;
+  int wg_base, red_base;
+  long long slab_base;                   // floats
+};
+constexpr int SMALL_CHUNK = 24;
+struct SmallChunk { SmallDev f[SMALL_CHUNK]; };
+static_assert(sizeof(SmallChunk) <= 3840, "kernel argument block must stay below 4 KB");
+
+typedef __attribute__((address_space(1))) float gfl;
+
+__device__ __forceinline__ void small_pair(int nb, int pair, int& bi, int& bj) {
+  bi = 0;
+  while (pair >= nb - bi) { pair -= nb - bi; ++bi; }
+  bj = bi + pair;
+}
+
+// one operand row of the unfolded matrix: kind 0 = patch row (plane offset, kernel offsets), 1 = ones (bias), 2 = zero
+struct SmallRow { int kind, plane, oy, ox; };
+__device__ __forceinline__ SmallRow small_row(const SmallDev& d, int i) {
+  SmallRow r;
+  if (i < d.rows) {
+    const int khkw = d.kh * d.kw, c = i / khkw, rem = i - c * khkw, a = rem / d.kw, b = rem - a * d.kw;
+    r.kind = 0; r.plane = c * d.H * d.W; r.oy = a - d.ph; r.ox = b - d.pw;
+  } else {
+    r.kind = (i == d.rows && d.has_bias) ? 1 : 2; r.plane = 0; r.oy = 0; r.ox = 0;
+  }
+  return r;
+}
+
+constexpr int SMALL_U = 8;               // steps of loads in flight
+constexpr int SMALL_WAVES = 8;           // waves per workgroup: they split the slice's K range (16 accumulator registers / 8)
+
+__global__ void __launch_bounds__(64 * SMALL_WAVES)
+syrk_small_kernel(SmallChunk chunk, int count, float* __restrict__ slabs) {
+  __shared__ float part[SMALL_WAVES][16][64];
+  int f = 0;
+  while (f + 1 < count && chunk.f[f + 1].wg_base <= (int)blockIdx.x) ++f;
+  const SmallDev& d = chunk.f[f];
+  const int local = blockIdx.x - d.wg_base;
+  const int pair = local / d.n_slices, slice = local - pair * d.n_slices;
+  int bi, bj;
+  small_pair(d.nb, pair, bi, bj);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+  // this wave's share of the slice (whole k pairs)
+  const int ks0 = slice * d.kslice, ks1 = min(d.K, ks0 + d.kslice);
+  const int q = (((ks1 - ks0 + SMALL_WAVES - 1) / SMALL_WAVES) + 1) & ~1;
+  const int kb = ks0 + wave * q, ke = min(ks1, kb + q);
+  const SmallRow ra = small_row(d, 32 * bi + r32), rb = small_row(d, 32 * bj + r32);
+  const int H = d.H, W = d.W, Ho = d.Ho, Wo = d.Wo, sh = d.sh, sw = d.sw, sample = d.C * H * W;
+  const gfl* src = (const gfl*)d.src;
+  // lane constants of the two rows: offset of the row's window corner inside a sample, and the window's displacement
+  const int ca = ra.plane + ra.oy * W + ra.ox, cb = rb.plane + rb.oy * W + rb.ox;
+  f32x16 acc = {0};
+  if (kb < ke) {
+    // the lane's pixel (sample n, output row y, column x) of its k value kk = kb + h (+ 2 per step), kept as
+    // ys = y sh, xs = x sw and off = n sample + ys W + xs (all advanced incrementally)
+    int kk = kb + h;
+    const int n0 = kk / (Ho * Wo), rem = kk - n0 * (Ho * Wo), y0 = rem / Wo, x0 = rem - y0 * Wo;
+    int x = x0, y = y0, xs = x0 * sw, ys = y0 * sh, off = n0 * sample + ys * W + xs;
+    const int nsteps = (ke - kb + 1) >> 1;
+    const int row_step = sh * W - Wo * sw, img_step = sample - Ho * sh * W;
+    const bool diag = bi == bj;                            // (wave-uniform)
+    // Two register sets: the loads of the next SMALL_U steps are in flight behind the MFMAs of the current ones.  A step
+    // is branch-free and does not look at what it loaded: the load is always issued (element 0 of the tensor when the
+    // lane has nothing to read), the pixel counters carry through selects, and the "zero / one / loaded" choice is made
+    // from per-step mask bits when the value is consumed (`v = ok ? src[..] : c` made the compiler wait for memory
+    // inside every step).  What bounds the kernel now is the address arithmetic: ~90 scalar / vector instructions per
+    // step next to its one MFMA - 165 k steps for LeNet-5's ten factors, 25 of the launch's 31 us (6 us with the loop
+    // compiled out).  A per-slice pixel table in LDS would cut that; not built.
+    struct Batch { float a[SMALL_U], b[SMALL_U]; unsigned oka, okb, live; };
+    auto fetch = [&](Batch& t, int s0) __attribute__((always_inline)) {
+      t.oka = t.okb = t.live = 0u;
+#pragma unroll
+      for (int u = 0; u < SMALL_U; ++u) {
+        const bool live = s0 + u < nsteps && kk < ke;
+        const bool oka = live && ra.kind == 0 && (unsigned)(ys + ra.oy) < (unsigned)H && (unsigned)(xs + ra.ox) < (unsigned)W;
+        const bool okb = live && rb.kind == 0 && (unsigned)(ys + rb.oy) < (unsigned)H && (unsigned)(xs + rb.ox) < (unsigned)W;
+        t.a[u] = src[oka ? off + ca : 0];
+        if (!diag) t.b[u] = src[okb ? off + cb : 0];          // (wave-uniform: a diagonal block has one operand)
+        t.oka |= (oka ? 1u : 0u) << u; t.okb |= (okb ? 1u : 0u) << u; t.live |= (live ? 1u : 0u) << u;
+        kk += 2;
+        x += 2; xs += 2 * sw; off += 2 * sw;
+#pragma unroll
+        for (int carry = 0; carry < 2; ++carry) {             // at most two row ends per step (Wo = 1)
+          const bool cx = x >= Wo;
+          x -= cx ? Wo : 0; xs -= cx ? Wo * sw : 0; ys += cx ? sh : 0; off += cx ? row_step : 0; y += cx ? 1 : 0;
+          const bool cy = y == Ho;
+          y = cy ? 0 : y; ys = cy ? 0 : ys; off += cy ? img_step : 0;
+        }
+      }
+    };
+    const float one_a = ra.kind == 1 ? 1.0f : 0.0f, one_b = rb.kind == 1 ? 1.0f : 0.0f;
+    auto compute = [&](const Batch& t, int s0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < SMALL_U; ++u) {
+        if (s0 + u < nsteps) {
+          const bool live = (t.live >> u) & 1u;
+          const float va = ((t.oka >> u) & 1u) ? t.a[u] : (live ? one_a : 0.0f);
+          const float vb = diag ? va : (((t.okb >> u) & 1u) ? t.b[u] : (live ? one_b : 0.0f));
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, acc, 0, 0, 0);
+        }
+      }
+    };
+    Batch t0, t1;
+    fetch(t0, 0);
+    for (int s0 = 0; s0 < nsteps; s0 += 2 * SMALL_U) {
+      if (s0 + SMALL_U < nsteps) fetch(t1, s0 + SMALL_U);
+      compute(t0, s0);
+      if (s0 + 2 * SMALL_U < nsteps) fetch(t0, s0 + 2 * SMALL_U);
+      if (s0 + SMALL_U < nsteps) compute(t1, s0 + SMALL_U);
+    }
+  }
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) part[wave][reg][lane] = acc[reg];
+  __syncthreads();
+  // C/D map of the 32x32 block: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); wave w finishes
+  // registers 2 w, 2 w + 1 (the partial blocks summed in wave order)
+  gfl* slab = (gfl*)slabs + d.slab_base + ((long long)pair * d.n_slices + slice) * 1024;
+#pragma unroll
+  for (int qq = 0; qq < 16 / SMALL_WAVES; ++qq) {
+    const int reg = (16 / SMALL_WAVES) * wave + qq;
+    float v = part[0][reg][lane];
+#pragma unroll
+    for (int p = 1; p < SMALL_WAVES; ++p) v += part[p][reg][lane];
+    slab[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 32 + r32] = v;
+  }
+}
+
+// One workgroup of 1024 threads per block: thread group g (of four) sums the g-th quarter of the block's slices, 16 loads
+// per element in flight (a slab written by another XCD is a 2 us round trip: summing 64 slices eight at a time took 15 us);
+// the four partial sums meet in LDS and are added in group order, so the result is a fixed function of the slabs.
+__global__ void __launch_bounds__(1024)
+syrk_small_reduce_kernel(SmallChunk chunk, int count, const float* __restrict__ slabs) {
+  __shared__ float partial[3][1024];
+  int f = 0;
+  while (f + 1 < count && chunk.f[f + 1].red_base <= (int)blockIdx.x) ++f;
+  const SmallDev& d = chunk.f[f];
+  const int pair = blockIdx.x - d.red_base;
+  int bi, bj;
+  small_pair(d.nb, pair, bi, bj);
+  const int dim = d.dim, n_slices = d.n_slices;
+  const float scale = d.scale;
+  const bool first = d.first != 0;
+  const float* base = slabs + d.slab_base + (long long)pair * n_slices * 1024;
+  gfl* dst = (gfl*)d.dst;
+  const int g = threadIdx.x >> 8, t = threadIdx.x & 255;
+  const int per = (n_slices + 3) >> 2, s_lo = g * per, s_hi = min(n_slices, s_lo + per);
+  float v[4];
+  bool live[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = t + 256 * u;
+    live[u] = 32 * bi + (e >> 5) < dim && 32 * bj + (e & 31) < dim;
+    v[u] = 0.0f;
+  }
+  int s = s_lo;
+  for (; s + 16 <= s_hi; s += 16) {
+    float w[4][16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (live[u]) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[u][k] = base[(long long)(s + k) * 1024 + t + 256 * u];
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (live[u]) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[u] += w[u][k];
+      }
+  }
+  for (; s < s_hi; ++s) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (live[u]) v[u] += base[(long long)s * 1024 + t + 256 * u];
+  }
+  if (g > 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) partial[g - 1][t + 256 * u] = v[u];
+  }
+  __syncthreads();
+  if (g > 0) return;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (!live[u]) continue;
+    const int e = t + 256 * u, gi = 32 * bi + (e >> 5), gj = 32 * bj + (e & 31);
+    const float out = (((v[u] + partial[0][e]) + partial[1][e]) + partial[2][e]) * scale;
+    const long long idx = (long long)gi * dim + gj;
+    dst[idx] = first ? out : dst[idx] + out;
+    if (bi != bj) {
+      const long long mdx = (long long)gj * dim + gi;
+      dst[mdx] = first ? out : dst[mdx] + out;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+#ifndef CURV_SMALL_MAX_FLOP
+#define CURV_SMALL_MAX_FLOP 2.0e9      // executed multiply-add flops (32 x 32 blocks on and above the diagonal) of the launch
+#endif
+constexpr int SMALL_TARGET_WGS = 1024;   // ~4 workgroups per CU
+constexpr int SMALL_MIN_KSLICE = 256, SMALL_MAX_KSLICE = 8192;   // (a wave sums at most a quarter of a slice in one chain)
+constexpr int SMALL_MAX_SLICES = 64;     // the reduce pass walks a block's slices eight at a time: a round trip each
+
+struct SmallPlan { std::vector<SmallDev> f; long long wgs = 0, red_wgs = 0, slab_floats = 0; };
+
+static bool small_plan(const curv_factor_desc* descs, int n, SmallPlan& plan) {
+  const char* env = getenv("CURV_KFAC_SMALL");
+  if (env != nullptr && atoi(env) == 0) return false;
+  if (n <= 0 || n > 4 * SMALL_CHUNK) return false;
+  plan.f.resize(n);
+  double flop = 0.0, work = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const curv_factor_desc& s = descs[i];
+    SmallDev& d = plan.f[i];
+    memset(&d, 0, sizeof(d));
+    if (s.N <= 0 || s.C <= 0 || s.H <= 0 || s.W <= 0 || s.kh <= 0 || s.kw <= 0 || s.sh <= 0 || s.sw <= 0 || s.ph < 0 || s.pw < 0)
+      return false;                                                       // (the grouped path reports the error)
+    if (s.H + 2 * s.ph < s.kh || s.W + 2 * s.pw < s.kw) return false;
+    if ((long long)s.N * s.C * s.H * s.W >= (1LL << 31)) return false;
+    d.src = s.src; d.dst = s.dst;
+    d.N = s.N; d.C = s.C; d.H = s.H; d.W = s.W; d.kh = s.kh; d.kw = s.kw; d.sh = s.sh; d.sw = s.sw; d.ph = s.ph; d.pw = s.pw;
+    d.Ho = (s.H + 2 * s.ph - s.kh) / s.sh + 1;
+    d.Wo = (s.W + 2 * s.pw - s.kw) / s.sw + 1;
+    d.rows = s.C * s.kh * s.kw;
+    d.has_bias = s.has_bias ? 1 : 0;
+    d.dim = d.rows + d.has_bias;
+    d.first = s.first; d.scale = s.scale;
+    const long long K = (long long)s.N * d.Ho * d.Wo;
+    if (K >= (1LL << 30) || (long long)d.dim * d.dim >= (1LL << 31)) return false;
+    d.K = (int)K;
+    d.nb = cdiv(d.dim, 32);
+    d.n_pairs = d.nb * (d.nb + 1) / 2;
+    flop += 2.0 * 1024.0 * d.n_pairs * (double)K;
+    work += (double)d.n_pairs * (double)K;
+    if (flop > CURV_SMALL_MAX_FLOP) return false;
+  }
+  // one slicing rule for the launch: ~SMALL_TARGET_WGS workgroups of equal work
+  long long px = (long long)(work / SMALL_TARGET_WGS) + 1;
+  px = std::min<long long>(std::max<long long>(px, SMALL_MIN_KSLICE), SMALL_MAX_KSLICE);
+  for (int i = 0; i < n; ++i) {
+    SmallDev& d = plan.f[i];
+    d.n_slices = (int)std::min<long long>(cdivll(d.K, px), SMALL_MAX_SLICES);
+    d.kslice = (cdiv(d.K, d.n_slices) + 7) & ~7;
+    if (d.kslice > SMALL_MAX_KSLICE) return false;            // a factor this long is not a small launch's
+    d.n_slices = cdiv(d.K, d.kslice);
+    d.wg_base = (int)plan.wgs;
+    d.red_base = (int)plan.red_wgs;
+    d.slab_base = plan.slab_floats;
+    plan.wgs += (long long)d.n_pairs * d.n_slices;
+    plan.red_wgs += d.n_pairs;
+    plan.slab_floats += (long long)d.n_pairs * d.n_slices * 1024;
+    if (plan.wgs >= (1LL << 24)) return false;
+  }
+  return true;
+}
+
+// bytes of workspace the small path needs for these factors; 0: the launch is not a small one
+size_t kfac_small_workspace_bytes(const curv_factor_desc* descs, int n) {
+  SmallPlan plan;
+  if (!small_plan(descs, n, plan)) return 0;
+  return align_up((size_t)plan.slab_floats * sizeof(float), 256);
+}
+
+// CURV_OK: done.  CURV_ERR_WORKSPACE (without an error text): not a small launch, or the workspace does not hold its
+// slabs - the caller takes the grouped path.
+int kfac_accumulate_small(hipStream_t stream, const curv_factor_desc* descs, int n, void* workspace, size_t workspace_bytes,
+                          void* ev_start, void* ev_stop) {
+  SmallPlan plan;
+  if (!small_plan(descs, n, plan)) return CURV_ERR_WORKSPACE;
+  if (workspace == nullptr || workspace_bytes < (size_t)plan.slab_floats * sizeof(float)) return CURV_ERR_WORKSPACE;
+  for (int i = 0; i < n; ++i)
+    CURV_REQUIRE(descs[i].src != nullptr && descs[i].dst != nullptr, "curv_kfac: factor %d: null pointer", i);
+  float* slabs = reinterpret_cast<float*>(workspace);
+  if (ev_start) CURV_HIP_CHECK(hipEventRecord((hipEvent_t)ev_start, stream));
+  for (int b = 0; b < n; b += SMALL_CHUNK) {
+    SmallChunk chunk;
+    memset(&chunk, 0, sizeof(chunk));
+    const int count = std::min(SMALL_CHUNK, n - b);
+    long long wgs = 0, red = 0;
+    for (int k = 0; k < count; ++k) {
+      chunk.f[k] = plan.f[b + k];
+      chunk.f[k].wg_base = (int)wgs;
+      chunk.f[k].red_base = (int)red;
+      wgs += (long long)chunk.f[k].n_pairs * chunk.f[k].n_slices;
+      red += chunk.f[k].n_pairs;
+    }
+    hipLaunchKernelGGL(syrk_small_kernel, dim3((unsigned)wgs), dim3(64 * SMALL_WAVES), 0, stream, chunk, count, slabs);
+    CURV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(syrk_small_reduce_kernel, dim3((unsigned)red), dim3(1024), 0, stream, chunk, count, (const float*)slabs);
+    CURV_LAUNCH_CHECK();
+  }
+  if (ev_stop) CURV_HIP_CHECK(hipEventRecord((hipEvent_t)ev_stop, stream));
+  return CURV_OK;
+}
+
+}  // namespace curv

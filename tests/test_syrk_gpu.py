@@ -10,6 +10,16 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
 
+
+@pytest.fixture(autouse=True, params=["grouped", "small"])
+def build_path(request, monkeypatch):
+    """Every case of this file runs twice: through the grouped build of syrk.hip (what a model that fills the GPU gets)
+    and with the two-launch small-model build of syrk_small.hip allowed (what most of these geometries - a handful of
+    samples - are routed to by default; cases above its size limit take the grouped path in both runs)."""
+    monkeypatch.setenv("CURV_KFAC_SMALL", "0" if request.param == "grouped" else "1")
+    return request.param
+
+
 # (N, C, H, W, kernel, stride, padding, bias)
 CONV_CASES = [
     (3, 1, 28, 28, 5, 1, 2, True),      # LeNet conv1

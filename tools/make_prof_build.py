@@ -52,7 +52,7 @@ extern "C" int curv_debug_syrk_prof(unsigned long long* out, int reset) {
     src = "/tmp/syrk_prof.hip"
     open(src, "w").write(s)
     out = os.path.join(ROOT, "tools", "micro", "libcurv_prof.so")
-    others = ["api.cpp", "elementwise.hip", "syrk_flat.hip", "syrk_corr.hip", "syrk_pre.hip", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
+    others = ["api.cpp", "elementwise.hip", "syrk_flat.hip", "syrk_corr.hip", "syrk_pre.hip", "syrk_small.hip", "collective.cpp", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
     # -DCURV_DIAG: the only build in which CURV_SYRK_ABLATE (phase ablation switches) is read
     cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DCURV_DIAG", "-I" + os.path.join(ROOT, "include"),
            "-I" + CSRC, "-o", out, src] + [os.path.join(CSRC, o) for o in others]

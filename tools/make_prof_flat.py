@@ -44,7 +44,7 @@ extern "C" int curv_debug_flat_prof(unsigned long long* out, int reset) {
     src = "/tmp/syrk_flat_prof.hip"
     open(src, "w").write(s)
     out = os.path.join(ROOT, "tools", "micro", "libcurv_prof_flat.so")
-    others = ["api.cpp", "elementwise.hip", "syrk.hip", "syrk_corr.hip", "syrk_pre.hip", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
+    others = ["api.cpp", "elementwise.hip", "syrk.hip", "syrk_corr.hip", "syrk_pre.hip", "syrk_small.hip", "collective.cpp", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
     cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
            "-I" + CSRC, "-o", out, src] + [os.path.join(CSRC, o) for o in others]
     subprocess.check_call(cmd)
