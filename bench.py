@@ -214,7 +214,7 @@ def other_configs_gpu(dev, model50, kfac50, batch):
     ms = (time.perf_counter() - t0) / 50 * 1e3
     out["config2_lenet5_n100"] = {"workload": "LeNet-5 N=100: KFAC.update + invert(0.5, 1) + sample_and_replace, 5 layers",
                                   "ms_per_step": ms, "layers_per_s": 5 / ms * 1e3,
-                                  "bound": "launch latency (0.6 GFLOP and 0.04 MB per sample: ~20 launches per step)"}
+                                  "bound": "launch latency (0.6 GFLOP and 0.04 MB per sample: ~16 launches per step)"}
     try:        # the same step captured once and replayed as a HIP graph (curvature_amd.graph; bit-identical to eager)
         from curvature_amd.graph import KFACStepGraph
         k2.restart_accumulation()
