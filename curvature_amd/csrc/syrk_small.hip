@@ -57,11 +57,13 @@ __device__ __forceinline__ SmallRow small_row(const SmallDev& d, int i) {
 }
 
 constexpr int SMALL_U = 8;               // steps of loads in flight
+constexpr int SMALL_MAX_KSLICE = 2048;   // k values of a slice: the pixel table of a workgroup (16 KB); a wave sums a 1/8 of it in one chain
 constexpr int SMALL_WAVES = 8;           // waves per workgroup: they split the slice's K range (16 accumulator registers / 8)
 
 __global__ void __launch_bounds__(64 * SMALL_WAVES)
 syrk_small_kernel(SmallChunk chunk, int count, float* __restrict__ slabs) {
   __shared__ float part[SMALL_WAVES][16][64];
+  __shared__ int2 ktab[SMALL_MAX_KSLICE];
   int f = 0;
   while (f + 1 < count && chunk.f[f + 1].wg_base <= (int)blockIdx.x) ++f;
   const SmallDev& d = chunk.f[f];
@@ -81,43 +83,39 @@ syrk_small_kernel(SmallChunk chunk, int count, float* __restrict__ slabs) {
   const gfl* src = (const gfl*)d.src;
   // lane constants of the two rows: offset of the row's window corner inside a sample, and the window's displacement
   const int ca = ra.plane + ra.oy * W + ra.ox, cb = rb.plane + rb.oy * W + rb.ox;
+  const bool diag = bi == bj;                              // (wave-uniform: a diagonal block has one operand)
+  // Pixel table of the slice: entry k - ks0 = {offset of pixel k's window origin in the tensor, y sh << 16 | x sw} (two
+  // integer divisions per pixel, once per workgroup; carrying (sample, y, x) through every step in registers cost ~90
+  // instructions per step).  The launch is bound by this per-element work all the same - a table read, two window tests,
+  // an address and a select per operand value, ~50 instructions per step beside its one MFMA: LeNet-5's ten factors are
+  // 165 k wave-steps, 29 us, of which 6 remain with the K loop compiled out and 23-25 with either the loads or the MFMAs
+  // compiled out.  Staging zero-padded images in LDS, as the grouped kernels do, would remove the tests; not built.
+  for (int e = tid; e < ks1 - ks0; e += 64 * SMALL_WAVES) {
+    const int k = ks0 + e, n = k / (Ho * Wo), rem = k - n * (Ho * Wo), y = rem / Wo, x = rem - y * Wo;
+    ktab[e] = make_int2(n * sample + y * sh * W + x * sw, (y * sh) << 16 | (x * sw));
+  }
+  __syncthreads();
   f32x16 acc = {0};
   if (kb < ke) {
-    // the lane's pixel (sample n, output row y, column x) of its k value kk = kb + h (+ 2 per step), kept as
-    // ys = y sh, xs = x sw and off = n sample + ys W + xs (all advanced incrementally)
-    int kk = kb + h;
-    const int n0 = kk / (Ho * Wo), rem = kk - n0 * (Ho * Wo), y0 = rem / Wo, x0 = rem - y0 * Wo;
-    int x = x0, y = y0, xs = x0 * sw, ys = y0 * sh, off = n0 * sample + ys * W + xs;
     const int nsteps = (ke - kb + 1) >> 1;
-    const int row_step = sh * W - Wo * sw, img_step = sample - Ho * sh * W;
-    const bool diag = bi == bj;                            // (wave-uniform)
     // Two register sets: the loads of the next SMALL_U steps are in flight behind the MFMAs of the current ones.  A step
-    // is branch-free and does not look at what it loaded: the load is always issued (element 0 of the tensor when the
-    // lane has nothing to read), the pixel counters carry through selects, and the "zero / one / loaded" choice is made
-    // from per-step mask bits when the value is consumed (`v = ok ? src[..] : c` made the compiler wait for memory
-    // inside every step).  What bounds the kernel now is the address arithmetic: ~90 scalar / vector instructions per
-    // step next to its one MFMA - 165 k steps for LeNet-5's ten factors, 25 of the launch's 31 us (6 us with the loop
-    // compiled out).  A per-slice pixel table in LDS would cut that; not built.
+    // does not look at what it loaded: the load is always issued (element 0 of the tensor when the lane has nothing to
+    // read) and the "zero / one / loaded" choice is made from per-step mask bits when the value is consumed
+    // (`v = ok ? src[..] : c` made the compiler wait for memory inside every step).
     struct Batch { float a[SMALL_U], b[SMALL_U]; unsigned oka, okb, live; };
     auto fetch = [&](Batch& t, int s0) __attribute__((always_inline)) {
       t.oka = t.okb = t.live = 0u;
 #pragma unroll
       for (int u = 0; u < SMALL_U; ++u) {
+        const int kk = kb + 2 * (s0 + u) + h;
         const bool live = s0 + u < nsteps && kk < ke;
+        const int2 px = ktab[live ? kk - ks0 : 0];
+        const int ys = px.y >> 16, xs = px.y & 0xffff;
         const bool oka = live && ra.kind == 0 && (unsigned)(ys + ra.oy) < (unsigned)H && (unsigned)(xs + ra.ox) < (unsigned)W;
         const bool okb = live && rb.kind == 0 && (unsigned)(ys + rb.oy) < (unsigned)H && (unsigned)(xs + rb.ox) < (unsigned)W;
-        t.a[u] = src[oka ? off + ca : 0];
-        if (!diag) t.b[u] = src[okb ? off + cb : 0];          // (wave-uniform: a diagonal block has one operand)
+        t.a[u] = src[oka ? px.x + ca : 0];
+        if (!diag) t.b[u] = src[okb ? px.x + cb : 0];
         t.oka |= (oka ? 1u : 0u) << u; t.okb |= (okb ? 1u : 0u) << u; t.live |= (live ? 1u : 0u) << u;
-        kk += 2;
-        x += 2; xs += 2 * sw; off += 2 * sw;
-#pragma unroll
-        for (int carry = 0; carry < 2; ++carry) {             // at most two row ends per step (Wo = 1)
-          const bool cx = x >= Wo;
-          x -= cx ? Wo : 0; xs -= cx ? Wo * sw : 0; ys += cx ? sh : 0; off += cx ? row_step : 0; y += cx ? 1 : 0;
-          const bool cy = y == Ho;
-          y = cy ? 0 : y; ys = cy ? 0 : ys; off += cy ? img_step : 0;
-        }
       }
     };
     const float one_a = ra.kind == 1 ? 1.0f : 0.0f, one_b = rb.kind == 1 ? 1.0f : 0.0f;
@@ -229,7 +227,7 @@ syrk_small_reduce_kernel(SmallChunk chunk, int count, const float* __restrict__ 
 #define CURV_SMALL_MAX_FLOP 2.0e9      // executed multiply-add flops (32 x 32 blocks on and above the diagonal) of the launch
 #endif
 constexpr int SMALL_TARGET_WGS = 1024;   // ~4 workgroups per CU
-constexpr int SMALL_MIN_KSLICE = 256, SMALL_MAX_KSLICE = 8192;   // (a wave sums at most a quarter of a slice in one chain)
+constexpr int SMALL_MIN_KSLICE = 256;
 constexpr int SMALL_MAX_SLICES = 64;     // the reduce pass walks a block's slices eight at a time: a round trip each
 
 struct SmallPlan { std::vector<SmallDev> f; long long wgs = 0, red_wgs = 0, slab_floats = 0; };
@@ -247,7 +245,7 @@ static bool small_plan(const curv_factor_desc* descs, int n, SmallPlan& plan) {
     if (s.N <= 0 || s.C <= 0 || s.H <= 0 || s.W <= 0 || s.kh <= 0 || s.kw <= 0 || s.sh <= 0 || s.sw <= 0 || s.ph < 0 || s.pw < 0)
       return false;                                                       // (the grouped path reports the error)
     if (s.H + 2 * s.ph < s.kh || s.W + 2 * s.pw < s.kw) return false;
-    if ((long long)s.N * s.C * s.H * s.W >= (1LL << 31)) return false;
+    if ((long long)s.N * s.C * s.H * s.W >= (1LL << 31) || s.H >= (1 << 15) || s.W >= (1 << 15)) return false;   // (pixel table packs y sh, x sw in 16 bits)
     d.src = s.src; d.dst = s.dst;
     d.N = s.N; d.C = s.C; d.H = s.H; d.W = s.W; d.kh = s.kh; d.kw = s.kw; d.sh = s.sh; d.sw = s.sw; d.ph = s.ph; d.pw = s.pw;
     d.Ho = (s.H + 2 * s.ph - s.kh) / s.sh + 1;
