@@ -83,7 +83,8 @@ class curv_gemm64_desc(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p)] + \
                [(k, ctypes.c_longlong) for k in ("a_rs", "a_cs", "b_rs", "b_cs", "c_rs", "c_cs")] + \
                [("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("tri", ctypes.c_int32),
-                ("alpha", ctypes.c_double), ("beta", ctypes.c_double)]
+                ("alpha", ctypes.c_double), ("beta", ctypes.c_double),
+                ("E", ctypes.c_void_p), ("row_scale", ctypes.c_void_p), ("col_scale", ctypes.c_void_p), ("C32", ctypes.c_void_p)]
 
 
 class curv_sq_desc(ctypes.Structure):
@@ -161,7 +162,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 5                     # CURV_ABI_VERSION of include/curv_hip.h
+ABI_VERSION = 6                     # CURV_ABI_VERSION of include/curv_hip.h
 KFAC_TABLE_RESIDENT = 1             # CURV_KFAC_TABLE_RESIDENT
 GEMM_TABLE_RESIDENT = 1             # CURV_GEMM_TABLE_RESIDENT
 ERR_NOT_PD, ERR_INVALID, ERR_WORKSPACE, ERR_HIP, ERR_NOT_CONVERGED = 1, 2, 3, 4, 5     # CURV_ERR_* of the header

@@ -549,14 +549,34 @@ struct Gemm64Dev {
   int M, N, K;
   int tiles_n, tile_base, tri;
   double alpha, beta;
+  const double* E;             // optional: C = alpha acc + beta E
+  const float* rs;             // optional fp32 output C32[i][j] = (float)(alpha rs[i] cs[j] acc)
+  const float* cs;
+  float* C32;
 };
 
 typedef __attribute__((address_space(1))) double gdbl;
 
+// C[i][j] = alpha acc + beta (E ? E : C)[i][j], or the scaled fp32 form
+__device__ __forceinline__ void gemm64_store(const Gemm64Dev& d, int i, int j, double acc) {
+  typedef __attribute__((address_space(1))) float gflt;
+  const long long ci = i * d.c_rs + j * d.c_cs;
+  if (d.C32 != nullptr) {
+    double v = d.alpha * acc;
+    if (d.rs != nullptr) v *= (double)((const gflt*)d.rs)[i];
+    if (d.cs != nullptr) v *= (double)((const gflt*)d.cs)[j];
+    ((gflt*)d.C32)[ci] = (float)v;
+    return;
+  }
+  double v = d.alpha * acc;
+  if (d.beta != 0.0) v += d.beta * (d.E != nullptr ? ((const gdbl*)d.E)[ci] : ((const gdbl*)d.C)[ci]);
+  ((gdbl*)d.C)[ci] = v;
+}
+
 // descriptors travel as kernel arguments, G64_BATCH per launch: a ResNet-scale INF.invert hands over 54 products of
 // 500-1100 tiles each, and four per launch (the first form) ended every launch with a partly filled round of its
 // longest tiles - 14 tails per call
-constexpr int G64_BATCH = 32;
+constexpr int G64_BATCH = 24;
 struct Gemm64Table { Gemm64Dev d[G64_BATCH]; };
 static_assert(sizeof(Gemm64Table) <= 3840, "kernel argument block must stay below 4 KB");
 
@@ -622,7 +642,7 @@ gemm_f64_kernel(const Gemm64Table tab, int n_desc) {
   if (d.tri & 4) k_lo = max(k_lo, j0);           // B lower: b[k][j] = 0 for k < j
   if (d.tri & 8) k_hi = min(k_hi, j0 + GT);      // B upper: b[k][j] = 0 for k > j
   k_lo &= ~(GK - 1);
-  if (k_lo >= k_hi && d.beta == 1.0) return;     // nothing to add
+  if (k_lo >= k_hi && d.beta == 1.0 && d.E == nullptr && d.C32 == nullptr) return;     // nothing to add
   if (k_lo < k_hi) fetch(k_lo);
   for (int k0 = k_lo; k0 < k_hi; k0 += GK) {
 #pragma unroll
@@ -647,7 +667,6 @@ gemm_f64_kernel(const Gemm64Table tab, int n_desc) {
     }
     __syncthreads();
   }
-  gdbl* C = (gdbl*)d.C;
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -655,12 +674,7 @@ gemm_f64_kernel(const Gemm64Table tab, int n_desc) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + 32 * wm + 16 * m + kq + 4 * r, j = j0 + 32 * wn + 16 * n + r16;
-        if (i < M && j < N) {
-          const long long ci = i * d.c_rs + j * d.c_cs;
-          double v = d.alpha * acc[m][n][r];
-          if (d.beta != 0.0) v += d.beta * C[ci];
-          C[ci] = v;
-        }
+        if (i < M && j < N) gemm64_store(d, i, j, acc[m][n][r]);
       }
 }
 
@@ -708,7 +722,7 @@ gemm_f64_macro_kernel(const Gemm64Table tab, int n_desc) {
   if (d.tri & 4) k_lo = max(k_lo, j0);               // B lower: b[k][j] = 0 for k < j
   if (d.tri & 8) k_hi = min(k_hi, j0 + G64M_T);      // B upper: b[k][j] = 0 for k > j
   k_lo &= ~(GK - 1);
-  if (k_lo >= k_hi && d.beta == 1.0) return;         // nothing to add
+  if (k_lo >= k_hi && d.beta == 1.0 && d.E == nullptr && d.C32 == nullptr) return;     // nothing to add
   double ra[8], rb[8];
   auto fetch = [&](int k0) __attribute__((always_inline)) {
     const gdbl* Ak = A + (long long)k0 * d.a_cs;
@@ -749,8 +763,6 @@ gemm_f64_macro_kernel(const Gemm64Table tab, int n_desc) {
     }
     __syncthreads();
   }
-  gdbl* C = (gdbl*)d.C;
-  const double alpha = d.alpha, beta = d.beta;
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -758,12 +770,7 @@ gemm_f64_macro_kernel(const Gemm64Table tab, int n_desc) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + 64 * wm + 16 * m + kq + 4 * r, j = j0 + 64 * wn + 16 * n + r16;
-        if (i < M && j < N) {
-          const long long ci = i * d.c_rs + j * d.c_cs;
-          double v = alpha * acc[m][n][r];
-          if (beta != 0.0) v += beta * C[ci];
-          C[ci] = v;
-        }
+        if (i < M && j < N) gemm64_store(d, i, j, acc[m][n][r]);
       }
 }
 
@@ -1123,7 +1130,9 @@ extern "C" int curv_gemm_f64_batched(void* stream_, const curv_gemm64_desc* desc
   CURV_REQUIRE(n_desc >= 0 && (n_desc == 0 || descs), "curv_gemm_f64_batched: bad arguments");
   for (int i = 0; i < n_desc; ++i) {
     const curv_gemm64_desc& s = descs[i];
-    CURV_REQUIRE(s.M > 0 && s.N > 0 && s.K >= 0 && s.A && s.B && s.C, "curv_gemm_f64_batched: desc %d invalid", i);
+    CURV_REQUIRE(s.M > 0 && s.N > 0 && s.K >= 0 && s.A && s.B && (s.C || s.C32), "curv_gemm_f64_batched: desc %d invalid", i);
+    CURV_REQUIRE(s.C32 == nullptr || (s.beta == 0.0 && s.E == nullptr), "curv_gemm_f64_batched: desc %d: the fp32 output takes no beta / E", i);
+    CURV_REQUIRE(s.E == nullptr || (s.C != nullptr && s.E != s.C), "curv_gemm_f64_batched: desc %d: E needs an output C of its own", i);
     CURV_REQUIRE((s.tri & ~15) == 0 && (s.tri & 3) != 3 && (s.tri & 12) != 12, "curv_gemm_f64_batched: desc %d: bad tri flags", i);
   }
   // launches of up to G64_BATCH descriptors (they travel as kernel arguments), per tile size, in the caller's order
@@ -1151,6 +1160,7 @@ extern "C" int curv_gemm_f64_batched(void* stream_, const curv_gemm64_desc* desc
       o.a_rs = s.a_rs; o.a_cs = s.a_cs; o.b_rs = s.b_rs; o.b_cs = s.b_cs; o.c_rs = s.c_rs; o.c_cs = s.c_cs;
       o.M = s.M; o.N = s.N; o.K = s.K; o.alpha = s.alpha; o.beta = s.beta;
       o.tri = s.tri;
+      o.E = s.E; o.rs = s.row_scale; o.cs = s.col_scale; o.C32 = s.C32;
       o.tiles_n = cdiv(s.N, T);
       o.tile_base = (int)tiles;
       tiles += (long long)cdiv(s.M, T) * o.tiles_n;

@@ -1315,19 +1315,24 @@ class INF(Curvature):
         # leave the GPU idle while the ~170 launches below are described and enqueued (14 of 115 ms on ResNet-50)
         inv = ops.chol_factor_inverse(mats, adds, check=False)
         info = ops.chol_factor_inverse.last_info
-        # T = (I - B^-1) A^-1 = A^-1 - B^-1 A^-1 (accumulated onto a copy of A^-1); L_c = A^-T T
-        Ts = [torch.empty_like(inv[2 * i]) for i in range(len(regs))]
-        ops.CopyPlan(Ts, [inv[2 * i] for i in range(len(regs))]).run()
-        # both inverses are lower triangular (zeros above), so is T: two thirds of the flops of INF.invert were these
+        # T = (I - B^-1) A^-1 = A^-1 - B^-1 A^-1 (the product's epilogue reads A^-1 as its E operand: no copy first);
+        # P_c = diag(sigma) A^-T T diag(sigma) (:570), scaled and rounded to float32 in the second product's epilogue.
+        # Both inverses are lower triangular (zeros above), so is T: two thirds of the flops of INF.invert were these
         # two products done densely - with the triangles declared they cost 1/6 and 1/3 of that
-        ops.gemm_f64_batched([ops.Gemm64(inv[2 * i + 1], inv[2 * i], T, alpha=-1.0, beta=1.0,
+        Ts = [torch.empty_like(inv[2 * i]) for i in range(len(regs))]
+        ops.gemm_f64_batched([ops.Gemm64(inv[2 * i + 1], inv[2 * i], T, alpha=-1.0, beta=1.0, E=inv[2 * i],
                                          tri=ops.TRI64_A_LOWER | ops.TRI64_B_LOWER) for i, T in enumerate(Ts)])
-        L_cs = ops.gemm_f64_batched([ops.Gemm64(inv[2 * i].t(), T, tri=ops.TRI64_A_UPPER | ops.TRI64_B_LOWER)
-                                     for i, T in enumerate(Ts)])
         out = []
         for i, (_, _, sigma, _) in enumerate(regs):
             prev = outs[i] if outs is not None else None
-            out.append(ops.diag_scale(L_cs[i], sigma, sigma, out=prev))
+            shape = tuple(Ts[i].shape)
+            if prev is None or tuple(prev.shape) != shape or prev.dtype != torch.float32 or prev.device != Ts[i].device \
+                    or not prev.is_contiguous():
+                prev = torch.empty(shape, dtype=torch.float32, device=Ts[i].device)
+            out.append(prev)
+        ops.gemm_f64_batched([ops.Gemm64(inv[2 * i].t(), T, tri=ops.TRI64_A_UPPER | ops.TRI64_B_LOWER, out32=out[i],
+                                         row_scale=regs[i][2].contiguous(), col_scale=regs[i][2].contiguous())
+                              for i, T in enumerate(Ts)])
         ops.check_factor_inverse_info(info)                              # RuntimeError where curvatures.py:566-567 raises: inside invert()
         return out
 

@@ -647,14 +647,18 @@ class Gemm64:
     """float64 C = alpha * A @ B [+ beta * C] on strided 2-D GPU views; C = None allocates the output.
     `tri`: TRI64_* flags for triangular operands (their other triangle must hold zeros; only the K range that can
     contribute to a tile is visited)."""
-    __slots__ = ("A", "B", "C", "alpha", "beta", "tri")
+    __slots__ = ("A", "B", "C", "alpha", "beta", "tri", "E", "row_scale", "col_scale", "out32")
 
-    def __init__(self, A, B, C=None, alpha=1.0, beta=0.0, tri=0):
+    def __init__(self, A, B, C=None, alpha=1.0, beta=0.0, tri=0, E=None, row_scale=None, col_scale=None, out32=None):
+        """`E` (float64, shape of C, not C itself): C = alpha A B + beta E.  `out32` (float32, shape of the product): the
+        result goes there instead, as float32(alpha * row_scale[i] * col_scale[j] * (A B)[i, j]) - either scale vector
+        (float32, length M / N) may be None; no C, beta or E in that form."""
         self.A, self.B, self.C, self.alpha, self.beta, self.tri = A, B, C, float(alpha), float(beta), int(tri)
+        self.E, self.row_scale, self.col_scale, self.out32 = E, row_scale, col_scale, out32
 
 
 def gemm_f64_batched(jobs: Sequence[Gemm64]) -> List[torch.Tensor]:
-    """All products through one call of curv_gemm_f64_batched (up to 32 descriptors per launch; the products must be
+    """All products through one call of curv_gemm_f64_batched (up to 24 descriptors per launch; the products must be
     independent of each other: large ones run in a launch of their own behind the small ones)."""
     n = len(jobs)
     if n == 0:
@@ -670,17 +674,37 @@ def gemm_f64_batched(jobs: Sequence[Gemm64]) -> List[torch.Tensor]:
         if K != K2:
             raise RuntimeError("gemm_f64: shape mismatch")
         C = j.C
-        if C is None:
-            if j.beta != 0.0:
-                raise RuntimeError("gemm_f64: beta needs an existing C")
-            C = torch.empty(M, N, dtype=torch.float64, device=j.A.device)
-        elif not C.is_cuda or C.dtype != torch.float64 or tuple(C.shape) != (M, N):
-            raise RuntimeError("gemm_f64: bad output tensor")
-        outs.append(C)
-        d[k].A, d[k].B, d[k].C = j.A.data_ptr(), j.B.data_ptr(), C.data_ptr()
+        if j.out32 is not None:
+            o = j.out32
+            if not o.is_cuda or o.dtype != torch.float32 or tuple(o.shape) != (M, N) or j.beta != 0.0 or j.E is not None \
+                    or C is not None:
+                raise RuntimeError("gemm_f64: the float32 output is an (M, N) float32 GPU tensor and takes no C / beta / E")
+            for v, length in ((j.row_scale, M), (j.col_scale, N)):
+                if v is not None and (not v.is_cuda or v.dtype != torch.float32 or not v.is_contiguous() or v.numel() != length):
+                    raise RuntimeError("gemm_f64: scale vectors are contiguous float32 GPU tensors of length M / N")
+            outs.append(o)
+            d[k].A, d[k].B, d[k].C, d[k].C32 = j.A.data_ptr(), j.B.data_ptr(), None, o.data_ptr()
+            d[k].row_scale = j.row_scale.data_ptr() if j.row_scale is not None else None
+            d[k].col_scale = j.col_scale.data_ptr() if j.col_scale is not None else None
+            d[k].c_rs, d[k].c_cs = o.stride()
+        else:
+            if C is None:
+                if j.beta != 0.0 and j.E is None:
+                    raise RuntimeError("gemm_f64: beta needs an existing C (or E)")
+                C = torch.empty(M, N, dtype=torch.float64, device=j.A.device)
+            elif not C.is_cuda or C.dtype != torch.float64 or tuple(C.shape) != (M, N):
+                raise RuntimeError("gemm_f64: bad output tensor")
+            if j.E is not None:
+                E = j.E
+                if not E.is_cuda or E.dtype != torch.float64 or tuple(E.shape) != (M, N) or E.stride() != C.stride() \
+                        or E.data_ptr() == C.data_ptr():
+                    raise RuntimeError("gemm_f64: E is a float64 GPU tensor with C's shape and strides, not C itself")
+                d[k].E = E.data_ptr()
+            outs.append(C)
+            d[k].A, d[k].B, d[k].C = j.A.data_ptr(), j.B.data_ptr(), C.data_ptr()
+            d[k].c_rs, d[k].c_cs = C.stride()
         d[k].a_rs, d[k].a_cs = j.A.stride()
         d[k].b_rs, d[k].b_cs = j.B.stride()
-        d[k].c_rs, d[k].c_cs = C.stride()
         d[k].M, d[k].N, d[k].K, d[k].alpha, d[k].beta, d[k].tri = M, N, K, j.alpha, j.beta, j.tri
     _lib.check(_lib.lib().curv_gemm_f64_batched(_lib.stream_ptr(), d, n), "curv_gemm_f64_batched")
     return outs

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CURV_ABI_VERSION 5
+#define CURV_ABI_VERSION 6
 
 #define CURV_OK 0
 #define CURV_ERR_NOT_PD 1
@@ -215,7 +215,7 @@ int curv_gemm_batched_ex(void* stream, const curv_gemm_desc* descs, int n_desc, 
  * diagonal): the products of the two triangular inverses of pre_sampler (curvatures.py:566-572) are 2/3 of INF.invert's
  * flops when done densely.  A lower x B lower leaves the tiles above the diagonal of C untouched for beta = 1 and
  * zero for beta = 0.  The products of one call are INDEPENDENT (no C of one may be an operand of another): they run
- * up to 32 to a launch, products with both output edges >= 1024 on 128 x 128 tiles in a launch of their own behind the
+ * up to 24 to a launch, products with both output edges >= 1024 on 128 x 128 tiles in a launch of their own behind the
  * others - not in the caller's order. */
 #define CURV_TRI64_A_LOWER 1
 #define CURV_TRI64_A_UPPER 2
@@ -229,6 +229,16 @@ typedef struct curv_gemm64_desc {
   int32_t M, N, K;
   int32_t tri;      /* CURV_TRI64_* flags, 0 = dense */
   double alpha, beta;
+  /* optional fused epilogues (all NULL: C = alpha * acc + beta * C as above):
+   *   E          C = alpha * acc + beta * E with E != C (same strides as C): T = A^-1 - B^-1 A^-1 of INF.pre_sampler
+   *              without a copy of A^-1 first; tiles whose K range is empty are still written (beta * E)
+   *   C32        fp32 output instead of C (C may be NULL; strides c_rs / c_cs count floats; beta must be 0):
+   *              C32[i][j] = (float)(alpha * row_scale[i] * col_scale[j] * acc), either scale vector may be NULL (= 1):
+   *              P_c = diag(sigma) L_c diag(sigma) of pre_sampler (:570) straight from the product */
+  const double* E;
+  const float* row_scale;
+  const float* col_scale;
+  float* C32;
 } curv_gemm64_desc;
 int curv_gemm_f64_batched(void* stream, const curv_gemm64_desc* descs, int n_desc);
 

@@ -246,7 +246,7 @@ def test_gemm_f64_macro_tiles_all_layouts(gpu):
 
 @pytest.mark.gpu
 def test_gemm_f64_many_products_per_call(gpu):
-    """More products than one launch carries (32 descriptors travel as kernel arguments): 70 small ones and three
+    """More products than one launch carries (24 descriptors travel as kernel arguments): 70 small ones and three
     macro-tile ones in one call, with triangular flags on some - every product against torch's fp64 result."""
     from curvature_amd import ops
     torch.manual_seed(9)
@@ -266,3 +266,29 @@ def test_gemm_f64_many_products_per_call(gpu):
     for c, want in zip(outs, wants):
         assert c.shape == want.shape
         assert float((c - want).abs().max()) <= 1e-12 * max(float(want.abs().max()), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [200, 1100])
+def test_gemm_f64_fused_epilogues(gpu, n):
+    """The two epilogues INF.pre_sampler uses: C = alpha A B + beta E with E not C (also where a triangular cut leaves a
+    tile's K range empty: the tile must still be written), and the float32 output alpha * rs[i] * cs[j] * (A B)[i, j];
+    on 64-wide and on macro tiles."""
+    from curvature_amd import ops
+    torch.manual_seed(n)
+    lo = [torch.tril(torch.randn(n, n, dtype=torch.float64, device=gpu)) for _ in range(2)]
+    T = torch.full((n, n), float("nan"), dtype=torch.float64, device=gpu)
+    ops.gemm_f64_batched([ops.Gemm64(lo[1], lo[0], T, alpha=-1.0, beta=1.0, E=lo[0], tri=ops.TRI64_A_LOWER | ops.TRI64_B_LOWER)])
+    want = lo[0] - lo[1] @ lo[0]
+    assert float((T - want).abs().max()) <= 1e-12 * float(want.abs().max())
+    assert float(torch.triu(T, 1).abs().max()) == 0.0          # tiles above the diagonal: beta * E = 0, written
+    rs = torch.rand(n, device=gpu) + 0.5
+    cs = torch.rand(n, device=gpu) + 0.5
+    out = torch.full((n, n), float("nan"), dtype=torch.float32, device=gpu)
+    ops.gemm_f64_batched([ops.Gemm64(lo[0].t(), T, tri=ops.TRI64_A_UPPER | ops.TRI64_B_LOWER, out32=out, row_scale=rs, col_scale=cs,
+                                     alpha=0.5)])
+    ref = (0.5 * rs.double()[:, None] * (lo[0].t() @ T) * cs.double()[None, :]).float()
+    assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+    out2 = torch.empty(n, n, dtype=torch.float32, device=gpu)
+    ops.gemm_f64_batched([ops.Gemm64(lo[0].t(), T, out32=out2)])          # no scale vectors, dense
+    assert float((out2 - (lo[0].t() @ T).float()).abs().max()) <= 1e-6 * float(ref.abs().max())
