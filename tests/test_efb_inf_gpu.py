@@ -292,3 +292,34 @@ def test_gemm_f64_fused_epilogues(gpu, n):
     out2 = torch.empty(n, n, dtype=torch.float32, device=gpu)
     ops.gemm_f64_batched([ops.Gemm64(lo[0].t(), T, out32=out2)])          # no scale vectors, dense
     assert float((out2 - (lo[0].t() @ T).float()).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_eigh_varied_spectra_batched(gpu):
+    """One batched call over matrices that stress different parts of the block-Jacobi iteration (its sub-problem visits
+    rotate the cross pairs of two 32-blocks, each block's inner pairs once per sweep): sizes around the 32 / 64 block edges,
+    low rank, identity and diagonal (nothing to rotate), indefinite, rank one, two eigenvalues of high multiplicity.
+    Residual, orthogonality and ascending order for every one of them."""
+    from curvature_amd import ops
+    torch.manual_seed(1)
+    mats, names = [], []
+    for n in (1, 2, 33, 64, 65, 129, 257, 600):
+        X = torch.randn(n, max(1, n // 3), device=gpu)
+        mats.append((X @ X.t() / X.shape[1]).contiguous()); names.append(f"lowrank{n}")
+        mats.append(torch.eye(n, device=gpu)); names.append(f"eye{n}")
+        mats.append(torch.diag(torch.rand(n, device=gpu) + 0.1)); names.append(f"diag{n}")
+        Y = torch.randn(n, n, device=gpu)
+        mats.append(((Y + Y.t()) / 2).contiguous()); names.append(f"indefinite{n}")
+        v = torch.randn(n, 1, device=gpu)
+        mats.append((v @ v.t()).contiguous()); names.append(f"rank1_{n}")
+        Q, _ = torch.linalg.qr(torch.randn(n, n, device=gpu, dtype=torch.float64))
+        lam = torch.cat([torch.full((n // 2,), 1.0), torch.full((n - n // 2,), 3.0)]).to(gpu, torch.float64)
+        mats.append(((Q * lam) @ Q.t()).float().contiguous()); names.append(f"cluster{n}")
+    vecs, vals = ops.eigh(mats, with_values=True)
+    for M, U, w, name in zip(mats, vecs, vals, names):
+        Md, Ud, wd = M.double(), U.double(), w.double()
+        scale = max(float(Md.abs().max()), 1e-30)
+        assert float((Md @ Ud - Ud * wd).abs().max()) <= 5e-5 * scale, name
+        assert float((Ud.t() @ Ud - torch.eye(M.shape[0], device=gpu, dtype=torch.float64)).abs().max()) <= 1e-5, name
+        if M.shape[0] > 1:
+            assert bool((wd[1:] >= wd[:-1] - 1e-6 * scale).all()), name
