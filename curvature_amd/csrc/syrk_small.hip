@@ -12,7 +12,7 @@
 // src[sample][channel][y sh + kh - ph][x sw + kw - pw], zero outside, 1 for the bias row (curvatures.py:329-343) -
 // eight steps of loads in flight behind eight MFMAs; no LDS staging, no chunk planning.  The partial
 // blocks go to slabs; syrk_small_reduce_kernel sums a block's slices in a fixed order (bit-reproducible), scales, adds
-// into the factor and writes the mirror block.  The slicing aims at ~4 workgroups per CU for the launch as a whole.
+// into the factor and writes the mirror block.
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -226,8 +226,7 @@ syrk_small_reduce_kernel(SmallChunk chunk, int count, const float* __restrict__ 
 #ifndef CURV_SMALL_MAX_FLOP
 #define CURV_SMALL_MAX_FLOP 2.0e9      // executed multiply-add flops (32 x 32 blocks on and above the diagonal) of the launch
 #endif
-constexpr int SMALL_TARGET_WGS = 1024;   // ~4 workgroups per CU
-constexpr int SMALL_MIN_KSLICE = 256;
+constexpr int SMALL_KSLICE = 320;        // k values per slice (LeNet-5 at N = 100: 764 workgroups, ~3 per CU)
 constexpr int SMALL_MAX_SLICES = 64;     // the reduce pass walks a block's slices eight at a time: a round trip each
 
 struct SmallPlan { std::vector<SmallDev> f; long long wgs = 0, red_wgs = 0, slab_floats = 0; };
@@ -263,9 +262,10 @@ static bool small_plan(const curv_factor_desc* descs, int n, SmallPlan& plan) {
     work += (double)d.n_pairs * (double)K;
     if (flop > CURV_SMALL_MAX_FLOP) return false;
   }
-  // one slicing rule for the launch: ~SMALL_TARGET_WGS workgroups of equal work
-  long long px = (long long)(work / SMALL_TARGET_WGS) + 1;
-  px = std::min<long long>(std::max<long long>(px, SMALL_MIN_KSLICE), SMALL_MAX_KSLICE);
+  // one slicing rule per FACTOR (slices of ~SMALL_KSLICE k values, at most SMALL_MAX_SLICES of them): what a factor's
+  // sums look like does not depend on what else is in the launch - a layer-sharded rank gets the bits of the unsharded run
+  const long long px = SMALL_KSLICE;
+  (void)work;
   for (int i = 0; i < n; ++i) {
     SmallDev& d = plan.f[i];
     d.n_slices = (int)std::min<long long>(cdivll(d.K, px), SMALL_MAX_SLICES);

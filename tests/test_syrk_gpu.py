@@ -267,3 +267,34 @@ def test_two_estimators_of_different_size_share_a_workspace(gpu):
             torch.cuda.synchronize()
             for j, w in zip(jobs, want):
                 assert torch.equal(j.dst, w)
+
+
+def test_small_build_does_not_depend_on_the_rest_of_the_launch(gpu, build_path):
+    """The two-launch small-model build slices every factor by a rule of its own: a factor built alone and the same factor
+    built beside others (what a layer-sharded rank and the unsharded run do) come out bit for bit the same, also with
+    more factors than one argument block carries (24)."""
+    if build_path != "small":
+        pytest.skip("property of the small-model build")
+    from curvature_amd import ops
+    torch.manual_seed(3)
+    x1 = torch.randn(100, 1, 28, 28, device=gpu)               # LeNet conv1 at its real batch size: 64 slices
+    x2 = torch.randn(100, 6, 14, 14, device=gpu)               # conv2: 15 blocks x 32 slices
+    lin = [torch.randn(100, 7 + 13 * k, device=gpu) for k in range(26)]
+
+    def job(x, k, p, bias, n):
+        return ops.FactorJob(x, torch.empty(n, n, device=gpu), (k, k), (1, 1), (p, p), bias, 1.0 / x.shape[0], True)
+    alone1, alone2 = job(x1, 5, 2, True, 26), job(x2, 5, 0, True, 151)
+    ops.kfac_accumulate([alone1])
+    ops.kfac_accumulate([alone2])
+    together = [ops.FactorJob(t, torch.empty(t.shape[1], t.shape[1], device=gpu), scale=0.01, first=True) for t in lin[:13]]
+    t1, t2 = job(x1, 5, 2, True, 26), job(x2, 5, 0, True, 151)
+    together += [t1] + [ops.FactorJob(t, torch.empty(t.shape[1], t.shape[1], device=gpu), scale=0.01, first=True) for t in lin[13:]] + [t2]
+    assert len(together) > 24
+    ops.kfac_accumulate(together)
+    assert torch.equal(alone1.dst, t1.dst) and torch.equal(alone2.dst, t2.dst)
+    ref = torch.nn.functional.unfold(x1.double(), 5, padding=2)
+    ref = torch.cat([ref, torch.ones(100, 1, ref.shape[2], device=gpu, dtype=torch.float64)], 1)
+    want = sum(r @ r.t() for r in ref) / 100
+    assert rel_fro(t1.dst.cpu().double(), want.cpu()) < TOL
+    for j, t in zip(together[:3], lin[:3]):
+        assert rel_fro(j.dst.cpu().double(), (0.01 * t.double().t() @ t.double()).cpu()) < TOL
