@@ -76,7 +76,7 @@ class curv_gemm_desc(ctypes.Structure):
 
 class curv_cholinv_desc(ctypes.Structure):
     _fields_ = [("M", ctypes.c_void_p), ("X", ctypes.c_void_p), ("n", ctypes.c_int32), ("m_is_f64", ctypes.c_int32),
-                ("diag_add", ctypes.c_double)]
+                ("diag_add", ctypes.c_double), ("R", ctypes.c_void_p), ("r_minus", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class curv_gemm64_desc(ctypes.Structure):

@@ -64,6 +64,14 @@ struct InvDev {
   int reverse;          // 1: factor J M J and emit L = J X^T J (KFAC.invert); 0: plain M, emit X = chol(M)^-1
   int f64_in;           // reverse == 0 only: F points to an fp64 matrix (INF's V_s^T V_s), damping added in fp64
   double* Xout;         // reverse == 0: (n x n) fp64 output, lower triangular
+  // reverse == 0, right-hand side mode: emit Z = chol(M)^-1 R for a lower-triangular (n x n) fp64 R instead of the inverse
+  // itself - INF.pre_sampler's B_c^-1 A_c^-1 without B_c^-1 and without the product (curvatures.py:566-570).  The forward
+  // substitution is the sweep's own inverse accumulation with R in the place of the identity: Zm (np x np, workspace) starts
+  // as R, every outer panel subtracts C[i][panel] Z[panel][j] from the rows below it and multiplies its own rows by the
+  // inverse X_sq of its block square - which is all of C^-1 that is formed (X holds the squares, nothing between them).
+  const double* R;
+  double* Zm;
+  int r_minus, pad_;    // emit R - Z instead of Z
 };
 
 // block -> (factor, local tile) for per-factor tile counts cnt(f) that depend on the step
@@ -113,6 +121,19 @@ inv_prepare_kernel(const InvDev* __restrict__ t, int nf, int* __restrict__ flags
   gdouble* W = (gdouble*)d.W;
   if (bi == 0 && bj == 0 && threadIdx.x == 0) *d.info = 0;
   if (bi == 0 && bj == 0 && threadIdx.x < SQ_FLAGS) flags[(long long)f * SQ_FLAGS + threadIdx.x] = 0;
+  if (d.Zm != nullptr) {
+    // right-hand side mode: the work matrix starts as R (lower triangle, zeros above inside the diagonal tiles and in
+    // the padding; tiles above the diagonal are never read)
+    const gdouble* Rg = (const gdouble*)d.R;
+    gdouble* Z = (gdouble*)d.Zm;
+    const int w0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c0 = threadIdx.x & 63;
+    const int jj = bj * NB + c0;
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+      const int i = bi * NB + w0 + 4 * u;
+      Z[(long long)i * np + jj] = (i < n && jj <= i) ? Rg[(long long)i * n + jj] : 0.0;
+    }
+  }
   if (d.f64_in) {
     // fp64 input (already symmetric by construction; symmetrised again at no cost): W = (M + M^T) / 2 + add * I
     const gdouble* M = (const gdouble*)d.F;
@@ -446,11 +467,13 @@ __device__ __forceinline__ void outer_update_body(const InvDev* __restrict__ t, 
   o.bt = trailing;
   o.same = trailing && i == j;
   o.a0 = (const gbyte*)(W + (long long)i * NB * np);
-  o.b0 = trailing ? (const gbyte*)(W + (long long)j * NB * np) : (const gbyte*)(X + j * NB);
+  // right-hand side mode: the accumulation runs on Zm (= R - S, so it SUBTRACTS), not on X
+  gdouble* Sx = d.Zm != nullptr ? (gdouble*)d.Zm : X;
+  o.b0 = trailing ? (const gbyte*)(W + (long long)j * NB * np) : (const gbyte*)(Sx + j * NB);
   o.ke0 = (trailing ? k0 : (j > k0 ? j : k0)) * NB;
   o.ke1 = kend * NB;
-  o.C = trailing ? (gdouble*)d.W + (long long)i * NB * np + j * NB : X + (long long)i * NB * np + j * NB;
-  o.mode = trailing ? 0 : (j >= k0 ? 1 : 2);
+  o.C = trailing ? (gdouble*)d.W + (long long)i * NB * np + j * NB : Sx + (long long)i * NB * np + j * NB;
+  o.mode = trailing ? 0 : (d.Zm != nullptr ? 0 : (j >= k0 ? 1 : 2));
   tile_product_k32<WV>(o, As, Bs);
 }
 __global__ void __launch_bounds__(INV_THREADS, 3)
@@ -1020,7 +1043,7 @@ __device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t,
                                                    double* __restrict__ As, double* __restrict__ Bs) {
   int f, local;
   if (!locate(t, nf, blockIdx.x,
-              [k0, kend](const InvDev& d) { return d.P > k0 ? (d.P > kend ? d.P - kend : 0) + k0 : 0; }, f, local))
+              [k0, kend](const InvDev& d) { return d.P > k0 ? (d.P > kend ? d.P - kend : 0) + (d.Zm != nullptr ? (kend < d.P ? kend : d.P) : k0) : 0; }, f, local))
     return;
   const InvDev& d = t[f];
   const int np = d.np, nb = (kend < d.P ? kend : d.P) - k0;
@@ -1035,11 +1058,18 @@ __device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t,
   o.same = false;
   o.ke0 = 0;
   o.mode = below ? 1 : 3;
+  // right-hand side mode: the columns-left part works on Zm instead of X - rows of the panel <- + X_sq (R - S) - and covers
+  // the panel's own column blocks as well (Z_sq = X_sq R_sq: block column j starts at block row j - k0 of the square)
+  gdouble* Zm = (gdouble*)d.Zm;
+  const bool rhs = !below && Zm != nullptr;
+  gdouble* S = rhs ? Zm : X;
+  if (rhs) { o.mode = 1; o.ke0 = (j > k0 ? j - k0 : 0) * NB; }
   for (int c = nb - 1; c >= 0; --c) {      // descending: output c reads only inputs k <= c
+    if (rhs && k0 + c < j) break;          // above the diagonal of the solution: never read
     const gdouble* xsq = X + (long long)(k0 + c) * NB * np + k0 * NB;              // block row c of X_sq
     o.a0 = below ? (const gbyte*)(W + (long long)i * NB * np + k0 * NB) : (const gbyte*)xsq;
-    o.b0 = below ? (const gbyte*)xsq : (const gbyte*)(X + (long long)k0 * NB * np + j * NB);
-    o.C = below ? W + (long long)i * NB * np + (k0 + c) * NB : X + (long long)(k0 + c) * NB * np + j * NB;
+    o.b0 = below ? (const gbyte*)xsq : (const gbyte*)(S + (long long)k0 * NB * np + j * NB);
+    o.C = below ? W + (long long)i * NB * np + (k0 + c) * NB : S + (long long)(k0 + c) * NB * np + j * NB;
     o.ke1 = (c + 1) * NB;
     tile_product_k32<WV>(o, As, Bs);
   }
@@ -1156,7 +1186,7 @@ panel_product_quarter_kernel(const InvDev* __restrict__ t, int nf, int k0, int k
   int f, local;
   KT_BEGIN(236)
   if (!locate(t, nf, job,
-              [k0, kend](const InvDev& d) { return d.P > k0 ? (d.P > kend ? d.P - kend : 0) + k0 : 0; }, f, local))
+              [k0, kend](const InvDev& d) { return d.P > k0 ? (d.P > kend ? d.P - kend : 0) + (d.Zm != nullptr ? (kend < d.P ? kend : d.P) : k0) : 0; }, f, local))
     return;
   const InvDev& d = t[f];
   const int nb = (kend < d.P ? kend : d.P) - k0;
@@ -1193,10 +1223,15 @@ inv_finalize_kernel(const InvDev* __restrict__ t, int nf) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = threadIdx.x & 63;   // a wave owns rows w, w + 4, ...
   if (!d.reverse) {                                          // plain copy of the lower triangle, fp64
     gdouble* Xo = (gdouble*)d.Xout;
+    const gdouble* S = d.Zm != nullptr ? (const gdouble*)d.Zm : X;     // the solution of the right-hand side mode, or C^-1
 #pragma unroll 4
     for (int u = 0; u < 16; ++u) {
       const int i = ti * NB + w + 4 * u, j = tj * NB + c;
-      if (i < n && j < n) Xo[(long long)i * n + j] = (j <= i) ? X[(long long)i * np + j] : 0.0;
+      if (i < n && j < n) {
+        double v = (j <= i) ? S[(long long)i * np + j] : 0.0;
+        if (d.r_minus && j <= i) v = ((const gdouble*)d.R)[(long long)i * n + j] - v;
+        Xo[(long long)i * n + j] = v;
+      }
     }
     return;
   }
@@ -1227,7 +1262,7 @@ inv_finalize_kernel(const InvDev* __restrict__ t, int nf) {
   }
 }
 
-constexpr int INV_UPLOAD_CHUNK = 48;
+constexpr int INV_UPLOAD_CHUNK = 36;
 struct InvChunk { InvDev f[INV_UPLOAD_CHUNK]; };
 static_assert(sizeof(InvChunk) <= 3840, "kernel argument block must stay below 4 KB");
 
@@ -1445,7 +1480,7 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
       }
     }
     for (const InvDev& d : tab)
-      if (d.P > k0) prod_tiles += std::max(0, d.P - kend) + k0;
+      if (d.P > k0) prod_tiles += std::max(0, d.P - kend) + (d.Zm != nullptr ? std::min(kend, d.P) : k0);
     if (prod_tiles > 0) {   // rows below / columns left of the square: one triangular product each
       if (prod_tiles <= quarter_prod)
         hipLaunchKernelGGL(panel_product_quarter_kernel, dim3((unsigned)(cdivll(prod_tiles, 8) * 32)), dim3(INV_THREADS), 0, stream,
@@ -1509,9 +1544,12 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
                       const char* who) {
   const int n_factors = (int)tab.size();
   static const int latency_max = getenv("CURV_LATENCY_MAX") ? atoi(getenv("CURV_LATENCY_MAX")) : 64;
-  const bool latency_bound = n_factors <= latency_max;
+  bool any_rhs = false;
+  for (const InvDev& d : tab) any_rhs = any_rhs || d.R != nullptr;
+  // (the right-hand side mode lives in the per-step kernels: the chain-bound forms keep their operands elsewhere)
+  const bool latency_bound = n_factors <= latency_max && !any_rhs;
   size_t need = 2 * inv_table_bytes(n_factors) + 2 * inv_flags_bytes(n_factors);
-  for (const InvDev& d : tab) need += 2 * (size_t)d.np * d.np * sizeof(double);
+  for (const InvDev& d : tab) need += (d.R != nullptr ? 3 : 2) * (size_t)d.np * d.np * sizeof(double);
   if (workspace == nullptr || workspace_bytes < need) {
     set_error("%s: workspace too small (%zu < %zu bytes)", who, workspace_bytes, need);
     return CURV_ERR_WORKSPACE;
@@ -1534,6 +1572,7 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   for (InvDev& d : tab) {
     d.W = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double);
     d.X = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double);
+    if (d.R != nullptr) { d.Zm = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double); }
     (d.P > split || one_group ? big : small).push_back(d);
   }
   StreamSet* ss = nullptr;
@@ -1620,7 +1659,7 @@ extern "C" size_t curv_chol_factor_inverse_workspace_bytes(const curv_cholinv_de
   for (int i = 0; i < n; ++i) {
     if (descs[i].n <= 0) return 0;
     const size_t np = (size_t)cdiv(descs[i].n, NB) * NB;
-    total += 2 * np * np * sizeof(double);
+    total += (descs[i].R != nullptr ? 3 : 2) * np * np * sizeof(double);
   }
   return total;
 }
@@ -1642,6 +1681,8 @@ extern "C" int curv_chol_factor_inverse(void* stream_, const curv_cholinv_desc* 
     d.sqrt_s = 1.0f;
     d.sqrt_n = (float)s.diag_add;            // added in fp32 like the reference's `vtv + eye` (:567)
     d.reverse = 0;
+    d.R = s.R;                               // (Zm: a third work matrix, placed by chol_sweep)
+    d.r_minus = (s.R != nullptr && s.r_minus) ? 1 : 0;
   }
   return chol_sweep((hipStream_t)stream_, tab, workspace, workspace_bytes, "curv_chol_factor_inverse");
 }

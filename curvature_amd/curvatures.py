@@ -1307,21 +1307,17 @@ class INF(Curvature):
         V4s = ops.gemm_f64_batched([ops.Gemm64(M, PG) for M, (PG, _, _, _) in zip(Ms, parts)])
         vtvs = [ops.inf_vtv_assemble_sym(V4.contiguous(), sigma, a, b) for V4, (_, sigma, a, b) in zip(V4s, parts)]
         del first, Ms, V4s, parts
-        mats, adds = [], []
-        for v in vtvs:
-            mats += [v, v]
-            adds += [0.0, 1.0]
-        # float64, lower triangular.  The status words are read at the END of this function: a read-back here would
-        # leave the GPU idle while the ~170 launches below are described and enqueued (14 of 115 ms on ResNet-50)
-        inv = ops.chol_factor_inverse(mats, adds, check=False)
+        # float64, lower triangular: A^-1 = chol(vtv)^-1, then T = (I - B^-1) A^-1 = A^-1 - chol(vtv + I)^-1 A^-1 by forward
+        # substitution INSIDE the second sweep (`rhs`): no explicit B^-1, no product with it (a sixth of the call's flops).
+        # The status words are read at the END of this function: a read-back here would leave the GPU idle while the
+        # launches below are described and enqueued (14 of 115 ms on ResNet-50)
+        invA = ops.chol_factor_inverse(vtvs, [0.0] * len(vtvs), check=False)
         info = ops.chol_factor_inverse.last_info
-        # T = (I - B^-1) A^-1 = A^-1 - B^-1 A^-1 (the product's epilogue reads A^-1 as its E operand: no copy first);
-        # P_c = diag(sigma) A^-T T diag(sigma) (:570), scaled and rounded to float32 in the second product's epilogue.
-        # Both inverses are lower triangular (zeros above), so is T: two thirds of the flops of INF.invert were these
-        # two products done densely - with the triangles declared they cost 1/6 and 1/3 of that
-        Ts = [torch.empty_like(inv[2 * i]) for i in range(len(regs))]
-        ops.gemm_f64_batched([ops.Gemm64(inv[2 * i + 1], inv[2 * i], T, alpha=-1.0, beta=1.0, E=inv[2 * i],
-                                         tri=ops.TRI64_A_LOWER | ops.TRI64_B_LOWER) for i, T in enumerate(Ts)])
+        Ts = ops.chol_factor_inverse(vtvs, [1.0] * len(vtvs), check=False, rhs=invA, rhs_minus=True)
+        info = torch.cat([info, ops.chol_factor_inverse.last_info])
+        inv = [None] * (2 * len(regs))
+        for i, a in enumerate(invA):
+            inv[2 * i] = a
         out = []
         for i, (_, _, sigma, _) in enumerate(regs):
             prev = outs[i] if outs is not None else None

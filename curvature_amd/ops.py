@@ -543,10 +543,14 @@ def diag_scale(src: torch.Tensor, dl: torch.Tensor, dr: torch.Tensor, out: Optio
     return out
 
 
-def chol_factor_inverse(mats: Sequence[torch.Tensor], diag_adds: Sequence[float], check: bool = True) -> List[torch.Tensor]:
+def chol_factor_inverse(mats: Sequence[torch.Tensor], diag_adds: Sequence[float], check: bool = True,
+                        rhs: Optional[Sequence[Optional[torch.Tensor]]] = None, rhs_minus: bool = False) -> List[torch.Tensor]:
     """[chol_lower(M + d I)^-1] in float64 for symmetric float32 or float64 matrices (batched).  `check=False` leaves
     the status words on the device (``chol_factor_inverse.last_info``) for `check_factor_inverse_info`: a caller with
-    more launches to enqueue does that first and synchronises once, at its end."""
+    more launches to enqueue does that first and synchronises once, at its end.  `rhs[i]` (lower triangular, float64):
+    entry i of the result is chol_lower(M_i + d_i I)^-1 rhs[i] instead - the forward substitution runs inside the sweep, at
+    the cost of the inverse it replaces (with `rhs_minus`: rhs[i] minus that); the right-hand side may be ANOTHER entry's
+    result only across calls."""
     n = len(mats)
     arr = (curv_cholinv_desc * n)()
     outs = []
@@ -554,9 +558,15 @@ def chol_factor_inverse(mats: Sequence[torch.Tensor], diag_adds: Sequence[float]
         if not M.is_cuda or not M.is_contiguous() or M.dtype not in (torch.float32, torch.float64) or M.dim() != 2:
             raise RuntimeError("chol_factor_inverse: contiguous float32 / float64 GPU matrices expected")
         X = torch.empty(M.shape, dtype=torch.float64, device=M.device)
-        outs.append(X)
         d.M, d.X, d.n, d.diag_add = M.data_ptr(), X.data_ptr(), M.shape[0], float(da)
         d.m_is_f64 = int(M.dtype == torch.float64)
+        R = rhs[len(outs)] if rhs is not None else None
+        if R is not None:
+            if not R.is_cuda or R.dtype != torch.float64 or R.shape != M.shape or not R.is_contiguous():
+                raise RuntimeError("chol_factor_inverse: a right-hand side is a contiguous float64 GPU matrix of M's shape")
+            d.R = R.data_ptr()
+            d.r_minus = int(bool(rhs_minus))
+        outs.append(X)
     dev = mats[0].device
     info = torch.empty(n, dtype=torch.int32, device=dev)
     L = _lib.lib()

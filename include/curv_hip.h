@@ -155,6 +155,13 @@ typedef struct curv_cholinv_desc {
   int32_t n;
   int32_t m_is_f64;
   double diag_add;
+  /* optional (NULL: X = chol(M + d I)^-1 as above).  Non-NULL: RIGHT-HAND SIDE mode - R is an (n x n) fp64 lower-triangular
+   * matrix and X receives chol(M + d I)^-1 R (lower triangular): the forward substitution runs inside the sweep, in the place
+   * of the inverse accumulation and at its cost, and saves the explicit inverse's product with R afterwards
+   * (INF.pre_sampler's B_c^-1 A_c^-1, :566-570).  Needs a third work matrix (curv_chol_factor_inverse_workspace_bytes). */
+  const double* R;
+  int32_t r_minus;   /* with R: X = R - chol(M + d I)^-1 R (pre_sampler's T = (I - B_c^-1) A_c^-1 in one go) */
+  int32_t reserved;
 } curv_cholinv_desc;
 
 size_t curv_chol_factor_inverse_workspace_bytes(const curv_cholinv_desc* descs, int n_mats);

@@ -323,3 +323,32 @@ def test_eigh_varied_spectra_batched(gpu):
         assert float((Ud.t() @ Ud - torch.eye(M.shape[0], device=gpu, dtype=torch.float64)).abs().max()) <= 1e-5, name
         if M.shape[0] > 1:
             assert bool((wd[1:] >= wd[:-1] - 1e-6 * scale).all()), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("count", [3, 70])
+def test_chol_factor_inverse_with_right_hand_side(gpu, count):
+    """`chol_factor_inverse(rhs=...)`: chol(M + d I)^-1 R by forward substitution inside the sweep (INF.pre_sampler's
+    B_c^-1 A_c^-1 without B_c^-1), for sizes around the 64 / 256 block edges, with ordinary (inverting) matrices in the
+    same call; against torch.linalg.solve_triangular in fp64."""
+    from curvature_amd import ops
+    torch.manual_seed(count)
+    base = [100, 256, 300, 513, 700, 1100]
+    sizes = base[:3] if count == 3 else (base[:4] * 18)[:count]
+    mats, rhs, want = [], [], []
+    for k, n in enumerate(sizes):
+        X = torch.randn(n, n + 5, dtype=torch.float64, device=gpu)
+        V = X @ X.t() / n
+        C = torch.linalg.cholesky(V + torch.eye(n, dtype=torch.float64, device=gpu))
+        mats.append(V)
+        if k % 3 == 2:
+            rhs.append(None)
+            want.append(torch.linalg.inv(C))
+        else:
+            R = torch.tril(torch.randn(n, n, dtype=torch.float64, device=gpu))
+            rhs.append(R)
+            want.append(torch.linalg.solve_triangular(C, R, upper=False))
+    got = ops.chol_factor_inverse(mats, [1.0] * len(mats), rhs=rhs)
+    for g, w in zip(got, want):
+        assert float((g - w).abs().max()) <= 1e-9 * float(w.abs().max())
+        assert float(torch.triu(g, 1).abs().max()) == 0.0

@@ -56,23 +56,28 @@ def main():
         return [ops.inf_vtv_assemble_sym(V4.contiguous(), sigma, a, b) for V4, (_, sigma, a, b) in zip(V4s, parts)]
 
     vtvs = stage("V_s^T V_s (closed form)", vtv)
+    invA = stage("sweep A: chol(vtv)^-1 (1 per layer)", lambda: ops.chol_factor_inverse(vtvs, [0.0] * len(vtvs)))
+    Ts = stage("sweep B with right-hand side: T = A^-1 - chol(vtv + I)^-1 A^-1",
+               lambda: ops.chol_factor_inverse(vtvs, [1.0] * len(vtvs), rhs=invA, rhs_minus=True))
+    # the round-3 / early round-4 form of the same two stages, for comparison: both inverses explicitly, then a product
     mats, adds = [], []
     for v in vtvs:
         mats += [v, v]
         adds += [0.0, 1.0]
-    inv = stage("factor-and-invert sweep (2 per layer)", lambda: ops.chol_factor_inverse(mats, adds))
-    half = stage("  the same, vtv only (1 per layer)", lambda: ops.chol_factor_inverse(vtvs, [0.0] * len(vtvs)))
-    del half
-    Ts = [torch.empty_like(inv[2 * i]) for i in range(len(regs))]
-    cp = ops.CopyPlan(Ts, [inv[2 * i] for i in range(len(regs))])
-    stage("T <- A^-1 (copy)", cp.run)
-    stage("T -= B^-1 A^-1 (tri x tri)", lambda: ops.gemm_f64_batched(
-        [ops.Gemm64(inv[2 * i + 1], inv[2 * i], T, alpha=-1.0, beta=1.0, tri=ops.TRI64_A_LOWER | ops.TRI64_B_LOWER)
-         for i, T in enumerate(Ts)]))
-    stage("L_c = A^-T T (upper x lower)", lambda: ops.gemm_f64_batched(
-        [ops.Gemm64(inv[2 * i].t(), T, tri=ops.TRI64_A_UPPER | ops.TRI64_B_LOWER) for i, T in enumerate(Ts)]))
+    inv = stage("  (explicit form: factor-and-invert sweep, 2 per layer)", lambda: ops.chol_factor_inverse(mats, adds))
+    T2 = [torch.empty_like(t) for t in Ts]
+    stage("  (explicit form: T = A^-1 - B^-1 A^-1, tri x tri product)", lambda: ops.gemm_f64_batched(
+        [ops.Gemm64(inv[2 * i + 1], inv[2 * i], T, alpha=-1.0, beta=1.0, E=inv[2 * i], tri=ops.TRI64_A_LOWER | ops.TRI64_B_LOWER)
+         for i, T in enumerate(T2)]))
+    print("  explicit vs right-hand side form of T: max difference",
+          max(float((a - b).abs().max()) for a, b in zip(Ts, T2)))
+    del inv, T2
+    outs = [torch.empty(t.shape, dtype=torch.float32, device=t.device) for t in Ts]
+    stage("P_c = diag(s) A^-T T diag(s) (upper x lower, fp32 out)", lambda: ops.gemm_f64_batched(
+        [ops.Gemm64(invA[i].t(), T, tri=ops.TRI64_A_UPPER | ops.TRI64_B_LOWER, out32=outs[i], row_scale=regs[i][2].contiguous(),
+                    col_scale=regs[i][2].contiguous()) for i, T in enumerate(Ts)]))
     n3 = sum(float(v.shape[0]) ** 3 for v in vtvs)
-    print(f"sum (ab)^3 = {n3:.3e}: sweep {4 / 3 * n3 / 1e12:.2f} TFLOP, tri x tri {n3 / 3 / 1e12:.2f}, upper x lower {2 * n3 / 3 / 1e12:.2f}")
+    print(f"sum (ab)^3 = {n3:.3e}: each sweep {2 / 3 * n3 / 1e12:.2f} TFLOP, the tri x tri product it replaces {n3 / 3 / 1e12:.2f}, upper x lower {2 * n3 / 3 / 1e12:.2f}")
     stage("inf.invert(1, 1000) as a whole", lambda: inf.invert(1.0, 1000.0))
 
 
