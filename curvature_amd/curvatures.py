@@ -1264,6 +1264,8 @@ class INF(Curvature):
         for layer, (ua, ug, _, r), pre_sample in zip(layers, regs, pre_samples):
             self.inv_state[layer] = (ua, ug, r, pre_sample)
 
+    RHS_SWEEP_ABOVE = 16        # layers per call from which T is built by the sweep's right-hand side mode (pre_sampler_many)
+
     @staticmethod
     def pre_sampler_many(regs, outs: Optional[Sequence[Optional[Tensor]]] = None) -> List[Tensor]:
         """`pre_sampler` for a list of (U_A_lr, U_G_lr, sigma, r) tuples, stage by stage.  `outs`: previous
@@ -1311,10 +1313,25 @@ class INF(Curvature):
         # substitution INSIDE the second sweep (`rhs`): no explicit B^-1, no product with it (a sixth of the call's flops).
         # The status words are read at the END of this function: a read-back here would leave the GPU idle while the
         # launches below are described and enqueued (14 of 115 ms on ResNet-50)
-        invA = ops.chol_factor_inverse(vtvs, [0.0] * len(vtvs), check=False)
-        info = ops.chol_factor_inverse.last_info
-        Ts = ops.chol_factor_inverse(vtvs, [1.0] * len(vtvs), check=False, rhs=invA, rhs_minus=True)
-        info = torch.cat([info, ops.chol_factor_inverse.last_info])
+        if len(vtvs) > INF.RHS_SWEEP_ABOVE:
+            invA = ops.chol_factor_inverse(vtvs, [0.0] * len(vtvs), check=False)
+            info = ops.chol_factor_inverse.last_info
+            Ts = ops.chol_factor_inverse(vtvs, [1.0] * len(vtvs), check=False, rhs=invA, rhs_minus=True)
+            info = torch.cat([info, ops.chol_factor_inverse.last_info])
+        else:
+            # few layers (a small model, a layer-sharded rank): such a sweep is bound by its chain, and the chain-bound
+            # kernels have no right-hand side form - both inverses explicitly in ONE sweep, then the product (its epilogue
+            # reads A^-1 as the E operand)
+            mats, adds = [], []
+            for v in vtvs:
+                mats += [v, v]
+                adds += [0.0, 1.0]
+            both = ops.chol_factor_inverse(mats, adds, check=False)
+            info = ops.chol_factor_inverse.last_info
+            invA = [both[2 * i] for i in range(len(vtvs))]
+            Ts = [torch.empty_like(a) for a in invA]
+            ops.gemm_f64_batched([ops.Gemm64(both[2 * i + 1], invA[i], T, alpha=-1.0, beta=1.0, E=invA[i],
+                                             tri=ops.TRI64_A_LOWER | ops.TRI64_B_LOWER) for i, T in enumerate(Ts)])
         inv = [None] * (2 * len(regs))
         for i, a in enumerate(invA):
             inv[2 * i] = a
