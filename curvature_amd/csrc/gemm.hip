@@ -607,6 +607,7 @@ gemm_f64_kernel(const Gemm64Table tab, int n_desc) {
   int tm, tn;
   gemm64_tile(d, local, GT, tm, tn);
   const int i0 = tm * GT, j0 = tn * GT;
+  if ((d.tri & 16) && j0 > i0 + GT - 1) return;   // C lower: the tile lies strictly above the diagonal
   const int M = d.M, N = d.N, K = d.K;
   const gdbl* A = (const gdbl*)d.A;
   const gdbl* B = (const gdbl*)d.B;
@@ -697,6 +698,7 @@ gemm_f64_macro_kernel(const Gemm64Table tab, int n_desc) {
   int tm, tn;
   gemm64_tile(d, local, G64M_T, tm, tn);
   const int i0 = tm * G64M_T, j0 = tn * G64M_T;
+  if ((d.tri & 16) && j0 > i0 + G64M_T - 1) return;   // C lower: the tile lies strictly above the diagonal
   const int M = d.M, N = d.N, K = d.K;
   const gdbl* A = (const gdbl*)d.A;
   const gdbl* B = (const gdbl*)d.B;
@@ -1133,7 +1135,8 @@ extern "C" int curv_gemm_f64_batched(void* stream_, const curv_gemm64_desc* desc
     CURV_REQUIRE(s.M > 0 && s.N > 0 && s.K >= 0 && s.A && s.B && (s.C || s.C32), "curv_gemm_f64_batched: desc %d invalid", i);
     CURV_REQUIRE(s.C32 == nullptr || (s.beta == 0.0 && s.E == nullptr), "curv_gemm_f64_batched: desc %d: the fp32 output takes no beta / E", i);
     CURV_REQUIRE(s.E == nullptr || (s.C != nullptr && s.E != s.C), "curv_gemm_f64_batched: desc %d: E needs an output C of its own", i);
-    CURV_REQUIRE((s.tri & ~15) == 0 && (s.tri & 3) != 3 && (s.tri & 12) != 12, "curv_gemm_f64_batched: desc %d: bad tri flags", i);
+    CURV_REQUIRE((s.tri & ~31) == 0 && (s.tri & 3) != 3 && (s.tri & 12) != 12, "curv_gemm_f64_batched: desc %d: bad tri flags", i);
+    CURV_REQUIRE(!(s.tri & CURV_TRI64_C_LOWER) || s.M == s.N, "curv_gemm_f64_batched: desc %d: CURV_TRI64_C_LOWER needs a square product", i);
   }
   // launches of up to G64_BATCH descriptors (they travel as kernel arguments), per tile size, in the caller's order
   for (int pass = 0; pass < 2; ++pass) {

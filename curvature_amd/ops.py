@@ -650,13 +650,14 @@ def concat(parts: Sequence[torch.Tensor]) -> torch.Tensor:
     return out
 
 
-TRI64_A_LOWER, TRI64_A_UPPER, TRI64_B_LOWER, TRI64_B_UPPER = 1, 2, 4, 8      # CURV_TRI64_*
+TRI64_A_LOWER, TRI64_A_UPPER, TRI64_B_LOWER, TRI64_B_UPPER, TRI64_C_LOWER = 1, 2, 4, 8, 16      # CURV_TRI64_*
 
 
 class Gemm64:
     """float64 C = alpha * A @ B [+ beta * C] on strided 2-D GPU views; C = None allocates the output.
     `tri`: TRI64_* flags for triangular operands (their other triangle must hold zeros; only the K range that can
-    contribute to a tile is visited)."""
+    contribute to a tile is visited); TRI64_C_LOWER for a square product known to be symmetric (tiles strictly above the
+    diagonal of C are not computed and keep what they held)."""
     __slots__ = ("A", "B", "C", "alpha", "beta", "tri", "E", "row_scale", "col_scale", "out32")
 
     def __init__(self, A, B, C=None, alpha=1.0, beta=0.0, tri=0, E=None, row_scale=None, col_scale=None, out32=None):

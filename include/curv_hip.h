@@ -228,6 +228,8 @@ int curv_gemm_batched_ex(void* stream, const curv_gemm_desc* descs, int n_desc, 
 #define CURV_TRI64_A_UPPER 2
 #define CURV_TRI64_B_LOWER 4
 #define CURV_TRI64_B_UPPER 8
+#define CURV_TRI64_C_LOWER 16 /* square product known to be symmetric: tiles strictly above the diagonal are not computed
+                                 * (their part of C is left untouched; elements above the diagonal inside diagonal tiles are written) */
 typedef struct curv_gemm64_desc {
   const double* A;
   const double* B;

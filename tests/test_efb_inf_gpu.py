@@ -245,6 +245,27 @@ def test_gemm_f64_macro_tiles_all_layouts(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [200, 1100])
+def test_gemm_f64_symmetric_product_lower_tiles_only(gpu, n):
+    """TRI64_C_LOWER (the eigensolver's V^T V and V^T F V at its precision switch): every element on or below the diagonal
+    equals the full product's BIT FOR BIT (same tiles, same K order), tiles strictly above the diagonal keep what C held;
+    64-wide tiles (n = 200) and 128-wide macro tiles (n = 1100).  A non-square product with the flag is refused."""
+    from curvature_amd import ops
+    torch.manual_seed(n)
+    V = torch.randn(n, n, dtype=torch.float64, device=gpu)
+    full = ops.gemm_f64_batched([ops.Gemm64(V.t(), V)])[0]
+    C = torch.full((n, n), 7.0, dtype=torch.float64, device=gpu)
+    ops.gemm_f64_batched([ops.Gemm64(V.t(), V, C, tri=ops.TRI64_C_LOWER)])
+    i, j = torch.tril_indices(n, n, device=gpu)
+    assert torch.equal(C[i, j], full[i, j])
+    T = 64 if n < 1024 else 128
+    bi, bj = torch.arange(n, device=gpu)[:, None] // T, torch.arange(n, device=gpu)[None, :] // T
+    assert bool((C[bj > bi] == 7.0).all())
+    with pytest.raises(RuntimeError, match="square"):
+        ops.gemm_f64_batched([ops.Gemm64(V[:50], V, tri=ops.TRI64_C_LOWER)])
+
+
+@pytest.mark.gpu
 def test_gemm_f64_many_products_per_call(gpu):
     """More products than one launch carries (24 descriptors travel as kernel arguments): 70 small ones and three
     macro-tile ones in one call, with triangular flags on some - every product against torch's fp64 result."""
