@@ -167,7 +167,10 @@ __device__ __forceinline__ void jacobi_pair_body(const EighDev& d, int tp, int s
 #ifndef CURV_EIG_CROSS
 #define CURV_EIG_CROSS 1
 #endif
-  const bool cross_only = CURV_EIG_CROSS && std::is_same<T, float>::value && d.Nb > 2 && (step % d.spf) != 0;
+
+  // Both phases (in the fp64 finish: 0.825 -> 0.805 s on the ResNet-50 factors once the iteration ran in
+  // descending-diagonal order; before that it cost the finish a second sweep).
+  const bool cross_only = CURV_EIG_CROSS && d.Nb > 2 && (step % d.spf) != 0;
   const int n_rounds = cross_only ? JB : NB - 1;
   for (int sweep = 0; sweep < inner_sweeps; ++sweep) {
     for (int rr = 0; rr < n_rounds; ++rr) {
@@ -376,7 +379,9 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 // largest diagonal entry; rows n..np-1 stay where they are) and starts V at P^T, so that F = V A' V^T holds throughout
 // and the eigenvectors come out in F's own coordinates.  On the 108 ResNet-50 factors the ordering saves one of the
 // fp32 sweeps of the largest matrices: 0.898 -> 0.853 s on one box (ascending order: 0.902 s).  Bitonic sort of
-// (value, index) in LDS; ties by index, so the order is a function of F alone.
+// (value, index) in LDS; ties by index, so the order is a function of F alone.  (SORTING rotations - the large-angle
+// form of a 2x2 rotation wherever the small-angle one leaves the pair's diagonal out of order - keep the order up during
+// the iteration at no cost in passes; measured: 0.80 -> 1.90 s, 18-19 sweeps.)
 #ifndef CURV_EIG_ORDER
 #define CURV_EIG_ORDER 1
 #endif
