@@ -249,7 +249,7 @@ jacobi_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int inner_sw
   __shared__ double red[EIG_THREADS];
   int f, tp;
   if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return eig_active(d) ? d.Nb / 2 : 0; }, f, tp)) return;
-  jacobi_pair_body<double, double>(t[f], tp, step, 0, inner_sweeps, inner_tol2, S, Qs, cs, pairs, red);
+  jacobi_pair_body<double, double>(t[f], tp, step, step & 1, inner_sweeps, inner_tol2, S, Qs, cs, pairs, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -272,11 +272,12 @@ jacobi_rows_kernel(const EighDev* __restrict__ t, int nf, int step) {
   const EighDev& d = t[f];
   const int nct = d.np / NB, ng = eig_groups(nct), etw = eig_etw(nct), tp = local / ng, ct0 = (local - tp * ng) * etw, np = d.np, tid = threadIdx.x;
   const int ct1 = ct0 + etw < nct ? ct0 + etw : nct;
-  if (d.skip[tp]) return;                                 // the pair kernel left this pair alone
+  const int par = step & 1;                               // which of the two Q / skip buffers this round uses
+  if (d.skip[par * (d.Nb / 2) + tp]) return;              // the pair kernel left this pair alone
   int p, q;
   rr_pair(d.Nb, step, tp, p, q);
   gdouble* A = (gdouble*)d.A;
-  const gdouble* Qg = (const gdouble*)d.Q + (long long)tp * NB * NB;
+  const gdouble* Qg = (const gdouble*)d.Q + ((long long)par * (d.Nb / 2) + tp) * NB * NB;
   // a wave owns the rows w, w + 4, ... of both operand tiles: every row base is wave-uniform (SGPR base +
   // constant lane offset), and all loads of a lane are in flight before the first LDS store
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), c = tid & 63;
@@ -310,22 +311,16 @@ jacobi_rows_kernel(const EighDev* __restrict__ t, int nf, int step) {
 // ------------------------------------------------------------------------------------------------
 // (3) cols {p,q} of A and of V <- cols * Q, eig_etw() 64-row tiles per workgroup
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(EIG_THREADS)
-jacobi_cols_kernel(const EighDev* __restrict__ t, int nf, int step) {
-  __shared__ double As[NB * LDA], Bs[NB * LDA];
-  int f, local;
-  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return eig_active(d) ? (d.Nb / 2) * eig_groups(d.np / NB) * 2 : 0; }, f, local)) return;
-  const EighDev& d = t[f];
+// `local`: (pair, group of row tiles) of matrix d; Mx: d.A or d.V
+__device__ __forceinline__ void jacobi_cols_body(const EighDev& d, int local, int step, gdouble* Mx, double* As, double* Bs) {
   const int nrt = d.np / NB, ng = eig_groups(nrt), np = d.np, tid = threadIdx.x;
-  const int which = local / ((d.Nb / 2) * ng);                      // 0: A, 1: V
-  const int l2 = local - which * (d.Nb / 2) * ng;
-  const int etw = eig_etw(nrt), tp = l2 / ng, rt0 = (l2 - tp * ng) * etw;
+  const int etw = eig_etw(nrt), tp = local / ng, rt0 = (local - tp * ng) * etw;
   const int rt1 = rt0 + etw < nrt ? rt0 + etw : nrt;
-  if (d.skip[tp]) return;
+  const int par = step & 1;
+  if (d.skip[par * (d.Nb / 2) + tp]) return;
   int p, q;
   rr_pair(d.Nb, step, tp, p, q);
-  gdouble* Mx = which ? (gdouble*)d.V : (gdouble*)d.A;
-  const gdouble* Qg = (const gdouble*)d.Q + (long long)tp * NB * NB;
+  const gdouble* Qg = (const gdouble*)d.Q + ((long long)par * (d.Nb / 2) + tp) * NB * NB;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), c = tid & 63;
   const int lane = tid & 63, wm = w >> 1, wn = w & 1;
   const int gc = gidx(p, q, c);                                      // this lane's column of the matrix
@@ -353,6 +348,34 @@ jacobi_cols_kernel(const EighDev* __restrict__ t, int nf, int step) {
     store_acc(C, np, acc, wm, wn, lane, 1);
     __syncthreads();
   }
+}
+
+// columns {p, q} of A <- columns * Q of round `step`
+__global__ void __launch_bounds__(EIG_THREADS)
+jacobi_cols_kernel(const EighDev* __restrict__ t, int nf, int step) {
+  __shared__ double As[NB * LDA], Bs[NB * LDA];
+  int f, local;
+  if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return eig_active(d) ? (d.Nb / 2) * eig_groups(d.np / NB) : 0; }, f, local)) return;
+  jacobi_cols_body(t[f], local, step, (gdouble*)t[f].A, As, Bs);
+}
+
+// The fp64 finish's second launch of a round, laid out like phase A's (jacobi_cols_pair32_kernel below): the sub-problems of
+// round `step + 1` - everything they read is final once the A columns of round `step` are - come first in the grid, the
+// columns {p, q} of V <- columns * Q of round `step` run beside them.  Rotation blocks and skip flags by round parity.
+__global__ void __launch_bounds__(EIG_THREADS)
+jacobi_colsv_pair_kernel(const EighDev* __restrict__ t, int nf, int step, int pair_wgs, int inner_sweeps, double inner_tol2) {
+  __shared__ double buf[2 * NB * LDA];
+  __shared__ double cs[2 * 32];
+  __shared__ int pairs[2 * 32];
+  __shared__ double red[EIG_THREADS];
+  int f, local;
+  if ((int)blockIdx.x < pair_wgs) {
+    if (!eig_locate(t, nf, blockIdx.x, [](const EighDev& d) { return eig_active(d) ? d.Nb / 2 : 0; }, f, local)) return;
+    jacobi_pair_body<double, double>(t[f], local, step + 1, (step + 1) & 1, inner_sweeps, inner_tol2, buf, buf + NB * LDA, cs, pairs, red);
+    return;
+  }
+  if (!eig_locate(t, nf, (int)blockIdx.x - pair_wgs, [](const EighDev& d) { return eig_active(d) ? (d.Nb / 2) * eig_groups(d.np / NB) : 0; }, f, local)) return;
+  jacobi_cols_body(t[f], local, step, (gdouble*)t[f].V, buf, buf + NB * LDA);
 }
 
 
@@ -826,7 +849,7 @@ static bool eigh_layout(const curv_eigh_desc* descs, int n, EighLayout& L) {
     L.v_off[i] = off; off += np * np * sizeof(double);
     L.t2_off[i] = off; off += np * np * sizeof(double);
     L.t3_off[i] = off; off += np * np * sizeof(double);
-    L.q_off[i] = off; off += (np / NB) * NB * NB * sizeof(double);
+    L.q_off[i] = off; off += 2 * (np / NB) * NB * NB * sizeof(double);    // rotation blocks of two rounds (by parity)
     off += align_up(2 * (np / NB) * sizeof(int), 256);      // skip flags, one per pair and round parity, behind the rotation blocks
   }
   L.total = off;
@@ -890,7 +913,7 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
     {
       const size_t P = (size_t)cdiv(descs[i].n, NB), np_ = P * NB;
       d.scale = d.norms + 2 * P * P;
-      d.skip = reinterpret_cast<int*>(base + L.q_off[i] + (np_ / NB) * NB * NB * sizeof(double));
+      d.skip = reinterpret_cast<int*>(base + L.q_off[i] + 2 * (np_ / NB) * NB * NB * sizeof(double));
     }
     d.spf = std::max(1, d.Nb - 1);
     {
@@ -944,11 +967,16 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
         hipLaunchKernelGGL(jacobi_cols_pair32_kernel, dim3((unsigned)(pair_wgs + row_tiles)), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step, (int)pair_wgs, inner_sweeps, inner_tol2);
         CURV_LAUNCH_CHECK();
       } else {
-        hipLaunchKernelGGL(jacobi_pair_kernel, dim3((unsigned)pair_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step, inner_sweeps, inner_tol2);
-        CURV_LAUNCH_CHECK();
+        if (step == 0) {                                       // the sub-problems of round 0
+          hipLaunchKernelGGL(jacobi_pair_kernel, dim3((unsigned)pair_wgs), dim3(EIG_THREADS), 0, stream, table, n_mats, 0, inner_sweeps, inner_tol2);
+          CURV_LAUNCH_CHECK();
+        }
         hipLaunchKernelGGL(jacobi_rows_kernel, dim3((unsigned)row_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step);
         CURV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(jacobi_cols_kernel, dim3((unsigned)(2 * row_tiles)), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step);
+        hipLaunchKernelGGL(jacobi_cols_kernel, dim3((unsigned)row_tiles), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step);
+        CURV_LAUNCH_CHECK();
+        // V of this round and, beside it, the sub-problems of the next one
+        hipLaunchKernelGGL(jacobi_colsv_pair_kernel, dim3((unsigned)(pair_wgs + row_tiles)), dim3(EIG_THREADS), 0, stream, table, n_mats, (int)step, (int)pair_wgs, inner_sweeps, inner_tol2);
         CURV_LAUNCH_CHECK();
       }
       const int step1 = (int)(step + 1);
