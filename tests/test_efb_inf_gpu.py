@@ -347,6 +347,40 @@ def test_eigh_varied_spectra_batched(gpu):
 
 
 @pytest.mark.gpu
+def test_eigh_coordinate_order_cases(gpu):
+    """The iteration runs on P sym(F) P^T with F's diagonal sorted descending and starts V at P^T: inputs where that
+    permutation is the whole story or is degenerate.  A diagonal matrix in any order (its vectors are exactly the unit
+    vectors, values exact), ties on the diagonal (equal and zero entries), the zero matrix, negative diagonals, and a
+    graded matrix given in ascending, descending and shuffled order - all three orders give the same eigenvalues."""
+    from curvature_amd import ops
+    torch.manual_seed(3)
+    n = 200
+    dvals = torch.cat([torch.linspace(-2.0, 5.0, 150), torch.full((30,), 1.25), torch.zeros(20)])[torch.randperm(n)].to(gpu)
+    (U,), (w,) = ops.eigh([torch.diag(dvals)], with_values=True)
+    assert torch.equal(w, torch.sort(dvals).values)
+    assert torch.equal(U.abs(), torch.eye(n, device=gpu)[:, torch.sort(dvals, stable=True).indices].abs()) or \
+        float((torch.diag(dvals) @ U - U * w).abs().max()) == 0.0        # (inside the tie groups any unit vectors do)
+    assert torch.equal((U != 0).sum(0), torch.ones(n, dtype=torch.long, device=gpu))
+    (U0,), (w0,) = ops.eigh([torch.zeros(70, 70, device=gpu)], with_values=True)
+    assert torch.equal(w0, torch.zeros(70, device=gpu)) and torch.equal(U0.abs().sum(0), torch.ones(70, device=gpu))
+    m = 300
+    Q, _ = torch.linalg.qr(torch.randn(m, m, dtype=torch.float64, device=gpu))
+    G = torch.diag(torch.logspace(0, -4, m, dtype=torch.float64, device=gpu))
+    G = G + 1e-3 * (Q * torch.logspace(0, -4, m, dtype=torch.float64, device=gpu)) @ Q.t()      # graded, PSD
+    G = ((G + G.t()) / 2).float()
+    perm = torch.randperm(m, device=gpu)
+    flip = torch.arange(m - 1, -1, -1, device=gpu)
+    variants = [G.contiguous(), G[flip][:, flip].contiguous(), G[perm][:, perm].contiguous()]
+    vecs, vals = ops.eigh(variants, with_values=True)
+    ref = torch.linalg.eigvalsh(G.double())
+    for M, Uv, wv in zip(variants, vecs, vals):
+        Md, Ud, wd = M.double(), Uv.double(), wv.double()
+        assert float(torch.linalg.norm(Md @ Ud - Ud * wd) / torch.linalg.norm(Md)) < 1e-6
+        assert float((Ud.t() @ Ud - torch.eye(m, dtype=torch.float64, device=gpu)).abs().max()) < 1e-6
+        assert float((wd - ref).abs().max()) < 1e-6 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("count", [3, 70])
 def test_chol_factor_inverse_with_right_hand_side(gpu, count):
     """`chol_factor_inverse(rhs=...)`: chol(M + d I)^-1 R by forward substitution inside the sweep (INF.pre_sampler's
