@@ -922,8 +922,12 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
       // usually passes the test of the exact A at the switch and skips the fp64 finish.  From 4096 wide up the exact A lies
       // above the final tolerance wherever the fp32 phase stops (the rounding of ~1500 rounds), the fp64 sweep is needed
       // either way and converges quadratically from there: those matrices hand over at 0.8 tol and save their last fp32
-      // sweep (ResNet-50 factors: 0.829 -> 0.781 s on one box; 1.6 tol: 0.80 s).
-      const double ta = std::max(tb * (d.np >= 4096 ? 0.8 : 0.4), 2e-6);
+      // sweep (ResNet-50 factors: 0.829 -> 0.781 s on one box; 1.6 tol: 0.80 s; the rule from 2048 or 1024 wide: 0.80 s -
+      // those matrices mostly pass at the switch today, and then all of them take the finish's sweep).
+#ifndef CURV_EIG_HANDOVER_NP
+#define CURV_EIG_HANDOVER_NP 4096
+#endif
+      const double ta = std::max(tb * (d.np >= CURV_EIG_HANDOVER_NP ? 0.8 : 0.4), 2e-6);
       d.tol2_a = ta * ta; d.tol2_b = tb * tb;
     }
     maxNb = std::max(maxNb, d.Nb);
