@@ -57,23 +57,36 @@ __global__ void __launch_bounds__(256) patch_prep_kernel(PreChunk chunk, int cou
   const int r0 = (int)(w0 - (long long)plane0 * PS);
   gfl_t* out = (gfl_t*)d.xq + w0;
   const int n = (int)min((long long)SEG, d.words - w0);
-  for (int t = threadIdx.x; t < n; t += 256) {
-    const int r = r0 + t;                                   // < SEG + PS
-    const int dp = (int)__umulhi((unsigned)r, d.ps_magic);
-    const int w = r - dp * PS;
-    const int plane = plane0 + dp;
-    const int cs = divu(plane, C, d.c_magic);               // chunk * NS + sample of the chunk
-    const int c = plane - cs * C;
-    const int ch = divu(cs, NS, d.ns_magic), s_in = cs - ch * NS;
-    const int sg = divu(ch, n_rg, d.rg_magic), rg = ch - sg * n_rg;
-    const int s = sg * NS + s_in;
-    const int y = divu(w, RS, d.rs_magic);
-    const int x = w - y * RS;
-    const int ih = rg * d.R * d.sh - d.ph + y, iw = x - d.pw;
-    float v = 0.0f;
-    if (s < d.N && y < d.rows_in && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-      v = d.src[(((long long)s * C + c) * H + ih) * W + iw];
-    out[t] = v;
+  // four words per thread and pass, the four loads issued before the first store (one word per pass left 1 KB per
+  // workgroup in flight)
+#ifndef CURV_PREP_U
+#define CURV_PREP_U 4
+#endif
+  constexpr int U = CURV_PREP_U;
+  for (int t0 = threadIdx.x; t0 < n; t0 += 256 * U) {
+    float val[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int r = r0 + min(t0 + 256 * k, n - 1);           // < SEG + PS (passes beyond n repeat its last word)
+      const int dp = (int)__umulhi((unsigned)r, d.ps_magic);
+      const int w = r - dp * PS;
+      const int plane = plane0 + dp;
+      const int cs = divu(plane, C, d.c_magic);             // chunk * NS + sample of the chunk
+      const int c = plane - cs * C;
+      const int ch = divu(cs, NS, d.ns_magic), s_in = cs - ch * NS;
+      const int sg = divu(ch, n_rg, d.rg_magic), rg = ch - sg * n_rg;
+      const int s_ = sg * NS + s_in;
+      const int y = divu(w, RS, d.rs_magic);
+      const int x = w - y * RS;
+      const int ih = rg * d.R * d.sh - d.ph + y, iw = x - d.pw;
+      float v = 0.0f;
+      if (s_ < d.N && y < d.rows_in && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+        v = d.src[(((long long)s_ * C + c) * H + ih) * W + iw];
+      val[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+      if (t0 + 256 * k < n) out[t0 + 256 * k] = val[k];
   }
   // the tail behind the last plane: a panel whose channel range ends past C reads up to nch planes (+ one DMA lane)
   // beyond it; those values are never MFMA operands of a live row, but must be finite
