@@ -127,8 +127,10 @@ SIGNATURES = {
     "curv_event_create": (_vp, []),
     "curv_event_destroy": (None, [_vp]),
     "curv_event_elapsed_ms": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
+    "curv_event_synchronize": (_i, [_vp]),
     "curv_chol_inv_workspace_bytes": (_sz, [ctypes.POINTER(curv_inv_desc), _i]),
     "curv_chol_inv_lower": (_i, [_vp, ctypes.POINTER(curv_inv_desc), _i, _vp, _vp, _sz]),
+    "curv_chol_inv_lower_status": (_i, [_vp, ctypes.POINTER(curv_inv_desc), _i, _vp, _vp, _sz, _vp, _vp]),
     "curv_chol_factor_inverse_workspace_bytes": (_sz, [ctypes.POINTER(curv_cholinv_desc), _i]),
     "curv_chol_factor_inverse": (_i, [_vp, ctypes.POINTER(curv_cholinv_desc), _i, _vp, _vp, _sz]),
     "curv_gemm_f64_batched": (_i, [_vp, ctypes.POINTER(curv_gemm64_desc), _i]),

@@ -26,6 +26,11 @@ extern "C" void* curv_event_create(void) {
 extern "C" void curv_event_destroy(void* e) {
   if (e) (void)hipEventDestroy((hipEvent_t)e);
 }
+extern "C" int curv_event_synchronize(void* e) {
+  CURV_REQUIRE(e != nullptr, "curv_event_synchronize: null argument");
+  CURV_HIP_CHECK(hipEventSynchronize((hipEvent_t)e));
+  return CURV_OK;
+}
 extern "C" int curv_event_elapsed_ms(void* start, void* stop, float* ms) {
   CURV_REQUIRE(start && stop && ms, "curv_event_elapsed_ms: null argument");
   CURV_HIP_CHECK(hipEventSynchronize((hipEvent_t)stop));

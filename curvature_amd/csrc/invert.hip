@@ -1292,6 +1292,7 @@ struct StreamSet {
                                          // faster than running it on the caller's stream; confining it to a
                                          // CU subset with hipExtStreamCreateWithCUMask did not help)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+  hipEvent_t ev_chain[2] = {nullptr, nullptr};      // a group's last chain step is enqueued (its finalize pass is not)
 };
 // CU-masked streams are destroyed explicitly when the process exits: left to the runtime's own teardown they
 // crashed inside __cxa_finalize when a profiler (rocprofv3) was attached.  The handler is registered after the
@@ -1326,6 +1327,7 @@ static int stream_set(StreamSet** out) {
   int prio_low = 0, prio_high = 0;
   CURV_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
   CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_join2, hipEventDisableTiming));
+  for (int g = 0; g < 2; ++g) CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_chain[g], hipEventDisableTiming));
   CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.masked, hipStreamNonBlocking));
   for (int g = 0; g < 2; ++g) {
     {
@@ -1409,7 +1411,8 @@ extern "C" size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int 
 // One batched sweep over the factors of `tab` (work matrices already assigned), everything enqueued on
 // `stream` except the far outer updates, which go to side->stream.
 static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vector<InvDev>& tab, InvDev* table, int* flags,
-                            bool latency_bound, hipEvent_t progress_event = nullptr, int progress_panel = -1) {
+                            bool latency_bound, hipEvent_t progress_event = nullptr, int progress_panel = -1,
+                            hipEvent_t chain_done = nullptr) {
   const int n_factors = (int)tab.size();
   int Pmax = 0;
   long long prep_tiles = 0, fin_tiles = 0;
@@ -1527,6 +1530,8 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
       far_pending = true;
     }
   }
+  // the status words are final here: every factorisation step is enqueued on `stream`, the finalize pass does not touch them
+  if (chain_done != nullptr) CURV_HIP_CHECK(hipEventRecord(chain_done, stream));
   if (far_pending) CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_side[(panel + 1) & 1], 0));
   hipLaunchKernelGGL(inv_finalize_kernel, dim3((unsigned)fin_tiles), dim3(INV_THREADS), 0, stream, table, n_factors);
   CURV_LAUNCH_CHECK();
@@ -1540,8 +1545,16 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
 // interleaves the small group's wide, throughput-bound kernels with the large group's short ones.
 constexpr int SPLIT_P = 16;
 
+// `early` (optional): the status words of the call are copied to pinned host memory as soon as the last factorisation
+// step of every factor has run - BEFORE the finalize passes - and `ev` is recorded behind that copy: a host that waits
+// for `ev` instead of for the caller's stream gets the verdict while the finalize passes (0.15 ms for a ResNet-50) still
+// run, and prepares its next launches in their shadow.  The copy travels on the small group's far-update stream, idle by
+// then: one more stream in the process would change the mapping of the sweep's streams onto hardware queues (see
+// curv_internal_side_stream).
+struct EarlyStatus { int* host; const int* dev; size_t bytes; hipEvent_t ev; };
+
 static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* workspace, size_t workspace_bytes,
-                      const char* who) {
+                      const char* who, const EarlyStatus* early = nullptr) {
   const int n_factors = (int)tab.size();
   static const int latency_max = getenv("CURV_LATENCY_MAX") ? atoi(getenv("CURV_LATENCY_MAX")) : 64;
   bool any_rhs = false;
@@ -1586,6 +1599,10 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
   CURV_HIP_CHECK(hipStreamIsCapturing(stream, &capture));
   if (capture != hipStreamCaptureStatusNone) {
+    if (early != nullptr) {
+      set_error("%s: the early status read-back is a host copy and cannot be captured", who);
+      return CURV_ERR_INVALID;
+    }
     if (!big.empty()) {
       const int rc = chol_sweep_group(stream, &ss->side[0], big, table0, flags0, latency_bound);
       if (rc != CURV_OK) return rc;
@@ -1600,8 +1617,14 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
     // caller's stream may be.
     CURV_HIP_CHECK(hipEventRecord(ss->ev_fork, stream));
     CURV_HIP_CHECK(hipStreamWaitEvent(ss->aux, ss->ev_fork, 0));
-    const int rc1 = chol_sweep_group(ss->aux, &ss->side[0], big.empty() ? small : big, table0, flags0, latency_bound);
+    const int rc1 = chol_sweep_group(ss->aux, &ss->side[0], big.empty() ? small : big, table0, flags0, latency_bound, nullptr, -1,
+                                     early ? ss->ev_chain[0] : nullptr);
     if (rc1 != CURV_OK) return rc1;
+    if (early != nullptr) {
+      CURV_HIP_CHECK(hipStreamWaitEvent(ss->side[0].stream, ss->ev_chain[0], 0));
+      CURV_HIP_CHECK(hipMemcpyAsync(early->host, early->dev, early->bytes, hipMemcpyDeviceToHost, ss->side[0].stream));
+      CURV_HIP_CHECK(hipEventRecord(early->ev, ss->side[0].stream));
+    }
     CURV_HIP_CHECK(hipEventRecord(ss->ev_join, ss->aux));
     CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->ev_join, 0));
     return CURV_OK;
@@ -1620,11 +1643,18 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   // only a far-bound large group has such a tail to fill (a chain step is ~54 us, a far tile ~0.04 us of the
   // whole GPU): with [2048 | 1024, 512, 256] the delay costs 8 %
   const int start_panel = far0 >= 5000 ? std::min(n_panels - 1, n_panels * start_frac / 100) : 0;
-  int rc = chol_sweep_group(ss->aux, &ss->side[0], big, table0, flags0, latency_bound, start_panel > 0 ? ss->ev_join2 : nullptr, start_panel);
+  int rc = chol_sweep_group(ss->aux, &ss->side[0], big, table0, flags0, latency_bound, start_panel > 0 ? ss->ev_join2 : nullptr, start_panel,
+                            early ? ss->ev_chain[0] : nullptr);
   if (rc != CURV_OK) return rc;
   if (start_panel > 0) CURV_HIP_CHECK(hipStreamWaitEvent(ss->masked, ss->ev_join2, 0));
-  rc = chol_sweep_group(ss->masked, &ss->side[1], small, table1, flags1, latency_bound);
+  rc = chol_sweep_group(ss->masked, &ss->side[1], small, table1, flags1, latency_bound, nullptr, -1, early ? ss->ev_chain[1] : nullptr);
   if (rc != CURV_OK) return rc;
+  if (early != nullptr) {
+    CURV_HIP_CHECK(hipStreamWaitEvent(ss->side[1].stream, ss->ev_chain[0], 0));
+    CURV_HIP_CHECK(hipStreamWaitEvent(ss->side[1].stream, ss->ev_chain[1], 0));
+    CURV_HIP_CHECK(hipMemcpyAsync(early->host, early->dev, early->bytes, hipMemcpyDeviceToHost, ss->side[1].stream));
+    CURV_HIP_CHECK(hipEventRecord(early->ev, ss->side[1].stream));
+  }
   CURV_HIP_CHECK(hipEventRecord(ss->ev_join, ss->aux));
   CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->ev_join, 0));
   CURV_HIP_CHECK(hipEventRecord(ss->ev_join2, ss->masked));
@@ -1632,8 +1662,24 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   return CURV_OK;
 }
 
+static int chol_inv_lower_impl(void* stream_, const curv_inv_desc* descs, int n_factors, int* info,
+                               void* workspace, size_t workspace_bytes, const EarlyStatus* early);
+
 extern "C" int curv_chol_inv_lower(void* stream_, const curv_inv_desc* descs, int n_factors, int* info,
                                    void* workspace, size_t workspace_bytes) {
+  return chol_inv_lower_impl(stream_, descs, n_factors, info, workspace, workspace_bytes, nullptr);
+}
+
+extern "C" int curv_chol_inv_lower_status(void* stream_, const curv_inv_desc* descs, int n_factors, int* info,
+                                          void* workspace, size_t workspace_bytes, int* host_status, void* ev_status) {
+  CURV_REQUIRE(host_status != nullptr && ev_status != nullptr, "curv_chol_inv_lower_status: null argument");
+  if (n_factors == 0) return CURV_OK;
+  EarlyStatus early{host_status, info, (size_t)n_factors * sizeof(int), (hipEvent_t)ev_status};
+  return chol_inv_lower_impl(stream_, descs, n_factors, info, workspace, workspace_bytes, &early);
+}
+
+static int chol_inv_lower_impl(void* stream_, const curv_inv_desc* descs, int n_factors, int* info,
+                               void* workspace, size_t workspace_bytes, const EarlyStatus* early) {
   if (n_factors == 0) return CURV_OK;
   CURV_REQUIRE(descs != nullptr && info != nullptr, "curv_chol_inv_lower: null argument");
   std::vector<InvDev> tab(n_factors);
@@ -1651,7 +1697,7 @@ extern "C" int curv_chol_inv_lower(void* stream_, const curv_inv_desc* descs, in
     d.sqrt_n = (float)sqrt(s.add);
     d.reverse = 1;
   }
-  return chol_sweep((hipStream_t)stream_, tab, workspace, workspace_bytes, "curv_chol_inv_lower");
+  return chol_sweep((hipStream_t)stream_, tab, workspace, workspace_bytes, "curv_chol_inv_lower", early);
 }
 
 extern "C" size_t curv_chol_factor_inverse_workspace_bytes(const curv_cholinv_desc* descs, int n) {

@@ -122,6 +122,7 @@ int curv_kfac_accumulate_ex(void* stream, const curv_factor_desc* descs, int n_f
 void* curv_event_create(void);
 void curv_event_destroy(void* event);
 int curv_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* waits for ev_stop */
+int curv_event_synchronize(void* event);                                /* blocks the host until the event has fired */
 
 /* ------------------------------------------------------------------------------------------------
  * KFAC.invert:  L = lower Cholesky factor of (sqrt(multiply) * F + sqrt(add) * I)^-1
@@ -145,6 +146,15 @@ typedef struct curv_inv_desc {
 size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int n_factors);
 int curv_chol_inv_lower(void* stream, const curv_inv_desc* descs, int n_factors, int* info, void* workspace,
                         size_t workspace_bytes);
+/* The same call with an EARLY verdict for a host that must raise on "not positive definite" before it goes on (the
+ * reference's invert() raises from torch.cholesky, curvatures.py:378-380): the n status words are also copied to
+ * `host_status` (PINNED host memory, n ints) by an internal stream as soon as the last factorisation step of every factor
+ * has run - before the finalize passes that write L, which do not touch them - and `ev_status` (curv_event_create) is
+ * recorded behind that copy.  curv_event_synchronize(ev_status) then returns while the finalize passes still run (0.15 ms
+ * for a ResNet-50), and the host prepares its next launches in their shadow; work enqueued on `stream` afterwards is
+ * ordered behind the whole call as always.  Not available under stream capture (CURV_ERR_INVALID). */
+int curv_chol_inv_lower_status(void* stream, const curv_inv_desc* descs, int n_factors, int* info, void* workspace,
+                               size_t workspace_bytes, int* host_status, void* ev_status);
 
 /* X = chol_lower(M + diag_add * I)^-1 in fp64 for a batch of symmetric fp32 matrices (same blocked sweep,
  * no index reversal; M may also be given in fp64): the A_c^-1 and B_c^-1 of INF.pre_sampler (curvatures.py:566-567).  X is (n x n)

@@ -98,6 +98,45 @@ def test_not_positive_definite_raises(gpu):
         ops.chol_inv_lower([(v @ v.t()).contiguous()], [0.0], [1.0])
 
 
+@pytest.mark.parametrize("count", [3, 80])
+def test_early_verdict_equals_the_status_words(gpu, count, monkeypatch):
+    """`curv_chol_inv_lower_status`: the status words copied to pinned host memory before the finalize passes are the
+    words the device holds when the call is complete, for a chain-bound call (3 factors: one group) and a whole-model call
+    (80: two groups on two streams) with failing factors among them; the inverse factors are bit-identical to the plain
+    call's, and the failure is reported for the same factors with the same pivots."""
+    from curvature_amd import ops
+    torch.manual_seed(count)
+    sizes = ([70, 300, 1100] * 27)[:count]
+    Fs = []
+    for k, n in enumerate(sizes):
+        X = torch.randn(n, n + 5, device=gpu)
+        Fs.append((X @ X.t() / n).contiguous())
+    adds, muls = [0.5] * count, [1.0] * count
+    good = [t.clone() for t in ops.chol_inv_lower(Fs, adds, muls)]
+    monkeypatch.setenv("CURV_EARLY_STATUS", "0")
+    plain = ops.chol_inv_lower(Fs, adds, muls)
+    assert all(torch.equal(a, b) for a, b in zip(good, plain))
+    monkeypatch.delenv("CURV_EARLY_STATUS")
+    bad = [1, count - 1]
+    for b in bad:
+        Fs[b] = Fs[b].clone()
+        Fs[b][5, 5] = -3.0                         # pivot 6 fails (no damping can save it at add = 0.5)
+    messages = []
+    for switch in ("1", "0"):
+        monkeypatch.setenv("CURV_EARLY_STATUS", switch)
+        with pytest.raises(RuntimeError) as err:
+            ops.chol_inv_lower(Fs, adds, muls)
+        messages.append(str(err.value))
+    assert messages[0] == messages[1] and str(bad) in messages[0].replace(" ", "").replace(",", ", ")
+    monkeypatch.delenv("CURV_EARLY_STATUS")
+    outs = ops.chol_inv_lower(Fs, adds, muls, check=False)
+    words = outs.info.cpu()
+    assert sorted(torch.nonzero(words).flatten().tolist()) == bad
+    for k in range(count):
+        if k not in bad:
+            assert torch.equal(outs[k], good[k])
+
+
 def test_many_large_factors_no_race(gpu):
     """More block-column workgroups than the chip holds at once: late workgroups must still see the
     un-factorised diagonal block (regression test for an in-place write-back race)."""
