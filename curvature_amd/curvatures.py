@@ -1216,23 +1216,33 @@ class INF(Curvature):
             [vecs[layer] for layer in need],
             [(self.eigvecs[layer][0].shape[0], self.eigvecs[layer][1].shape[0]) for layer in need], rank)))
         stage1, stage2 = [], []
+        # Lambda_lr and D of all layers live in one arena each: invert() with one pair of hyper-parameters then clamps,
+        # scales and inverts them in three launches instead of three per layer
+        dev = vecs[layers[0]].device if layers else None
+        shapes = []
         for layer in layers:
+            n, m = self.eigvecs[layer][0].shape[0], self.eigvecs[layer][1].shape[0]
+            a, b = (picked[layer][0].numel(), picked[layer][1].numel()) if layer in picked else (n, m)
+            shapes.append((n, m, a, b))
+        self._corr_flat, corrs = _arena([(n, m) for n, m, _, _ in shapes], dev) if layers else (None, [])
+        self._lam_flat, lams = _arena([(a * b,) for _, _, a, b in shapes], dev) if layers else (None, [])
+        for layer, corr, lam in zip(layers, corrs, lams):
             xxt_eigvecs, ggt_eigvecs = self.eigvecs[layer]
             n, m = xxt_eigvecs.shape[0], ggt_eigvecs.shape[0]
             lambda_vec = vecs[layer]
             diag_vec = ops.gather2d(self.diags[layer].t())                          # (n, m): index i*m + j
             if layer not in picked:
-                ua, ug, lam = xxt_eigvecs, ggt_eigvecs, lambda_vec
+                ua, ug = xxt_eigvecs, ggt_eigvecs
+                lam.copy_(lambda_vec)
             else:
                 I, J = picked[layer]
                 ua = ops.gather2d(xxt_eigvecs, cols=I)
                 ug = ops.gather2d(ggt_eigvecs, cols=J)
-                lam = ops.gather2d(lambda_vec.view(n, m), rows=I, cols=J).view(-1)
+                ops.gather2d(lambda_vec.view(n, m), rows=I, cols=J, out=lam)
             a, b = ua.shape[1], ug.shape[1]
             # D = diag_vec - ((U_A**2) Lambda_lr (U_G**2)^T).flatten()
             ua2, ug2 = ops.mul(ua, ua), ops.mul(ug, ug)
             tmp = torch.empty(n, b, dtype=torch.float32, device=ua.device)
-            corr = torch.empty(n, m, dtype=torch.float32, device=ua.device)
             stage1.append(ops.Gemm(ua2, lam.view(a, b), tmp))
             stage2.append(ops.Gemm(tmp, ug2.t(), corr, alpha=-1.0, epilogue=ops.EPI_ADD_E, E=diag_vec))
             self.state[layer] = (ua, ug, lam, corr.view(-1))
@@ -1252,8 +1262,25 @@ class INF(Curvature):
         if not rs or not _is_arena(getattr(self, "_r_flat", None), rs) or \
                 any(r.numel() != self.state[l][3].numel() for r, l in zip(rs, layers)):
             self._r_flat, rs = _arena([(self.state[l][3].numel(),) for l in layers], self.state[layers[0]][3].device)
-        for position, (layer, r) in enumerate(zip(layers, rs)):
-            n, s = self._hyper(add, multiply, gindex.get(layer, position), max(len(gindex), len(layers)))
+        hypers = [self._hyper(add, multiply, gindex.get(layer, position), max(len(gindex), len(layers)))
+                  for position, layer in enumerate(layers)]
+        one_pair = len(set(hypers)) == 1 and \
+            _is_arena(getattr(self, "_corr_flat", None), [self.state[l][3] for l in layers]) and \
+            _is_arena(getattr(self, "_lam_flat", None), [self.state[l][2] for l in layers]) and \
+            self._corr_flat.numel() == self._r_flat.numel() == sum(self.state[l][3].numel() for l in layers) and \
+            self._lam_flat.numel() == sum(self.state[l][2].numel() for l in layers)
+        if one_pair:
+            # the three elementwise steps of :521-530 over the arenas of update(): three launches for the whole model
+            n, s = hypers[0]
+            ops.clamp_min0_(self._corr_flat)                             # in place on `state`, like :523
+            reg_flat = ops.sqrt_scale(self._lam_flat, s)
+            ops.rsqrt_affine(self._corr_flat, n, s, out=self._r_flat)
+            pos = 0
+            for layer, r in zip(layers, rs):
+                lr_frst_eigvecs, lr_scnd_eigvecs, lr_lambda, _ = self.state[layer]
+                regs.append((lr_frst_eigvecs, lr_scnd_eigvecs, reg_flat[pos:pos + lr_lambda.numel()], r))
+                pos += lr_lambda.numel()
+        for (n, s), (layer, r) in zip(hypers if not one_pair else [], zip(layers, rs)):
             lr_frst_eigvecs, lr_scnd_eigvecs, lr_lambda, correction = self.state[layer]
             ops.clamp_min0_(correction)                                  # in place on `state`, like :523
             reg_lr_lambda = ops.sqrt_scale(lr_lambda, s)
