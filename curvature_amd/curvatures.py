@@ -1324,12 +1324,22 @@ class INF(Curvature):
         # badly conditioned weighted Gram matrix, and an fp32 evaluation caps P_c - and the samples - at ~1e-3
         # (measured on ResNet-50's stem: 1.7e-3; with fp64: at the level of the fp32 inputs)
         first, parts = [], []
+        # r**2 in fp64: one launch for the model when the r of its layers lie back to back (invert()'s arena)
+        rs = [reg[3] for reg in regs]
+        r2_flat = None
+        if len(rs) > 1 and all(t.is_contiguous() and t.dtype == torch.float32 for t in rs) and \
+                all(rs[k + 1].data_ptr() == rs[k].data_ptr() + 4 * rs[k].numel() for k in range(len(rs) - 1)):
+            total = sum(t.numel() for t in rs)
+            if rs[0].untyped_storage().nbytes() >= 4 * (rs[0].storage_offset() + total):      # ... inside ONE allocation
+                r2_flat = ops.square_f64(torch.as_strided(rs[0].reshape(-1), (total,), (1,)))
+        pos = 0
         for ua, ug, sigma, r in regs:
             (n, a), (m, b) = ua.shape, ug.shape
             # distinct column pairs only (i <= k): (n, a (a + 1) / 2), (m, b (b + 1) / 2) - half the flops of the first
             # product, a quarter of the second, the same values
             PA, PG = ops.colpairs_sym(ua), ops.colpairs_sym(ug)
-            r2 = ops.square_f64(r).view(n, m)
+            r2 = (r2_flat[pos:pos + n * m] if r2_flat is not None else ops.square_f64(r)).view(n, m)
+            pos += n * m
             first.append(ops.Gemm64(PA.t(), r2))
             parts.append((PG, sigma, a, b))
         Ms = ops.gemm_f64_batched(first)
