@@ -152,7 +152,11 @@ __global__ void __launch_bounds__(256) corr_assemble_kernel(CorrChunk chunk, int
   while (l + 1 < count && chunk.l[l + 1].tile_base <= (int)blockIdx.x) ++l;
   const CorrDev& d = chunk.l[l];
   const int C = d.C, nct = C / CT;
-  const int t = blockIdx.x - d.tile_base;
+  // Workgroups b, b + 8, b + 16, b + 24 share an XCD (and its L2); they take four NEIGHBOURING tiles of a row of channel
+  // tiles, whose 8-float component rows are the four quarters of one 128-byte line (one tile per workgroup in launch
+  // order fetched every such line four times, each time on another XCD)
+  int t = blockIdx.x - d.tile_base;
+  if (t < ((nct * nct) & ~31)) { const int w = t & 31; t = (t & ~31) + ((w & 7) << 2) + (w >> 3); }
   const int cb = t / nct, cb2 = t - cb * nct;
   for (int e = threadIdx.x; e < 29 * CT * CT; e += 256) {
     const int k = e / (CT * CT), rc = e - k * (CT * CT), r = rc / CT, c = rc - r * CT;
