@@ -1280,12 +1280,13 @@ class INF(Curvature):
                 lr_frst_eigvecs, lr_scnd_eigvecs, lr_lambda, _ = self.state[layer]
                 regs.append((lr_frst_eigvecs, lr_scnd_eigvecs, reg_flat[pos:pos + lr_lambda.numel()], r))
                 pos += lr_lambda.numel()
-        for (n, s), (layer, r) in zip(hypers if not one_pair else [], zip(layers, rs)):
-            lr_frst_eigvecs, lr_scnd_eigvecs, lr_lambda, correction = self.state[layer]
-            ops.clamp_min0_(correction)                                  # in place on `state`, like :523
-            reg_lr_lambda = ops.sqrt_scale(lr_lambda, s)
-            ops.rsqrt_affine(correction, n, s, out=r)
-            regs.append((lr_frst_eigvecs, lr_scnd_eigvecs, reg_lr_lambda, r))
+        else:
+            for (n, s), layer, r in zip(hypers, layers, rs):
+                lr_frst_eigvecs, lr_scnd_eigvecs, lr_lambda, correction = self.state[layer]
+                ops.clamp_min0_(correction)                              # in place on `state`, like :523
+                reg_lr_lambda = ops.sqrt_scale(lr_lambda, s)
+                ops.rsqrt_affine(correction, n, s, out=r)
+                regs.append((lr_frst_eigvecs, lr_scnd_eigvecs, reg_lr_lambda, r))
         prev = [self.inv_state[l][3] if l in self.inv_state else None for l in layers]
         pre_samples = self.pre_sampler_many(regs, outs=prev)
         for layer, (ua, ug, _, r), pre_sample in zip(layers, regs, pre_samples):

@@ -145,6 +145,26 @@ def test_inf_select_exact_and_ties(gpu):
     assert set([0, 2, 5]).issubset(set(I.tolist())) and len(I) <= 5 and len(J) <= 5
 
 
+def test_inf_invert_per_layer_hyperparameters_match_the_one_pair_path(gpu):
+    """`INF.invert` with ONE pair of hyper-parameters clamps / scales / inverts the arenas of `update()` in three launches;
+    with per-layer lists it walks the layers.  Layer k of a list call must equal layer k of the one-pair call made with
+    layer k's pair, bit for bit (r, P_c and the clamped D); a list of equal pairs takes the one-pair path again."""
+    pairs = [(0.5, 2.0), (1.0, 10.0), (0.25, 1.0), (3.0, 0.5), (1.0, 1.0)]
+    inf, layers, _, _ = inf_from_golden(gpu, 10)
+    assert len(layers) == len(pairs)
+    want = []
+    for k, (a, m) in enumerate(pairs):
+        inf.invert(add=a, multiply=m)
+        want.append((inf.inv_state[layers[k]][2].clone(), inf.inv_state[layers[k]][3].clone(), inf.state[layers[k]][3].clone()))
+    inf.invert(add=[a for a, _ in pairs], multiply=[m for _, m in pairs])
+    for k, layer in enumerate(layers):
+        assert torch.equal(inf.inv_state[layer][2], want[k][0])
+        assert torch.equal(inf.inv_state[layer][3], want[k][1])
+        assert torch.equal(inf.state[layer][3], want[k][2])
+    inf.invert(add=[pairs[0][0]] * len(pairs), multiply=[pairs[0][1]] * len(pairs))
+    assert torch.equal(inf.inv_state[layers[0]][2], want[0][0]) and torch.equal(inf.inv_state[layers[0]][3], want[0][1])
+
+
 def test_inf_invert_and_sample(gpu):
     g8, g9 = load("g8_inf_invert.npz"), load("g9_inf_sample.npz")
     inf, layers, g5, g6 = inf_from_golden(gpu, 10)
