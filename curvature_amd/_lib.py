@@ -31,18 +31,43 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into ``csrc/libcurv_hip.so``; returns the library path."""
+    """Compile every HIP source for gfx950 into ``csrc/libcurv_hip.so``; returns the library path.  Each source is
+    compiled to an object of its own under ``csrc/build/`` (in parallel, only when it or a header is newer than its
+    object unless ``force``), then linked."""
     if not force and not _stale():
         return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "curv_hip.h")]
+    t_headers = max(os.path.getmtime(h) for h in headers)
+    compile_flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-ldl")] + ["-c"]
+
+    def compile_one(src):
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, src + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), t_headers):
+            return obj, 0, ""
+        cmd = [hipcc] + compile_flags + ["-o", obj, path]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return obj, proc.returncode, proc.stdout
+
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("CURV_BUILD_JOBS", "6"))) as pool:
+        results = list(pool.map(compile_one, SOURCES))
+    for obj, rc, out in results:
+        if rc != 0:
+            raise RuntimeError("hipcc failed:\n" + out)
+        if verbose and out:
+            print(out)
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + [r[0] for r in results] + ["-ldl"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + proc.stdout)
-    if verbose and proc.stdout:
-        print(proc.stdout)
+        raise RuntimeError("hipcc (link) failed:\n" + proc.stdout)
     return LIB_PATH
 
 
@@ -116,6 +141,7 @@ SIGNATURES = {
     "curv_last_error": (ctypes.c_char_p, []),
     "curv_init_streams": (_i, []),
     "curv_allgather_weights": (_i, [_vp, _vp, _vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
+    "curv_rccl_available": (_i, []),
     "curv_comm_unique_id": (_i, [_vp]),
     "curv_comm_init": (_i, [ctypes.POINTER(_vp), _i, _vp, _i]),
     "curv_comm_destroy": (_i, [_vp]),
@@ -164,7 +190,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 6                     # CURV_ABI_VERSION of include/curv_hip.h
+ABI_VERSION = 7                     # CURV_ABI_VERSION of include/curv_hip.h
 KFAC_TABLE_RESIDENT = 1             # CURV_KFAC_TABLE_RESIDENT
 GEMM_TABLE_RESIDENT = 1             # CURV_GEMM_TABLE_RESIDENT
 ERR_NOT_PD, ERR_INVALID, ERR_WORKSPACE, ERR_HIP, ERR_NOT_CONVERGED = 1, 2, 3, 4, 5     # CURV_ERR_* of the header

@@ -27,6 +27,7 @@ struct Rccl {
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
+  char why[256] = "";                       // why `ok` is false (dlerror() is read ONCE: reading it clears it)
 };
 constexpr int kNcclFloat32 = 7;           // rccl.h: ncclFloat32 = 7
 constexpr int kUniqueIdBytes = 128;       // rccl.h: NCCL_UNIQUE_ID_BYTES
@@ -39,7 +40,11 @@ Rccl& rccl() {
     for (const char* n : names) { r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (r.handle) break; }   // already in the process?
     for (const char* n : names) { if (r.handle) break; r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
     if (!r.handle) r.handle = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!r.handle) return;
+    if (!r.handle) {
+      const char* e = dlerror();
+      snprintf(r.why, sizeof(r.why), "dlopen librccl.so: %s", e ? e : "unknown error");
+      return;
+    }
     auto sym = [&](const char* name) { return dlsym(r.handle, name); };
     r.GroupStart = (int (*)())sym("ncclGroupStart");
     r.GroupEnd = (int (*)())sym("ncclGroupEnd");
@@ -52,6 +57,7 @@ Rccl& rccl() {
     r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
     r.ok = r.GroupStart && r.GroupEnd && r.Broadcast && r.CommCount && r.CommUserRank && r.GetUniqueId && r.CommInitRank &&
            r.CommDestroy && r.GetErrorString;
+    if (!r.ok) snprintf(r.why, sizeof(r.why), "librccl.so is loaded but lacks a symbol of the nccl* API this library binds");
   });
   return r;
 }
@@ -59,7 +65,7 @@ Rccl& rccl() {
 int need_rccl(Rccl** out) {
   Rccl& r = rccl();
   if (!r.ok) {
-    set_error("RCCL is not available in this process (dlopen librccl.so: %s)", dlerror() ? dlerror() : "symbols missing");
+    set_error("RCCL is not available in this process (%s)", r.why);
     return CURV_ERR_HIP;
   }
   *out = &r;
@@ -78,6 +84,10 @@ int need_rccl(Rccl** out) {
 }  // namespace curv
 
 using namespace curv;
+
+// 1 when RCCL can be reached through this library (dlopen + every symbol bound), 0 otherwise.  Local and free of side
+// effects: no communicator, no bootstrap socket - the probe a caller runs before the collective steps.
+extern "C" int curv_rccl_available(void) { return rccl().ok ? 1 : 0; }
 
 extern "C" int curv_allgather_weights(void* comm, void* stream, float* flat, const long long* counts,
                                       const long long* displs) {

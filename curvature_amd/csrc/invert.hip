@@ -25,6 +25,7 @@
 #include "mma64.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -72,7 +73,20 @@ struct InvDev {
   const double* R;
   double* Zm;
   int r_minus, pad_;    // emit R - Z instead of Z
+  // reverse == 1 (KFAC.invert): the triangular inverse outside the block squares is accumulated in fp32, off the chain
+  // (supd32_kernel, xrows32_kernel): C32 = fp32 copy of the rows of C below each square (written by the panel product),
+  // S32 = the running sums, X32 = the finished rows of C^-1 outside the squares (the squares themselves stay in X, fp64).
+  // All (np x np) fp32.
+  float* C32;
+  float* X32;           // finished rows of C^-1 (outside the squares)
+  float* S32;           // the running sums S
 };
+typedef __attribute__((address_space(1))) float gfloat;
+// does this factor accumulate S in fp64 inside the sweep (the round-1 form: curv_chol_factor_inverse, whose fp64 outputs
+// feed INF's chain), or in fp32 off the chain (KFAC.invert)?
+__device__ __host__ __forceinline__ bool s_in_sweep(const InvDev& d) { return d.X32 == nullptr; }
+// 0: fp32 inverse off the chain (KFAC.invert), 1: fp64 inverse inside the sweep, 2: right-hand side mode (Zm)
+__device__ __host__ __forceinline__ int s_kind(const InvDev& d) { return d.X32 != nullptr ? 0 : (d.Zm != nullptr ? 2 : 1); }
 
 // block -> (factor, local tile) for per-factor tile counts cnt(f) that depend on the step
 template <typename CountFn>
@@ -116,7 +130,6 @@ inv_prepare_kernel(const InvDev* __restrict__ t, int nf, int* __restrict__ flags
   const int bj = tile;
   const int n = d.n, np = d.np, rev = d.reverse;
   const float ss = d.sqrt_s, sn = d.sqrt_n;
-  typedef __attribute__((address_space(1))) float gfloat;
   const gfloat* F = (const gfloat*)d.F;
   gdouble* W = (gdouble*)d.W;
   if (bi == 0 && bj == 0 && threadIdx.x == 0) *d.info = 0;
@@ -212,19 +225,20 @@ __device__ __host__ __forceinline__ long long inner_tiles(int P, int k, int k0, 
 // above the diagonal and exit.
 constexpr int SB = 4;
 // far part of an outer update: rows/cols from row0 on (trailing) and rows from row0 on x cols < kend (S)
-__device__ __host__ __forceinline__ long long outer_tiles(int P, int kend, int row0) {
+// (s_part: the factor accumulates S in this sweep - see s_in_sweep)
+__device__ __host__ __forceinline__ long long outer_tiles(int P, int kend, int row0, bool s_part) {
   const long long r = P - row0;
   if (r <= 0) return 0;
-  const long long nsb = (r + SB - 1) / SB, ncb = (kend + SB - 1) / SB;
+  const long long nsb = (r + SB - 1) / SB, ncb = s_part ? (kend + SB - 1) / SB : 0;
   return (nsb * (nsb + 1) / 2 + nsb * ncb) * (SB * SB);
 }
 // a "strip" of an outer update: trailing tiles of the block columns [lo, hi) and S tiles of the block rows
 // [lo, hi) (S columns < kend).  [kend, kend + 4) is what the next panel's chain touches ("near").
-__device__ __host__ __forceinline__ long long strip_tiles(int P, int kend, int lo, int hi) {
+__device__ __host__ __forceinline__ long long strip_tiles(int P, int kend, int lo, int hi, bool s_part) {
   const int re = hi < P ? hi : P;
   long long n = 0;
   for (int j = lo; j < re; ++j) n += P - j;
-  if (re > lo) n += (long long)(re - lo) * kend;
+  if (s_part && re > lo) n += (long long)(re - lo) * kend;
   return n;
 }
 
@@ -315,7 +329,22 @@ struct TileJob {                        // everything wave-uniform
   gdouble* C;                           // output tile, pitch np
   int np, ke0, ke1, mode;               // K range in elements; mode of store_acc
   bool bt, same;                        // same: B is A (diagonal tile of a symmetric update)
+  gfloat* C32 = nullptr;                // F32 = false: also store the tile as fp32 here (pitch np); F32 = true: THE output
 };
+// fp32 twin of store_acc: tile (pitch ld floats) = sign * acc
+__device__ __forceinline__ void store_acc_f32(gfloat* __restrict__ C, int ld, const f64x4 (&acc)[2][2], int wm, int wn, int lane,
+                                              float sign) {
+  const int c16 = lane & 15, rq = lane >> 4;
+  const unsigned voff = (unsigned)(((long long)(32 * wm + rq) * ld + 32 * wn + c16) * 4);
+  gbyte* base = (gbyte*)C;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(gfloat*)(base + ((long long)(16 * m + 4 * q) * ld + 16 * n) * 4 + voff) = sign * (float)acc[m][n][q];
+}
 // WV x WV waves per workgroup.  WV = 2 (256 threads, a 32x32 quadrant per wave) is the throughput form: <= 128 VGPRs,
 // four workgroups per CU hide each other's latencies.  When a launch has fewer workgroups than the GPU has CUs -
 // the near update and the panel product of a single large factor, both on the chain's critical path - nobody
@@ -327,8 +356,11 @@ struct TileJob {                        // everything wave-uniform
 // flags tested inside it, every step carried ~13 scalar branches, 9 v_cndmask and 16 v_mov next to its 16 MFMAs,
 // and VALU instructions do not overlap with another wave's MFMAs on this chip (tools/micro/f64_mfma_overlap.hip:
 // a wave issuing MFMAs back to back starves the VALU work of the other wave of its SIMD completely).
-template <int WV, int MODE>
+// F32 (MODE 2 only, the columns-left product of the fp32 inverse): B is an fp32 matrix (pitch np floats, converted on the
+// way into LDS) and the output goes to o.C32 as -acc in fp32.
+template <int WV, int MODE, bool F32 = false>
 __device__ __forceinline__ void tile_product_impl(const TileJob& o, double* __restrict__ As, double* __restrict__ Bs) {
+  static_assert(!F32 || MODE == 2, "fp32 B operand: [k][col] form only");
   constexpr int THREADS = 64 * WV * WV, T = 4 / WV, LPT = NB * OKS / THREADS;   // MFMA tiles per wave edge, loads per thread
   const int np = o.np;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WV, wn = wave % WV;
@@ -336,15 +368,17 @@ __device__ __forceinline__ void tile_product_impl(const TileJob& o, double* __re
   const int r16 = lane & 15, kq = lane >> 4;
   double ra[LPT], rb[LPT];
   const unsigned voff_k = (unsigned)(((long long)(tid / OKS) * np + (tid % OKS)) * 8);   // [rows][OKS k] operands
-  const unsigned voff_n = (unsigned)(((long long)(tid >> 6) * np + (tid & 63)) * 8);   // [OKS k][64 cols] operand
-  const long long step_k = (long long)(THREADS / OKS) * np * 8, step_n = (long long)(THREADS / 64) * np * 8;
+  constexpr int BE = F32 ? 4 : 8;                                                      // bytes per element of the [k][col] operand
+  const unsigned voff_n = (unsigned)(((long long)(tid >> 6) * np + (tid & 63)) * BE);   // [OKS k][64 cols] operand
+  const long long step_k = (long long)(THREADS / OKS) * np * 8, step_n = (long long)(THREADS / 64) * np * BE;
   auto fetch = [&](int ke) __attribute__((always_inline)) {                            // ke: first K element of the step
     const gbyte* ga = o.a0 + (long long)ke * 8;
-    const gbyte* gb = trailing ? o.b0 + (long long)ke * 8 : o.b0 + (long long)ke * np * 8;
+    const gbyte* gb = trailing ? o.b0 + (long long)ke * 8 : o.b0 + (long long)ke * np * BE;
 #pragma unroll
     for (int u = 0; u < LPT; ++u) {
       ra[u] = *(const gdouble*)(ga + u * step_k + voff_k);
       if (trailing) rb[u] = same ? 0.0 : *(const gdouble*)(gb + u * step_k + voff_k);
+      else if (F32) rb[u] = (double)*(const gfloat*)(gb + u * step_n + voff_n);
       else rb[u] = *(const gdouble*)(gb + u * step_n + voff_n);
     }
   };
@@ -378,11 +412,28 @@ __device__ __forceinline__ void tile_product_impl(const TileJob& o, double* __re
     }
     __syncthreads();
   }
-  if constexpr (WV == 2) {
+  if constexpr (F32) {
+    if constexpr (WV == 2) {
+      store_acc_f32(o.C32, np, acc, wm, wn, lane, -1.0f);
+    } else {
+      const int c16 = lane & 15, rq = lane >> 4;
+      gbyte* base = (gbyte*)o.C32;
+      const unsigned voff = (unsigned)(((long long)(16 * wm + rq) * np + 16 * wn + c16) * 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *(gfloat*)(base + (long long)(4 * q) * np * 4 + voff) = -(float)acc[0][0][q];
+    }
+  } else if constexpr (WV == 2) {
     store_acc(o.C, np, acc, wm, wn, lane, o.mode);
+    if (o.C32 != nullptr) store_acc_f32(o.C32, np, acc, wm, wn, lane, 1.0f);
   } else {
     // one 16x16 tile per wave: rows 16 wm + rq + 4 q, column 16 wn + c16
     const int c16 = lane & 15, rq = lane >> 4;
+    if (o.C32 != nullptr) {
+      gbyte* b32 = (gbyte*)o.C32;
+      const unsigned v32 = (unsigned)(((long long)(16 * wm + rq) * np + 16 * wn + c16) * 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *(gfloat*)(b32 + (long long)(4 * q) * np * 4 + v32) = (float)acc[0][0][q];
+    }
     gbyte* base = (gbyte*)o.C;
     const unsigned voff = (unsigned)(((long long)(16 * wm + rq) * np + 16 * wn + c16) * 8);
     double old[4];
@@ -413,7 +464,7 @@ __device__ __forceinline__ void outer_update_body(const InvDev* __restrict__ t, 
   int i, j, f, local;
   if (strip) {
     // strip: block columns / rows [lo, hi)
-    if (!locate(t, nf, blockIdx.x, [kend, lo, hi](const InvDev& d) { return (int)strip_tiles(d.P, kend, lo, hi); }, f, local))
+    if (!locate(t, nf, blockIdx.x, [kend, lo, hi](const InvDev& d) { return (int)strip_tiles(d.P, kend, lo, hi, s_in_sweep(d)); }, f, local))
       return;
     const int P = t[f].P, re = hi < P ? hi : P;
     trailing = false;
@@ -437,7 +488,7 @@ __device__ __forceinline__ void outer_update_body(const InvDev* __restrict__ t, 
       item = ((jj / (SB * SB)) * 8 + xcd) * (SB * SB) + (jj % (SB * SB));
     }
     if (item >= n_items) return;
-    if (!locate(t, nf, item, [kend, row0](const InvDev& d) { return (int)outer_tiles(d.P, kend, row0); }, f, local)) return;
+    if (!locate(t, nf, item, [kend, row0](const InvDev& d) { return (int)outer_tiles(d.P, kend, row0, s_in_sweep(d)); }, f, local)) return;
     const int r = t[f].P - row0;
     const int nsb = (r + SB - 1) / SB;
     const int sb = local / (SB * SB), in = local - sb * (SB * SB);
@@ -1038,25 +1089,49 @@ chol_square_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int* 
 // doing these rows step by step (nb panel solves + nb (nb - 1) / 2 rank-64 updates, each a read-modify-
 // write of 64x64 tiles) the row panel is read and written once.
 // ------------------------------------------------------------------------------------------------
+// Jobs of a panel product launch per factor (kind: s_kind).  part 0 (the chain): the block rows below the square; for the
+// factors that carry their inverse in the sweep also the block columns left of the square (right-hand side mode: the
+// block columns of Zm).  part 1 (off the chain): the block columns left of the square of the fp32 inverse.
+__device__ __host__ __forceinline__ int panel_jobs(int P, int kind, int k0, int kend, int part) {
+  if (P <= k0) return 0;
+  if (part == 1) return kind == 0 ? k0 : 0;
+  return (P > kend ? P - kend : 0) + (kind == 2 ? (kend < P ? kend : P) : kind == 1 ? k0 : 0);
+}
 template <int WV>
-__device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t, int nf, int k0, int kend,
+__device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t, int nf, int k0, int kend, int part,
                                                    double* __restrict__ As, double* __restrict__ Bs) {
   int f, local;
   if (!locate(t, nf, blockIdx.x,
-              [k0, kend](const InvDev& d) { return d.P > k0 ? (d.P > kend ? d.P - kend : 0) + (d.Zm != nullptr ? (kend < d.P ? kend : d.P) : k0) : 0; }, f, local))
+              [k0, kend, part](const InvDev& d) { return panel_jobs(d.P, s_kind(d), k0, kend, part); }, f, local))
     return;
   const InvDev& d = t[f];
   const int np = d.np, nb = (kend < d.P ? kend : d.P) - k0;
-  const int n_below = d.P > kend ? d.P - kend : 0;
   gdouble* W = (gdouble*)d.W;
   gdouble* X = (gdouble*)d.X;
-  const bool below = local < n_below;
-  const int i = kend + local, j = local - n_below;
   TileJob o;
   o.np = np;
-  o.bt = below;
   o.same = false;
   o.ke0 = 0;
+  if (part == 1) {
+    // fp32 inverse: X32[k0 + c][j] <- - sum_{k <= c} X_sq[c][k] S32[k0 + k][j], in place (descending c)
+    const int j = local;
+    gfloat* S = (gfloat*)d.X32;
+    o.bt = false;
+    o.mode = 3;
+    for (int c = nb - 1; c >= 0; --c) {
+      o.a0 = (const gbyte*)(X + (long long)(k0 + c) * NB * np + k0 * NB);
+      o.b0 = (const gbyte*)(S + (long long)k0 * NB * np + j * NB);
+      o.C = nullptr;
+      o.C32 = S + (long long)(k0 + c) * NB * np + j * NB;
+      o.ke1 = (c + 1) * NB;
+      tile_product_impl<WV, 2, true>(o, As, Bs);
+    }
+    return;
+  }
+  const int n_below = d.P > kend ? d.P - kend : 0;
+  const bool below = local < n_below;
+  const int i = kend + local, j = local - n_below;
+  o.bt = below;
   o.mode = below ? 1 : 3;
   // right-hand side mode: the columns-left part works on Zm instead of X - rows of the panel <- + X_sq (R - S) - and covers
   // the panel's own column blocks as well (Z_sq = X_sq R_sq: block column j starts at block row j - k0 of the square)
@@ -1064,12 +1139,14 @@ __device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t,
   const bool rhs = !below && Zm != nullptr;
   gdouble* S = rhs ? Zm : X;
   if (rhs) { o.mode = 1; o.ke0 = (j > k0 ? j - k0 : 0) * NB; }
+  gfloat* C32 = below ? (gfloat*)d.C32 : nullptr;      // the rows below the square also go to the fp32 copy of C
   for (int c = nb - 1; c >= 0; --c) {      // descending: output c reads only inputs k <= c
     if (rhs && k0 + c < j) break;          // above the diagonal of the solution: never read
     const gdouble* xsq = X + (long long)(k0 + c) * NB * np + k0 * NB;              // block row c of X_sq
     o.a0 = below ? (const gbyte*)(W + (long long)i * NB * np + k0 * NB) : (const gbyte*)xsq;
     o.b0 = below ? (const gbyte*)xsq : (const gbyte*)(S + (long long)k0 * NB * np + j * NB);
     o.C = below ? W + (long long)i * NB * np + (k0 + c) * NB : S + (long long)(k0 + c) * NB * np + j * NB;
+    o.C32 = C32 != nullptr ? C32 + (long long)i * NB * np + (k0 + c) * NB : nullptr;
     o.ke1 = (c + 1) * NB;
     tile_product_k32<WV>(o, As, Bs);
   }
@@ -1086,9 +1163,11 @@ __device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t,
 constexpr int PQ_PITCH = 4 * NB + 1;                 // [16][257]: rows of the workgroup's slice of W
 constexpr int PQ_OWN = 16 * PQ_PITCH > 4 * NB * 17 ? 16 * PQ_PITCH : 4 * NB * 17;   // or [256][17]: columns of S
 // `below` is a template parameter: tested inside the K loop it put a scalar branch in front of every operand read
-template <bool below>
+// F32 (columns-left form only): S is read from / the result written to the fp32 matrix X32 (fp32 inverse, off the chain)
+template <bool below, bool F32 = false>
 __device__ __forceinline__ void panel_quarter_body(const InvDev& d, int k0, int nb, int i, int j, int q,
                                                    double* __restrict__ Own, double* __restrict__ Ts) {
+  static_assert(!(below && F32), "fp32 form: columns left of the square only");
   const int np = d.np;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
   PQT(240)
@@ -1107,11 +1186,15 @@ __device__ __forceinline__ void panel_quarter_body(const InvDev& d, int k0, int 
     }
   } else {
     // S[k0*64 + k][j*64 + 16 q + c], k < 64 nb, c < 16: element (k = tid / 16 + 16 u, c = tid % 16)
-    const gbyte* g = Xb + ((long long)k0 * NB * np + (long long)j * NB + 16 * q) * 8;
+    constexpr int SE = F32 ? 4 : 8;
+    const gbyte* g = (F32 ? (const gbyte*)d.X32 : Xb) + ((long long)k0 * NB * np + (long long)j * NB + 16 * q) * SE;
     for (int v = 0; v < nb; ++v) {
       double x[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) x[u] = *(const gdouble*)(g + ((long long)((tid >> 4) + 16 * u + 64 * v) * np + (tid & 15)) * 8);
+      for (int u = 0; u < 4; ++u) {
+        const gbyte* e = g + ((long long)((tid >> 4) + 16 * u + 64 * v) * np + (tid & 15)) * SE;
+        x[u] = F32 ? (double)*(const gfloat*)e : *(const gdouble*)e;
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) Own[((tid >> 4) + 16 * u + 64 * v) * 17 + (tid & 15)] = x[u];
     }
@@ -1156,13 +1239,19 @@ __device__ __forceinline__ void panel_quarter_body(const InvDev& d, int k0, int 
       // 16x16 tile of output block c: rows 16 wm + rq + 4 qq, column 16 wn + c16
       const int wm = below ? q : wave, wn = below ? wave : q;
       const int c16 = lane & 15, rq = lane >> 4;
+      constexpr int OE = F32 ? 4 : 8;
       gbyte* base = below ? (gbyte*)d.W + (((long long)i * NB) * np + (long long)(k0 + c) * NB) * 8
-                          : (gbyte*)d.X + (((long long)(k0 + c) * NB) * np + (long long)j * NB) * 8;
-      const unsigned voff = (unsigned)(((long long)(16 * wm + rq) * np + 16 * wn + c16) * 8);
+                          : (F32 ? (gbyte*)d.X32 : (gbyte*)d.X) + (((long long)(k0 + c) * NB) * np + (long long)j * NB) * OE;
+      const unsigned voff = (unsigned)(((long long)(16 * wm + rq) * np + 16 * wn + c16) * OE);
+      // (below) the fp32 copy of C for the off-chain inverse
+      gbyte* base32 = (below && d.C32 != nullptr) ? (gbyte*)d.C32 + (((long long)i * NB) * np + (long long)(k0 + c) * NB) * 4 : nullptr;
+      const unsigned voff32 = (unsigned)(((long long)(16 * wm + rq) * np + 16 * wn + c16) * 4);
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const double v = (acc[0][qq] + acc[1][qq]) + (acc[2][qq] + acc[3][qq]);
-        *(gdouble*)(base + (long long)(4 * qq) * np * 8 + voff) = below ? v : -v;
+        if (F32) *(gfloat*)(base + (long long)(4 * qq) * np * 4 + voff) = -(float)v;
+        else *(gdouble*)(base + (long long)(4 * qq) * np * 8 + voff) = below ? v : -v;
+        if (below && base32 != nullptr) *(gfloat*)(base32 + (long long)(4 * qq) * np * 4 + voff32) = (float)v;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc[u] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -1180,30 +1269,193 @@ __device__ __forceinline__ void panel_quarter_body(const InvDev& d, int k0, int 
   }
 }
 __global__ void __launch_bounds__(INV_THREADS)
-panel_product_quarter_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
+panel_product_quarter_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int part) {
   __shared__ double Own[PQ_OWN], Ts[NB * LDA];
   const int job = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7), q = (blockIdx.x >> 3) & 3;   // the four quarters of a job on one XCD
   int f, local;
   KT_BEGIN(236)
   if (!locate(t, nf, job,
-              [k0, kend](const InvDev& d) { return d.P > k0 ? (d.P > kend ? d.P - kend : 0) + (d.Zm != nullptr ? (kend < d.P ? kend : d.P) : k0) : 0; }, f, local))
+              [k0, kend, part](const InvDev& d) { return panel_jobs(d.P, s_kind(d), k0, kend, part); }, f, local))
     return;
   const InvDev& d = t[f];
   const int nb = (kend < d.P ? kend : d.P) - k0;
-  const int n_below = d.P > kend ? d.P - kend : 0;
-  if (local < n_below) panel_quarter_body<true>(d, k0, nb, kend + local, 0, q, Own, Ts);
+  const int n_below = part == 1 ? 0 : (d.P > kend ? d.P - kend : 0);
+  if (part == 1) panel_quarter_body<false, true>(d, k0, nb, 0, local, q, Own, Ts);
+  else if (local < n_below) panel_quarter_body<true>(d, k0, nb, kend + local, 0, q, Own, Ts);
   else panel_quarter_body<false>(d, k0, nb, 0, local - n_below, q, Own, Ts);
   KT_END(237)
 }
 __global__ void __launch_bounds__(INV_THREADS, 3)
-panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
+panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int part) {
   __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
-  panel_product_body<2>(t, nf, k0, kend, As, Bs);
+  panel_product_body<2>(t, nf, k0, kend, part, As, Bs);
 }
 __global__ void __launch_bounds__(1024)
-panel_product_wide_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
+panel_product_wide_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int part) {
   __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
-  panel_product_body<4>(t, nf, k0, kend, As, Bs);
+  panel_product_body<4>(t, nf, k0, kend, part, As, Bs);
+}
+
+// ------------------------------------------------------------------------------------------------
+// (4') The triangular inverse X = C^-1 OUTSIDE the block squares, for KFAC.invert: in fp32 and off the chain.
+//     S32[i][j] (+)= C32[i][panel] X[panel][j]      for block rows i below the panel, block columns j <= panel
+// (the forward substitution of C X = I, right-looking, one K = 256 product per tile and panel), followed one panel later
+// by the columns-left product with the square's fp64 inverse (panel_product, part 1), which turns the S rows of the next
+// panel into rows of X.  Everything the chain computes - the Cholesky factor, the inverses of the 256 x 256 block squares -
+// stays fp64; only these sums, n^3 / 3 of the sweep's (2/3) n^3 flops, run on v_mfma_f32_32x32x2_f32 at twice the fp64
+// rate and half the bytes.  Forward substitution is far better conditioned than the factorisation: on damped ResNet
+// factors (condition 1e4 .. 2e5) the fp32 sums cost 1e-7 .. 6e-7 relative Frobenius error of L against 2e-8 for the
+// all-fp64 sweep (both below what the rounding of L itself to fp32 contributes to any product with it), while a fp32
+// trailing update of the factorisation would cost cond x 6e-8 (DESIGN K2).
+// The launches run on the far-update stream behind the far update of their panel; the chain (panel product, near
+// update) carries no part of the inverse any more.
+// One 64 x 64 tile per workgroup, 4 waves x one 32x32x2 accumulator; K advances in steps of 32 through register-staged
+// LDS tiles (16-byte loads: a row of C32 is K-contiguous, a row of X32 column-contiguous).  The B operand of the panel's
+// OWN block columns is the fp64 square X_sq (lower triangular: K starts at the column's block).
+// ------------------------------------------------------------------------------------------------
+constexpr int SKS = 32;                // K step
+constexpr int SPA = SKS + 1;           // [64 rows][SKS] pitch (floats)
+constexpr int SPB = NB + 32;           // [SKS][64 cols] pitch: the two lane halves of a 32x32x2 operand read 32 banks apart
+// One 64 x 64 fp32 tile: out (=, +=) sign * A[64 x K] B[K x 64], K = [ke0, ke1) in steps of 32.  A rows are K-contiguous
+// (fp32, or fp64 converted on the way into LDS), B is [k][col] (fp32 or fp64); everything wave-uniform.
+struct Tile32 {
+  const gbyte* a;        // element (row, ke) at a + (row * np + ke) * (a64 ? 8 : 4)
+  const gbyte* b;        // element (ke, col) at b + (ke * np + col) * (b64 ? 8 : 4)
+  gfloat* out;           // tile, pitch np
+  int np, ke0, ke1;
+  bool a64, b64, accumulate, negate;
+};
+__device__ __forceinline__ void tile32(const Tile32& o, float* __restrict__ As, float* __restrict__ Bs) {
+  const int np = o.np;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int l32 = lane & 31, h = lane >> 5;
+  // A: thread -> row = tid / 8 + 32 u, k = 4 (tid % 8);  B: thread -> k = tid / 16 + 16 u, col = 4 (tid % 16)
+  const long long a_off = (long long)(tid >> 3) * np + 4 * (tid & 7), a_step = 32ll * np;
+  const long long b_off = (long long)(tid >> 4) * np + 4 * (tid & 15), b_step = 16ll * np;
+  typedef const __attribute__((address_space(1))) f32x4 gf4;
+  typedef const __attribute__((address_space(1))) f64x4 gd4;
+  f32x4 ra[2], rb[2];
+  auto fetch = [&](int ke) __attribute__((always_inline)) {
+    if (o.a64) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f64x4 v = *(gd4*)(o.a + (a_off + u * a_step + ke) * 8);
+        ra[u] = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) ra[u] = *(gf4*)(o.a + (a_off + u * a_step + ke) * 4);
+    }
+    if (o.b64) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f64x4 v = *(gd4*)(o.b + (b_off + u * b_step + (long long)ke * np) * 8);
+        rb[u] = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) rb[u] = *(gf4*)(o.b + (b_off + u * b_step + (long long)ke * np) * 4);
+    }
+  };
+  f32x16 acc = {0};
+  fetch(o.ke0);
+  for (int ke = o.ke0; ke < o.ke1; ke += SKS) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        As[((tid >> 3) + 32 * u) * SPA + 4 * (tid & 7) + e] = ra[u][e];
+        Bs[((tid >> 4) + 16 * u) * SPB + 4 * (tid & 15) + e] = rb[u][e];
+      }
+    __syncthreads();
+    if (ke + SKS < o.ke1) fetch(ke + SKS);
+#pragma unroll
+    for (int kk = 0; kk < SKS; kk += 2) {
+      const float av = As[(32 * wm + l32) * SPA + kk + h];
+      const float bv = Bs[(kk + h) * SPB + 32 * wn + l32];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D map of the 32x32 block: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  gbyte* base = (gbyte*)(o.out + (long long)(32 * wm + 4 * h) * np + 32 * wn + l32);
+  if (!o.accumulate) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg)
+      *(gfloat*)(base + (long long)((reg & 3) + 8 * (reg >> 2)) * np * 4) = o.negate ? -acc[reg] : acc[reg];
+  } else {
+    float old[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) old[reg] = *(const gfloat*)(base + (long long)((reg & 3) + 8 * (reg >> 2)) * np * 4);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) *(gfloat*)(base + (long long)((reg & 3) + 8 * (reg >> 2)) * np * 4) = old[reg] + acc[reg];
+  }
+}
+// S update of panel [k0, kend): tiles (i, j), i >= kend, j < kend, in SB x SB super-blocks (see outer_tiles)
+__device__ __host__ __forceinline__ long long supd_tiles(int P, int kind, int kend) {
+  if (kind != 0 || P <= kend) return 0;
+  const long long nsb = (P - kend + SB - 1) / SB, ncb = (kend + SB - 1) / SB;
+  return nsb * ncb * (SB * SB);
+}
+__global__ void __launch_bounds__(INV_THREADS, 3)
+supd32_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int n_items) {
+  __shared__ float As[NB * SPA], Bs[SKS * SPB];
+  int item;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3;       // whole super-blocks per XCD (see outer_update_body)
+    item = ((jj / (SB * SB)) * 8 + xcd) * (SB * SB) + (jj % (SB * SB));
+  }
+  if (item >= n_items) return;
+  int f, local;
+  if (!locate(t, nf, item, [kend](const InvDev& d) { return (int)supd_tiles(d.P, s_kind(d), kend); }, f, local)) return;
+  const InvDev& d = t[f];
+  const int np = d.np, r = d.P - kend;
+  const int ncb = (kend + SB - 1) / SB;
+  const int sb = local / (SB * SB), in = local - sb * (SB * SB);
+  const int a = sb / ncb, cb = sb - a * ncb;
+  const int ri = a * SB + in / SB, j = cb * SB + in % SB;
+  if (ri >= r || j >= kend) return;
+  const int i = kend + ri;
+  const bool own = j >= k0;                                       // B = the fp64 square; first contribution to S[i][j]
+  Tile32 o;
+  o.np = np;
+  o.a = (const gbyte*)((const gfloat*)d.C32 + (long long)i * NB * np);
+  o.a64 = false;
+  o.b = own ? (const gbyte*)((const gdouble*)d.X + j * NB) : (const gbyte*)((const gfloat*)d.X32 + j * NB);
+  o.b64 = own;
+  o.ke0 = (own ? j : k0) * NB;
+  o.ke1 = kend * NB;
+  o.out = (gfloat*)d.S32 + (long long)i * NB * np + j * NB;
+  o.accumulate = !own;
+  o.negate = false;
+  tile32(o, As, Bs);
+}
+// the rows of X of panel [k0, kend) left of its square: X32[k0 + c][j] = - sum_{k <= c} X_sq[c][k] S32[k0 + k][j], j < k0
+// (the output has a buffer of its own, so the block rows c of a panel are independent tiles)
+__device__ __host__ __forceinline__ long long xrow_tiles(int P, int kind, int k0, int kend) {
+  if (kind != 0 || P <= k0) return 0;
+  return (long long)((kend < P ? kend : P) - k0) * k0;
+}
+__global__ void __launch_bounds__(INV_THREADS, 3)
+xrows32_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
+  __shared__ float As[NB * SPA], Bs[SKS * SPB];
+  int f, local;
+  if (!locate(t, nf, blockIdx.x, [k0, kend](const InvDev& d) { return (int)xrow_tiles(d.P, s_kind(d), k0, kend); }, f, local)) return;
+  const InvDev& d = t[f];
+  const int np = d.np, nb = (kend < d.P ? kend : d.P) - k0;
+  const int j = local / nb, c = nb - 1 - (local - j * nb);          // longest K first
+  Tile32 o;
+  o.np = np;
+  o.a = (const gbyte*)((const gdouble*)d.X + (long long)(k0 + c) * NB * np);
+  o.a64 = true;
+  o.b = (const gbyte*)((const gfloat*)d.S32 + j * NB);
+  o.b64 = false;
+  o.ke0 = k0 * NB;
+  o.ke1 = (k0 + c + 1) * NB;
+  o.out = (gfloat*)d.X32 + (long long)(k0 + c) * NB * np + j * NB;
+  o.accumulate = false;
+  o.negate = true;
+  tile32(o, As, Bs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1218,7 +1470,7 @@ inv_finalize_kernel(const InvDev* __restrict__ t, int nf) {
   const int n = d.n, np = d.np, q = d.P;
   const int ti = local / q, tj = local - ti * q;       // output tile (rows ti*64.., cols tj*64..)
   const gdouble* X = (const gdouble*)d.X;
-  typedef __attribute__((address_space(1))) float gfloat;
+  const gfloat* X32 = (const gfloat*)d.X32;
   gfloat* L = (gfloat*)d.L;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = threadIdx.x & 63;   // a wave owns rows w, w + 4, ...
   if (!d.reverse) {                                          // plain copy of the lower triangle, fp64
@@ -1250,7 +1502,11 @@ inv_finalize_kernel(const InvDev* __restrict__ t, int nf) {
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     const int j = tj * NB + w + 4 * u;                       // output column -> source row n-1-j
-    xv[u] = (i_l < n && j < n && j <= i_l) ? X[(long long)(n - 1 - j) * np + (n - 1 - i_l)] : 0.0;
+    // (the 256 x 256 block squares of C^-1 are fp64 in X, everything between them fp32 in X32)
+    const int rs = n - 1 - j, cs = n - 1 - i_l;
+    const bool live = i_l < n && j < n && j <= i_l;
+    if (X32 == nullptr || (rs >> 8) == (cs >> 8)) xv[u] = live ? X[(long long)rs * np + cs] : 0.0;
+    else xv[u] = live ? (double)X32[(long long)rs * np + cs] : 0.0;
   }
 #pragma unroll
   for (int u = 0; u < 16; ++u) tile[w + 4 * u][c] = (float)xv[u];
@@ -1262,7 +1518,7 @@ inv_finalize_kernel(const InvDev* __restrict__ t, int nf) {
   }
 }
 
-constexpr int INV_UPLOAD_CHUNK = 36;
+constexpr int INV_UPLOAD_CHUNK = 30;
 struct InvChunk { InvDev f[INV_UPLOAD_CHUNK]; };
 static_assert(sizeof(InvChunk) <= 3840, "kernel argument block must stay below 4 KB");
 
@@ -1284,6 +1540,9 @@ struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t ev_main[2] = {nullptr, nullptr};
   hipEvent_t ev_side[2] = {nullptr, nullptr};
+  hipEvent_t ev_tail = nullptr;          // the last row panel of the triangular inverse is done
+  hipStream_t inv = nullptr;             // the fp32 inverse (xrows32 / supd32): CU-masked like `stream`
+  hipEvent_t ev_near[2] = {nullptr, nullptr};   // the near update of a panel is done (when it runs on `stream`)
 };
 struct StreamSet {
   SideStream side[2];
@@ -1319,7 +1578,8 @@ static int stream_set(StreamSet** out) {
   int plo = 0, phi = 0;
   CURV_HIP_CHECK(hipDeviceGetStreamPriorityRange(&plo, &phi));
   // the large group's chain of short launches is the critical path of the sweep: highest priority
-  CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.aux, hipStreamNonBlocking, phi));
+  static const int aux_prio = getenv("CURV_AUX_PRIO") ? atoi(getenv("CURV_AUX_PRIO")) : 1;
+  CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.aux, hipStreamNonBlocking, aux_prio ? phi : plo));
   CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
   CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
   // the far updates are throughput work: lowest priority, so that the latency-critical chain launches of
@@ -1328,39 +1588,49 @@ static int stream_set(StreamSet** out) {
   CURV_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
   CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_join2, hipEventDisableTiming));
   for (int g = 0; g < 2; ++g) CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_chain[g], hipEventDisableTiming));
-  CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.masked, hipStreamNonBlocking));
-  for (int g = 0; g < 2; ++g) {
-    {
-      // The far updates fill every workgroup slot they can get (4 per CU), and a retiring far workgroup frees
-      // half the LDS a chain kernel's workgroup needs: the slot is refilled before a second one retires, and
-      // stream priorities do not reserve anything - traced: a 9-workgroup chol_panel launch waited 200-260 us
-      // for the far update beside it to drain.  So the side streams may not use the last CURV_FREE_CUS CUs
-      // (mask bits are dealt round-robin over the XCDs: 2 CUs of every XCD), which the chain then finds free.
-      static const int free_cus = getenv("CURV_FREE_CUS") ? atoi(getenv("CURV_FREE_CUS")) : 32;
-      hipDeviceProp_t prop;
-      int dev_id = 0;
-      CURV_HIP_CHECK(hipGetDevice(&dev_id));
-      CURV_HIP_CHECK(hipGetDeviceProperties(&prop, dev_id));
-      const int n_cu = prop.multiProcessorCount;
-      bool masked_ok = false;
-      if (free_cus > 0 && 2 * free_cus <= n_cu) {
-        std::vector<uint32_t> mask((size_t)cdiv(n_cu, 32), 0u);
-        for (int c = 0; c < n_cu - free_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
-        if (hipExtStreamCreateWithCUMask(&s.side[g].stream, (uint32_t)mask.size(), mask.data()) == hipSuccess) {
-          masked_ok = true;
-          std::lock_guard<std::mutex> lock(g_masked_mutex);
-          if (g_masked_streams.empty()) atexit(destroy_masked_streams);
-          g_masked_streams.emplace_back(dev_id, s.side[g].stream);
-        } else {
-          (void)hipGetLastError();            // a runtime without CU masks: plain low-priority stream below
-        }
+  static const int masked_prio = getenv("CURV_MASKED_PRIO") ? atoi(getenv("CURV_MASKED_PRIO")) : 0;
+  if (masked_prio) CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.masked, hipStreamNonBlocking, phi));
+  else CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.masked, hipStreamNonBlocking));
+  // The far updates fill every workgroup slot they can get (4 per CU), and a retiring far workgroup frees
+  // half the LDS a chain kernel's workgroup needs: the slot is refilled before a second one retires, and
+  // stream priorities do not reserve anything - traced: a 9-workgroup chol_panel launch waited 200-260 us
+  // for the far update beside it to drain.  So the streams that carry wide, throughput-bound launches may not use the
+  // last CURV_FREE_CUS CUs (mask bits are dealt round-robin over the XCDs: 2 CUs of every XCD), which the chains' small
+  // launches then find free.
+  auto wide_stream = [&](hipStream_t* out) -> int {
+    static const int free_cus = getenv("CURV_FREE_CUS") ? atoi(getenv("CURV_FREE_CUS")) : 32;
+    hipDeviceProp_t prop;
+    int dev_id = 0;
+    CURV_HIP_CHECK(hipGetDevice(&dev_id));
+    CURV_HIP_CHECK(hipGetDeviceProperties(&prop, dev_id));
+    const int n_cu = prop.multiProcessorCount;
+    if (free_cus > 0 && 2 * free_cus <= n_cu) {
+      std::vector<uint32_t> mask((size_t)cdiv(n_cu, 32), 0u);
+      for (int c = 0; c < n_cu - free_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
+      if (hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()) == hipSuccess) {
+        std::lock_guard<std::mutex> lock(g_masked_mutex);
+        if (g_masked_streams.empty()) atexit(destroy_masked_streams);
+        g_masked_streams.emplace_back(dev_id, *out);
+        return CURV_OK;
       }
-      if (!masked_ok) CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.side[g].stream, hipStreamNonBlocking, prio_low));
+      (void)hipGetLastError();            // a runtime without CU masks: plain low-priority stream below
     }
+    CURV_HIP_CHECK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio_low));
+    return CURV_OK;
+  };
+  for (int g = 0; g < 2; ++g) {
+    { const int rc = wide_stream(&s.side[g].stream); if (rc != CURV_OK) return rc; }
+    // (a stream of its own for the fp32 inverse only on request: every additional hardware queue of the process slows
+    // the whole sweep down - two more CU-masked streams, even unused: invert() of the ResNet-50 factors 7.5 -> 11.1 ms)
+    static const int inv_stream = getenv("CURV_INV_STREAM") ? atoi(getenv("CURV_INV_STREAM")) : 0;
+    if (inv_stream == 1 || (inv_stream == 2 && g == 0)) { const int rc = wide_stream(&s.side[g].inv); if (rc != CURV_OK) return rc; }
+    else if (inv_stream == 2) s.side[g].inv = s.side[0].inv;
+    for (int i = 0; i < 2; ++i) CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_near[i], hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) {
       CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_main[i], hipEventDisableTiming));
       CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_side[i], hipEventDisableTiming));
     }
+    CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_tail, hipEventDisableTiming));
   }
   cache.emplace_back(dev, s);
   *out = &cache.back().second;
@@ -1403,19 +1673,37 @@ extern "C" size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int 
   for (int i = 0; i < n_factors; ++i) {
     if (descs[i].n <= 0) return 0;
     const size_t np = (size_t)cdiv(descs[i].n, NB) * NB;
-    total += 2 * np * np * sizeof(double);
+    total += 2 * np * np * sizeof(double) + 3 * np * np * sizeof(float);     // W, X; C32, X32, S32
   }
   return total;
 }
 
-// One batched sweep over the factors of `tab` (work matrices already assigned), everything enqueued on
-// `stream` except the far outer updates, which go to side->stream.
-static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vector<InvDev>& tab, InvDev* table, int* flags,
-                            bool latency_bound, hipEvent_t progress_event = nullptr, int progress_panel = -1,
-                            hipEvent_t chain_done = nullptr) {
-  const int n_factors = (int)tab.size();
-  int Pmax = 0;
-  long long prep_tiles = 0, fin_tiles = 0;
+// One batched sweep over the factors of `tab` (work matrices already assigned), everything enqueued on `stream` except
+// the far outer updates and the fp32 inverse, which go to side->stream.  The sweep is ENQUEUED panel by panel
+// (begin / panel_step / end), so that the host can interleave the panels of two groups: a hipStreamWaitEvent issued
+// after a whole sweep has been enqueued waits for that stream's tail, not for the event's position in it (measured: the
+// second group of a whole-model inversion started when the first one's last panels ran, whatever event it waited for;
+// tools/trace_buckets.py), so a group that is to start beside another one must be enqueued beside it.
+struct GroupSweep {
+  hipStream_t stream;
+  SideStream* side;
+  const std::vector<InvDev>* tabp;
+  InvDev* table;
+  int* flags;
+  bool latency_bound;
+  int n_factors = 0, Pmax = 0, NBO = 4, k0 = 0, panel = 0;
+  long long fin_tiles = 0, quarter_prod = 0;
+  bool use_square = false, far_pending = false, inv_pending = false;
+
+  GroupSweep(hipStream_t st, SideStream* sd, const std::vector<InvDev>& tab, InvDev* tb, int* fl, bool lb)
+      : stream(st), side(sd), tabp(&tab), table(tb), flags(fl), latency_bound(lb) {}
+  bool done() const { return k0 >= Pmax; }
+  int panels() const { return cdiv(Pmax, NBO); }
+
+  int begin() {
+    const std::vector<InvDev>& tab = *tabp;
+    n_factors = (int)tab.size();
+    long long prep_tiles = 0;
   for (const InvDev& d : tab) {
     Pmax = std::max(Pmax, d.P);
     prep_tiles += (long long)d.P * (d.P + 1) / 2;
@@ -1432,7 +1720,13 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
   hipLaunchKernelGGL(inv_prepare_kernel, dim3((unsigned)prep_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, flags);
   CURV_LAUNCH_CHECK();
   static const int nbo_env = getenv("CURV_NBO") ? atoi(getenv("CURV_NBO")) : 0;
-  const int NBO = (nbo_env > 0 && !latency_bound) ? nbo_env : 4;      // outer panel: 4 block columns = 256
+  NBO = (nbo_env > 0 && !latency_bound) ? nbo_env : 4;      // outer panel: 4 block columns = 256
+    return CURV_OK;
+  }
+
+  // one outer panel: its chain, the near update, and on the side stream the far update and the fp32 inverse
+  int panel_step() {
+    const std::vector<InvDev>& tab = *tabp;
   // Per panel: the chain of diagonal steps (small, latency-bound launches) runs on the caller's stream,
   // then the near part of the outer update (the block columns / rows the NEXT chain touches); the rest of
   // the outer update goes to a second stream and overlaps the following chains (see below).
@@ -1441,19 +1735,16 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
   static const long long wide_prod = getenv("CURV_WIDE_PROD") ? atoll(getenv("CURV_WIDE_PROD")) : 256;
   // ... and below this many jobs the quarter form of the panel product (panel_product_quarter_kernel)
   static const long long quarter_prod_env = getenv("CURV_QUARTER_PROD") ? atoll(getenv("CURV_QUARTER_PROD")) : 512;
-  const long long quarter_prod = latency_bound ? quarter_prod_env : 0;
+  quarter_prod = latency_bound ? quarter_prod_env : 0;
   // A call with few factors (a layer-sharded rank, a single large factor) is bound by the latency of its chain: the block
   // square of a panel then goes into one launch whose workgroups hand tiles to each other (chol_square_kernel), and the
   // panel product takes the quarter form.  A whole model on one GPU is bound by its far updates: there the workgroups
   // of the square kernel (109 KB of LDS each, most of them waiting) only take CUs away - ResNet-50's 108 factors:
   // 8.40 ms with the per-step launches, 8.55 with the square kernel for the large group, 8.66 with both; its shards
   // over 2 / 4 / 8 ranks (tools/emulate_sharding.py): step 9.6 / 6.3 / 4.4 -> 9.2 / 5.6 / 3.8 ms.
-  const bool use_square = latency_bound;
-  bool far_pending = false;
-  int panel = 0;
-  for (int k0 = 0; k0 < Pmax; k0 += NBO, ++panel) {
+  use_square = latency_bound;
     const int kend = k0 + NBO, row0 = kend + NBO;
-    if (progress_event != nullptr && panel == progress_panel) CURV_HIP_CHECK(hipEventRecord(progress_event, stream));
+
     long long prod_tiles = 0;
     if (use_square) {
       long long sq_wgs = 0;
@@ -1482,17 +1773,27 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
         CURV_LAUNCH_CHECK();
       }
     }
-    for (const InvDev& d : tab)
-      if (d.P > k0) prod_tiles += std::max(0, d.P - kend) + (d.Zm != nullptr ? std::min(kend, d.P) : k0);
-    if (prod_tiles > 0) {   // rows below / columns left of the square: one triangular product each
-      if (prod_tiles <= quarter_prod)
-        hipLaunchKernelGGL(panel_product_quarter_kernel, dim3((unsigned)(cdivll(prod_tiles, 8) * 32)), dim3(INV_THREADS), 0, stream,
-                           table, n_factors, k0, kend);
-      else if (prod_tiles <= wide_prod)
-        hipLaunchKernelGGL(panel_product_wide_kernel, dim3((unsigned)prod_tiles), dim3(1024), 0, stream, table, n_factors, k0, kend);
+    // the launch form of a panel product by its number of jobs; part 0 on the chain, part 1 (fp32 inverse) on the side stream
+    auto launch_product = [&](hipStream_t st, long long jobs, int part) -> int {
+      if (jobs <= quarter_prod)
+        hipLaunchKernelGGL(panel_product_quarter_kernel, dim3((unsigned)(cdivll(jobs, 8) * 32)), dim3(INV_THREADS), 0, st,
+                           table, n_factors, k0, kend, part);
+      else if (jobs <= wide_prod)
+        hipLaunchKernelGGL(panel_product_wide_kernel, dim3((unsigned)jobs), dim3(1024), 0, st, table, n_factors, k0, kend, part);
       else
-        hipLaunchKernelGGL(panel_product_kernel, dim3((unsigned)prod_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend);
+        hipLaunchKernelGGL(panel_product_kernel, dim3((unsigned)jobs), dim3(INV_THREADS), 0, st, table, n_factors, k0, kend, part);
       CURV_LAUNCH_CHECK();
+      return CURV_OK;
+    };
+    long long inv_jobs = 0, inv_tiles = 0;    // fp32 inverse: columns-left products of this panel, then its S update
+    for (const InvDev& d : tab) {
+      prod_tiles += panel_jobs(d.P, s_kind(d), k0, kend, 0);
+      inv_jobs += xrow_tiles(d.P, s_kind(d), k0, kend);
+      inv_tiles += supd_tiles(d.P, s_kind(d), kend);
+    }
+    if (prod_tiles > 0) {   // rows below the square (right-hand side mode: and the columns of Zm): one triangular product each
+      const int rc = launch_product(stream, prod_tiles, 0);
+      if (rc != CURV_OK) return rc;
     }
     // Outer update of this panel in two parts: near = the strip the next chain touches (this stream, on the
     // critical path), far = everything beyond, on the side stream beside the next panel's chain.  The two
@@ -1501,41 +1802,94 @@ static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vec
     // 2-4 % slower: the far updates are throughput-bound, not waited for.)
     long long near_tiles = 0, far_tiles = 0;
     for (const InvDev& d : tab) {
-      near_tiles += strip_tiles(d.P, kend, kend, row0);
-      far_tiles += outer_tiles(d.P, kend, row0);
+      near_tiles += strip_tiles(d.P, kend, kend, row0, s_in_sweep(d));
+      far_tiles += outer_tiles(d.P, kend, row0, s_in_sweep(d));
     }
-    if (far_tiles > 0) {                         // fork: the far part needs this panel's chain
+    static const int near_side = getenv("CURV_NEAR_SIDE") ? atoi(getenv("CURV_NEAR_SIDE")) : 0;
+    static const int inv_stream = getenv("CURV_INV_STREAM") ? atoi(getenv("CURV_INV_STREAM")) : 0;
+    hipStream_t inv_st = inv_stream ? side->inv : side->stream;
+    // CURV_NEAR_SIDE=1: near update on the side stream, in front of the far update (a wide launch on the chain's unmasked
+    // stream fills the CUs the mask keeps free, and the small chain launches of this and of the OTHER group then wait for
+    // it to drain).  Measured slower: ResNet-50 factors 7.75 -> 8.66 ms, one 4608^2 2.69 -> 3.10 ms - the chain pays two
+    // cross-stream waits per panel instead of one.  CURV_INV_STREAM: the fp32 inverse on a stream of its own - every
+    // additional hardware queue costs far more than it brings (7.5 -> 11.1 ms with one more CU-masked stream)
+    const bool near_on_side = near_side != 0 && near_tiles > 0;
+    const bool side_work = far_tiles > 0 || near_on_side || (!inv_stream && (inv_jobs > 0 || inv_tiles > 0));
+    const bool inv_work = inv_jobs > 0 || inv_tiles > 0;
+    if (side_work || inv_work) {                 // fork: the other streams' work needs this panel's chain
       CURV_HIP_CHECK(hipEventRecord(side->ev_main[panel & 1], stream));
-      CURV_HIP_CHECK(hipStreamWaitEvent(side->stream, side->ev_main[panel & 1], 0));
+      if (side_work) CURV_HIP_CHECK(hipStreamWaitEvent(side->stream, side->ev_main[panel & 1], 0));
+      if (inv_work && inv_stream) CURV_HIP_CHECK(hipStreamWaitEvent(side->inv, side->ev_main[panel & 1], 0));
     }
     if (near_tiles > 0) {
-      if (far_pending) {                         // join: the previous far part wrote the tiles updated here
+      hipStream_t near_st = near_on_side ? side->stream : stream;
+      if (far_pending && !near_on_side) {        // join: the previous far part wrote the tiles updated here
         CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_side[(panel + 1) & 1], 0));
-        far_pending = false;
       }
+      far_pending = false;                       // (near on the side stream: ordered behind the previous far part there)
       if (near_tiles <= wide_near)
-        hipLaunchKernelGGL(outer_update_wide_kernel, dim3((unsigned)near_tiles), dim3(1024), 0, stream, table, n_factors,
+        hipLaunchKernelGGL(outer_update_wide_kernel, dim3((unsigned)near_tiles), dim3(1024), 0, near_st, table, n_factors,
                            k0, kend, kend, row0, 1, (int)near_tiles);
       else
-        hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)near_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0,
+        hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)near_tiles), dim3(INV_THREADS), 0, near_st, table, n_factors, k0,
                            kend, kend, row0, 1, (int)near_tiles);
       CURV_LAUNCH_CHECK();
+      if (near_on_side) {                        // the next panel's chain starts behind it
+        CURV_HIP_CHECK(hipEventRecord(side->ev_near[panel & 1], side->stream));
+        CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_near[panel & 1], 0));
+      }
     }
     if (far_tiles > 0) {
       const long long grid = cdivll(far_tiles, 8 * SB * SB) * 8 * SB * SB;
       hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, side->stream, table, n_factors, k0,
                          kend, row0, 0, 0, (int)far_tiles);
       CURV_LAUNCH_CHECK();
-      CURV_HIP_CHECK(hipEventRecord(side->ev_side[panel & 1], side->stream));
-      far_pending = true;
+      if (!near_side) {
+        CURV_HIP_CHECK(hipEventRecord(side->ev_side[panel & 1], side->stream));
+        far_pending = true;
+      }
     }
+    // the fp32 inverse on its stream: the rows of this panel x X_sq (needs the square, i.e. this panel's chain, and the S
+    // updates of all earlier panels: stream order), then this panel's S update of the rows below
+    if (inv_jobs > 0) {
+      hipLaunchKernelGGL(xrows32_kernel, dim3((unsigned)inv_jobs), dim3(INV_THREADS), 0, inv_st, table, n_factors, k0, kend);
+      CURV_LAUNCH_CHECK();
+      inv_pending = true;
+    }
+    if (inv_tiles > 0) {
+      const long long grid = cdivll(inv_tiles, 8 * SB * SB) * 8 * SB * SB;
+      hipLaunchKernelGGL(supd32_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, inv_st, table, n_factors, k0, kend,
+                         (int)inv_tiles);
+      CURV_LAUNCH_CHECK();
+      inv_pending = true;
+    }
+    k0 += NBO;
+    ++panel;
+    return CURV_OK;
   }
+
+  int end(hipEvent_t chain_done = nullptr) {
   // the status words are final here: every factorisation step is enqueued on `stream`, the finalize pass does not touch them
   if (chain_done != nullptr) CURV_HIP_CHECK(hipEventRecord(chain_done, stream));
   if (far_pending) CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_side[(panel + 1) & 1], 0));
+  if (inv_pending) {
+    static const int inv_stream = getenv("CURV_INV_STREAM") ? atoi(getenv("CURV_INV_STREAM")) : 0;
+    hipStream_t inv_st = inv_stream ? side->inv : side->stream;
+    CURV_HIP_CHECK(hipEventRecord(side->ev_tail, inv_st));
+    CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_tail, 0));
+  }
   hipLaunchKernelGGL(inv_finalize_kernel, dim3((unsigned)fin_tiles), dim3(INV_THREADS), 0, stream, table, n_factors);
   CURV_LAUNCH_CHECK();
-  return CURV_OK;
+    return CURV_OK;
+  }
+};
+
+static int chol_sweep_group(hipStream_t stream, SideStream* side, const std::vector<InvDev>& tab, InvDev* table, int* flags,
+                            bool latency_bound, hipEvent_t chain_done = nullptr) {
+  GroupSweep g(stream, side, tab, table, flags, latency_bound);
+  int rc = g.begin();
+  while (rc == CURV_OK && !g.done()) rc = g.panel_step();
+  return rc == CURV_OK ? g.end(chain_done) : rc;
 }
 
 // Factors advance in lock step (step k touches every factor with more than k blocks), so a sweep over
@@ -1562,7 +1916,8 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   // (the right-hand side mode lives in the per-step kernels: the chain-bound forms keep their operands elsewhere)
   const bool latency_bound = n_factors <= latency_max && !any_rhs;
   size_t need = 2 * inv_table_bytes(n_factors) + 2 * inv_flags_bytes(n_factors);
-  for (const InvDev& d : tab) need += (d.R != nullptr ? 3 : 2) * (size_t)d.np * d.np * sizeof(double);
+  for (const InvDev& d : tab)
+    need += (d.R != nullptr ? 3 : 2) * (size_t)d.np * d.np * sizeof(double) + (d.reverse ? 3 * (size_t)d.np * d.np * sizeof(float) : 0);
   if (workspace == nullptr || workspace_bytes < need) {
     set_error("%s: workspace too small (%zu < %zu bytes)", who, workspace_bytes, need);
     return CURV_ERR_WORKSPACE;
@@ -1581,11 +1936,17 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   // factors do not widen the large one's chain launches, and half the launches, events and waits remain (the host needs
   // 0.5 ms to enqueue the two sweeps of an 18-factor shard whose kernels take 0.6 ms)
   static const int one_group_env = getenv("CURV_ONE_GROUP") ? atoi(getenv("CURV_ONE_GROUP")) : 1;
-  const bool one_group = latency_bound && one_group_env != 0;
+  static const int force_one = getenv("CURV_FORCE_ONE_GROUP") ? atoi(getenv("CURV_FORCE_ONE_GROUP")) : 0;
+  const bool one_group = (latency_bound && one_group_env != 0) || force_one != 0;
   for (InvDev& d : tab) {
     d.W = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double);
     d.X = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double);
     if (d.R != nullptr) { d.Zm = reinterpret_cast<double*>(p); p += (size_t)d.np * d.np * sizeof(double); }
+    if (d.reverse) {                     // KFAC.invert: the inverse outside the block squares in fp32, off the chain
+      d.C32 = reinterpret_cast<float*>(p); p += (size_t)d.np * d.np * sizeof(float);
+      d.X32 = reinterpret_cast<float*>(p); p += (size_t)d.np * d.np * sizeof(float);
+      d.S32 = reinterpret_cast<float*>(p); p += (size_t)d.np * d.np * sizeof(float);
+    }
     (d.P > split || one_group ? big : small).push_back(d);
   }
   StreamSet* ss = nullptr;
@@ -1617,7 +1978,7 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
     // caller's stream may be.
     CURV_HIP_CHECK(hipEventRecord(ss->ev_fork, stream));
     CURV_HIP_CHECK(hipStreamWaitEvent(ss->aux, ss->ev_fork, 0));
-    const int rc1 = chol_sweep_group(ss->aux, &ss->side[0], big.empty() ? small : big, table0, flags0, latency_bound, nullptr, -1,
+    const int rc1 = chol_sweep_group(ss->aux, &ss->side[0], big.empty() ? small : big, table0, flags0, latency_bound,
                                      early ? ss->ev_chain[0] : nullptr);
     if (rc1 != CURV_OK) return rc1;
     if (early != nullptr) {
@@ -1639,15 +2000,39 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   // (ResNet-50: 0 -> 9.25 ms, 20 -> 9.2, 30 -> 9.0, 40 -> 9.2, 50 -> 9.5)
   const int n_panels = cdiv(Pmax, 4);
   long long far0 = 0;                          // far tiles of the large group's first panel
-  for (const InvDev& d : big) far0 += outer_tiles(d.P, 4, 8);
+  for (const InvDev& d : big) far0 += outer_tiles(d.P, 4, 8, s_in_sweep(d));
   // only a far-bound large group has such a tail to fill (a chain step is ~54 us, a far tile ~0.04 us of the
   // whole GPU): with [2048 | 1024, 512, 256] the delay costs 8 %
   const int start_panel = far0 >= 5000 ? std::min(n_panels - 1, n_panels * start_frac / 100) : 0;
-  int rc = chol_sweep_group(ss->aux, &ss->side[0], big, table0, flags0, latency_bound, start_panel > 0 ? ss->ev_join2 : nullptr, start_panel,
-                            early ? ss->ev_chain[0] : nullptr);
+  // the large group of a whole model (a handful of factors with the longest chain) may take the chain-bound forms too
+  static const int square_big = getenv("CURV_SQUARE_BIG") ? atoi(getenv("CURV_SQUARE_BIG")) : 0;
+  bool big_rhs = false;
+  for (const InvDev& d : big) big_rhs = big_rhs || d.R != nullptr;
+  const bool big_latency = latency_bound || (square_big != 0 && (int)big.size() <= square_big && !big_rhs);
+  // The two sweeps are enqueued panel by panel, the small group's panel t - start_panel behind the large group's panel t:
+  // the event the small group's stream waits for (the large group has done `start_panel` panels) is then the large
+  // group's stream TAIL at the moment of the wait, which is what hipStreamWaitEvent effectively waits for.
+  GroupSweep gb(ss->aux, &ss->side[0], big, table0, flags0, big_latency);
+  GroupSweep gs(ss->masked, &ss->side[1], small, table1, flags1, latency_bound);
+  int rc = gb.begin();
   if (rc != CURV_OK) return rc;
-  if (start_panel > 0) CURV_HIP_CHECK(hipStreamWaitEvent(ss->masked, ss->ev_join2, 0));
-  rc = chol_sweep_group(ss->masked, &ss->side[1], small, table1, flags1, latency_bound, nullptr, -1, early ? ss->ev_chain[1] : nullptr);
+  bool small_started = false;
+  for (int t = 0; !gb.done() || !small_started || !gs.done(); ++t) {
+    if (!small_started && (t >= start_panel || gb.done())) {
+      if (t > 0) {
+        CURV_HIP_CHECK(hipEventRecord(ss->ev_join2, ss->aux));
+        CURV_HIP_CHECK(hipStreamWaitEvent(ss->masked, ss->ev_join2, 0));
+      }
+      rc = gs.begin();
+      if (rc != CURV_OK) return rc;
+      small_started = true;
+    }
+    if (!gb.done()) { rc = gb.panel_step(); if (rc != CURV_OK) return rc; }
+    if (small_started && !gs.done()) { rc = gs.panel_step(); if (rc != CURV_OK) return rc; }
+  }
+  rc = gb.end(early ? ss->ev_chain[0] : nullptr);
+  if (rc != CURV_OK) return rc;
+  rc = gs.end(early ? ss->ev_chain[1] : nullptr);
   if (rc != CURV_OK) return rc;
   if (early != nullptr) {
     CURV_HIP_CHECK(hipStreamWaitEvent(ss->side[1].stream, ss->ev_chain[0], 0));

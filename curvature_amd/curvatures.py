@@ -373,6 +373,11 @@ class Curvature(ABC):
         S = int(count)
         assert S >= 1
         owned = [l for _, l in self._owned() if getattr(l, "weight", None) is not None]
+        # every parameter sample_and_replace modifies goes into the bank: Diagonal also samples the projections of the
+        # selected nn.MultiheadAttention modules (string keys, outside `_layers()`); left out, `replace_from` would reset
+        # them to their means
+        for mha in (self._attention() if self._supports_mha else []):
+            owned += [_InProjection.of(mha), mha.out_proj]
         weights = {l: torch.empty(S, *l.weight.shape, dtype=l.weight.dtype, device=l.weight.device) for l in owned}
         biases = {l: (torch.empty(S, *l.bias.shape, dtype=l.bias.dtype, device=l.bias.device) if l.bias is not None else None)
                   for l in owned}
@@ -947,6 +952,27 @@ class KFAC(Curvature):
         plan[1].run()
         plan[2].run()
         return plan[3]
+
+
+class _InProjection:
+    """``in_proj_weight`` / ``in_proj_bias`` of an nn.MultiheadAttention presented as a layer with ``weight`` / ``bias``
+    (a `SampleBank` key; one object per module, so the key is stable)."""
+
+    def __init__(self, mha: Module):
+        self.mha = mha
+
+    @classmethod
+    def of(cls, mha: Module) -> "_InProjection":
+        if "_curv_in_projection" not in mha.__dict__:
+            mha.__dict__["_curv_in_projection"] = cls(mha)
+        return mha.__dict__["_curv_in_projection"]
+
+    weight = property(lambda self: self.mha.in_proj_weight)
+    bias = property(lambda self: self.mha.in_proj_bias)
+
+    @property
+    def _parameters(self):
+        return {'weight': self.mha.in_proj_weight, 'bias': self.mha.in_proj_bias}
 
 
 class SampleBank:

@@ -217,12 +217,13 @@ class Shard:
                 d.copy_(s_)
         backend = dist.get_backend(self.group)
         if flat.is_cuda and backend == "nccl" and flat.dtype == torch.float32 and self._rccl_ready(flat.device):
-            # the one collective: variable-count all-gather in place over RCCL (curv_allgather_weights), each segment
-            # travelling once - the shards differ several-fold in size, nothing is padded to the largest
+            # opt-in (CURV_RCCL_ALLGATHER=1): variable-count all-gather in place over RCCL (curv_allgather_weights), each
+            # segment travelling once - the shards differ several-fold in size, nothing is padded to the largest
             self._allgather_rccl(flat, sizes, displs)
         elif flat.is_cuda and backend == "nccl":
-            # the library's own communicator could not be built on every rank (decided collectively, once): torch's
-            # all_gather_into_tensor on equal-sized, padded shards
+            # the default: the one collective is torch's all_gather_into_tensor (RCCL) on equal-sized, padded shards.
+            # The library's own communicator stays opt-in until a run with >= 2 RCCL ranks has compared `flat` bit for
+            # bit between the two paths (no such run exists: this pool has one GPU per box)
             cap = max(max(sizes), 1)
             pad = cache.get("pad")
             if pad is None:
@@ -252,21 +253,24 @@ class Shard:
 
     # ------------------------------------------------------------------ RCCL communicator of this shard
     def _rccl_ready(self, device: torch.device) -> bool:
-        """True when every rank of the shard has the library's RCCL communicator (built at the first call).  The decision
-        is collective - one all-reduce(MIN) of a success flag - so that all ranks take the same branch; CURV_TORCH_ALLGATHER=1
-        forces torch's all_gather_into_tensor instead."""
+        """True when the library's own RCCL communicator was asked for (CURV_RCCL_ALLGATHER=1; the default is torch's
+        all_gather_into_tensor) and every rank of the shard has it (built at the first call).  The decision is collective -
+        one all-reduce(MIN) of a success flag - so that all ranks take the same branch."""
         ready = self.__dict__.get("_rccl_ok")
         if ready is None:
             import os
-            ok = 0 if os.environ.get("CURV_TORCH_ALLGATHER") else 1
+            if os.environ.get("CURV_RCCL_ALLGATHER", "0") in ("", "0"):
+                # same environment on every rank of a torchrun job; no collective step needed for "off"
+                self.__dict__["_rccl_ok"] = False
+                return False
+            ok = 1
             if ok:
-                # can THIS rank reach RCCL through the library at all (dlopen, symbols)?  A local, communication-free probe:
-                # the collective steps below must not start unless every rank can take part in them
-                import ctypes
+                # can THIS rank reach RCCL through the library at all (dlopen, symbols)?  A local probe without side effects
+                # (curv_rccl_available: no ncclGetUniqueId, whose bootstrap listener would stay behind on every rank): the
+                # collective steps below must not start unless every rank can take part in them
                 from . import _lib
                 try:
-                    probe = (ctypes.c_ubyte * 128)()
-                    ok = int(_lib.lib().curv_comm_unique_id(probe) == 0)
+                    ok = int(_lib.lib().curv_rccl_available() == 1)
                 except Exception:                                         # noqa: BLE001
                     ok = 0
                 if not ok:

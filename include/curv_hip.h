@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CURV_ABI_VERSION 6
+#define CURV_ABI_VERSION 7
 
 #define CURV_OK 0
 #define CURV_ERR_NOT_PD 1
@@ -392,7 +392,10 @@ int curv_mul2d(void* stream, const float* A, long long a_rs, long long a_cs, con
  * curv_comm_unique_id / curv_comm_init / curv_comm_destroy: thin wrappers of ncclGetUniqueId / ncclCommInitRank /
  * ncclCommDestroy for callers without RCCL bindings (`id` is the 128-byte ncclUniqueId drawn on rank 0 and shipped to
  * the other ranks by the caller; the calling thread's current device is the rank's device).
+ * curv_rccl_available: 1 when RCCL could be bound (dlopen and every symbol), 0 otherwise - local, no communicator, no
+ * bootstrap socket: the probe to run on every rank before the collective set-up steps.
  * ---------------------------------------------------------------------------------------------- */
+int curv_rccl_available(void);
 int curv_allgather_weights(void* comm, void* stream, float* flat, const long long* counts, const long long* displs);
 int curv_comm_unique_id(void* id_out_128_bytes);
 int curv_comm_init(void** comm_out, int n_ranks, const void* id_128_bytes, int rank);

@@ -101,7 +101,9 @@ def _rccl_world1(rank, port, out_dir, fallback=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if fallback:
-        os.environ["CURV_TORCH_ALLGATHER"] = "1"                  # torch's all_gather_into_tensor on padded shards
+        os.environ.pop("CURV_RCCL_ALLGATHER", None)               # the default: torch's all_gather_into_tensor on padded shards
+    else:
+        os.environ["CURV_RCCL_ALLGATHER"] = "1"                   # opt-in: the library's own communicator
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)          # as bench.py does for N > 1
@@ -162,8 +164,8 @@ def test_rccl_backend_runs_the_allgather_branch(tmp_path, fallback):
     ranks on one device), so the nccl backend is initialised with world_size 1 and `force_collective` sends
     sample_and_replace through pack -> curv_allgather_weights (RCCL group of broadcasts) -> unpack instead of the
     world == 1 early return.  No run with more than one RCCL rank exists: 8-GPU nodes are the driver's.
-    `fallback`: CURV_TORCH_ALLGATHER=1 - the path taken when a rank cannot bind RCCL through the library (decided
-    collectively): torch's all_gather_into_tensor on padded shards, same parameters."""
+    `fallback` = the DEFAULT path: torch's all_gather_into_tensor on padded shards; curv_allgather_weights is opt-in
+    (CURV_RCCL_ALLGATHER=1) until a run with >= 2 RCCL ranks has compared the two bit for bit.  Same parameters."""
     mp.spawn(_rccl_world1, args=(_free_port(), str(tmp_path), fallback), nprocs=1, join=True)
     res = torch.load(os.path.join(tmp_path, "rccl.pt"))
     assert res == {"ok": True, "ok_gather": True, "copy": True, "max": 3.0}, res
