@@ -258,6 +258,7 @@ def other_configs_gpu(dev, model50, kfac50, batch):
     r18.load_state_dict(k3.model_state)
     _backward_once(r18, torch.randn(32, 3, 224, 224, device=dev))
     c3["efb_update_ms"] = _timed_gpu(lambda: e3.update(32))
+    c3.update(_efb_eig_fracs(k3.state, c3["efb_update_ms"], c3["efb_eigenvectors_ms"], c3["efb_eigensolver_sweeps"], "efb_"))
     c3["efb_invert_ms"] = _timed_gpu(lambda: e3.invert(1.0, 1000.0))
     c3["efb_sample_and_replace_ms"] = _timed_gpu(e3.sample_and_replace)
     out["config3_resnet18_kfac_efb"] = c3
@@ -277,6 +278,7 @@ def other_configs_gpu(dev, model50, kfac50, batch):
     model50.load_state_dict(kfac50.model_state)
     _backward_once(model50, torch.randn(batch, 3, 224, 224, device=dev))
     c5["efb_update_ms"] = _timed_gpu(lambda: e5.update(batch))
+    c5.update(_efb_eig_fracs(kfac50.state, c5["efb_update_ms"], c5["eigenvectors_ms"], c5["eigensolver_sweeps"], ""))
     inf = INF(model50, e5.diags, kfac50.state, e5.state, eigvecs=e5.eigvecs)
     c5["inf_update_rank100_ms"] = _timed_gpu(lambda: inf.update(rank=100), reps=2)
     c5["inf_invert_1_1000_ms"] = _timed_gpu(lambda: inf.invert(1.0, 1000.0), reps=2)
@@ -455,6 +457,25 @@ def stream_probe(mode: str, batch: int):
     print(json.dumps({"invert_ms": statistics.median(ts)}))
 
 
+def _efb_eig_fracs(state, efb_update_ms, eig_ms, sweeps, prefix):
+    """Roofline fractions a reader can recompute from the line: EFB.update = U_G^T grad U_A per layer (curvatures.py:424-427),
+    2 (m^2 n + m n^2) flops on the fp32 MFMA path; the block-Jacobi eigensolver is HBM-bound: per sweep every matrix and
+    its eigenvector accumulator are read and written once in each of the row and the column pass (4 passes x 2 matrices x
+    n^2 x 8 bytes: the fp64 finish; the fp32 phase moves half of that - priced here at the fp64 figure, an upper bound
+    on the bytes, so a lower bound on the fraction is what a cheaper phase would show)."""
+    flops = sum(2.0 * (G.shape[0] ** 2 * A.shape[0] + G.shape[0] * A.shape[0] ** 2) for A, G in state.values())
+    n2 = sum(float(A.shape[0]) ** 2 + float(G.shape[0]) ** 2 for A, G in state.values())
+    bytes_per_sweep = 4.0 * 2.0 * n2 * 8.0
+    out = {prefix + "efb_update_gflop" if prefix == "" else "efb_update_gflop": flops / 1e9,
+           "efb_update_frac": flops / (efb_update_ms * 1e-3) / PEAK_F32_MFMA,
+           "efb_update_frac_of": "2 (m^2 n + m n^2) flops per layer / time / 157.3 TFLOP/s (fp32 MFMA)"}
+    if sweeps:
+        out["eigensolver_hbm_gbytes_per_sweep"] = bytes_per_sweep / 1e9
+        out["eigensolver_frac"] = bytes_per_sweep * sweeps / (eig_ms * 1e-3) / PEAK_HBM
+        out["eigensolver_frac_of"] = "sweeps x 64 n^2 bytes over all factors / time / 8 TB/s (HBM spec)"
+    return out
+
+
 def stream_probe_subprocess(mode: str, batch: int, timeout_s=180):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--stream-probe", mode, "--batch", str(batch)]
@@ -466,6 +487,41 @@ def stream_probe_subprocess(mode: str, batch: int, timeout_s=180):
         return f"failed (rc {proc.returncode}): {proc.stderr.strip()[-200:]}"
     except subprocess.TimeoutExpired:
         return f"did not finish within {timeout_s} s"
+
+
+def roofline_phases(dims, owned, invert_ms, sample_ms):
+    """Roofline of the two phases that are not the factor build, from quantities in the line itself.
+    invert(): (2/3)(n^3 + m^3) flops per layer (one Cholesky factorisation + one triangular inverse, curvatures.py:368-385);
+    since round 5 the factorisation half runs on fp64 MFMA (78.6 TFLOP/s) and the inverse half on fp32 MFMA (157.3):
+    `frac` = time at those two roofs / measured time; `frac_all_fp64_roof` prices all flops at 78.6 (rounds 1-4's figure).
+    sample_and_replace(): (L_A z L_G^T)^T per layer (:387-392) after the triangular cut: n^2 m + n m^2 flops, fp32 MFMA."""
+    n3 = sum(float(dims[i][0]) ** 3 + float(dims[i][1]) ** 3 for i in owned)
+    inv_flops = (2.0 / 3.0) * n3
+    roof_s = (n3 / 3.0) / PEAK_F64_MFMA + (n3 / 3.0) / PEAK_F32_MFMA
+    smp_flops = sum(float(dims[i][0]) ** 2 * dims[i][1] + float(dims[i][0]) * float(dims[i][1]) ** 2 for i in owned)
+    return {
+        "invert": {"bound": "mfma (factorisation fp64, triangular inverse fp32)", "gflop": inv_flops / 1e9,
+                   "gflop_fp64": n3 / 3.0 / 1e9, "gflop_fp32": n3 / 3.0 / 1e9,
+                   "peak_fp64": PEAK_F64_MFMA / 1e12, "peak_fp32": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                   "achieved": inv_flops / (invert_ms * 1e-3) / 1e12,
+                   "roof_ms": roof_s * 1e3, "frac": roof_s / (invert_ms * 1e-3),
+                   "frac_all_fp64_roof": inv_flops / (invert_ms * 1e-3) / PEAK_F64_MFMA},
+        "sample_and_replace": {"bound": "mfma", "gflop": smp_flops / 1e9, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                               "achieved": smp_flops / (sample_ms * 1e-3) / 1e12,
+                               "frac": smp_flops / (sample_ms * 1e-3) / PEAK_F32_MFMA,
+                               "flops_counted": "n^2 m + n m^2 per layer: both products after the triangular cut"},
+    }
+
+
+def syrk_source_sha16() -> str:
+    """sha256 (first 16 hex digits) over the factor-build sources: what `roofline.traffic`'s PMC file must match."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "curvature_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "syrk*.hip")) + [os.path.join(csrc, "syrk_plan.h")]):
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def spawn_ranks(args) -> int:
@@ -614,10 +670,34 @@ def main():
         ms = __import__("ctypes").c_float(0.0)
         _lib.check(L.curv_event_elapsed_ms(hip_ev[k][0], hip_ev[k][1], ms), "curv_event_elapsed_ms")
         syrk_ms += ms.value
+    rank_phases = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        cdev = dev if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+        # per-rank phase times (max / min over ranks) and the number of ranks of the library's own RCCL communicator
+        mine = torch.tensor([p / args.steps for p in phase], dtype=torch.float64, device=cdev)
+        hi, lo = mine.clone(), mine.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        owned_n = torch.tensor([float(len(owned))], dtype=torch.float64, device=cdev)
+        owned_hi, owned_lo = owned_n.clone(), owned_n.clone()
+        dist.all_reduce(owned_hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(owned_lo, op=dist.ReduceOp.MIN)
+        # every rank must hold the same parameters after the all-gather of sample_and_replace
+        digest = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1).to(cdev)
+        d_hi, d_lo = digest.clone(), digest.clone()
+        dist.all_reduce(d_hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(d_lo, op=dist.ReduceOp.MIN)
+        rank_phases = {"update_ms": [float(lo[0]), float(hi[0])], "invert_ms": [float(lo[1]), float(hi[1])],
+                       "sample_and_replace_ms": [float(lo[2]), float(hi[2])], "what": "[min, max] over ranks",
+                       "layers_owned": [int(owned_lo), int(owned_hi)],
+                       "parameters_identical_on_all_ranks": bool(float(d_hi) == float(d_lo)),
+                       "collective_backend": dist.get_backend(),
+                       "allgather": "curv_allgather_weights (library communicator)" if kfac.shard.rccl_ranks() else
+                                    "torch.distributed all-gather on padded shards",
+                       "rccl_ranks": kfac.shard.rccl_ranks() if kfac.shard.rccl_ranks() else (world if dist.get_backend() == "nccl" else 0)}
 
     # work of the dominant kernels (the factor build) on this rank.  `plan_flops`: the multiply-add flops the launch
     # plan really executes (curv_kfac_plan_info): n (n + 1) K per symmetric factor, and for the 3x3 / stride 1 / pad 1
@@ -632,13 +712,20 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they are
     # collected by tools/collect_profiles.sh (rocprofv3, separate FETCH_SIZE / WRITE_SIZE passes, gfx950
     # correction of MI355X_MICROARCH.md) on this same workload and committed under profiles/
+    # The figure is only reported while the factor-build sources are the ones it was measured on (`source_sha16` of the
+    # file = sha256 over csrc/syrk*.hip + syrk_plan.h, written by tools/collect_profiles.sh); otherwise null.
     traffic, traffic_source = None, None
-    for name in ("r04_syrk_pmc.json",):
+    for name in ("r05_syrk_pmc.json",):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if world == 1 and args.batch == 32 and os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
-                traffic_source = f"profiles/{name}: rocprofv3 PMC passes of this workload, NOT measured in this run"
+                rec = json.load(open(pmc_path))
+                if rec.get("source_sha16") == syrk_source_sha16():
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = f"profiles/{name}: rocprofv3 PMC passes of this workload on these sources, NOT measured in this run"
+                else:
+                    traffic_source = (f"profiles/{name} was measured on other factor-build sources (sha {rec.get('source_sha16')} "
+                                      f"vs {syrk_source_sha16()}): not reported; re-run tools/collect_profiles.sh")
                 break
             except Exception:
                 traffic = None
@@ -682,7 +769,10 @@ def main():
                          "frac_of_update_call": plan_flops / (phase[0] / args.steps * 1e-3) / PEAK_F32_MFMA},
             "phases_ms": {"update": phase[0] / args.steps, "invert": phase[1] / args.steps,
                           "sample_and_replace": phase[2] / args.steps},
+            "roofline_phases": roofline_phases(dims, owned, phase[1] / args.steps, phase[2] / args.steps),
         }
+        if rank_phases is not None:
+            out["ranks"] = rank_phases
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args.batch)
         if world == 1 and not args.no_other_configs:

@@ -79,7 +79,7 @@ class curv_factor_desc(ctypes.Structure):
         ("kh", ctypes.c_int32), ("kw", ctypes.c_int32), ("sh", ctypes.c_int32), ("sw", ctypes.c_int32),
         ("ph", ctypes.c_int32), ("pw", ctypes.c_int32),
         ("has_bias", ctypes.c_int32), ("first", ctypes.c_int32),
-        ("scale", ctypes.c_float), ("reserved", ctypes.c_int32),
+        ("scale", ctypes.c_float), ("path_hint", ctypes.c_int32),
     ]
 
 
@@ -192,6 +192,8 @@ SIGNATURES = {
 
 ABI_VERSION = 7                     # CURV_ABI_VERSION of include/curv_hip.h
 KFAC_TABLE_RESIDENT = 1             # CURV_KFAC_TABLE_RESIDENT
+PATH_AUTO, PATH_SMALL, PATH_GROUPED = 0, 1, 2     # CURV_PATH_* (curv_factor_desc.path_hint)
+SMALL_MAX_FLOP = 2.0e9              # CURV_SMALL_MAX_FLOP
 GEMM_TABLE_RESIDENT = 1             # CURV_GEMM_TABLE_RESIDENT
 ERR_NOT_PD, ERR_INVALID, ERR_WORKSPACE, ERR_HIP, ERR_NOT_CONVERGED = 1, 2, 3, 4, 5     # CURV_ERR_* of the header
 

@@ -1588,9 +1588,6 @@ static int stream_set(StreamSet** out) {
   CURV_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
   CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_join2, hipEventDisableTiming));
   for (int g = 0; g < 2; ++g) CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_chain[g], hipEventDisableTiming));
-  static const int masked_prio = getenv("CURV_MASKED_PRIO") ? atoi(getenv("CURV_MASKED_PRIO")) : 0;
-  if (masked_prio) CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.masked, hipStreamNonBlocking, phi));
-  else CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.masked, hipStreamNonBlocking));
   // The far updates fill every workgroup slot they can get (4 per CU), and a retiring far workgroup frees
   // half the LDS a chain kernel's workgroup needs: the slot is refilled before a second one retires, and
   // stream priorities do not reserve anything - traced: a 9-workgroup chol_panel launch waited 200-260 us
@@ -1618,6 +1615,11 @@ static int stream_set(StreamSet** out) {
     CURV_HIP_CHECK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio_low));
     return CURV_OK;
   };
+  // the small group's chain: its launches are wide (a hundred factors advance together); CURV_SMALL_MASKED=1 keeps them off
+  // the CUs the mask reserves, which then belong to the large group's chain alone
+  static const int small_masked = getenv("CURV_SMALL_MASKED") ? atoi(getenv("CURV_SMALL_MASKED")) : 0;
+  if (small_masked) { const int rc = wide_stream(&s.masked); if (rc != CURV_OK) return rc; }
+  else CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.masked, hipStreamNonBlocking));
   for (int g = 0; g < 2; ++g) {
     { const int rc = wide_stream(&s.side[g].stream); if (rc != CURV_OK) return rc; }
     // (a stream of its own for the fp32 inverse only on request: every additional hardware queue of the process slows

@@ -223,9 +223,7 @@ syrk_small_reduce_kernel(SmallChunk chunk, int count, const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-#ifndef CURV_SMALL_MAX_FLOP
-#define CURV_SMALL_MAX_FLOP 2.0e9      // executed multiply-add flops (32 x 32 blocks on and above the diagonal) of the launch
-#endif
+// (CURV_SMALL_MAX_FLOP, include/curv_hip.h: executed multiply-add flops of the launch up to which it takes this form)
 constexpr int SMALL_KSLICE = 320;        // k values per slice (LeNet-5 at N = 100: 764 workgroups, ~3 per CU)
 constexpr int SMALL_MAX_SLICES = 64;     // the reduce pass walks a block's slices eight at a time: a round trip each
 
@@ -235,6 +233,12 @@ static bool small_plan(const curv_factor_desc* descs, int n, SmallPlan& plan) {
   const char* env = getenv("CURV_KFAC_SMALL");
   if (env != nullptr && atoi(env) == 0) return false;
   if (n <= 0 || n > 4 * SMALL_CHUNK) return false;
+  // the caller may have decided for the whole (unsharded) model: a rank's share must not switch forms on its own size
+  bool forced = n > 0;
+  for (int i = 0; i < n; ++i) {
+    if (descs[i].path_hint == CURV_PATH_GROUPED) return false;
+    forced = forced && descs[i].path_hint == CURV_PATH_SMALL;
+  }
   plan.f.resize(n);
   double flop = 0.0, work = 0.0;
   for (int i = 0; i < n; ++i) {
@@ -260,7 +264,7 @@ static bool small_plan(const curv_factor_desc* descs, int n, SmallPlan& plan) {
     d.n_pairs = d.nb * (d.nb + 1) / 2;
     flop += 2.0 * 1024.0 * d.n_pairs * (double)K;
     work += (double)d.n_pairs * (double)K;
-    if (flop > CURV_SMALL_MAX_FLOP) return false;
+    if (!forced && flop > CURV_SMALL_MAX_FLOP) return false;
   }
   // one slicing rule per FACTOR (slices of ~SMALL_KSLICE k values, at most SMALL_MAX_SLICES of them): what a factor's
   // sums look like does not depend on what else is in the launch - a layer-sharded rank gets the bits of the unsharded run

@@ -60,13 +60,21 @@ _kfac_last = {}                        # thread ident -> the "kfac" workspace it
 
 class FactorJob:
     """One Kronecker-factor accumulation: dst (+)= scale * unfold(src) unfold(src)^T."""
-    __slots__ = ("src", "dst", "kernel", "stride", "padding", "has_bias", "scale", "first")
+    __slots__ = ("src", "dst", "kernel", "stride", "padding", "has_bias", "scale", "first", "path_hint")
 
     def __init__(self, src, dst, kernel=(1, 1), stride=(1, 1), padding=(0, 0), has_bias=False,
-                 scale=1.0, first=False):
+                 scale=1.0, first=False, path_hint=0):
         self.src, self.dst = src, dst
         self.kernel, self.stride, self.padding = tuple(kernel), tuple(stride), tuple(padding)
         self.has_bias, self.scale, self.first = bool(has_bias), float(scale), bool(first)
+        self.path_hint = int(path_hint)            # _lib.PATH_*: which launch form the UNSHARDED model takes
+
+
+def small_path_flop(dim: int, K: int) -> float:
+    """Executed flops of one factor in the small launch form (32 x 32 blocks on and above the diagonal): the quantity
+    CURV_SMALL_MAX_FLOP bounds (csrc/syrk_small.hip)."""
+    nb = (int(dim) + 31) // 32
+    return 2.0 * 1024.0 * (nb * (nb + 1) // 2) * float(K)
 
 
 def _factor_descs(jobs: Sequence[FactorJob]):
@@ -89,6 +97,7 @@ def _factor_descs(jobs: Sequence[FactorJob]):
         d.sh, d.sw = j.stride
         d.ph, d.pw = j.padding
         d.has_bias, d.first, d.scale = int(j.has_bias), int(j.first), j.scale
+        d.path_hint = getattr(j, "path_hint", 0)
     return arr
 
 
@@ -221,7 +230,7 @@ def chol_inv_lower(factors: Sequence[torch.Tensor], adds: Sequence[float], multi
         # the verdict travels to pinned host memory BEFORE the finalize passes (curv_chol_inv_lower_status): the host
         # waits for that copy only, and what it does next - raising, or preparing the sampler's launches - runs in the
         # shadow of the finalize passes instead of behind them (0.12 ms of idle GPU per ResNet-50 step otherwise)
-        host, event = _status_box(n)
+        host, event = _status_box(n, dev)
         _lib.check(L.curv_chol_inv_lower_status(_lib.stream_ptr(), arr, n, info.data_ptr(), ws.data_ptr(), ws.numel(),
                                                 host.data_ptr(), event), "curv_chol_inv_lower_status")
     else:
@@ -241,17 +250,23 @@ def chol_inv_lower(factors: Sequence[torch.Tensor], adds: Sequence[float], multi
 _status_boxes = threading.local()
 
 
-def _status_box(n: int):
-    """Pinned host words and a HIP event for the early verdict of one `chol_inv_lower` call (per thread, grown on demand;
-    a call waits for its own copy before it returns, so one box per thread is enough)."""
-    box = getattr(_status_boxes, "box", None)
+def _status_box(n: int, device):
+    """Pinned host words and a HIP event for the early verdict of one `chol_inv_lower` call: one box per thread AND
+    device (a HIP event belongs to the device that was current when it was created; recording it on a stream of another
+    device is an invalid-handle error), grown on demand; a call waits for its own copy before it returns."""
+    boxes = _status_boxes.__dict__.setdefault("boxes", {})
+    key = torch.device(device).index
+    if key is None:
+        key = torch.cuda.current_device()
+    box = boxes.get(key)
     if box is None or box[0].numel() < n:
-        if box is not None:
-            _lib.lib().curv_event_destroy(box[1])
-        event = _lib.lib().curv_event_create()
+        with torch.cuda.device(key):
+            if box is not None:
+                _lib.lib().curv_event_destroy(box[1])
+            event = _lib.lib().curv_event_create()
         if not event:
             raise RuntimeError("curv_event_create failed")
-        box = _status_boxes.box = (torch.empty(max(n, 256), dtype=torch.int32).pin_memory(), event)
+        box = boxes[key] = (torch.empty(max(n, 256), dtype=torch.int32).pin_memory(), event)
     return box[0][:n], box[1]
 
 

@@ -73,8 +73,17 @@ typedef struct curv_factor_desc {
   int32_t has_bias;
   int32_t first;
   float scale;
-  int32_t reserved;
+  int32_t path_hint;   /* 0: the library picks the launch form from the launch's own size; CURV_PATH_SMALL / CURV_PATH_GROUPED:
+                        * the caller says which form the UNSHARDED model's launch takes, so that a layer-sharded rank
+                        * (whose share may fall under the small-launch threshold) sums every factor in the same order as
+                        * the unsharded run.  All descriptors of a call carry the same value. */
 } curv_factor_desc;
+#define CURV_PATH_AUTO 0
+#define CURV_PATH_SMALL 1
+#define CURV_PATH_GROUPED 2
+/* executed multiply-add flops (32 x 32 blocks on and above the diagonal, 2 * 1024 * pairs * K per factor) up to which a
+ * launch takes the two-launch small form (csrc/syrk_small.hip) */
+#define CURV_SMALL_MAX_FLOP 2.0e9
 
 /* Device scratch needed by curv_kfac_accumulate for this set of factors (bytes). */
 size_t curv_kfac_workspace_bytes(const curv_factor_desc* descs, int n_factors);

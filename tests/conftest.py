@@ -27,3 +27,12 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def identity_residual_bound(M) -> float:
+    """Bound for ||(L L^T) M - I||_F / sqrt(n) of an inverse factor L delivered in fp32 whose triangular inverse was
+    accumulated in fp32 (csrc/invert.hip, round 5): the residual multiplies the forward error of L (~eps_fp32, below 1e-6)
+    by ||M||, i.e. eps_fp32 * cond(M); 1e-4 where that is smaller (what an all-fp64 sweep rounded to fp32 meets)."""
+    import torch
+    w = torch.linalg.eigvalsh(M.double())
+    return max(1e-4, 6e-8 * float(w[-1] / w[0]))

@@ -216,3 +216,34 @@ def test_sharded_diagonal_attention_entries_agree_across_ranks(tmp_path):
     for k in r0["after"]:
         assert torch.equal(r0["after"][k], r1["after"][k]), k
         assert not torch.equal(r0["after"][k], r0["mean"][k]), k           # every parameter received a sample
+
+
+def test_shard_under_the_small_launch_threshold_sums_like_the_unsharded_model(gpu):
+    """The factor build has a two-launch form for small launches (csrc/syrk_small.hip, up to CURV_SMALL_MAX_FLOP executed
+    flops) that sums in another order than the grouped kernels.  The choice must follow the MODEL, not a rank's share
+    (curv_factor_desc.path_hint): here the model is above the threshold and each of the two shares below it, and every
+    rank's factors must equal the unsharded run's bit for bit (advisor finding of round 4)."""
+    from curvature_amd import _lib, ops, sharding
+    from curvature_amd.curvatures import KFAC
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(640, 640), torch.nn.Tanh(), torch.nn.Linear(640, 512), torch.nn.Tanh(),
+                                torch.nn.Linear(512, 10)).to(gpu)
+    layers = [m for m in model if isinstance(m, torch.nn.Linear)]
+    N = 1024
+    flop = [ops.small_path_flop(l.in_features + 1, N) + ops.small_path_flop(l.out_features, N) for l in layers]
+    owner = [0, 1, 1]
+    assert sum(flop) > _lib.SMALL_MAX_FLOP
+    for r in range(2):
+        assert 0 < sum(f for f, o in zip(flop, owner) if o == r) < _lib.SMALL_MAX_FLOP
+    x = torch.randn(N, 640, device=gpu)
+    full = KFAC(model)
+    parts = [KFAC(model, shard=sharding.Shard(owner, r, 2)) for r in range(2)]
+    torch.nn.functional.cross_entropy(model(x), torch.randint(0, 10, (N,), device=gpu)).backward()
+    for est in [full] + parts:
+        est.update(N)
+    torch.cuda.synchronize()
+    for li, layer in enumerate(layers):
+        mine = parts[owner[li]]
+        assert layer in mine.state and layer not in parts[1 - owner[li]].state
+        for a, b in zip(full.state[layer], mine.state[layer]):
+            assert torch.equal(a, b), li

@@ -98,7 +98,11 @@ def main():
             v["launches_per_update"] = v.get("launches_profiled", 0) / updates
             v["hbm_bytes_per_update"] = v.get("hbm_bytes_per_launch", 0.0) * v["launches_per_update"]
             total += v["hbm_bytes_per_update"]
-        print(json.dumps({"kernel": " + ".join("curv::" + k for k in parts),
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import syrk_source_sha16                  # bench.py reports the figure only for these very sources
+        print(json.dumps({"source_sha16": syrk_source_sha16(),
+                          "kernel": " + ".join("curv::" + k for k in parts),
                           "per": "update() (everything curv_kfac_accumulate_ex enqueues), average over the profiled updates",
                           "hbm_bytes_per_launch": total,
                           "mfma_kernels_bytes_per_update": sum(parts[k]["hbm_bytes_per_update"] for k in ("syrk_pre_kernel", "syrk_patch_kernel", "syrk_flat_kernel") if k in parts),
