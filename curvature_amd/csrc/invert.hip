@@ -1462,7 +1462,7 @@ xrows32_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
 // (5) L[i][j] = (float) X[n-1-j][n-1-i] for j <= i, 0 above the diagonal (64x64 tiles via LDS)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(INV_THREADS)
-inv_finalize_kernel(const InvDev* __restrict__ t, int nf) {
+inv_finalize_kernel(const InvDev* __restrict__ t, int nf, int sq) {   // sq: edge of the block squares (elements)
   __shared__ float tile[NB][NB + 1];
   int f, local;
   if (!locate(t, nf, blockIdx.x, [](const InvDev& d) { return d.P * d.P; }, f, local)) return;
@@ -1505,7 +1505,7 @@ inv_finalize_kernel(const InvDev* __restrict__ t, int nf) {
     // (the 256 x 256 block squares of C^-1 are fp64 in X, everything between them fp32 in X32)
     const int rs = n - 1 - j, cs = n - 1 - i_l;
     const bool live = i_l < n && j < n && j <= i_l;
-    if (X32 == nullptr || (rs >> 8) == (cs >> 8)) xv[u] = live ? X[(long long)rs * np + cs] : 0.0;
+    if (X32 == nullptr || rs / sq == cs / sq) xv[u] = live ? X[(long long)rs * np + cs] : 0.0;
     else xv[u] = live ? (double)X32[(long long)rs * np + cs] : 0.0;
   }
 #pragma unroll
@@ -1722,7 +1722,11 @@ struct GroupSweep {
   hipLaunchKernelGGL(inv_prepare_kernel, dim3((unsigned)prep_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, flags);
   CURV_LAUNCH_CHECK();
   static const int nbo_env = getenv("CURV_NBO") ? atoi(getenv("CURV_NBO")) : 0;
-  NBO = (nbo_env > 0 && !latency_bound) ? nbo_env : 4;      // outer panel: 4 block columns = 256
+  // outer panel: 4 block columns = 256 for the chain-bound forms (the square kernel is built for 4); 6 = 384 for the
+  // per-step launches of a whole model - same-box sweeps on the ResNet-50 factors, two rounds each: NBO 4 / 5 / 6 / 7 =
+  // 7.5 / 7.2 / 6.8 / 7.3 ms (8: 7.4, 12: 7.3): fewer panel products, near updates and cross-stream hand-offs per block
+  // step, and 72 = 12 x 6, 36 = 6 x 6: the widest factors end on a full panel
+  NBO = latency_bound ? 4 : (nbo_env > 0 ? nbo_env : 6);
     return CURV_OK;
   }
 
@@ -1880,7 +1884,7 @@ struct GroupSweep {
     CURV_HIP_CHECK(hipEventRecord(side->ev_tail, inv_st));
     CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_tail, 0));
   }
-  hipLaunchKernelGGL(inv_finalize_kernel, dim3((unsigned)fin_tiles), dim3(INV_THREADS), 0, stream, table, n_factors);
+  hipLaunchKernelGGL(inv_finalize_kernel, dim3((unsigned)fin_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, NBO * NB);
   CURV_LAUNCH_CHECK();
     return CURV_OK;
   }
@@ -2000,7 +2004,8 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   // `start_panel` panels, so that its throughput work fills the large group's chain-bound tail.
   static const int start_frac = getenv("CURV_SMALL_START") ? atoi(getenv("CURV_SMALL_START")) : 30;  // percent of the panels
   // (ResNet-50: 0 -> 9.25 ms, 20 -> 9.2, 30 -> 9.0, 40 -> 9.2, 50 -> 9.5)
-  const int n_panels = cdiv(Pmax, 4);
+  static const int nbo_env2 = getenv("CURV_NBO") ? atoi(getenv("CURV_NBO")) : 0;
+  const int n_panels = cdiv(Pmax, latency_bound ? 4 : (nbo_env2 > 0 ? nbo_env2 : 6));
   long long far0 = 0;                          // far tiles of the large group's first panel
   for (const InvDev& d : big) far0 += outer_tiles(d.P, 4, 8, s_in_sweep(d));
   // only a far-bound large group has such a tail to fill (a chain step is ~54 us, a far tile ~0.04 us of the
