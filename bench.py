@@ -265,6 +265,34 @@ def other_configs_gpu(dev, model50, kfac50, batch):
     del e3, k3, r18
     torch.cuda.empty_cache()
 
+    # ---- the README's other model family (README.rst:259-267): DenseNet-121, N = batch, KFAC step
+    try:
+        torch.manual_seed(0)
+        dn = models.densenet121().to(dev).train()
+        kd = KFAC(dn)
+        _backward_once(dn, torch.randn(batch, 3, 224, 224, device=dev))
+        kd._count_flops = True
+        kd.update(batch_size=batch)
+        kd._count_flops = False
+        plan = float(getattr(kd, "_last_flops", 0.0))
+        cd = {"workload": f"DenseNet-121 N={batch}, 121 layers (1x1 inputs 64 + 32 k wide, 58 3x3 with C = 128): KFAC update / "
+                          "invert(1, 1000) / sample_and_replace"}
+        cd["kfac_update_ms"] = _timed_gpu(lambda: kd.update(batch_size=batch))
+        cd["kfac_update_plan_gflop"] = plan / 1e9
+        cd["kfac_update_frac"] = plan / (cd["kfac_update_ms"] * 1e-3) / PEAK_F32_MFMA
+        kd.restart_accumulation()
+        kd.update(batch_size=batch)
+        cd["kfac_invert_ms"] = _timed_gpu(lambda: kd.invert(1.0, 1000.0))
+        cd["kfac_sample_and_replace_ms"] = _timed_gpu(kd.sample_and_replace)
+        cd["kfac_step_ms"] = cd["kfac_update_ms"] + cd["kfac_invert_ms"] + cd["kfac_sample_and_replace_ms"]
+        out["densenet121_kfac"] = cd
+        for h in kd.hooks:
+            h.remove()
+        del kd, dn
+        torch.cuda.empty_cache()
+    except Exception as exc:                                                           # a leg of its own: never the headline
+        out["densenet121_kfac"] = {"error": f"{type(exc).__name__}: {exc}"}
+
     # ---- config 5: ResNet-50 chain on the headline's factors: eigenvectors, EFB update, INF update / invert / sample
     c5 = {"workload": f"ResNet-50 N={batch}, 54 layers, on the headline run's KFAC factors: EFB constructor (eigenvectors of "
                       "the 108 factors), efb.update, INF(..., eigvecs=efb.eigvecs).update(rank=100), inf.invert at "

@@ -11,7 +11,7 @@ by batch and converts every sample to numpy).  SURVEY.md section 8(f), rank 3.
 k + 1 (and, with a layer shard, its all-gather) is produced on a second HIP stream into the set the forward sweep of
 sample k is NOT reading.  Two events per set order the streams (sample written -> forward may read; forward done ->
 next sample may overwrite).  The noise stream and every launch are the serial loop's, so the predictions are the
-same bit for bit (tests/test_round2_gpu.py).  Measured on one MI355X (tools/bench_bnn_loop.py, KFAC, ms per
+same bit for bit (tests/test_estimator_chain_gpu.py).  Measured on one MI355X (tools/bench_bnn_loop.py, KFAC, ms per
 Monte-Carlo sample, serial -> overlapped): ResNet-50 batch 32: 6.36 -> 6.28; batch 32 x 4 sweeps: 21.6 -> 21.8; batch
 256: 37.9 -> 37.9; LeNet-5 batch 100: 0.30 -> 0.64.  On one GPU there is nothing to win: a throughput-bound forward
 sweep leaves no idle CUs for the 1.5 ms of sampling work, a launch-bound one (batch 32) is bound by the same Python

@@ -1,4 +1,4 @@
-"""Plain ``torch.nn`` definitions of the benchmark networks (LeNet-5, ImageNet ResNet-18 / ResNet-50).
+"""Plain ``torch.nn`` definitions of the benchmark networks (LeNet-5, ImageNet ResNet-18 / ResNet-50, DenseNet-121 / 161).
 
 torchvision is not available on the target image, and the estimators select layers by class NAME
 (``Conv2d`` / ``Linear``; curvature/curvatures.py:121, :298), so these are ordinary torch modules with
@@ -100,6 +100,62 @@ def resnet18(num_classes: int = 1000) -> ResNet:
 
 def resnet50(num_classes: int = 1000) -> ResNet:
     return ResNet((3, 4, 6, 3), bottleneck=True, num_classes=num_classes)
+
+
+class _DenseUnit(nn.Module):
+    """BN-ReLU-Conv1x1 (to bn_size * growth channels) then BN-ReLU-Conv3x3 (to growth channels); the output is appended
+    to the unit's input (Huang et al. 2017; the README's DenseNet-121 / 161 rows, README.rst:259-267)."""
+
+    def __init__(self, cin: int, growth: int, bn_size: int):
+        super().__init__()
+        self.norm1, self.conv1 = nn.BatchNorm2d(cin), nn.Conv2d(cin, bn_size * growth, 1, bias=False)
+        self.norm2, self.conv2 = nn.BatchNorm2d(bn_size * growth), nn.Conv2d(bn_size * growth, growth, 3, padding=1, bias=False)
+
+    def forward(self, x):
+        y = self.conv1(torch.relu(self.norm1(x)))
+        y = self.conv2(torch.relu(self.norm2(y)))
+        return torch.cat([x, y], 1)
+
+
+class DenseNet(nn.Module):
+    """ImageNet DenseNet-BC: 7x7 / stride-2 stem, dense blocks of `_DenseUnit`s joined by 1x1 transitions that halve the
+    channels and the resolution.  Its layer geometries differ from a ResNet's in what matters to the factor build:
+    1x1 convolutions whose input width grows by `growth` per unit (64 + 32 k, 96 + 48 k: most of them no multiple of
+    128) and 3x3 convolutions with 128 / 192 input channels."""
+
+    def __init__(self, growth: int, blocks: Sequence[int], init_features: int, bn_size: int = 4, num_classes: int = 1000):
+        super().__init__()
+        feats = [nn.Conv2d(3, init_features, 7, stride=2, padding=3, bias=False), nn.BatchNorm2d(init_features),
+                 nn.ReLU(inplace=True), nn.MaxPool2d(3, stride=2, padding=1)]
+        c = init_features
+        for bi, depth in enumerate(blocks):
+            for _ in range(depth):
+                feats.append(_DenseUnit(c, growth, bn_size))
+                c += growth
+            if bi + 1 < len(blocks):
+                feats += [nn.BatchNorm2d(c), nn.ReLU(inplace=True), nn.Conv2d(c, c // 2, 1, bias=False), nn.AvgPool2d(2, 2)]
+                c //= 2
+        feats.append(nn.BatchNorm2d(c))
+        self.features = nn.Sequential(*feats)
+        self.classifier = nn.Linear(c, num_classes)
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv2d):
+                nn.init.kaiming_normal_(mod.weight)
+            elif isinstance(mod, nn.BatchNorm2d):
+                nn.init.constant_(mod.weight, 1)
+                nn.init.constant_(mod.bias, 0)
+
+    def forward(self, x):
+        x = torch.relu(self.features(x))
+        return self.classifier(torch.nn.functional.adaptive_avg_pool2d(x, (1, 1)).flatten(1))
+
+
+def densenet121(num_classes: int = 1000) -> DenseNet:
+    return DenseNet(32, (6, 12, 24, 16), 64, num_classes=num_classes)
+
+
+def densenet161(num_classes: int = 1000) -> DenseNet:
+    return DenseNet(48, (6, 12, 36, 24), 96, num_classes=num_classes)
 
 
 def layer_table(model: nn.Module, input_chw: Tuple[int, int, int]) -> List[dict]:

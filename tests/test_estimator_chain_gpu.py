@@ -1,7 +1,7 @@
-"""Round-2 parity cases ("next round" item 1): the reference's golden vectors that had not reached
-the HIP path yet (g2 conv shapes, g10 kron), INF end-to-end with the path's OWN eigenvectors and P_c against the
-reference's sample (g9), KFAC.invert at the README stress hyper-parameters against the fp64 oracle, device-side
-state round trip, the eigenvector-cache regression, Diagonal with MultiheadAttention, get_eigenvalues."""
+"""Parity of the estimator chain through the API, against the reference's golden vectors and the fp64 oracle: g2 conv
+shapes, g10 kron, INF end-to-end with the path's OWN eigenvectors and P_c against the reference's sample (g9), KFAC.invert
+at the README hyper-parameters against the fp64 oracle, device-side state round trip, the eigenvector-cache regression,
+Diagonal with MultiheadAttention, get_eigenvalues.  (Shared helpers of the other GPU test files: load / lenet / backward.)"""
 import os
 
 import numpy as np

@@ -201,7 +201,7 @@ def _rel(a, b):
 
 
 def test_inf_sampler_gauge_dependence_of_the_reference():
-    """The measurement behind the gauge remark in tests/test_round2_gpu.py::test_inf_end_to_end_own_chain, on the CPU oracle (a restatement of the reference's sampler,
+    """The measurement behind the gauge remark in tests/test_estimator_chain_gpu.py::test_inf_end_to_end_own_chain, on the CPU oracle (a restatement of the reference's sampler,
     pinned against g9): same state, eigenvector columns negated -> a different sample."""
     import oracle.curvature_oracle as o
     g1, g5, g6, g8, g9 = (load(n) for n in ("g1_kfac_lenet.npz", "g5_eigvecs_lenet.npz", "g6_efb_lenet.npz",

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import rel_fro
-from test_round2_gpu import backward, lenet, load
+from test_estimator_chain_gpu import backward, lenet, load
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4

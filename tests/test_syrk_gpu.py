@@ -53,6 +53,16 @@ CONV_CASES = [
     (9, 64, 12, 21, 3, 1, 1, False),    # non-square, odd width, odd sample count
     (8, 64, 3, 3, 3, 1, 1, False),      # smallest image
     (8, 64, 56, 56, 3, 1, 1, False),    # ResNet-50 layer1 geometry (K = 26 k positions per sample: many k-slices)
+    # DenseNet-121 / 161 (README.rst:259-267): 1x1 convolutions whose input width grows by 32 / 48 per unit, 3x3 with 128 /
+    # 192 input channels (192: no multiple of 128 - not eligible for the shifted-correlation path), transitions
+    (8, 96, 56, 56, 1, 1, 0, False),    # block 1, unit 2: C = 64 + 32
+    (8, 224, 56, 56, 1, 1, 0, False),   # block 1, last unit
+    (8, 128, 56, 56, 3, 1, 1, False),   # every 3x3 of DenseNet-121, at block 1's resolution
+    (8, 256, 56, 56, 1, 1, 0, False),   # transition 1
+    (8, 480, 28, 28, 1, 1, 0, False),   # block 2, last unit
+    (8, 992, 7, 7, 1, 1, 0, False),     # block 4, last unit
+    (8, 192, 28, 28, 3, 1, 1, False),   # DenseNet-161's 3x3
+    (8, 336, 28, 28, 1, 1, 0, False),   # DenseNet-161 block 2: C = 192 + 3 * 48
 ]
 
 
