@@ -1615,8 +1615,13 @@ static int stream_set(StreamSet** out) {
     CURV_HIP_CHECK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio_low));
     return CURV_OK;
   };
-  // the small group's chain: its launches are wide (a hundred factors advance together); CURV_SMALL_MASKED=1 keeps them off
-  // the CUs the mask reserves, which then belong to the large group's chain alone
+  // The small group's chain: a plain stream.  Measured alternatives (round 5, ResNet-50 factors): CU-masked like the far
+  // updates' streams (CURV_SMALL_MASKED=1; the reserved CUs then belong to the large group's chain alone) 7.5 -> 8.5 ms -
+  // the small group's own chain starves beside the far updates; on the LOW priority level (the runtime keeps a pool of
+  // hardware queues per level, so the stream would not share a queue with normal streams the process created earlier):
+  // no effect on the creation-order sensitivity, 6.9 / 6.9 / 11.0 ms for none / three streams after / three before the
+  // set, as with a normal stream.  What the four busy streams of a sweep need is four different hardware pipes; a
+  // fifth busy stream of any kind (CU-masked, low priority, shared between the groups) costs 4-5 ms.
   static const int small_masked = getenv("CURV_SMALL_MASKED") ? atoi(getenv("CURV_SMALL_MASKED")) : 0;
   if (small_masked) { const int rc = wide_stream(&s.masked); if (rc != CURV_OK) return rc; }
   else CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.masked, hipStreamNonBlocking));

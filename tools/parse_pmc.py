@@ -14,6 +14,7 @@ import sys
 
 DEFAULT = ["syrk_pre_kernel", "syrk_patch_kernel", "syrk_flat_kernel", "patch_prep_kernel", "syrk_reduce_kernel", "gemv_rows_kernel", "outer_update_kernel", "outer_update_wide_kernel",
            "inner_update_kernel", "panel_product_kernel", "panel_product_wide_kernel", "chol_diag_kernel", "chol_panel_kernel",
+           "supd32_kernel", "xrows32_kernel",
            "gemm_f32_kernel", "gemm_nt_kernel", "gemm_f64_kernel", "corr_prep_kernel", "corr_assemble_kernel", "jacobi_pair_kernel", "jacobi_rows_kernel", "jacobi_cols_kernel"]
 
 
