@@ -670,14 +670,8 @@ static long long nt_tiles_of(const curv_gemm_desc* descs, int n_desc) {
     if (descs[i].M > 0 && descs[i].N > 0 && nt_eligible(descs[i])) t += (long long)cdiv(descs[i].M, 128) * cdiv(descs[i].N, 128);
   return t;
 }
-// K slices of a product.  An underfilled launch slices whatever is long enough to have two slices; a full launch only its
-// LONG products (K >= NT_LONG_K): its tiles are dealt longest first, so without slicing it lasts at least as long as its
-// longest tile - 128 x 128 x 4608 on one workgroup slot is 0.5 ms, the whole second product of ResNet-50's
-// sample_and_replace took 0.6 (round 5).  The rule looks at the product alone, never at the rest of the launch.
-constexpr int NT_LONG_K = 2 * NT_KSLICE;
 static int nt_slices(const curv_gemm_desc& s, bool underfilled) {
-  (void)underfilled;
-  return (nt_eligible(s) && s.K >= NT_LONG_K) ? cdiv(s.K, NT_KSLICE) : 1;
+  return (underfilled && nt_eligible(s) && s.K >= 2 * NT_KSLICE) ? cdiv(s.K, NT_KSLICE) : 1;
 }
 
 // A small launch (see gemm_nt_small_kernel): every product in NT layout and short, and so few 128-wide tiles that most
@@ -696,19 +690,14 @@ static bool small_launch(const curv_gemm_desc* descs, int n_desc) {
   return blocks > 0 && blocks <= SMALL_MAX_BLOCKS && tiles128 <= SMALL_MAX_TILES128;
 }
 
-static int nt_slices(const curv_gemm_desc& s, bool underfilled);
-static size_t nt_order_bytes(const curv_gemm_desc* descs, int n_desc) {       // the K-sorted item list of an NT launch
-  long long items = 0;
-  for (int i = 0; i < n_desc; ++i)
-    if (descs[i].M > 0 && descs[i].N > 0 && nt_eligible(descs[i]))
-      items += (long long)cdiv(descs[i].M, 128) * cdiv(descs[i].N, 128) * nt_slices(descs[i], false);
-  return align_up((size_t)items * sizeof(int), 256);
+static size_t nt_order_bytes(const curv_gemm_desc* descs, int n_desc) {       // the K-sorted tile list of an unsplit NT launch
+  return align_up((size_t)nt_tiles_of(descs, n_desc) * sizeof(int), 256);
 }
 
 extern "C" size_t curv_gemm_workspace_bytes_for(const curv_gemm_desc* descs, int n_desc) {
   size_t total = curv_gemm_workspace_bytes(n_desc);
   const bool underfilled = nt_tiles_of(descs, n_desc) < NT_SPLIT_BELOW_TILES;
-  total += nt_order_bytes(descs, n_desc);                 // the K-sorted item list (items = tiles x slices)
+  if (!underfilled) return total + nt_order_bytes(descs, n_desc);
   for (int i = 0; i < n_desc; ++i) {
     const curv_gemm_desc& s = descs[i];
     if (s.M <= 0 || s.N <= 0) continue;
@@ -733,7 +722,7 @@ static int gemm_batched_impl(void* stream_, const curv_gemm_desc* descs, int n_d
   const bool small = small_launch(descs, n_desc);      // everything goes to gemm_nt_small_kernel (work list `tab`)
   // K slicing needs the slab area behind the table: only with a workspace sized by curv_gemm_workspace_bytes_for
   const bool underfilled = nt_tiles_of(descs, n_desc) < NT_SPLIT_BELOW_TILES;
-  const bool may_split = workspace_bytes >= curv_gemm_workspace_bytes_for(descs, n_desc);
+  const bool may_split = underfilled && workspace_bytes >= curv_gemm_workspace_bytes_for(descs, n_desc);
   for (int i = 0; i < n_desc; ++i) {
     const curv_gemm_desc& s = descs[i];
     CURV_REQUIRE(s.M >= 0 && s.N >= 0 && s.K >= 0, "curv_gemm_batched: desc %d: negative shape", i);
@@ -819,18 +808,18 @@ static int gemm_batched_impl(void* stream_, const curv_gemm_desc* descs, int n_d
     hipLaunchKernelGGL(gemm_upload_kernel, dim3(1), dim3(256), 0, stream, table + b, chunk, count);
     CURV_LAUNCH_CHECK();
   }
-  // behind the table: the item order list, then the slabs of the sliced products
-  int* dev_order = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + curv_gemm_workspace_bytes(n_desc));
-  float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(dev_order) + (may_split ? nt_order_bytes(descs, n_desc) : 0));
-  // a full launch (several items per workgroup slot): its items in descending K order
+  float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + curv_gemm_workspace_bytes(n_desc));
+  // a full launch (several tiles per workgroup slot, no K slicing): its tiles in descending K order, in the space the
+  // slabs of an underfilled launch would take
   const int* order = nullptr;
-  if (n_nt > 1 && !underfilled && may_split) {
+  if (n_nt > 1 && !underfilled && workspace_bytes >= curv_gemm_workspace_bytes_for(descs, n_desc)) {
+    int* dev_order = reinterpret_cast<int*>(slabs);
     order = dev_order;
     if (!(flags & CURV_GEMM_TABLE_RESIDENT)) {
       std::vector<std::pair<int, int>> keyed;               // (K of the tile, global tile id)
       keyed.reserve((size_t)tiles_nt);
       for (const GemmDev& d : tab_nt) {
-        const int tiles_m = cdiv(d.M, 128), ns = std::max(d.n_slices, 1);
+        const int tiles_m = cdiv(d.M, 128);
         for (int local = 0; local < tiles_m * d.tiles_n; ++local) {
           int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
           if (d.tri == CURV_TRI_A_LOWER) tm = tiles_m - 1 - tm;
@@ -838,9 +827,7 @@ static int gemm_batched_impl(void* stream_, const curv_gemm_desc* descs, int n_d
           int K = d.K;
           if (d.tri == CURV_TRI_A_LOWER) K = std::min(K, tm * 128 + 128);
           else if (d.tri == CURV_TRI_B_UPPER) K = std::min(K, tn * 128 + 128);
-          // (item = tile * n_slices + slice; a slice beyond a triangular cut is an empty item at the end of the list)
-          for (int sl = 0; sl < ns; ++sl)
-            keyed.emplace_back(ns > 1 ? std::max(0, std::min(d.kslice, K - sl * d.kslice)) : K, d.tile_base + local * ns + sl);
+          keyed.emplace_back(K, d.tile_base + local);
         }
       }
       std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
