@@ -880,7 +880,7 @@ extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats
   if (max_sweeps <= 0) max_sweeps = 60;   // the loop ends at convergence: ResNet factors need 16-24
   // tol <= 0: automatic.  off(A) <= 1e-8 ||A|| for matrices up to 1024 wide (fp64 sweeps are cheap there), 5e-6 ||A||
   // above: the reference's own decomposition - LAPACK's fp32 symeig - leaves off(A) ~ 1e-5 ||A|| and a residual of
-  // 1e-5 at n = 2304 (measured), and polishing a 4608-wide factor from the 4e-6 where the fp32 phase ends
+  // 1e-5 at n = 2304 (measured, LAB_NOTEBOOK.md K4), and polishing a 4608-wide factor from the 4e-6 where the fp32 phase ends
   // to 1e-8 costs eight more fp64 sweeps (its rank-deficient spectrum converges linearly down there).  An explicit
   // tol applies to every matrix.
   const bool auto_tol = tol <= 0.0;

@@ -87,7 +87,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, int local, float* ld
     const gfl* Bk = Bt + (long long)k0 * b_rs;
     if (interior && k0 + GK <= K) {               // tile and stage inside the matrices (wave-uniform): plain loads.
       // (A predicated load costs an exec-mask save / branch / restore and a v_mov around it: ~100 extra
-      // instructions per stage of 32 MFMAs, and vector instructions do not hide behind MFMAs)
+      // instructions per stage of 32 MFMAs, and vector instructions do not hide behind MFMAs, LAB_NOTEBOOK.md section 8.)
 #pragma unroll
       for (int u = 0; u < PER_T; ++u) {
         ra[u] = Ak[oa[u]];

@@ -1,6 +1,6 @@
 """Numerical check (fp64, CPU) of the parity-plane decomposition of the KFAC A factor of a 3x3 / stride 2 / padding 1
 convolution: 34 plane-against-plane correlations + 5 + 5 strip correlations + one corner product reproduce F.unfold.
-The HIP implementation built on it (round 4, syrk_corr2.hip) was measured and removed: DESIGN.md section 3 K1."""
+The HIP implementation built on it (round 4, syrk_corr2.hip) was measured and removed: LAB_NOTEBOOK.md, K1."""
 import numpy as np, itertools, torch
 torch.manual_seed(0)
 N,C,H,W=3,4,8,6

@@ -1,5 +1,5 @@
 # VALU / SALU / LDS instructions per MFMA of syrk_patch_kernel for factor classes (instruction accounting,
-# DESIGN.md section 8 item 0):  bash tools/pmc_valu_per_mfma.sh 3x3s1:2304 1x1s1:1024 G:1024
+# LAB_NOTEBOOK.md section 8 item 0):  bash tools/pmc_valu_per_mfma.sh 3x3s1:2304 1x1s1:1024 G:1024
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for C in "$@"; do
   rm -rf gpurun_out/pv
