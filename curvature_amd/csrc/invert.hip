@@ -248,6 +248,7 @@ __device__ __forceinline__ void store_sub(gdouble* C, int np, const f64x4 (&acc)
 }
 
 __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base);
+__device__ __forceinline__ void lds_sub_acc(double* s, const f64x4 (&acc)[2][2], int wm, int wn, int lane);
 
 // (2i)/(4i) inner updates of step k, restricted to the outer panel [.., kend).  The workgroup that
 // finishes the next diagonal block A[k+1][k+1] factorises it on the spot and stores X_{k+1,k+1}: step
@@ -310,6 +311,109 @@ inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int ken
     mma_64<false>(As, Bs, wm, wn, lane, acc);
     store_sub(X + (long long)i * NB * np + jj * NB, np, acc, wm, wn, lane, jj == k ? 1 : 2);
   }
+}
+
+// The panel solve FUSED into the inner update (per-step sweeps of a whole model): a step's launches were
+// chol_panel (A[i][k] <- A[i][k] X_kk^T for the rows of the square; row k of the square's inverse) and inner_update, i.e.
+// two boundaries per 64 columns on the critical path.  Nothing but this step's inner update ever reads the solved tiles
+// of the square (the rows below it come from the panel product at the end of the panel, the far updates and the fp32
+// inverse read those), so every tile recomputes the one or two solves it needs in LDS - the same products, the same bits -
+// and the solved tiles are never stored.  Row k of the square's inverse, X[k][jj] = -X_kk S[k][jj], is formed in LDS where
+// a tile needs it and stored by xsq_rows_kernel once per panel: S[k][jj] stays in place until then (the right-looking
+// accumulation touches row k of S only before step k), and other tiles of the launch still read it.
+__global__ void __launch_bounds__(INV_THREADS)
+inner_fused_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int kend) {
+  __shared__ double As[NB * LDA], Bs[NB * LDA], Xs[NB * LDA];
+  int f, local;
+  if (!locate(t, nf, blockIdx.x, [k, k0, kend](const InvDev& d) { return (int)inner_tiles(d.P, k, k0, kend); }, f, local)) return;
+  const InvDev& d = t[f];
+  const int np = d.np, P = d.P, ke = kend < P ? kend : P;
+  gdouble* W = (gdouble*)d.W;
+  gdouble* X = (gdouble*)d.X;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  f64x4 acc[2][2] = {}, c1[2][2] = {}, c2[2][2] = {};
+  int j = k + 1;
+  bool trailing = false;
+  for (; j < ke; ++j) {
+    if (local < ke - j) { trailing = true; break; }
+    local -= ke - j;
+  }
+  load_block(X + (long long)k * NB * np + k * NB, np, Xs);         // X_kk
+  if (trailing) {
+    const int i = j + local;                                       // A[i][j] -= C[i][k] C[j][k]^T,  C[r][k] = A[r][k] X_kk^T
+    load_block(W + (long long)i * NB * np + k * NB, np, As);
+    if (i != j) load_block(W + (long long)j * NB * np + k * NB, np, Bs);
+    __syncthreads();
+    mma_64<true>(As, Xs, wm, wn, lane, c1);
+    if (i != j) mma_64<true>(Bs, Xs, wm, wn, lane, c2);
+    __syncthreads();                                               // every wave is done reading A_ik / A_jk
+    acc_to_lds(c1, wm, wn, lane, As);
+    if (i != j) acc_to_lds(c2, wm, wn, lane, Bs);
+    __syncthreads();
+    mma_64<true>(As, (i != j) ? Bs : As, wm, wn, lane, acc);
+    if (i == j && j == k + 1) {
+      // next diagonal block: A_jj - acc is final.  Factorise it here (As/Bs become the two work tiles).
+      __shared__ int bad;
+      __syncthreads();                                             // all waves are done reading As
+      if (threadIdx.x == 0) bad = 0;
+      load_block(W + (long long)j * NB * np + j * NB, np, As);
+      __syncthreads();
+      lds_sub_acc(As, acc, wm, wn, lane);
+      __syncthreads();
+      factor_invert_64(As, Bs, &bad, j * NB);
+      store_block(X + (long long)j * NB * np + j * NB, np, Bs);
+      if (threadIdx.x == 0 && bad != 0) atomicCAS(d.info, 0, bad);
+    } else {
+      store_sub(W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);
+    }
+  } else {
+    const int w = k - k0 + 1;                                      // S[i][jj] (+)= C[i][k] X[k][jj], k0 <= jj <= k
+    const int a = local / w, jj = k0 + local - a * w;
+    const int i = k + 1 + a;
+    load_block(W + (long long)i * NB * np + k * NB, np, As);
+    if (jj != k) load_block(X + (long long)k * NB * np + jj * NB, np, Bs);      // S[k][jj]
+    __syncthreads();
+    mma_64<true>(As, Xs, wm, wn, lane, c1);                        // C[i][k]
+    if (jj != k) mma_64<false>(Xs, Bs, wm, wn, lane, c2);          // X_kk S[k][jj]
+    __syncthreads();
+    acc_to_lds(c1, wm, wn, lane, As);
+    if (jj != k) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) c2[m][n] = -c2[m][n];
+      acc_to_lds(c2, wm, wn, lane, Bs);                            // X[k][jj]
+    }
+    __syncthreads();
+    mma_64<false>(As, jj == k ? Xs : Bs, wm, wn, lane, acc);
+    store_sub(X + (long long)i * NB * np + jj * NB, np, acc, wm, wn, lane, jj == k ? 1 : 2);
+  }
+}
+// the rows of the square's inverse left of its diagonal, once per panel (see inner_fused_kernel):
+//   X[k][jj] = -X_kk S[k][jj]      k0 <= jj < k < min(kend, P)
+__device__ __host__ __forceinline__ int xsq_row_tiles(int P, int k0, int kend) {
+  if (P <= k0) return 0;
+  const int nb = (kend < P ? kend : P) - k0;
+  return nb * (nb - 1) / 2;
+}
+__global__ void __launch_bounds__(INV_THREADS)
+xsq_rows_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
+  __shared__ double As[NB * LDA], Bs[NB * LDA];
+  int f, local;
+  if (!locate(t, nf, blockIdx.x, [k0, kend](const InvDev& d) { return xsq_row_tiles(d.P, k0, kend); }, f, local)) return;
+  const InvDev& d = t[f];
+  const int np = d.np;
+  gdouble* X = (gdouble*)d.X;
+  int r = 1;
+  while (local >= r) { local -= r; ++r; }                          // row r of the square (1 ..), column local < r
+  const int k = k0 + r, jj = k0 + local;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  f64x4 acc[2][2] = {};
+  load_block(X + (long long)k * NB * np + k * NB, np, As);          // X_kk as [row][kk]
+  load_block(X + (long long)k * NB * np + jj * NB, np, Bs);         // S_k,jj as [kk][col]
+  __syncthreads();
+  mma_64<false>(As, Bs, wm, wn, lane, acc);
+  store_acc(X + (long long)k * NB * np + jj * NB, np, acc, wm, wn, lane, 3);
 }
 
 // (2o)/(4o) once per outer panel [k0, kend): everything beyond the panel, K = (kend - k0) * 64.
@@ -1765,15 +1869,23 @@ struct GroupSweep {
                          flags, panel + 1);
       CURV_LAUNCH_CHECK();
     }
+    static const int fused_step = getenv("CURV_FUSED_STEP") ? atoi(getenv("CURV_FUSED_STEP")) : 0;   // measured: 6.85-6.93 ms without, 6.81-7.14 with
     for (int k = k0; !use_square && k < std::min(kend, Pmax); ++k) {
       long long diag_tiles = 0, panel_tiles = 0, upd_tiles = 0;
       for (const InvDev& d : tab) {
         if (d.P > k) { ++diag_tiles; panel_tiles += std::min(kend, d.P) - k0 - 1; }
         upd_tiles += inner_tiles(d.P, k, k0, kend);
       }
-      if (k == k0) {    // later diagonal blocks of the panel are factorised by inner_update_kernel of step k - 1
+      if (k == k0) {    // later diagonal blocks of the panel are factorised by the inner update of step k - 1
         hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)diag_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
         CURV_LAUNCH_CHECK();
+      }
+      if (fused_step) {   // one launch per step: the panel solves are recomputed inside the inner update (inner_fused_kernel)
+        if (upd_tiles > 0) {
+          hipLaunchKernelGGL(inner_fused_kernel, dim3((unsigned)upd_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, k0, kend);
+          CURV_LAUNCH_CHECK();
+        }
+        continue;
       }
       if (panel_tiles > 0) {
         hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)panel_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, k0, kend);
@@ -1781,6 +1893,14 @@ struct GroupSweep {
       }
       if (upd_tiles > 0) {
         hipLaunchKernelGGL(inner_update_kernel, dim3((unsigned)upd_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, k0, kend);
+        CURV_LAUNCH_CHECK();
+      }
+    }
+    if (!use_square && fused_step) {   // ... and the rows of the squares' inverses once per panel
+      long long row_tiles = 0;
+      for (const InvDev& d : tab) row_tiles += xsq_row_tiles(d.P, k0, kend);
+      if (row_tiles > 0) {
+        hipLaunchKernelGGL(xsq_rows_kernel, dim3((unsigned)row_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend);
         CURV_LAUNCH_CHECK();
       }
     }
