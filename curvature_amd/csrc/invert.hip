@@ -1859,141 +1859,140 @@ struct GroupSweep {
     // over 2 / 4 / 8 ranks (tools/emulate_sharding.py): step 9.6 / 6.3 / 4.4 -> 9.2 / 5.6 / 3.8 ms.
     use_square = latency_bound;
     const int kend = k0 + NBO, row0 = kend + NBO;
-
-      long long prod_tiles = 0;
-      if (use_square) {
-        long long sq_wgs = 0;
-        for (const InvDev& d : tab)
-          if (d.P > k0) sq_wgs += std::min(kend, d.P) - k0;
-        hipLaunchKernelGGL(chol_square_kernel, dim3((unsigned)sq_wgs), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend,
-                           flags, panel + 1);
+    long long prod_tiles = 0;
+    if (use_square) {
+      long long sq_wgs = 0;
+      for (const InvDev& d : tab)
+        if (d.P > k0) sq_wgs += std::min(kend, d.P) - k0;
+      hipLaunchKernelGGL(chol_square_kernel, dim3((unsigned)sq_wgs), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend,
+                         flags, panel + 1);
+      CURV_LAUNCH_CHECK();
+    }
+    static const int fused_step = getenv("CURV_FUSED_STEP") ? atoi(getenv("CURV_FUSED_STEP")) : 0;   // measured: 6.85-6.93 ms without, 6.81-7.14 with
+    for (int k = k0; !use_square && k < std::min(kend, Pmax); ++k) {
+      long long diag_tiles = 0, panel_tiles = 0, upd_tiles = 0;
+      for (const InvDev& d : tab) {
+        if (d.P > k) { ++diag_tiles; panel_tiles += std::min(kend, d.P) - k0 - 1; }
+        upd_tiles += inner_tiles(d.P, k, k0, kend);
+      }
+      if (k == k0) {    // later diagonal blocks of the panel are factorised by the inner update of step k - 1
+        hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)diag_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
         CURV_LAUNCH_CHECK();
       }
-      static const int fused_step = getenv("CURV_FUSED_STEP") ? atoi(getenv("CURV_FUSED_STEP")) : 0;   // measured: 6.85-6.93 ms without, 6.81-7.14 with
-      for (int k = k0; !use_square && k < std::min(kend, Pmax); ++k) {
-        long long diag_tiles = 0, panel_tiles = 0, upd_tiles = 0;
-        for (const InvDev& d : tab) {
-          if (d.P > k) { ++diag_tiles; panel_tiles += std::min(kend, d.P) - k0 - 1; }
-          upd_tiles += inner_tiles(d.P, k, k0, kend);
-        }
-        if (k == k0) {    // later diagonal blocks of the panel are factorised by the inner update of step k - 1
-          hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)diag_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
-          CURV_LAUNCH_CHECK();
-        }
-        if (fused_step) {   // one launch per step: the panel solves are recomputed inside the inner update (inner_fused_kernel)
-          if (upd_tiles > 0) {
-            hipLaunchKernelGGL(inner_fused_kernel, dim3((unsigned)upd_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, k0, kend);
-            CURV_LAUNCH_CHECK();
-          }
-          continue;
-        }
-        if (panel_tiles > 0) {
-          hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)panel_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, k0, kend);
-          CURV_LAUNCH_CHECK();
-        }
+      if (fused_step) {   // one launch per step: the panel solves are recomputed inside the inner update (inner_fused_kernel)
         if (upd_tiles > 0) {
-          hipLaunchKernelGGL(inner_update_kernel, dim3((unsigned)upd_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, k0, kend);
+          hipLaunchKernelGGL(inner_fused_kernel, dim3((unsigned)upd_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, k0, kend);
           CURV_LAUNCH_CHECK();
         }
+        continue;
       }
-      if (!use_square && fused_step) {   // ... and the rows of the squares' inverses once per panel
-        long long row_tiles = 0;
-        for (const InvDev& d : tab) row_tiles += xsq_row_tiles(d.P, k0, kend);
-        if (row_tiles > 0) {
-          hipLaunchKernelGGL(xsq_rows_kernel, dim3((unsigned)row_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend);
-          CURV_LAUNCH_CHECK();
-        }
-      }
-      // the launch form of a panel product by its number of jobs; part 0 on the chain, part 1 (fp32 inverse) on the side stream
-      auto launch_product = [&](hipStream_t st, long long jobs, int part) -> int {
-        if (jobs <= quarter_prod)
-          hipLaunchKernelGGL(panel_product_quarter_kernel, dim3((unsigned)(cdivll(jobs, 8) * 32)), dim3(INV_THREADS), 0, st,
-                             table, n_factors, k0, kend, part);
-        else if (jobs <= wide_prod)
-          hipLaunchKernelGGL(panel_product_wide_kernel, dim3((unsigned)jobs), dim3(1024), 0, st, table, n_factors, k0, kend, part);
-        else
-          hipLaunchKernelGGL(panel_product_kernel, dim3((unsigned)jobs), dim3(INV_THREADS), 0, st, table, n_factors, k0, kend, part);
+      if (panel_tiles > 0) {
+        hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)panel_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, k0, kend);
         CURV_LAUNCH_CHECK();
-        return CURV_OK;
-      };
-      long long inv_jobs = 0, inv_tiles = 0;    // fp32 inverse: columns-left products of this panel, then its S update
-      for (const InvDev& d : tab) {
-        prod_tiles += panel_jobs(d.P, s_kind(d), k0, kend, 0);
-        inv_jobs += xrow_tiles(d.P, s_kind(d), k0, kend);
-        inv_tiles += supd_tiles(d.P, s_kind(d), kend);
       }
-      if (prod_tiles > 0) {   // rows below the square (right-hand side mode: and the columns of Zm): one triangular product each
-        const int rc = launch_product(stream, prod_tiles, 0);
-        if (rc != CURV_OK) return rc;
-      }
-      // Outer update of this panel in two parts: near = the strip the next chain touches (this stream, on the
-      // critical path), far = everything beyond, on the side stream beside the next panel's chain.  The two
-      // meet again at the next near part, which rewrites tiles the far part has written.  (Splitting off a
-      // "mid" strip so that a far update has two chain periods before anything waits for it was measured
-      // 2-4 % slower: the far updates are throughput-bound, not waited for.)
-      long long near_tiles = 0, far_tiles = 0;
-      for (const InvDev& d : tab) {
-        near_tiles += strip_tiles(d.P, kend, kend, row0, s_in_sweep(d));
-        far_tiles += outer_tiles(d.P, kend, row0, s_in_sweep(d));
-      }
-      static const int near_side = getenv("CURV_NEAR_SIDE") ? atoi(getenv("CURV_NEAR_SIDE")) : 0;
-      static const int inv_stream = getenv("CURV_INV_STREAM") ? atoi(getenv("CURV_INV_STREAM")) : 0;
-      hipStream_t inv_st = inv_stream ? side->inv : side->stream;
-      // CURV_NEAR_SIDE=1: near update on the side stream, in front of the far update (a wide launch on the chain's unmasked
-      // stream fills the CUs the mask keeps free, and the small chain launches of this and of the OTHER group then wait for
-      // it to drain).  Measured slower: ResNet-50 factors 7.75 -> 8.66 ms, one 4608^2 2.69 -> 3.10 ms - the chain pays two
-      // cross-stream waits per panel instead of one.  CURV_INV_STREAM: the fp32 inverse on a stream of its own - every
-      // additional hardware queue costs far more than it brings (7.5 -> 11.1 ms with one more CU-masked stream)
-      const bool near_on_side = near_side != 0 && near_tiles > 0;
-      const bool side_work = far_tiles > 0 || near_on_side || (!inv_stream && (inv_jobs > 0 || inv_tiles > 0));
-      const bool inv_work = inv_jobs > 0 || inv_tiles > 0;
-      if (side_work || inv_work) {                 // fork: the other streams' work needs this panel's chain
-        CURV_HIP_CHECK(hipEventRecord(side->ev_main[panel & 1], stream));
-        if (side_work) CURV_HIP_CHECK(hipStreamWaitEvent(side->stream, side->ev_main[panel & 1], 0));
-        if (inv_work && inv_stream) CURV_HIP_CHECK(hipStreamWaitEvent(side->inv, side->ev_main[panel & 1], 0));
-      }
-      if (near_tiles > 0) {
-        hipStream_t near_st = near_on_side ? side->stream : stream;
-        if (far_pending && !near_on_side) {        // join: the previous far part wrote the tiles updated here
-          CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_side[(panel + 1) & 1], 0));
-        }
-        far_pending = false;                       // (near on the side stream: ordered behind the previous far part there)
-        if (near_tiles <= wide_near)
-          hipLaunchKernelGGL(outer_update_wide_kernel, dim3((unsigned)near_tiles), dim3(1024), 0, near_st, table, n_factors,
-                             k0, kend, kend, row0, 1, (int)near_tiles);
-        else
-          hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)near_tiles), dim3(INV_THREADS), 0, near_st, table, n_factors, k0,
-                             kend, kend, row0, 1, (int)near_tiles);
+      if (upd_tiles > 0) {
+        hipLaunchKernelGGL(inner_update_kernel, dim3((unsigned)upd_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, k0, kend);
         CURV_LAUNCH_CHECK();
-        if (near_on_side) {                        // the next panel's chain starts behind it
-          CURV_HIP_CHECK(hipEventRecord(side->ev_near[panel & 1], side->stream));
-          CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_near[panel & 1], 0));
-        }
       }
-      if (far_tiles > 0) {
-        const long long grid = cdivll(far_tiles, 8 * SB * SB) * 8 * SB * SB;
-        hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, side->stream, table, n_factors, k0,
-                           kend, row0, 0, 0, (int)far_tiles);
+    }
+    if (!use_square && fused_step) {   // ... and the rows of the squares' inverses once per panel
+      long long row_tiles = 0;
+      for (const InvDev& d : tab) row_tiles += xsq_row_tiles(d.P, k0, kend);
+      if (row_tiles > 0) {
+        hipLaunchKernelGGL(xsq_rows_kernel, dim3((unsigned)row_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend);
         CURV_LAUNCH_CHECK();
-        if (!near_side) {
-          CURV_HIP_CHECK(hipEventRecord(side->ev_side[panel & 1], side->stream));
-          far_pending = true;
-        }
       }
-      // the fp32 inverse on its stream: the rows of this panel x X_sq (needs the square, i.e. this panel's chain, and the S
-      // updates of all earlier panels: stream order), then this panel's S update of the rows below
-      if (inv_jobs > 0) {
-        hipLaunchKernelGGL(xrows32_kernel, dim3((unsigned)inv_jobs), dim3(INV_THREADS), 0, inv_st, table, n_factors, k0, kend);
-        CURV_LAUNCH_CHECK();
-        inv_pending = true;
+    }
+    // the launch form of a panel product by its number of jobs; part 0 on the chain, part 1 (fp32 inverse) on the side stream
+    auto launch_product = [&](hipStream_t st, long long jobs, int part) -> int {
+      if (jobs <= quarter_prod)
+        hipLaunchKernelGGL(panel_product_quarter_kernel, dim3((unsigned)(cdivll(jobs, 8) * 32)), dim3(INV_THREADS), 0, st,
+                           table, n_factors, k0, kend, part);
+      else if (jobs <= wide_prod)
+        hipLaunchKernelGGL(panel_product_wide_kernel, dim3((unsigned)jobs), dim3(1024), 0, st, table, n_factors, k0, kend, part);
+      else
+        hipLaunchKernelGGL(panel_product_kernel, dim3((unsigned)jobs), dim3(INV_THREADS), 0, st, table, n_factors, k0, kend, part);
+      CURV_LAUNCH_CHECK();
+      return CURV_OK;
+    };
+    long long inv_jobs = 0, inv_tiles = 0;    // fp32 inverse: columns-left products of this panel, then its S update
+    for (const InvDev& d : tab) {
+      prod_tiles += panel_jobs(d.P, s_kind(d), k0, kend, 0);
+      inv_jobs += xrow_tiles(d.P, s_kind(d), k0, kend);
+      inv_tiles += supd_tiles(d.P, s_kind(d), kend);
+    }
+    if (prod_tiles > 0) {   // rows below the square (right-hand side mode: and the columns of Zm): one triangular product each
+      const int rc = launch_product(stream, prod_tiles, 0);
+      if (rc != CURV_OK) return rc;
+    }
+    // Outer update of this panel in two parts: near = the strip the next chain touches (this stream, on the
+    // critical path), far = everything beyond, on the side stream beside the next panel's chain.  The two
+    // meet again at the next near part, which rewrites tiles the far part has written.  (Splitting off a
+    // "mid" strip so that a far update has two chain periods before anything waits for it was measured
+    // 2-4 % slower: the far updates are throughput-bound, not waited for.)
+    long long near_tiles = 0, far_tiles = 0;
+    for (const InvDev& d : tab) {
+      near_tiles += strip_tiles(d.P, kend, kend, row0, s_in_sweep(d));
+      far_tiles += outer_tiles(d.P, kend, row0, s_in_sweep(d));
+    }
+    static const int near_side = getenv("CURV_NEAR_SIDE") ? atoi(getenv("CURV_NEAR_SIDE")) : 0;
+    static const int inv_stream = getenv("CURV_INV_STREAM") ? atoi(getenv("CURV_INV_STREAM")) : 0;
+    hipStream_t inv_st = inv_stream ? side->inv : side->stream;
+    // CURV_NEAR_SIDE=1: near update on the side stream, in front of the far update (a wide launch on the chain's unmasked
+    // stream fills the CUs the mask keeps free, and the small chain launches of this and of the OTHER group then wait for
+    // it to drain).  Measured slower: ResNet-50 factors 7.75 -> 8.66 ms, one 4608^2 2.69 -> 3.10 ms - the chain pays two
+    // cross-stream waits per panel instead of one.  CURV_INV_STREAM: the fp32 inverse on a stream of its own - every
+    // additional hardware queue costs far more than it brings (7.5 -> 11.1 ms with one more CU-masked stream)
+    const bool near_on_side = near_side != 0 && near_tiles > 0;
+    const bool side_work = far_tiles > 0 || near_on_side || (!inv_stream && (inv_jobs > 0 || inv_tiles > 0));
+    const bool inv_work = inv_jobs > 0 || inv_tiles > 0;
+    if (side_work || inv_work) {                 // fork: the other streams' work needs this panel's chain
+      CURV_HIP_CHECK(hipEventRecord(side->ev_main[panel & 1], stream));
+      if (side_work) CURV_HIP_CHECK(hipStreamWaitEvent(side->stream, side->ev_main[panel & 1], 0));
+      if (inv_work && inv_stream) CURV_HIP_CHECK(hipStreamWaitEvent(side->inv, side->ev_main[panel & 1], 0));
+    }
+    if (near_tiles > 0) {
+      hipStream_t near_st = near_on_side ? side->stream : stream;
+      if (far_pending && !near_on_side) {        // join: the previous far part wrote the tiles updated here
+        CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_side[(panel + 1) & 1], 0));
       }
-      if (inv_tiles > 0) {
-        const long long grid = cdivll(inv_tiles, 8 * SB * SB) * 8 * SB * SB;
-        hipLaunchKernelGGL(supd32_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, inv_st, table, n_factors, k0, kend,
-                           (int)inv_tiles);
-        CURV_LAUNCH_CHECK();
-        inv_pending = true;
+      far_pending = false;                       // (near on the side stream: ordered behind the previous far part there)
+      if (near_tiles <= wide_near)
+        hipLaunchKernelGGL(outer_update_wide_kernel, dim3((unsigned)near_tiles), dim3(1024), 0, near_st, table, n_factors,
+                           k0, kend, kend, row0, 1, (int)near_tiles);
+      else
+        hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)near_tiles), dim3(INV_THREADS), 0, near_st, table, n_factors, k0,
+                           kend, kend, row0, 1, (int)near_tiles);
+      CURV_LAUNCH_CHECK();
+      if (near_on_side) {                        // the next panel's chain starts behind it
+        CURV_HIP_CHECK(hipEventRecord(side->ev_near[panel & 1], side->stream));
+        CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_near[panel & 1], 0));
       }
+    }
+    if (far_tiles > 0) {
+      const long long grid = cdivll(far_tiles, 8 * SB * SB) * 8 * SB * SB;
+      hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, side->stream, table, n_factors, k0,
+                         kend, row0, 0, 0, (int)far_tiles);
+      CURV_LAUNCH_CHECK();
+      if (!near_side) {
+        CURV_HIP_CHECK(hipEventRecord(side->ev_side[panel & 1], side->stream));
+        far_pending = true;
+      }
+    }
+    // the fp32 inverse on its stream: the rows of this panel x X_sq (needs the square, i.e. this panel's chain, and the S
+    // updates of all earlier panels: stream order), then this panel's S update of the rows below
+    if (inv_jobs > 0) {
+      hipLaunchKernelGGL(xrows32_kernel, dim3((unsigned)inv_jobs), dim3(INV_THREADS), 0, inv_st, table, n_factors, k0, kend);
+      CURV_LAUNCH_CHECK();
+      inv_pending = true;
+    }
+    if (inv_tiles > 0) {
+      const long long grid = cdivll(inv_tiles, 8 * SB * SB) * 8 * SB * SB;
+      hipLaunchKernelGGL(supd32_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, inv_st, table, n_factors, k0, kend,
+                         (int)inv_tiles);
+      CURV_LAUNCH_CHECK();
+      inv_pending = true;
+    }
     k0 += NBO;
     ++panel;
     return CURV_OK;
