@@ -11,13 +11,18 @@
 //
 // Batched right-looking blocked algorithm, block 64, all factors of the model advance together; every
 // launch is a flat list of independent 64x64 tile operations, so the critical path per step is one block
-// operation whatever the matrix size:
+// operation whatever the matrix size.  Inside an outer panel (4 or 6 block columns):
 //   step k:  (1) one workgroup per factor factorises the 64x64 diagonal block in LDS and stores
 //                X_kk = L_kk^-1; then, in one launch with (3), A[i][k] <- A[i][k] X_kk^T
 //            (2) trailing update  A[i][j] -= A[i][k] A[j][k]^T           for k < j <= i
 //            (3) X[k][j] = -X_kk S[k][j]                                 for j < k   (row k of C^-1 final)
 //            (4) S[i][j] (+)= C[i][k] X[k][j]                            for i > k, j <= k
 //                (S accumulates sum_{k'} C[i][k'] X[k'][j] in the storage of X[i][j])
+// which leaves the panel's block square factorised and inverted (X_sq); everything beyond the panel is then updated
+// once per panel: the rows below through a triangular product with X_sq, the trailing matrix with K = panel width (near
+// strip on the chain's stream, the rest beside the next chain).  For KFAC.invert the inverse OUTSIDE the squares - (3) and
+// (4) for rows below / columns left of the panel - is accumulated in fp32 on a second stream (supd32_kernel,
+// xrows32_kernel); curv_chol_factor_inverse (INF's fp64 chain) keeps it in fp64 inside the sweep.
 // Matrices are padded to a multiple of 64 with an identity tail, so no kernel needs bounds checks.
 // "Not positive definite" is reported through a per-factor device info word (0 = ok).
 #include <type_traits>
@@ -1853,10 +1858,9 @@ struct GroupSweep {
     quarter_prod = latency_bound ? quarter_prod_env : 0;
     // A call with few factors (a layer-sharded rank, a single large factor) is bound by the latency of its chain: the block
     // square of a panel then goes into one launch whose workgroups hand tiles to each other (chol_square_kernel), and the
-    // panel product takes the quarter form.  A whole model on one GPU is bound by its far updates: there the workgroups
-    // of the square kernel (109 KB of LDS each, most of them waiting) only take CUs away - ResNet-50's 108 factors:
-    // 8.40 ms with the per-step launches, 8.55 with the square kernel for the large group, 8.66 with both; its shards
-    // over 2 / 4 / 8 ranks (tools/emulate_sharding.py): step 9.6 / 6.3 / 4.4 -> 9.2 / 5.6 / 3.8 ms.
+    // panel product takes the quarter form.  A whole model on one GPU gains nothing from them (round 3: 8.40 ms with the
+    // per-step launches, 8.55 with the square kernel for the large group; round 5: 6.7-6.8 vs 6.7-7.0), its shards over
+    // 2 / 4 / 8 ranks do (tools/emulate_sharding.py, round 3: step 9.6 / 6.3 / 4.4 -> 9.2 / 5.6 / 3.8 ms).
     use_square = latency_bound;
     const int kend = k0 + NBO, row0 = kend + NBO;
     long long prod_tiles = 0;
