@@ -487,20 +487,20 @@ def stream_probe(mode: str, batch: int):
 
 def _efb_eig_fracs(state, efb_update_ms, eig_ms, sweeps, prefix):
     """Roofline fractions a reader can recompute from the line: EFB.update = U_G^T grad U_A per layer (curvatures.py:424-427),
-    2 (m^2 n + m n^2) flops on the fp32 MFMA path; the block-Jacobi eigensolver is HBM-bound: per sweep every matrix and
-    its eigenvector accumulator are read and written once in each of the row and the column pass (4 passes x 2 matrices x
-    n^2 x 8 bytes: the fp64 finish; the fp32 phase moves half of that - priced here at the fp64 figure, an upper bound
-    on the bytes, so a lower bound on the fraction is what a cheaper phase would show)."""
+    2 (m^2 n + m n^2) flops on the fp32 MFMA path; the block-Jacobi eigensolver is HBM-bound: a sweep of an n-wide matrix is
+    n / 32 - 1 rounds, and a round of the fp32 phase moves 14 n^2 bytes (the symmetric two-sided pass over A32: 6 n^2, the
+    column pass over V32: 8 n^2; DESIGN K4).  Every matrix is priced at the sweep count of the slowest one and at the fp32
+    phase's bytes (the two or three fp64 sweeps move twice as much): the fraction is an estimate, good to ~20 %."""
     flops = sum(2.0 * (G.shape[0] ** 2 * A.shape[0] + G.shape[0] * A.shape[0] ** 2) for A, G in state.values())
-    n2 = sum(float(A.shape[0]) ** 2 + float(G.shape[0]) ** 2 for A, G in state.values())
-    bytes_per_sweep = 4.0 * 2.0 * n2 * 8.0
-    out = {prefix + "efb_update_gflop" if prefix == "" else "efb_update_gflop": flops / 1e9,
+    per_sweep = sum(max(n / 32.0 - 1.0, 1.0) * 14.0 * float(n) ** 2 for A, G in state.values() for n in (A.shape[0], G.shape[0]))
+    out = {"efb_update_gflop": flops / 1e9,
            "efb_update_frac": flops / (efb_update_ms * 1e-3) / PEAK_F32_MFMA,
            "efb_update_frac_of": "2 (m^2 n + m n^2) flops per layer / time / 157.3 TFLOP/s (fp32 MFMA)"}
     if sweeps:
-        out["eigensolver_hbm_gbytes_per_sweep"] = bytes_per_sweep / 1e9
-        out["eigensolver_frac"] = bytes_per_sweep * sweeps / (eig_ms * 1e-3) / PEAK_HBM
-        out["eigensolver_frac_of"] = "sweeps x 64 n^2 bytes over all factors / time / 8 TB/s (HBM spec)"
+        out["eigensolver_hbm_gbytes_per_sweep"] = per_sweep / 1e9
+        out["eigensolver_frac"] = per_sweep * sweeps / (eig_ms * 1e-3) / PEAK_HBM
+        out["eigensolver_frac_of"] = ("sweeps x sum over factors of (n / 32 - 1) rounds x 14 n^2 bytes / time / 8 TB/s (HBM spec); "
+                                      "every factor priced at the slowest one's sweep count")
     return out
 
 
