@@ -2,9 +2,10 @@
 cd $GRAFT_REPO_ROOT
 run() { echo -n "$* : "; env "$@" python tools/trace_invert.py 8 2>&1 | grep "invert" | tail -3 | tr '\n' ' '; echo; }
 for i in 1 2; do
-run CURV_FUSED_STEP=0
-run CURV_FUSED_STEP=1
-run CURV_FUSED_STEP=1 CURV_NBO=4
-run CURV_FUSED_STEP=1 CURV_NBO=8
-run CURV_FUSED_STEP=1 CURV_SMALL_START=15
+run CURV_SMALL_FREE_CUS=0
+run CURV_SMALL_FREE_CUS=16
+run CURV_SMALL_FREE_CUS=8
+run CURV_SMALL_FREE_CUS=16 CURV_FREE_CUS=48
+run CURV_SMALL_FREE_CUS=24 CURV_FREE_CUS=48
+run CURV_SMALL_FREE_CUS=16 CURV_FUSED_STEP=1
 done
