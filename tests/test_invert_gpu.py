@@ -316,3 +316,23 @@ def test_inversion_is_bit_identical_whatever_streams_the_process_holds(gpu):
     1501-wide factor is above the group split)."""
     shas = {order: _stream_probe(order)[0] for order in ("none", "before", "after")}
     assert shas["none"] == shas["before"] == shas["after"], shas
+
+
+def test_repeated_sweeps_are_bit_identical(gpu):
+    """The sweep runs on four streams (two chains, two streams for the far updates and the fp32 inverse) that hand over through
+    events; a missing dependency shows up as a flipped bit sooner or later.  Two factor groups, fp32 inverse, per-step chain
+    (more than 64 factors) and the chain-bound forms (a handful): the same inputs 25 times each, every output compared bit for
+    bit with the first call's (tools/stress_invert_determinism.py is the long version on the ResNet-50 sizes)."""
+    from curvature_amd import ops
+    for sizes in ([1536, 1000, 640, 401, 130, 64] * 12, [1536, 640, 130]):
+        Fs = []
+        for i, n in enumerate(sizes):
+            torch.manual_seed(i)
+            X = torch.randn(n, n + 8, device=gpu)
+            Fs.append((X @ X.t() / (n + 8)).contiguous())
+        add, mul = [1.0] * len(Fs), [100.0] * len(Fs)
+        ref = [o.clone() for o in ops.chol_inv_lower(Fs, add, mul)]
+        for _ in range(25):
+            outs = ops.chol_inv_lower(Fs, add, mul)
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(outs, ref))
