@@ -101,7 +101,8 @@ class curv_gemm_desc(ctypes.Structure):
 
 class curv_cholinv_desc(ctypes.Structure):
     _fields_ = [("M", ctypes.c_void_p), ("X", ctypes.c_void_p), ("n", ctypes.c_int32), ("m_is_f64", ctypes.c_int32),
-                ("diag_add", ctypes.c_double), ("R", ctypes.c_void_p), ("r_minus", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("diag_add", ctypes.c_double), ("R", ctypes.c_void_p), ("r_minus", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("pivot_min", ctypes.c_double)]
 
 
 class curv_gemm64_desc(ctypes.Structure):
@@ -190,7 +191,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 7                     # CURV_ABI_VERSION of include/curv_hip.h
+ABI_VERSION = 8                     # CURV_ABI_VERSION of include/curv_hip.h
 KFAC_TABLE_RESIDENT = 1             # CURV_KFAC_TABLE_RESIDENT
 PATH_AUTO, PATH_SMALL, PATH_GROUPED = 0, 1, 2     # CURV_PATH_* (curv_factor_desc.path_hint)
 SMALL_MAX_FLOP = 2.0e9              # CURV_SMALL_MAX_FLOP

@@ -85,6 +85,7 @@ struct InvDev {
   float* C32;
   float* X32;           // finished rows of C^-1 (outside the squares)
   float* S32;           // the running sums S
+  double pivot_min;     // pivots at or below this count as failed (0: the positive-definiteness test of the estimators)
 };
 typedef __attribute__((address_space(1))) float gfloat;
 // does this factor accumulate S in fp64 inside the sweep (the round-1 form: curv_chol_factor_inverse, whose fp64 outputs
@@ -252,7 +253,7 @@ __device__ __forceinline__ void store_sub(gdouble* C, int np, const f64x4 (&acc)
   store_acc(C, np, acc, wm, wn, lane, mode);
 }
 
-__device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base);
+__device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base, double pivot_min);
 __device__ __forceinline__ void lds_sub_acc(double* s, const f64x4 (&acc)[2][2], int wm, int wn, int lane);
 
 // (2i)/(4i) inner updates of step k, restricted to the outer panel [.., kend).  The workgroup that
@@ -300,7 +301,7 @@ inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int ken
               As[(32 * wm + 16 * m + rq + 4 * q) * LDA + 32 * wn + 16 * n + c16] -= acc[m][n][q];
       }
       __syncthreads();
-      factor_invert_64(As, Bs, &bad, j * NB);
+      factor_invert_64(As, Bs, &bad, j * NB, d.pivot_min);
       store_block(X + (long long)j * NB * np + j * NB, np, Bs);
       if (threadIdx.x == 0 && bad != 0) atomicCAS(d.info, 0, bad);
     } else {
@@ -365,7 +366,7 @@ inner_fused_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int kend
       __syncthreads();
       lds_sub_acc(As, acc, wm, wn, lane);
       __syncthreads();
-      factor_invert_64(As, Bs, &bad, j * NB);
+      factor_invert_64(As, Bs, &bad, j * NB, d.pivot_min);
       store_block(X + (long long)j * NB * np + j * NB, np, Bs);
       if (threadIdx.x == 0 && bad != 0) atomicCAS(d.info, 0, bad);
     } else {
@@ -696,7 +697,9 @@ __device__ __forceinline__ double rcp_pos(double x) {
   return fma(y, fma(e, e, e), y);
 }
 
-__device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base) {
+// `pivot_min`: a pivot at or below it is reported as "not positive definite" (0 for the estimators; a caller that looks for
+// the numerical rank of a Gram matrix - the low-rank eigensolver, ops.eigh - passes its threshold through curv_cholinv_desc)
+__device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base, double pivot_min) {
   __shared__ double Sc[4][16 * 17];
   __shared__ double dinv_s[NB];        // 1 / L_cc: the triangular inverse divides by the same pivots
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -816,7 +819,7 @@ __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* ba
 #undef CURV_COL
       // pivot test, once per panel (false for NaN too; a failed factor turns into NaN / garbage and is reported)
       const double mine = __hiloint2double(mine_hi, mine_lo);
-      const unsigned long long failed = __ballot(lane < 16 && !(mine > 0.0 && mine < 1.0e300));
+      const unsigned long long failed = __ballot(lane < 16 && !(mine > pivot_min && mine < 1.0e300));
       const int first_bad = failed != 0 ? pivot_base + c0 + __ffsll((long long)failed) : 0;
       // L_c = u_c / sqrt(d_c): the reciprocal roots of all 16 pivots at once, handed round through dinv_s
       const double rs = rsqrt_pos(lane < 16 ? mine : 1.0);
@@ -877,7 +880,7 @@ chol_diag_kernel(const InvDev* __restrict__ t, int nf, int k) {
   if (tid == 0) bad = 0;
   load_block(W + (long long)k * NB * np + k * NB, np, Ds);
   __syncthreads();
-  factor_invert_64(Ds, Is, &bad, k * NB);
+  factor_invert_64(Ds, Is, &bad, k * NB, d.pivot_min);
   store_block((gdouble*)d.X + (long long)k * NB * np + k * NB, np, Is);
   if (tid == 0 && bad != 0) atomicCAS(d.info, 0, bad);
 }
@@ -1085,7 +1088,7 @@ chol_square_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int* 
         sq_signal(fl + SQ_FLC + q, stamp);                        // L_{q,q-1} is out (also the barrier the step needs)
         SQT(8 * q + 4)
       }
-      factor_invert_64(Ds, Is, &bad, (k0 + q) * NB);
+      factor_invert_64(Ds, Is, &bad, (k0 + q) * NB, d.pivot_min);
       SQT(q == 0 ? 2 : 8 * q + 5)
       store_block_coh(Xt(q, q), np, Is);
       sq_signal(fl + SQ_FD + q, stamp);
@@ -1627,7 +1630,7 @@ inv_finalize_kernel(const InvDev* __restrict__ t, int nf, int sq) {   // sq: edg
   }
 }
 
-constexpr int INV_UPLOAD_CHUNK = 30;
+constexpr int INV_UPLOAD_CHUNK = 28;
 struct InvChunk { InvDev f[INV_UPLOAD_CHUNK]; };
 static_assert(sizeof(InvChunk) <= 3840, "kernel argument block must stay below 4 KB");
 
@@ -2247,6 +2250,7 @@ extern "C" int curv_chol_factor_inverse(void* stream_, const curv_cholinv_desc* 
     d.sqrt_s = 1.0f;
     d.sqrt_n = (float)s.diag_add;            // added in fp32 like the reference's `vtv + eye` (:567)
     d.reverse = 0;
+    d.pivot_min = s.pivot_min > 0.0 ? s.pivot_min : 0.0;
     d.R = s.R;                               // (Zm: a third work matrix, placed by chol_sweep)
     d.r_minus = (s.R != nullptr && s.r_minus) ? 1 : 0;
   }

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CURV_ABI_VERSION 7
+#define CURV_ABI_VERSION 8
 
 #define CURV_OK 0
 #define CURV_ERR_NOT_PD 1
@@ -181,6 +181,9 @@ typedef struct curv_cholinv_desc {
   const double* R;
   int32_t r_minus;   /* with R: X = R - chol(M + d I)^-1 R (pre_sampler's T = (I - B_c^-1) A_c^-1 in one go) */
   int32_t reserved;
+  double pivot_min;  /* a pivot <= pivot_min counts as "not positive definite" (0: the plain test).  info then reports the first
+                      * column whose pivot fell to the threshold, i.e. the numerical rank of a Gram matrix whose columns are
+                      * in general position: the rank detection of the low-rank eigensolver (curvature_amd/ops.py: eigh) */
 } curv_cholinv_desc;
 
 size_t curv_chol_factor_inverse_workspace_bytes(const curv_cholinv_desc* descs, int n_mats);

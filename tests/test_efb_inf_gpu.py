@@ -427,3 +427,50 @@ def test_chol_factor_inverse_with_right_hand_side(gpu, count):
     for g, w in zip(got, want):
         assert float((g - w).abs().max()) <= 1e-9 * float(w.abs().max())
         assert float(torch.triu(g, 1).abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_eigh_low_rank_path_and_its_fallback(gpu):
+    """Wide matrices whose numerical rank is below half their width are decomposed through their range (ops._eigh_lowrank:
+    Gaussian range finder, rank from a thresholded Cholesky of the Gram matrix, three Cholesky-QR passes, the iteration on
+    the projected k x k matrix, an orthonormal complement for the null space); a wide matrix of full rank must fall back to
+    the iteration on the whole matrix.  Same bars as the iteration: residual, orthogonality, ascending order, eigenvalues
+    against torch's fp64 solver; the path taken is checked through `ops.eigh.last_lowrank`."""
+    from curvature_amd import ops
+    torch.manual_seed(5)
+    n = 2304
+    X = torch.relu(torch.randn(n, 600, device=gpu) + 0.5)               # rank 600: a KFAC factor with N L = 600 samples
+    low = (X @ X.t() / 600).contiguous()
+    Y = torch.randn(n, 2 * n, device=gpu)
+    full = (Y @ Y.t() / (2 * n)).contiguous()
+    small = (X[:500] @ X[:500].t() / 600).contiguous()                  # below the width the path looks at
+    vecs, vals = ops.eigh([low, full, small], with_values=True)
+    assert ops.eigh.last_lowrank == 1
+    for F, U, w in zip((low, full, small), vecs, vals):
+        Fd, Ud, wd = F.double(), U.double(), w.double()
+        m = F.shape[0]
+        assert U.dtype == torch.float32 and U.shape == F.shape and w.shape == (m,)
+        assert bool((wd[1:] >= wd[:-1]).all())
+        assert float(torch.linalg.norm(Ud.t() @ Ud - torch.eye(m, device=gpu, dtype=torch.float64))) < 1e-5 * m ** 0.5
+        assert float(torch.linalg.norm(Fd @ Ud - Ud * wd)) < 1e-5 * float(torch.linalg.norm(Fd))
+        ref = torch.linalg.eigvalsh(Fd)
+        assert float(torch.linalg.norm(wd - ref)) < 1e-5 * float(torch.linalg.norm(ref))
+    # deterministic, and independent of what else is in the batch (what a layer-sharded rank relies on)
+    (U2,), (w2,) = ops.eigh([low], with_values=True)
+    assert torch.equal(U2, vecs[0]) and torch.equal(w2, vals[0])
+
+
+@pytest.mark.gpu
+def test_eigh_low_rank_path_sharp_rank(gpu):
+    """A classifier's input factor: 2049 wide, 32 samples - rank exactly 32, no oversampling for the range finder (its basis
+    then depends on one step of subspace iteration; without it the residual was 2e-5)."""
+    from curvature_amd import ops
+    torch.manual_seed(0)
+    X = torch.cat([torch.relu(torch.randn(2048, 32, device=gpu)), torch.ones(1, 32, device=gpu)])
+    F = (X @ X.t() / 32).contiguous()
+    (U,), (w,) = ops.eigh([F], with_values=True)
+    assert ops.eigh.last_lowrank == 1, ops.eigh.lowrank_log
+    Fd, Ud, wd = F.double(), U.double(), w.double()
+    assert float(torch.linalg.norm(Fd @ Ud - Ud * wd)) < 5e-6 * float(torch.linalg.norm(Fd))
+    assert float(torch.linalg.norm(Ud.t() @ Ud - torch.eye(2049, device=gpu, dtype=torch.float64))) < 1e-5 * 2049 ** 0.5
+    assert bool((wd[1:] >= wd[:-1]).all()) and int((wd > 1e-3).sum()) == 32
