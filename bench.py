@@ -255,10 +255,11 @@ def other_configs_gpu(dev, model50, kfac50, batch):
     torch.cuda.synchronize()
     c3["efb_eigenvectors_ms"] = (time.perf_counter() - t0) * 1e3
     c3["efb_eigensolver_sweeps"] = int(getattr(ops.eigh, "last_sweeps", 0))
+    ranks3 = dict(getattr(ops.eigh, "last_ranks", {}))
     r18.load_state_dict(k3.model_state)
     _backward_once(r18, torch.randn(32, 3, 224, 224, device=dev))
     c3["efb_update_ms"] = _timed_gpu(lambda: e3.update(32))
-    c3.update(_efb_eig_fracs(k3.state, c3["efb_update_ms"], c3["efb_eigenvectors_ms"], c3["efb_eigensolver_sweeps"], "efb_"))
+    c3.update(_efb_eig_fracs(k3.state, c3["efb_update_ms"], c3["efb_eigenvectors_ms"], c3["efb_eigensolver_sweeps"], "efb_", ranks3))
     c3["efb_invert_ms"] = _timed_gpu(lambda: e3.invert(1.0, 1000.0))
     c3["efb_sample_and_replace_ms"] = _timed_gpu(e3.sample_and_replace)
     out["config3_resnet18_kfac_efb"] = c3
@@ -303,10 +304,11 @@ def other_configs_gpu(dev, model50, kfac50, batch):
     torch.cuda.synchronize()
     c5["eigenvectors_ms"] = (time.perf_counter() - t0) * 1e3
     c5["eigensolver_sweeps"] = int(getattr(ops.eigh, "last_sweeps", 0))
+    ranks5 = dict(getattr(ops.eigh, "last_ranks", {}))
     model50.load_state_dict(kfac50.model_state)
     _backward_once(model50, torch.randn(batch, 3, 224, 224, device=dev))
     c5["efb_update_ms"] = _timed_gpu(lambda: e5.update(batch))
-    c5.update(_efb_eig_fracs(kfac50.state, c5["efb_update_ms"], c5["eigenvectors_ms"], c5["eigensolver_sweeps"], ""))
+    c5.update(_efb_eig_fracs(kfac50.state, c5["efb_update_ms"], c5["eigenvectors_ms"], c5["eigensolver_sweeps"], "", ranks5))
     inf = INF(model50, e5.diags, kfac50.state, e5.state, eigvecs=e5.eigvecs)
     c5["inf_update_rank100_ms"] = _timed_gpu(lambda: inf.update(rank=100), reps=2)
     c5["inf_invert_1_1000_ms"] = _timed_gpu(lambda: inf.invert(1.0, 1000.0), reps=2)
@@ -485,22 +487,28 @@ def stream_probe(mode: str, batch: int):
     print(json.dumps({"invert_ms": statistics.median(ts)}))
 
 
-def _efb_eig_fracs(state, efb_update_ms, eig_ms, sweeps, prefix):
+def _efb_eig_fracs(state, efb_update_ms, eig_ms, sweeps, prefix, ranks=None):
     """Roofline fractions a reader can recompute from the line: EFB.update = U_G^T grad U_A per layer (curvatures.py:424-427),
     2 (m^2 n + m n^2) flops on the fp32 MFMA path; the block-Jacobi eigensolver is HBM-bound: a sweep of an n-wide matrix is
     n / 32 - 1 rounds, and a round of the fp32 phase moves 14 n^2 bytes (the symmetric two-sided pass over A32: 6 n^2, the
     column pass over V32: 8 n^2; DESIGN K4).  Every matrix is priced at the sweep count of the slowest one and at the fp32
-    phase's bytes (the two or three fp64 sweeps move twice as much): the fraction is an estimate, good to ~20 %."""
+    phase's bytes (the two or three fp64 sweeps move twice as much): the fraction is an estimate, good to ~20 %.  A wide
+    rank-deficient factor that went through its range (ops._eigh_lowrank; `ranks` = position -> k) is priced at the k x k
+    problem the iteration ran on - the range finder's products are not counted."""
     flops = sum(2.0 * (G.shape[0] ** 2 * A.shape[0] + G.shape[0] * A.shape[0] ** 2) for A, G in state.values())
-    per_sweep = sum(max(n / 32.0 - 1.0, 1.0) * 14.0 * float(n) ** 2 for A, G in state.values() for n in (A.shape[0], G.shape[0]))
+    widths = [n for A, G in state.values() for n in (A.shape[0], G.shape[0])]
+    widths = [(ranks or {}).get(i, n) for i, n in enumerate(widths)]
+    per_sweep = sum(max(n / 32.0 - 1.0, 1.0) * 14.0 * float(n) ** 2 for n in widths)
     out = {"efb_update_gflop": flops / 1e9,
            "efb_update_frac": flops / (efb_update_ms * 1e-3) / PEAK_F32_MFMA,
            "efb_update_frac_of": "2 (m^2 n + m n^2) flops per layer / time / 157.3 TFLOP/s (fp32 MFMA)"}
     if sweeps:
+        out["eigensolver_projected"] = {str(i): k for i, k in (ranks or {}).items()}
         out["eigensolver_hbm_gbytes_per_sweep"] = per_sweep / 1e9
         out["eigensolver_frac"] = per_sweep * sweeps / (eig_ms * 1e-3) / PEAK_HBM
         out["eigensolver_frac_of"] = ("sweeps x sum over factors of (n / 32 - 1) rounds x 14 n^2 bytes / time / 8 TB/s (HBM spec); "
-                                      "every factor priced at the slowest one's sweep count")
+                                      "every factor priced at the slowest one's sweep count, a projected one (eigensolver_projected: position -> rank) at its "
+                                      "k x k problem")
     return out
 
 

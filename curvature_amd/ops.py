@@ -655,18 +655,21 @@ def eigh(mats: Sequence[torch.Tensor], with_values: bool = False, max_sweeps: in
     # range, the iteration on the small projected matrix only (see _eigh_lowrank); the others - and every matrix that
     # turns out not to be rank-deficient - take the block-Jacobi iteration on the whole matrix
     eigh.last_lowrank = 0
-    done = {}
+    eigh.last_ranks = {}                                 # position in `mats` -> rank the projected problem had
+    done, inner_sweeps = {}, 0
     if tol <= 0.0 and max_sweeps == 0 and os.environ.get("CURV_EIGH_LOWRANK", "1") != "0":
         wide = [i for i, F in enumerate(mats) if F.shape[0] >= LOWRANK_MIN_N and F.dtype == torch.float32]
         if wide:
             done = _eigh_lowrank([mats[i] for i in wide], wide)
+            inner_sweeps = getattr(eigh, "last_sweeps", 0) if done else 0
             eigh.last_lowrank = len(done)
+            eigh.last_ranks = {i: k for i, (_, _, k) in done.items()}
     rest = [i for i in range(len(mats)) if i not in done]
     vecs, vals = [None] * len(mats), [None] * len(mats)
-    for i, (U, w) in done.items():
+    for i, (U, w, _) in done.items():
         vecs[i], vals[i] = U, w
     if not rest:
-        eigh.last_sweeps, eigh.converged = 0, True
+        eigh.last_sweeps, eigh.converged = inner_sweeps, True
         return (vecs, vals) if with_values else vecs
     n = len(rest)
     arr = (curv_eigh_desc * n)()
@@ -684,13 +687,14 @@ def eigh(mats: Sequence[torch.Tensor], with_values: bool = False, max_sweeps: in
     sweeps = ctypes.c_int(0)
     rc = L.curv_syevd(_lib.stream_ptr(), arr, n, ws.data_ptr(), ws.numel(), int(max_sweeps), float(tol),
                       ctypes.byref(sweeps))
-    eigh.last_sweeps = sweeps.value
+    eigh.last_sweeps = max(sweeps.value, inner_sweeps)
     eigh.converged = rc == 0
     if not (rc == _lib.ERR_NOT_CONVERGED and allow_unconverged):
         _lib.check(rc, "curv_syevd")
     return (vecs, vals) if with_values else vecs
 
 
+LOWRANK_PROBE = 0.5           # columns of the range finder over the width: ranks up to this share take the path
 LOWRANK_MIN_N = 2048          # narrower matrices converge in a few cheap sweeps anyway
 LOWRANK_GRAM_PIVOT = 1e-13    # relative pivot of the Gram matrix below which a direction counts as noise (3e-7 of ||F||)
 LOWRANK_RESIDUAL = 3e-6       # ||F - P F P|| / ||F|| the projection must reach (the iteration's own bar above 1024: 5e-6)
@@ -710,7 +714,7 @@ def _eigh_lowrank(mats: Sequence[torch.Tensor], index: Sequence[int]) -> dict:
                                                    two Cholesky-QR passes): F Z is below the residual bar by construction
     Every product is curv_gemm_f64_batched, every factorisation curv_chol_factor_inverse; a matrix that fails any test
     (rank >= n/2, a failed factorisation, residual above the bar) is left to the caller's iteration on the whole matrix.
-    Returns {index: (U, w)} of the matrices it decomposed.  Deterministic: the Gaussian matrices depend on n only."""
+    Returns {index: (U, w, k)} of the matrices it decomposed.  Deterministic: the Gaussian matrices depend on n only."""
     out = {}
     log = eigh.lowrank_log = []                          # (index, what happened): diagnostics, tools/eigh_lowrank_breakdown.py
     dev = mats[0].device
@@ -722,7 +726,7 @@ def _eigh_lowrank(mats: Sequence[torch.Tensor], index: Sequence[int]) -> dict:
         Sd = (Fd + Fd.t()) * 0.5
         S.append(Sd)
         nS2.append((Sd * Sd).sum())
-        r = (n // 2 // 64) * 64
+        r = int(n * float(os.environ.get("CURV_EIGH_PROBE", LOWRANK_PROBE))) // 64 * 64
         r_of.append(r)
         om = randn((n, r), dev, 0x5EED0000 + n, 0).double()
         jobs.append(Gemm64(Sd, om))
@@ -813,7 +817,7 @@ def _eigh_lowrank(mats: Sequence[torch.Tensor], index: Sequence[int]) -> dict:
         Ucat[:, :n - k].copy_(z)
         w = torch.cat([torch.zeros(n - k, dtype=torch.float32, device=dev), lk])
         w_sorted, order = torch.sort(w, stable=True)
-        out[index[p]] = (Ucat.index_select(1, order).contiguous(), w_sorted.contiguous())
+        out[index[p]] = (Ucat.index_select(1, order).contiguous(), w_sorted.contiguous(), k)
     return out
 
 
