@@ -1691,7 +1691,6 @@ static int stream_set(StreamSet** out) {
   CURV_HIP_CHECK(hipDeviceGetStreamPriorityRange(&plo, &phi));
   // the large group's chain of short launches is the critical path of the sweep: highest priority
   static const int aux_prio = getenv("CURV_AUX_PRIO") ? atoi(getenv("CURV_AUX_PRIO")) : 1;
-  CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.aux, hipStreamNonBlocking, aux_prio ? phi : plo));
   CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
   CURV_HIP_CHECK(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
   // the far updates are throughput work: lowest priority, so that the latency-critical chain launches of
@@ -1727,6 +1726,25 @@ static int stream_set(StreamSet** out) {
     CURV_HIP_CHECK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio_low));
     return CURV_OK;
   };
+  // EXPERIMENT (CURV_STREAM_ORDER): creation order of the set's streams with dummies between them: a = large chain,
+  // m = small chain, 0 / 1 = far-update streams, x = unused CU-masked stream, p = unused plain stream, h = unused high-priority one
+  if (const char* order = getenv("CURV_STREAM_ORDER")) {
+    for (const char* c = order; *c; ++c) {
+      hipStream_t dummy = nullptr;
+      switch (*c) {
+        case 'a': CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.aux, hipStreamNonBlocking, phi)); break;
+        case 'm': CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.masked, hipStreamNonBlocking)); break;
+        case '0': { const int rc = wide_stream(&s.side[0].stream); if (rc != CURV_OK) return rc; } break;
+        case '1': { const int rc = wide_stream(&s.side[1].stream); if (rc != CURV_OK) return rc; } break;
+        case 'x': { const int rc = wide_stream(&dummy); if (rc != CURV_OK) return rc; } break;
+        case 'p': CURV_HIP_CHECK(hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking)); break;
+        case 'h': CURV_HIP_CHECK(hipStreamCreateWithPriority(&dummy, hipStreamNonBlocking, phi)); break;
+        case 'l': CURV_HIP_CHECK(hipStreamCreateWithPriority(&dummy, hipStreamNonBlocking, plo)); break;
+        default: break;
+      }
+    }
+  }
+  if (s.aux == nullptr) CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.aux, hipStreamNonBlocking, aux_prio ? phi : plo));
   // The small group's chain: a plain stream.  Measured alternatives (round 5, ResNet-50 factors): CU-masked like the far
   // updates' streams (CURV_SMALL_MASKED=1; the reserved CUs then belong to the large group's chain alone) 7.5 -> 8.5 ms -
   // the small group's own chain starves beside the far updates; on the LOW priority level (the runtime keeps a pool of
@@ -1735,10 +1753,25 @@ static int stream_set(StreamSet** out) {
   // set, as with a normal stream.  What the four busy streams of a sweep need is four different hardware pipes; a
   // fifth busy stream of any kind (CU-masked, low priority, shared between the groups) costs 4-5 ms.
   static const int small_masked = getenv("CURV_SMALL_MASKED") ? atoi(getenv("CURV_SMALL_MASKED")) : 0;
-  if (small_masked) { const int rc = wide_stream(&s.masked); if (rc != CURV_OK) return rc; }
+  static const int small_full = getenv("CURV_SMALL_FULLMASK") ? atoi(getenv("CURV_SMALL_FULLMASK")) : 0;
+  if (s.masked != nullptr) {}
+  else if (small_masked) { const int rc = wide_stream(&s.masked); if (rc != CURV_OK) return rc; }
+  else if (small_full) {
+    // a CU-masked stream with every CU in its mask: a hardware queue of its own (the runtime pools the queues of plain streams)
+    hipDeviceProp_t prop;
+    int dev_id = 0;
+    CURV_HIP_CHECK(hipGetDevice(&dev_id));
+    CURV_HIP_CHECK(hipGetDeviceProperties(&prop, dev_id));
+    std::vector<uint32_t> mask((size_t)cdiv(prop.multiProcessorCount, 32), 0u);
+    for (int c = 0; c < prop.multiProcessorCount; ++c) mask[c >> 5] |= 1u << (c & 31);
+    CURV_HIP_CHECK(hipExtStreamCreateWithCUMask(&s.masked, (uint32_t)mask.size(), mask.data()));
+    std::lock_guard<std::mutex> lock(g_masked_mutex);
+    if (g_masked_streams.empty()) atexit(destroy_masked_streams);
+    g_masked_streams.emplace_back(dev_id, s.masked);
+  }
   else CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.masked, hipStreamNonBlocking));
   for (int g = 0; g < 2; ++g) {
-    { const int rc = wide_stream(&s.side[g].stream); if (rc != CURV_OK) return rc; }
+    if (s.side[g].stream == nullptr) { const int rc = wide_stream(&s.side[g].stream); if (rc != CURV_OK) return rc; }
     // (a stream of its own for the fp32 inverse only on request: every additional hardware queue of the process slows
     // the whole sweep down - two more CU-masked streams, even unused: invert() of the ResNet-50 factors 7.5 -> 11.1 ms)
     static const int inv_stream = getenv("CURV_INV_STREAM") ? atoi(getenv("CURV_INV_STREAM")) : 0;
@@ -2044,6 +2077,22 @@ constexpr int SPLIT_P = 16;
 // curv_internal_side_stream).
 struct EarlyStatus { int* host; const int* dev; size_t bytes; hipEvent_t ev; };
 
+// The caller's stream joins the sweep through hipStreamWaitEvent, i.e. a barrier packet at the head of its hardware
+// queue for as long as the sweep runs - and a queue that sits on an unsatisfied barrier slows down every other queue on
+// its PIPE of the command processor (queues are dealt onto four pipes in creation order).  Measured on the ResNet-50
+// factors with the set's streams created in all 24 orders behind 0 / 2 other queues (LAB_NOTEBOOK R5.6): 6.8-7.1 ms unless
+// a chain's queue is the (4 k + 3)-th of the process - the caller's pipe -, then 9.0-9.5 ms (small group's chain there)
+// or 10.3-11.0 ms (large group's).  This is the "creation order" sensitivity of rounds 3-5: three streams created in
+// front of the set put the large chain on the caller's pipe.  With an early verdict the host waits for the status words
+// anyway, so the join is enqueued AFTER that wait - the caller's queue then holds its barrier for the finalize passes
+// only (6.9 / 6.8 / 10.9 -> 6.8 / 6.8 / 7.3 ms for none / three streams after / three before the set).  The plain entry
+// point (no host wait: graph capture, check=False) joins at once and keeps the sensitivity.
+static int await_verdict(const EarlyStatus* early) {
+  static const int late_join = getenv("CURV_LATE_JOIN") ? atoi(getenv("CURV_LATE_JOIN")) : 1;
+  if (early != nullptr && late_join) CURV_HIP_CHECK(hipEventSynchronize(early->ev));
+  return CURV_OK;
+}
+
 static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* workspace, size_t workspace_bytes,
                       const char* who, const EarlyStatus* early = nullptr) {
   const int n_factors = (int)tab.size();
@@ -2123,6 +2172,7 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
       CURV_HIP_CHECK(hipMemcpyAsync(early->host, early->dev, early->bytes, hipMemcpyDeviceToHost, ss->side[0].stream));
       CURV_HIP_CHECK(hipEventRecord(early->ev, ss->side[0].stream));
     }
+    { const int rc = await_verdict(early); if (rc != CURV_OK) return rc; }
     CURV_HIP_CHECK(hipEventRecord(ss->ev_join, ss->aux));
     CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->ev_join, 0));
     return CURV_OK;
@@ -2151,7 +2201,11 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   // the event the small group's stream waits for (the large group has done `start_panel` panels) is then the large
   // group's stream TAIL at the moment of the wait, which is what hipStreamWaitEvent effectively waits for.
   GroupSweep gb(ss->aux, &ss->side[0], big, table0, flags0, big_latency);
-  GroupSweep gs(ss->masked, &ss->side[1], small, table1, flags1, latency_bound);
+  // CURV_SMALL_ONE_STREAM=1: the small group's far updates and fp32 inverse on its chain's stream (three busy streams)
+  static const int small_one = getenv("CURV_SMALL_ONE_STREAM") ? atoi(getenv("CURV_SMALL_ONE_STREAM")) : 0;
+  SideStream side_small = ss->side[1];
+  if (small_one) side_small.stream = ss->masked;
+  GroupSweep gs(ss->masked, small_one ? &side_small : &ss->side[1], small, table1, flags1, latency_bound);
   int rc = gb.begin();
   if (rc != CURV_OK) return rc;
   bool small_started = false;
@@ -2178,6 +2232,7 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
     CURV_HIP_CHECK(hipMemcpyAsync(early->host, early->dev, early->bytes, hipMemcpyDeviceToHost, ss->side[1].stream));
     CURV_HIP_CHECK(hipEventRecord(early->ev, ss->side[1].stream));
   }
+  { const int rc = await_verdict(early); if (rc != CURV_OK) return rc; }
   CURV_HIP_CHECK(hipEventRecord(ss->ev_join, ss->aux));
   CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->ev_join, 0));
   CURV_HIP_CHECK(hipEventRecord(ss->ev_join2, ss->masked));

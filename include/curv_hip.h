@@ -161,7 +161,12 @@ int curv_chol_inv_lower(void* stream, const curv_inv_desc* descs, int n_factors,
  * has run - before the finalize passes that write L, which do not touch them - and `ev_status` (curv_event_create) is
  * recorded behind that copy.  curv_event_synchronize(ev_status) then returns while the finalize passes still run (0.15 ms
  * for a ResNet-50), and the host prepares its next launches in their shadow; work enqueued on `stream` afterwards is
- * ordered behind the whole call as always.  Not available under stream capture (CURV_ERR_INVALID). */
+ * ordered behind the whole call as always.  Not available under stream capture (CURV_ERR_INVALID).
+ * The call itself WAITS (host) for that copy before it makes `stream` wait for the sweep and returns (the status words are
+ * then in `host_status`; curv_event_synchronize(ev_status) returns at once): a stream that sits on an unsatisfied wait for
+ * the whole sweep slows the sweep's own streams down whenever they share a pipe of the command processor with it - the
+ * "streams created before the estimator" effect (10.9 -> 7.3 ms for a ResNet-50).  curv_chol_inv_lower, which never
+ * blocks the host, keeps that sensitivity. */
 int curv_chol_inv_lower_status(void* stream, const curv_inv_desc* descs, int n_factors, int* info, void* workspace,
                                size_t workspace_bytes, int* host_status, void* ev_status);
 
