@@ -475,13 +475,14 @@ def stream_probe(mode: str, batch: int):
         extra()
     _backward_once(model, torch.randn(batch, 3, 224, 224, device=dev))
     kfac.update(batch_size=batch)
+    check = os.environ.get("BENCH_PROBE_CHECK", "1") != "0"      # 0: the unchecked entry point (no host wait inside the call)
     for _ in range(3):
-        kfac.invert(add=1.0, multiply=1000.0)
+        kfac.invert(add=1.0, multiply=1000.0, check=check)
     ts = []
     for _ in range(10):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        kfac.invert(add=1.0, multiply=1000.0)
+        kfac.invert(add=1.0, multiply=1000.0, check=check)
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
     print(json.dumps({"invert_ms": statistics.median(ts)}))

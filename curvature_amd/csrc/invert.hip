@@ -1726,8 +1726,9 @@ static int stream_set(StreamSet** out) {
     CURV_HIP_CHECK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio_low));
     return CURV_OK;
   };
-  // EXPERIMENT (CURV_STREAM_ORDER): creation order of the set's streams with dummies between them: a = large chain,
-  // m = small chain, 0 / 1 = far-update streams, x = unused CU-masked stream, p = unused plain stream, h = unused high-priority one
+  // EXPERIMENT (CURV_STREAM_ORDER, LAB_NOTEBOOK R5.6): creation order of the set's streams with dummies between them: a = large
+  // chain, m = small chain, 0 / 1 = far-update streams, i / j = their fp32-inverse streams (CURV_INV_STREAM=1), x / p / h / l =
+  // unused CU-masked / plain / high-priority / low-priority stream
   if (const char* order = getenv("CURV_STREAM_ORDER")) {
     for (const char* c = order; *c; ++c) {
       hipStream_t dummy = nullptr;
@@ -1736,6 +1737,8 @@ static int stream_set(StreamSet** out) {
         case 'm': CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.masked, hipStreamNonBlocking)); break;
         case '0': { const int rc = wide_stream(&s.side[0].stream); if (rc != CURV_OK) return rc; } break;
         case '1': { const int rc = wide_stream(&s.side[1].stream); if (rc != CURV_OK) return rc; } break;
+        case 'i': { const int rc = wide_stream(&s.side[0].inv); if (rc != CURV_OK) return rc; } break;
+        case 'j': { const int rc = wide_stream(&s.side[1].inv); if (rc != CURV_OK) return rc; } break;
         case 'x': { const int rc = wide_stream(&dummy); if (rc != CURV_OK) return rc; } break;
         case 'p': CURV_HIP_CHECK(hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking)); break;
         case 'h': CURV_HIP_CHECK(hipStreamCreateWithPriority(&dummy, hipStreamNonBlocking, phi)); break;
@@ -1775,7 +1778,8 @@ static int stream_set(StreamSet** out) {
     // (a stream of its own for the fp32 inverse only on request: every additional hardware queue of the process slows
     // the whole sweep down - two more CU-masked streams, even unused: invert() of the ResNet-50 factors 7.5 -> 11.1 ms)
     static const int inv_stream = getenv("CURV_INV_STREAM") ? atoi(getenv("CURV_INV_STREAM")) : 0;
-    if (inv_stream == 1 || (inv_stream == 2 && g == 0)) { const int rc = wide_stream(&s.side[g].inv); if (rc != CURV_OK) return rc; }
+    if (s.side[g].inv != nullptr) {}
+    else if (inv_stream == 1 || (inv_stream == 2 && g == 0)) { const int rc = wide_stream(&s.side[g].inv); if (rc != CURV_OK) return rc; }
     else if (inv_stream == 2) s.side[g].inv = s.side[0].inv;
     for (int i = 0; i < 2; ++i) CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_near[i], hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) {
