@@ -1990,11 +1990,21 @@ struct GroupSweep {
     const bool near_on_side = near_side != 0 && near_tiles > 0;
     const bool side_work = far_tiles > 0 || near_on_side || (!inv_stream && (inv_jobs > 0 || inv_tiles > 0));
     const bool inv_work = inv_jobs > 0 || inv_tiles > 0;
-    if (side_work || inv_work) {                 // fork: the other streams' work needs this panel's chain
-      CURV_HIP_CHECK(hipEventRecord(side->ev_main[panel & 1], stream));
-      if (side_work) CURV_HIP_CHECK(hipStreamWaitEvent(side->stream, side->ev_main[panel & 1], 0));
-      if (inv_work && inv_stream) CURV_HIP_CHECK(hipStreamWaitEvent(side->inv, side->ev_main[panel & 1], 0));
-    }
+    // fork: the other streams' work needs this panel's chain.  CURV_FORK_AFTER_NEAR=1 forks BEHIND the near update (a far
+    // update launched beside it takes every CU but the reserved ones and the near update then runs in rounds on those: one
+    // 4608^2 40 -> 14 us per panel) - measured neutral: the side stream's work moves 25 us later and lands on the next panel
+    // product instead (17 -> 45 us); one 4608^2 2.63 vs 2.66 ms, whole model 6.87 vs 6.84 ms over six pairs
+    static const int fork_late_env = getenv("CURV_FORK_AFTER_NEAR") ? atoi(getenv("CURV_FORK_AFTER_NEAR")) : 0;
+    const bool fork_late = fork_late_env != 0 && !near_on_side;
+    auto fork = [&]() -> int {
+      if (side_work || inv_work) {
+        CURV_HIP_CHECK(hipEventRecord(side->ev_main[panel & 1], stream));
+        if (side_work) CURV_HIP_CHECK(hipStreamWaitEvent(side->stream, side->ev_main[panel & 1], 0));
+        if (inv_work && inv_stream) CURV_HIP_CHECK(hipStreamWaitEvent(side->inv, side->ev_main[panel & 1], 0));
+      }
+      return CURV_OK;
+    };
+    if (!fork_late) { const int rc = fork(); if (rc != CURV_OK) return rc; }
     if (near_tiles > 0) {
       hipStream_t near_st = near_on_side ? side->stream : stream;
       if (far_pending && !near_on_side) {        // join: the previous far part wrote the tiles updated here
@@ -2013,6 +2023,7 @@ struct GroupSweep {
         CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_near[panel & 1], 0));
       }
     }
+    if (fork_late) { const int rc = fork(); if (rc != CURV_OK) return rc; }
     if (far_tiles > 0) {
       const long long grid = cdivll(far_tiles, 8 * SB * SB) * 8 * SB * SB;
       hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, side->stream, table, n_factors, k0,

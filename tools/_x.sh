@@ -1,2 +1,1 @@
-for sj in 0 1; do for m in none before; do echo -n "unchecked sleep_join=$sj $m: "; BENCH_PROBE_CHECK=0 CURV_SLEEP_JOIN=$sj python bench.py --stream-probe $m --batch 32 2>/dev/null | tail -1; done
-for o in a01m m01a xxam01 xxxam01; do echo -n "unchecked sleep_join=$sj $o none: "; BENCH_PROBE_CHECK=0 CURV_SLEEP_JOIN=$sj CURV_STREAM_ORDER=$o python bench.py --stream-probe none --batch 32 2>/dev/null | tail -1; done; done
+for r in 1 2 3 4 5 6; do for v in 0 1; do echo -n "r$r fork_after_near=$v: "; CURV_FORK_AFTER_NEAR=$v python bench.py --stream-probe none --batch 32 2>/dev/null | tail -1; done; done
