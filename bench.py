@@ -249,11 +249,12 @@ def other_configs_gpu(dev, model50, kfac50, batch):
     c3["kfac_invert_ms"] = _timed_gpu(lambda: k3.invert(1.0, 1000.0))
     c3["kfac_sample_and_replace_ms"] = _timed_gpu(k3.sample_and_replace)
     c3["kfac_step_ms"] = c3["kfac_update_ms"] + c3["kfac_invert_ms"] + c3["kfac_sample_and_replace_ms"]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    e3 = EFB(r18, k3.state)
-    torch.cuda.synchronize()
-    c3["efb_eigenvectors_ms"] = (time.perf_counter() - t0) * 1e3
+    for key in ("efb_eigenvectors_first_call_ms", "efb_eigenvectors_ms"):   # the first call allocates the workspace
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e3 = EFB(r18, k3.state)
+        torch.cuda.synchronize()
+        c3[key] = (time.perf_counter() - t0) * 1e3
     c3["efb_eigensolver_sweeps"] = int(getattr(ops.eigh, "last_sweeps", 0))
     ranks3 = dict(getattr(ops.eigh, "last_ranks", {}))
     r18.load_state_dict(k3.model_state)
@@ -298,11 +299,12 @@ def other_configs_gpu(dev, model50, kfac50, batch):
     c5 = {"workload": f"ResNet-50 N={batch}, 54 layers, on the headline run's KFAC factors: EFB constructor (eigenvectors of "
                       "the 108 factors), efb.update, INF(..., eigvecs=efb.eigvecs).update(rank=100), inf.invert at "
                       "(1, 1000) and at the README's (145307, 60), inf.sample_and_replace"}
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    e5 = EFB(model50, kfac50.state)
-    torch.cuda.synchronize()
-    c5["eigenvectors_ms"] = (time.perf_counter() - t0) * 1e3
+    for key in ("eigenvectors_first_call_ms", "eigenvectors_ms"):     # the first call allocates the 5.6 GB workspace
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e5 = EFB(model50, kfac50.state)
+        torch.cuda.synchronize()
+        c5[key] = (time.perf_counter() - t0) * 1e3
     c5["eigensolver_sweeps"] = int(getattr(ops.eigh, "last_sweeps", 0))
     ranks5 = dict(getattr(ops.eigh, "last_ranks", {}))
     model50.load_state_dict(kfac50.model_state)

@@ -29,6 +29,12 @@ namespace curv {
 #ifndef CURV_FLAT_KC
 #define CURV_FLAT_KC 16
 #endif
+// Diagnostic builds only (tools/make_flat_ablate.py; results are WRONG by construction): what the kernel's time owes to
+//   1: half of its LDS operand reads (a1 <- a0, b1 <- b0)     2: all operand reads behind a stage's first step
+//   4: half of its LDS-DMA pieces (the odd ones)               8: half of its MFMAs (the lower quadrant row)
+#ifndef CURV_FLAT_ABLATE
+#define CURV_FLAT_ABLATE 0
+#endif
 
 namespace flat {
 constexpr int TM = 128;
@@ -79,8 +85,8 @@ __device__ __forceinline__ void flat_mfma_step(const f32x4& a0, const f32x4& a1,
     if (e < ne) {
       if (PART != 3) c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], c00, 0, 0, 0);
       if (PART != 2) c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], c01, 0, 0, 0);
-      if (PART == 0 || PART == 2) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], c10, 0, 0, 0);
-      if (PART != 2) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], c11, 0, 0, 0);
+      if ((PART == 0 || PART == 2) && !(CURV_FLAT_ABLATE & 8)) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], c10, 0, 0, 0);
+      if (PART != 2 && !(CURV_FLAT_ABLATE & 8)) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], c11, 0, 0, 0);
     }
     hook(e);                      // one LDS-DMA piece behind a group of MFMAs: its issue cost hides under them
   }
@@ -160,6 +166,7 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
   };
   auto piece = [&](int i) {
     const int p = i / PIECES, slot = i % PIECES;
+    if ((CURV_FLAT_ABLATE & 4) && (i & 1)) return;
     if (p < n_panels && g_lane < n_gmax) {
       const unsigned lbase = (p ? 2u * PANEL_B : 0u) + n_buf + (unsigned)(RPP * wave + 4 * RPP * slot) * ROW_B;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lbase), 16, voff,
@@ -182,13 +189,17 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
     // software pipeline over the stage's steps: operands of step j + 1 are read while the MFMAs of step j issue;
     // the DMA pieces of stage t + 1 go out during the first half of the stage, each behind a group of MFMAs, so
     // that the last one still has half of the stage's MFMA time to land before the wait at the top
-    f32x4 a0 = rd(0, 0), a1 = rd(1, 0), b0 = rd(2, 0), b1 = rd(3, 0);
+    f32x4 a0 = rd(0, 0), a1 = (CURV_FLAT_ABLATE & 1) ? a0 : rd(1, 0), b0 = rd(2, 0), b1 = (CURV_FLAT_ABLATE & 1) ? b0 : rd(3, 0);
     int next_piece = 0;
 #pragma unroll
     for (int j = 0; j < STEPS; ++j) {
       if (j < nsteps) {
         f32x4 na0, na1, nb0, nb1;
-        if (j + 1 < STEPS && j + 1 < nsteps) { na0 = rd(0, j + 1); na1 = rd(1, j + 1); nb0 = rd(2, j + 1); nb1 = rd(3, j + 1); }
+        if (CURV_FLAT_ABLATE & 2) { na0 = a0; na1 = a1; nb0 = b0; nb1 = b1; }
+        else if (j + 1 < STEPS && j + 1 < nsteps) {
+          na0 = rd(0, j + 1); nb0 = rd(2, j + 1);
+          na1 = (CURV_FLAT_ABLATE & 1) ? na0 : rd(1, j + 1); nb1 = (CURV_FLAT_ABLATE & 1) ? nb0 : rd(3, j + 1);
+        }
         int ne = 4;
         if (last && j == nsteps - 1 && nv_last < 8) {
           // the sample's final step: only nv_last of its 8 pixels exist (what the DMA fetched beyond them belongs to

@@ -1,1 +1,1 @@
-for r in 1 2 3 4 5 6; do for v in 0 1; do echo -n "r$r fork_after_near=$v: "; CURV_FORK_AFTER_NEAR=$v python bench.py --stream-probe none --batch 32 2>/dev/null | tail -1; done; done
+for r in 1 2; do for m in 0 1 2 3 4 8; do CURV_ALT_LIB=tools/micro/libcurv_flat_ab$m.so python tools/ab_update.py 2>&1 | grep update; done; done
