@@ -28,6 +28,7 @@
 #include <type_traits>
 #include "common.h"
 #include "mma64.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -1849,7 +1850,7 @@ struct GroupSweep {
   bool latency_bound;
   int n_factors = 0, Pmax = 0, NBO = 4, k0 = 0, panel = 0;
   long long fin_tiles = 0, quarter_prod = 0;
-  bool use_square = false, far_pending = false, inv_pending = false;
+  bool use_square = false, far_pending = false, inv_pending = false, capturing = false;
 
   GroupSweep(hipStream_t st, SideStream* sd, const std::vector<InvDev>& tab, InvDev* tb, int* fl, bool lb)
       : stream(st), side(sd), tabp(&tab), table(tb), flags(fl), latency_bound(lb) {}
@@ -1859,6 +1860,9 @@ struct GroupSweep {
   int begin() {
     const std::vector<InvDev>& tab = *tabp;
     n_factors = (int)tab.size();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    CURV_HIP_CHECK(hipStreamIsCapturing(stream, &cap));
+    capturing = cap != hipStreamCaptureStatusNone;      // (events ride on launches only outside a capture)
     long long prep_tiles = 0;
     for (const InvDev& d : tab) {
       Pmax = std::max(Pmax, d.P);
@@ -1948,14 +1952,19 @@ struct GroupSweep {
       }
     }
     // the launch form of a panel product by its number of jobs; part 0 on the chain, part 1 (fp32 inverse) on the side stream
-    auto launch_product = [&](hipStream_t st, long long jobs, int part) -> int {
+    // `done` (optional): recorded as the launch's own completion (hipExtLaunchKernelGGL's stop event) - no marker packet
+    // of its own in the chain's queue
+    auto launch_product = [&](hipStream_t st, long long jobs, int part, hipEvent_t done) -> int {
+      const InvDev* tb = table;
       if (jobs <= quarter_prod)
-        hipLaunchKernelGGL(panel_product_quarter_kernel, dim3((unsigned)(cdivll(jobs, 8) * 32)), dim3(INV_THREADS), 0, st,
-                           table, n_factors, k0, kend, part);
+        hipExtLaunchKernelGGL(panel_product_quarter_kernel, dim3((unsigned)(cdivll(jobs, 8) * 32)), dim3(INV_THREADS), 0, st,
+                              nullptr, done, 0, tb, n_factors, k0, kend, part);
       else if (jobs <= wide_prod)
-        hipLaunchKernelGGL(panel_product_wide_kernel, dim3((unsigned)jobs), dim3(1024), 0, st, table, n_factors, k0, kend, part);
+        hipExtLaunchKernelGGL(panel_product_wide_kernel, dim3((unsigned)jobs), dim3(1024), 0, st, nullptr, done, 0, tb, n_factors,
+                              k0, kend, part);
       else
-        hipLaunchKernelGGL(panel_product_kernel, dim3((unsigned)jobs), dim3(INV_THREADS), 0, st, table, n_factors, k0, kend, part);
+        hipExtLaunchKernelGGL(panel_product_kernel, dim3((unsigned)jobs), dim3(INV_THREADS), 0, st, nullptr, done, 0, tb,
+                              n_factors, k0, kend, part);
       CURV_LAUNCH_CHECK();
       return CURV_OK;
     };
@@ -1965,8 +1974,11 @@ struct GroupSweep {
       inv_jobs += xrow_tiles(d.P, s_kind(d), k0, kend);
       inv_tiles += supd_tiles(d.P, s_kind(d), kend);
     }
+    static const int ext_events = getenv("CURV_EXT_EVENTS") ? atoi(getenv("CURV_EXT_EVENTS")) : 1;
+    bool fork_recorded = false;           // ev_main rides on the panel product's completion
     if (prod_tiles > 0) {   // rows below the square (right-hand side mode: and the columns of Zm): one triangular product each
-      const int rc = launch_product(stream, prod_tiles, 0);
+      fork_recorded = ext_events != 0 && !capturing;
+      const int rc = launch_product(stream, prod_tiles, 0, fork_recorded ? side->ev_main[panel & 1] : nullptr);
       if (rc != CURV_OK) return rc;
     }
     // Outer update of this panel in two parts: near = the strip the next chain touches (this stream, on the
@@ -1998,7 +2010,7 @@ struct GroupSweep {
     const bool fork_late = fork_late_env != 0 && !near_on_side;
     auto fork = [&]() -> int {
       if (side_work || inv_work) {
-        CURV_HIP_CHECK(hipEventRecord(side->ev_main[panel & 1], stream));
+        if (!fork_recorded || fork_late) CURV_HIP_CHECK(hipEventRecord(side->ev_main[panel & 1], stream));
         if (side_work) CURV_HIP_CHECK(hipStreamWaitEvent(side->stream, side->ev_main[panel & 1], 0));
         if (inv_work && inv_stream) CURV_HIP_CHECK(hipStreamWaitEvent(side->inv, side->ev_main[panel & 1], 0));
       }
@@ -2026,11 +2038,13 @@ struct GroupSweep {
     if (fork_late) { const int rc = fork(); if (rc != CURV_OK) return rc; }
     if (far_tiles > 0) {
       const long long grid = cdivll(far_tiles, 8 * SB * SB) * 8 * SB * SB;
-      hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, side->stream, table, n_factors, k0,
-                         kend, row0, 0, 0, (int)far_tiles);
+      const bool ride = ext_events != 0 && !capturing && !near_side;
+      const InvDev* tb = table;
+      hipExtLaunchKernelGGL(outer_update_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, side->stream, nullptr,
+                            ride ? side->ev_side[panel & 1] : nullptr, 0, tb, n_factors, k0, kend, row0, 0, 0, (int)far_tiles);
       CURV_LAUNCH_CHECK();
       if (!near_side) {
-        CURV_HIP_CHECK(hipEventRecord(side->ev_side[panel & 1], side->stream));
+        if (!ride) CURV_HIP_CHECK(hipEventRecord(side->ev_side[panel & 1], side->stream));
         far_pending = true;
       }
     }

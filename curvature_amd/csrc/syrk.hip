@@ -1491,7 +1491,7 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
   // the side stream (register-staged MFMA kernel + its reduce pass) joins behind everything the caller's stream had to
   // do itself: none of the passes above reads what the side stream writes (LeNet-5: the two chains are 60 us each, and
   // ran one after the other when the join came first)
-  if (fork) CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->join, 0));
+  // (join_r is recorded behind join on the same stream: one wait covers both)
   if (fork) CURV_HIP_CHECK(hipStreamWaitEvent(stream, ss->join_r, 0));
   // the timed window (bench.py's roofline) spans the WHOLE build: padding / pre-tiling passes, the MFMA kernels, the
   // k-slice reduction of the sliced factors and the assembly of the 3x3 factors
