@@ -155,7 +155,7 @@ def test_many_large_factors_no_race(gpu):
         assert rel_fro(outs[idx], exact) < 1e-6
 
 
-def test_same_result_without_cu_masks(gpu, tmp_path):
+def test_same_result_whatever_the_stream_layout(gpu, tmp_path):
     """The sweep's stream layout (CU-masked side streams, or plain low-priority ones when CURV_FREE_CUS=0 / the
     runtime has no CU masks) must not change a single bit: every tile is written by exactly one workgroup and
     the accumulation order inside a tile is fixed.  The setting is read once per process, hence a subprocess."""
@@ -174,6 +174,9 @@ def test_same_result_without_cu_masks(gpu, tmp_path):
         return out
 
     here = [L.cpu() for L in ops.chol_inv_lower([F.to(gpu) for F in factors()], [1.0] * 4, [1000.0] * 4)]
+    # the same factors inside a call with more than 64 of them: two factor groups on four streams
+    filler = [torch.eye(8, device=gpu) * (i + 1.0) for i in range(70)]
+    here += [L.cpu() for L in ops.chol_inv_lower([F.to(gpu) for F in factors()] + filler, [1.0] * 74, [1000.0] * 74)[:4]]
     script = tmp_path / "inv.py"
     script.write_text(
         "import sys, torch\n"
@@ -185,13 +188,19 @@ def test_same_result_without_cu_masks(gpu, tmp_path):
         "    g = torch.Generator().manual_seed(100 + i)\n"
         "    X = torch.randn(n, n + 8, generator=g)\n"
         "    Fs.append((X @ X.t() / (n + 8)).contiguous().cuda())\n"
-        "Ls = ops.chol_inv_lower(Fs, [1.0] * 4, [1000.0] * 4)\n"
+        "Ls = list(ops.chol_inv_lower(Fs, [1.0] * 4, [1000.0] * 4))\n"
+        "filler = [torch.eye(8, device='cuda') * (i + 1.0) for i in range(70)]\n"
+        "Ls += list(ops.chol_inv_lower(Fs + filler, [1.0] * 74, [1000.0] * 74))[:4]\n"
         f"torch.save([L.cpu() for L in Ls], {str(tmp_path / 'out.pt')!r})\n")
-    env = dict(os.environ, CURV_FREE_CUS="0")
-    subprocess.run([sys.executable, str(script)], check=True, env=env, timeout=300)
-    there = torch.load(tmp_path / "out.pt")
-    for a, b in zip(here, there):
-        assert torch.equal(a, b)
+    # ... nor may any of the sweep's other orchestration switches: plain event records instead of events riding on the
+    # launches, the caller's stream joining at once, the set's streams created in another order (the large chain's queue on
+    # the caller's pipe), the small group on one stream
+    for extra in ({"CURV_FREE_CUS": "0"}, {"CURV_EXT_EVENTS": "0", "CURV_LATE_JOIN": "0"}, {"CURV_STREAM_ORDER": "xm01a"},
+                  {"CURV_SMALL_ONE_STREAM": "1", "CURV_FORK_AFTER_NEAR": "1"}):
+        subprocess.run([sys.executable, str(script)], check=True, env=dict(os.environ, **extra), timeout=300)
+        there = torch.load(tmp_path / "out.pt")
+        for a, b in zip(here, there):
+            assert torch.equal(a, b), extra
 
 
 def test_chain_bound_and_throughput_forms_agree(gpu):
