@@ -474,3 +474,22 @@ def test_eigh_low_rank_path_sharp_rank(gpu):
     assert float(torch.linalg.norm(Fd @ Ud - Ud * wd)) < 5e-6 * float(torch.linalg.norm(Fd))
     assert float(torch.linalg.norm(Ud.t() @ Ud - torch.eye(2049, device=gpu, dtype=torch.float64))) < 1e-5 * 2049 ** 0.5
     assert bool((wd[1:] >= wd[:-1]).all()) and int((wd > 1e-3).sum()) == 32
+
+
+@pytest.mark.gpu
+def test_eigh_low_rank_path_does_not_depend_on_the_batch(gpu):
+    """Layer-sharded ranks decompose different subsets of a model's factors and must end with the same eigenvectors bit for
+    bit: the projection path's products, factorisations and Gaussian matrices depend on the matrix alone."""
+    from curvature_amd import ops
+    torch.manual_seed(3)
+    X = torch.randn(2304, 200, device=gpu)
+    big = (X @ X.t() / 200).contiguous()
+    Y = torch.randn(2048, 64, device=gpu)
+    other = (Y @ Y.t() / 64).contiguous()
+    small = [torch.randn(96, 96, device=gpu) for _ in range(3)]
+    small = [(s + s.t()).contiguous() for s in small]
+    (U_alone,), (w_alone,) = ops.eigh([big], with_values=True)
+    assert ops.eigh.last_lowrank == 1
+    U_many, w_many = ops.eigh([small[0], other, big, small[1], small[2]], with_values=True)
+    assert ops.eigh.last_lowrank == 2 and sorted(ops.eigh.last_ranks) == [1, 2]
+    assert torch.equal(U_alone, U_many[2]) and torch.equal(w_alone, w_many[2])
