@@ -1171,6 +1171,8 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     for (int k = 0; k < layer.n_vf; ++k) {
       const FactorDev& v = plan.f[layer.vf0 + k];
       const int sps = syrk_flat_stages(v.W);
+      // (scaled by 1.5 / 2.0, i.e. dispatched earlier and sliced finer: flat kernel 4.06 -> 3.95 / 3.99 ms, pre-tiled kernel
+      // 1.30 -> 1.39 / 1.38 ms - the target item length moves with the total: a wash)
       const double cost = (double)v.W / sps * 32.0 * 4.0 + 800.0;
       chunk_cost.push_back(cost);
       chunk_px.push_back((double)v.W / sps);
@@ -1290,6 +1292,14 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     }
     plan.n_items[k] = (int)items;
     plan.n_sub[k] = (int)subs;
+    if (getenv("CURV_PLAN_DUMP")) {       // diagnostics: the dispatch order of a list (stderr)
+      for (int idx : plan.order[k]) {
+        const FactorDev& f = plan.f[idx];
+        fprintf(stderr, "list %d idx %4d dim %5d W %6d tiles %4d chunks %6d cpi %4d slices %3d items %5d direct %d group %d/%d nonsym %d cost/item %.0f chunk_cost %.0f\n",
+                k, idx, f.dim, f.W, f.n_tiles, f.n_chunks, f.cpi, f.n_slices, f.n_items, f.direct, f.group_pos, f.group_n, f.nonsym,
+                item_cost[idx], chunk_cost[idx]);
+      }
+    }
   }
   plan.slab_floats = slab;
   return CURV_OK;

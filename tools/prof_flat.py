@@ -41,10 +41,9 @@ def main():
     t0 = a[:, 0].min()
     st, en = (a[:, 0] - t0).astype(np.float64) / 100.0, (a[:, 1] - t0).astype(np.float64) / 100.0
     span = en.max()
-    print(f"timeline: {len(a)} items, span {span:.0f} us, occupancy {np.sum(en - st) / 512 / span:.2f}")
-    for frac in (0.5, 0.8, 0.9, 0.95):
-        t = span * frac
-        print(f"  active items at {frac:.2f} span: {int(np.sum((st <= t) & (en > t)))}")
+    print(f"timeline: {len(a)} items, span {span:.0f} us, mean active workgroups {np.sum(en - st) / span:.0f}")
+    print("  active workgroups at 5 % steps of the span: " +
+          " ".join(str(int(np.sum((st <= span * f) & (en > span * f)))) for f in np.arange(0.05, 1.0, 0.05)))
     keys = {}
     for (s0, e0, k) in zip(st, en, a[:, 2]):
         keys.setdefault(int(k), []).append((s0, e0))
