@@ -637,7 +637,7 @@ def check_factor_inverse_info(info: torch.Tensor) -> None:
 
 
 def eigh(mats: Sequence[torch.Tensor], with_values: bool = False, max_sweeps: int = 0, tol: float = 0.0,
-         allow_unconverged: bool = False):
+         allow_unconverged: bool = False, _project: bool = True):
     """Eigenvectors (columns, ascending eigenvalues) of symmetric float32 matrices, batched block-Jacobi.
 
     Raises ``RuntimeError`` when the iteration has not converged to `tol` within `max_sweeps` sweeps (default 60 sweeps;
@@ -657,7 +657,7 @@ def eigh(mats: Sequence[torch.Tensor], with_values: bool = False, max_sweeps: in
     eigh.last_lowrank = 0
     eigh.last_ranks = {}                                 # position in `mats` -> rank the projected problem had
     done, inner_sweeps = {}, 0
-    if tol <= 0.0 and max_sweeps == 0 and os.environ.get("CURV_EIGH_LOWRANK", "1") != "0":
+    if _project and tol <= 0.0 and max_sweeps == 0 and os.environ.get("CURV_EIGH_LOWRANK", "1") != "0":
         wide = [i for i, F in enumerate(mats) if F.shape[0] >= LOWRANK_MIN_N and F.dtype == torch.float32]
         if wide:
             done = _eigh_lowrank([mats[i] for i in wide], wide)
@@ -793,10 +793,8 @@ def _eigh_lowrank(mats: Sequence[torch.Tensor], index: Sequence[int]) -> dict:
     pos, ks, Q, B = keep(ok, pos, ks, Q, B)
     if not pos:
         return out
-    # the small problems: the block-Jacobi iteration (this function is not re-entered: they are narrower than LOWRANK_MIN_N or
-    # the environment switch is what the recursion sees - pass them below the width test by construction of k < n / 2 only
-    # when n < 2 LOWRANK_MIN_N; otherwise they may take this path again, which is as valid)
-    W, lam = eigh([b.float().contiguous() for b in B], with_values=True)
+    # the small problems: the block-Jacobi iteration (they have full rank by construction: not projected again)
+    W, lam = eigh([b.float().contiguous() for b in B], with_values=True, _project=False)
     # complement of Q: Gaussian, projected, orthonormalised twice
     Z = []
     for p, k, q in zip(pos, ks, Q):
