@@ -732,15 +732,20 @@ syrk_pre_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_items,
 }
 
 // Sum the k-slices of one 64x64 sub-tile in slice order, scale, add into the factor and its mirror.
+// (descs2 / n2 / split: a second work list behind the first one in the same launch - workgroups from `split` on serve it;
+// two consecutive launches of 700 and 190 workgroups took 92 + 113 us, one of 890 takes the longer of the two)
 __global__ void __launch_bounds__(SYRK_THREADS)
-syrk_reduce_kernel(const FactorDev* __restrict__ descs, int n_factors, const float* __restrict__ slabs) {
+syrk_reduce_kernel(const FactorDev* __restrict__ descs, int n_factors, const float* __restrict__ slabs,
+                   const FactorDev* __restrict__ descs2, int n2, int split) {
   __shared__ float tile[64][65];
   const int tid = threadIdx.x;
-  const int f = find_segment(descs, n_factors, blockIdx.x, true);
+  int bid = blockIdx.x;
+  if (descs2 != nullptr && bid >= split) { descs = descs2; n_factors = n2; bid -= split; }
+  const int f = find_segment(descs, n_factors, bid, true);
   const FactorDev& d = descs[f];
   const int TMv = d.TM;
   const int q = TMv >> 6;                       // sub-tiles per tile edge
-  const int sub = blockIdx.x - d.sub_base;
+  const int sub = bid - d.sub_base;
   const int t = sub / (q * q);
   const int qq = sub - t * (q * q);
   const int qi = qq / q, qj = qq - qi * q;
@@ -809,24 +814,40 @@ syrk_reduce_kernel(const FactorDev* __restrict__ descs, int n_factors, const flo
     }
   }
   __syncthreads();
-  for (int e = tid; e < 64 * 64; e += SYRK_THREADS) {
-    const int r = e >> 6, c = e & 63;
-    const int gi = i0 + r, gj = j0 + c;
-    if (gi < dim && gj < dim) {
-      const float v = diag ? tile[min(r, c)][max(r, c)] : tile[r][c];
-      const long long idx = (long long)gi * dim + gj;
-      dst[idx] = first ? v : dst[idx] + v;
+  // the factor's 16 + 16 elements of a thread are loaded before the first one is stored: one element per pass waited for
+  // its own load (32 dependent round trips per thread: most of the launch's 90 us)
+  constexpr int PASSES = 64 * 64 / SYRK_THREADS;
+  {
+    float old[PASSES];
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int e = tid + u * SYRK_THREADS, r = e >> 6, c = e & 63;
+      const int gi = i0 + r, gj = j0 + c;
+      old[u] = (!first && gi < dim && gj < dim) ? dst[(long long)gi * dim + gj] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int e = tid + u * SYRK_THREADS, r = e >> 6, c = e & 63;
+      const int gi = i0 + r, gj = j0 + c;
+      if (gi < dim && gj < dim) {
+        const float v = diag ? tile[min(r, c)][max(r, c)] : tile[r][c];
+        dst[(long long)gi * dim + gj] = first ? v : old[u] + v;
+      }
     }
   }
   if (!diag && !nonsym) {
-    for (int e = tid; e < 64 * 64; e += SYRK_THREADS) {
-      const int r = e >> 6, c = e & 63;      // r indexes panel j, c panel i
+    float old[PASSES];
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int e = tid + u * SYRK_THREADS, r = e >> 6, c = e & 63;      // r indexes panel j, c panel i
       const int gi = j0 + r, gj = i0 + c;
-      if (gi < dim && gj < dim) {
-        const float v = tile[c][r];
-        const long long idx = (long long)gi * dim + gj;
-        dst[idx] = first ? v : dst[idx] + v;
-      }
+      old[u] = (!first && gi < dim && gj < dim) ? dst[(long long)gi * dim + gj] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int e = tid + u * SYRK_THREADS, r = e >> 6, c = e & 63;
+      const int gi = j0 + r, gj = i0 + c;
+      if (gi < dim && gj < dim) dst[(long long)gi * dim + gj] = first ? tile[c][r] : old[u] + tile[c][r];
     }
   }
 }
@@ -1467,7 +1488,8 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
   }
   auto reduce = [&](hipStream_t on, int list, int first, int count) -> int {
     if (plan.n_sub[list] <= 0) return CURV_OK;
-    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub[list]), dim3(SYRK_THREADS), 0, on, table + first, count, slabs);
+    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub[list]), dim3(SYRK_THREADS), 0, on, table + first, count, slabs,
+                       (const FactorDev*)nullptr, 0, 0);
     CURV_LAUNCH_CHECK();
     return CURV_OK;
   };
@@ -1495,8 +1517,14 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
     if (rc1 != CURV_OK) return rc1;
   }
   if (!fork && (rc = reduce(stream, 0, 0, n0)) != CURV_OK) return rc;
-  if ((rc = reduce(stream, 1, n0, n1)) != CURV_OK) return rc;
-  if ((rc = reduce(stream, 2, n0 + n1, n2)) != CURV_OK) return rc;
+  if (plan.n_sub[1] > 0 && plan.n_sub[2] > 0) {      // the k-slices of both MFMA kernels of this stream in one launch
+    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.n_sub[1] + plan.n_sub[2]), dim3(SYRK_THREADS), 0, stream, table + n0, n1, slabs,
+                       (const FactorDev*)(table + n0 + n1), n2, plan.n_sub[1]);
+    CURV_LAUNCH_CHECK();
+  } else {
+    if ((rc = reduce(stream, 1, n0, n1)) != CURV_OK) return rc;
+    if ((rc = reduce(stream, 2, n0 + n1, n2)) != CURV_OK) return rc;
+  }
   if (!plan.corr.empty() && (rc = launch_corr_assemble(stream, plan.corr, plan.f, area)) != CURV_OK) return rc;
   // the side stream (register-staged MFMA kernel + its reduce pass) joins behind everything the caller's stream had to
   // do itself: none of the passes above reads what the side stream writes (LeNet-5: the two chains are 60 us each, and
