@@ -49,8 +49,10 @@ __device__ long long g_sq_trace[256];
 #define KT_BEGIN(slot) { if (threadIdx.x == 0 && k0 == 4 * (CURV_SQ_TRACE - 1)) atomicMax((unsigned long long*)&g_sq_trace[slot], (1ull << 62) - (unsigned long long)wall_clock64()); }
 #define KT_END(slot) { if (threadIdx.x == 0 && k0 == 4 * (CURV_SQ_TRACE - 1)) atomicMax((unsigned long long*)&g_sq_trace[slot], (unsigned long long)wall_clock64()); }
 #define SQT(slot) { if (threadIdx.x == 0 && f == 0 && stamp == CURV_SQ_TRACE) g_sq_trace[slot] = wall_clock64(); }
+#define FIT(k) { if (threadIdx.x == 0 && trace_base >= 0) g_sq_trace[trace_base + (k)] = wall_clock64(); }
 #else
 #define SQT(slot)
+#define FIT(k)
 #define KT_BEGIN(slot) {}
 #define KT_END(slot) {}
 #endif
@@ -254,7 +256,7 @@ __device__ __forceinline__ void store_sub(gdouble* C, int np, const f64x4 (&acc)
   store_acc(C, np, acc, wm, wn, lane, mode);
 }
 
-__device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base, double pivot_min);
+__device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base, double pivot_min, int trace_base = -1);
 __device__ __forceinline__ void lds_sub_acc(double* s, const f64x4 (&acc)[2][2], int wm, int wn, int lane);
 
 // (2i)/(4i) inner updates of step k, restricted to the outer panel [.., kend).  The workgroup that
@@ -700,7 +702,8 @@ __device__ __forceinline__ double rcp_pos(double x) {
 
 // `pivot_min`: a pivot at or below it is reported as "not positive definite" (0 for the estimators; a caller that looks for
 // the numerical rank of a Gram matrix - the low-rank eigensolver, ops.eigh - passes its threshold through curv_cholinv_desc)
-__device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base, double pivot_min) {
+__device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* bad, int pivot_base, double pivot_min, int trace_base) {
+  (void)trace_base;
   __shared__ double Sc[4][16 * 17];
   __shared__ double dinv_s[NB];        // 1 / L_cc: the triangular inverse divides by the same pivots
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -757,7 +760,13 @@ __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* ba
   };
   f64x4 y3 = {0.0, 0.0, 0.0, 0.0};         // this wave's partial sum for row 3 of X (waves 1..3 -> blocks 2, 0, 1)
   const int b3 = wave == 2 ? 0 : wave == 3 ? 1 : 2;
-#pragma unroll
+  // (unrolled: 35 KB of straight-line code, and the first factorisation of a launch runs it from a cold instruction cache -
+  // 18 us instead of 8, tools/sq_trace.py.  Rolled (-DCURV_FI_UNROLL=1: 13 KB; chol_square_kernel 64 -> 42 KB) the steady state
+  // loses more than the cold start gains: one 4608^2 2.48 -> 2.57 ms, 2304^2 1.08 -> 1.19, three 4608^2 and a whole model equal)
+#ifndef CURV_FI_UNROLL
+#define CURV_FI_UNROLL 4
+#endif
+#pragma unroll CURV_FI_UNROLL
   for (int p = 0; p < 4; ++p) {
     const int c0 = 16 * p;
     if (wave != 0) {
@@ -845,6 +854,7 @@ __device__ __forceinline__ void factor_invert_64(double* Ds, double* Is, int* ba
         }
     }
     __syncthreads();
+    FIT(p)
   }
   // behind the last panel: X_33 on wave 0 while the others add the terms of row 3 that needed row 2 of X
   if (wave == 0) {
@@ -1089,7 +1099,11 @@ chol_square_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int* 
         sq_signal(fl + SQ_FLC + q, stamp);                        // L_{q,q-1} is out (also the barrier the step needs)
         SQT(8 * q + 4)
       }
+#ifdef CURV_SQ_TRACE
+      factor_invert_64(Ds, Is, &bad, (k0 + q) * NB, d.pivot_min, (f == 0 && stamp == CURV_SQ_TRACE) ? 112 + 4 * q : -1);
+#else
       factor_invert_64(Ds, Is, &bad, (k0 + q) * NB, d.pivot_min);
+#endif
       SQT(q == 0 ? 2 : 8 * q + 5)
       store_block_coh(Xt(q, q), np, Is);
       sq_signal(fl + SQ_FD + q, stamp);

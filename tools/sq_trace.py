@@ -51,6 +51,8 @@ def main():
         b = 8 * q
         print("  step %d: FT seen %.1f | operands in LDS %.1f | solve %.1f | A' ready %.1f | FLC posted %.1f | D done %.1f | FD posted %.1f"
               % (q, us(t[b]), us(t[b + 1]), us(t[b + 2]), us(t[b + 3]), us(t[b + 4]), us(t[b + 5]), us(t[b + 6])))
+    print("  inside the factorisations (us after their start): " + " | ".join(
+        "step %d: " % q + " ".join("%.1f" % ((t[112 + 4 * q + p] - (t[1] if q == 0 else t[8 * q + 4])) / 100.0) for p in range(4)) for q in range(4)))
     for r in (1, 2, 3):
         b = 64 * r
         ms = " ".join("m%d: T %.1f X seen %.1f L %.1f |" % (m, us(t[b + 8 + 4 * m]), us(t[b + 9 + 4 * m]), us(t[b + 10 + 4 * m])) for m in range(max(r - 1, 0)))
