@@ -69,9 +69,13 @@ def _probe_threads():
         times[c] = best
     # the probe is 16-20 ms long and cannot tell 64 threads from 32; the whole workload can (same host: update 4.3 s at 64
     # threads, 2.0 s at 32; invert 6.6 s against 3.1): among the counts within 25 % of the fastest probe the SMALLEST one is used
+    return pick_threads(times), total, times
+
+
+def pick_threads(times):
+    """The smallest thread count whose probe time is within 25 % of the fastest one."""
     best = min(times.values())
-    pick = min(c for c, t in times.items() if t <= 1.25 * best)
-    return pick, total, times
+    return min(c for c, t in times.items() if t <= 1.25 * best)
 
 
 def cpu_baseline(batch_full, seed, budget_s=75.0):
