@@ -39,13 +39,15 @@ const char* curv_last_error(void);
 
 /* Create the library's internal streams (per calling thread and current device) NOW instead of at the first
  * curv_chol_inv_lower / curv_kfac_accumulate call.  Whole-model inversions run their factor groups on four internal
- * streams, and how the HIP runtime maps those onto hardware queues depends on which streams the process created BEFORE
- * them: unrelated streams created first (RCCL's, a data loader's) made invert() of the ResNet-50 factors 8.4 -> 12.6 ms,
- * the same streams created afterwards change nothing (profiles/r04_stream_sensitivity.txt).  Call this once, early -
- * but AFTER the caller's own stream has launched something: hardware queues are given out lazily, in order of first use,
- * and with the set created before the caller's stream was ever used the same inversion takes 13.2 ms.  The Python
- * estimators do it in their constructor (curvature_amd._lib.init_streams runs a one-element torch kernel first).
- * Idempotent. */
+ * streams; the runtime deals hardware queues onto the four pipes of the command processor in creation order, and a queue
+ * that is not empty - the caller's own stream, which waits for the sweep - slows every queue on its pipe.  Whether one of
+ * the sweep's two chains shares that pipe depends on how many streams the process created before the set (three raw
+ * streams in front of it: invert() of the ResNet-50 factors 6.9 -> 10.9 ms until round 5).  curv_chol_inv_lower_status
+ * no longer depends on it (it joins the caller's stream only after the host has the verdict: 6.83 / 6.80 / 6.87 ms for
+ * none / three streams after / three before the set); curv_chol_inv_lower and curv_chol_factor_inverse, which never wait
+ * on the host, still do: for those call this once, early - but AFTER the caller's own stream has launched something
+ * (hardware queues are given out lazily, in order of first use).  The Python estimators do it in their constructor
+ * (curvature_amd._lib.init_streams runs a one-element torch kernel first).  Idempotent.  (LAB_NOTEBOOK R5.6) */
 int curv_init_streams(void);
 
 /* ------------------------------------------------------------------------------------------------
