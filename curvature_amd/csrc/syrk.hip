@@ -1120,7 +1120,7 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
       f.dma = 1;
       f.pitch = f.W;
       f.TM = 128;
-      f.P = f.dim / 128;
+      f.P = cdiv(f.dim, 128);             // (the last tile row / column may be ragged: syrk_flat_eligible)
       f.n_tiles = f.P * (f.P + 1) / 2;
       const int sps = syrk_flat_stages(f.W);
       f.n_chunks = f.N * sps;

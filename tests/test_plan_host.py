@@ -25,7 +25,7 @@ def plan(descs):
     return [dict(zip(NAMES, out[NF * i:NF * i + NF])) for i in range(n)]
 
 
-def geom(N, C, H, W, k, s, p, bias):
+def geom(N, C, H, W, k, s, p, bias):   # (W: image width; CASES pass H twice)
     return dict(N=N, C=C, H=H, W=W, kh=k, kw=k, sh=s, sw=s, ph=p, pw=p, has_bias=bias)
 
 
@@ -35,7 +35,9 @@ CASES = [geom(N, C, H, H, k, s, p, b)
           (32, 256, 56, 1, 2, 0, 0), (32, 512, 7, 3, 1, 1, 0), (32, 2048, 7, 1, 1, 0, 0), (32, 2048, 1, 1, 1, 0, 1),
           (100, 1, 28, 5, 1, 2, 1), (100, 6, 14, 5, 1, 0, 1), (100, 400, 1, 1, 1, 0, 1), (1, 1, 1, 1, 1, 0, 0),
           (7, 33, 17, 3, 3, 0, 1), (2, 5, 300, 11, 4, 5, 0), (3, 700, 5, 1, 1, 0, 0), (3, 37, 28, 1, 1, 0, 0),
-          (3, 37, 1, 1, 1, 0, 0), (2, 37, 9, 1, 2, 0, 0)]]
+          (3, 37, 1, 1, 1, 0, 0), (2, 37, 9, 1, 2, 0, 0),
+          # DenseNet widths (64 + 32 k channels): the LDS-DMA kernel with a ragged last tile row / column
+          (8, 96, 56, 1, 1, 0, 0), (8, 224, 28, 1, 1, 0, 0), (3, 992, 7, 1, 1, 0, 0), (8, 160, 14, 1, 1, 0, 0)]]
 
 
 @pytest.mark.parametrize("d", CASES)
@@ -77,12 +79,13 @@ def test_plan_respects_budgets(d):
     assert p["direct"] == int(p["TM"] == 128 and p["nslices"] == 1)
     assert p["nsub"] == (0 if p["direct"] else p["ntiles"] * (p["TM"] // 64) ** 2)
     if p["dma"]:
-        # LDS-DMA kernel (syrk_flat.hip): flattened factor, whole 128-row tiles, no bias row; K in stages of at most
-        # 16 pixels of one sample, ceil(ceil(HW / 8) / 2) stages per sample
-        assert flat and not d["has_bias"] and p["dim"] % 128 == 0 and p["TM"] == 128
+        # LDS-DMA kernel (syrk_flat.hip): flattened factor, 128-row tiles (the last one may be ragged: widths of 32 k
+        # channels from 96 on), no bias row; K in stages of at most 16 pixels of one sample, ceil(ceil(HW / 8) / 2) stages
+        # per sample
+        assert flat and not d["has_bias"] and p["dim"] % 32 == 0 and p["dim"] >= 96 and p["TM"] == 128
         steps = -(-(Ho * Wo) // 8)
         assert p["nchunks"] == d["N"] * -(-steps // 2)
-        P = p["dim"] // 128
+        P = -(-p["dim"] // 128)
         assert p["ntiles"] == P * (P + 1) // 2 and p["nitems"] == p["ntiles"] * p["nslices"]
         assert p["cpi"] * p["nslices"] >= p["nchunks"] and p["cpi"] * (p["nslices"] - 1) < p["nchunks"]
         return
@@ -115,6 +118,13 @@ def test_plan_respects_budgets(d):
     assert p["cpi"] * p["nslices"] >= p["nchunks"] and p["cpi"] * (p["nslices"] - 1) < p["nchunks"]
     P = -(-p["dim"] // p["TM"])
     assert p["ntiles"] == P * (P + 1) // 2 and p["nitems"] == p["ntiles"] * p["nslices"]
+
+
+def test_densenet_widths_take_the_lds_dma_kernel():
+    for C in (96, 160, 224, 480, 992):
+        assert plan([geom(8, C, 14, 14, 1, 1, 0, 0)])[0]["dma"] == 1
+    for C in (64, 37, 100):          # narrower than 96 / no multiple of 32: the register-staged kernel
+        assert plan([geom(8, C, 14, 14, 1, 1, 0, 0)])[0]["dma"] == 0
 
 
 def test_item_bases_tile_the_work_list():
