@@ -71,12 +71,12 @@ int syrk_flat_stages(int HW) {
 bool syrk_flat_eligible(const FactorDev& f, const void* src) {
   // flattened per-pixel factor (1x1, stride 1, no padding: H = 1, W = pixels per (sample, channel) row), no bias row, and
   // the whole tensor addressable by one buffer descriptor (32-bit byte offsets).  The last tile row / column of a factor
-  // may be ragged (DenseNet: 64 + 32 k channels): the panel rows behind the factor's edge are the next sample's first
+  // may be ragged (DenseNet-121 / 161: 64 + 32 k / 96 + 48 k channels; any multiple of 16 from 96 on): the panel rows behind the factor's edge are the next sample's first
   // channels (zeros behind the tensor's end: the descriptor's range check) - finite values whose products land in tile rows
   // and columns that neither epilogue stores (direct_store_block masks them, syrk_reduce_kernel does not read them)
   static const int ragged = getenv("CURV_FLAT_RAGGED") ? atoi(getenv("CURV_FLAT_RAGGED")) : 1;
   if (!(f.compact && f.H == 1 && f.kh == 1 && f.kw == 1 && f.sh == 1 && f.sw == 1 && f.ph == 0 && f.pw == 0)) return false;
-  if (f.has_bias || f.dim < (ragged ? 96 : flat::TM) || f.dim % (ragged ? 32 : flat::TM) != 0) return false;
+  if (f.has_bias || f.dim < (ragged ? 96 : flat::TM) || f.dim % (ragged ? 16 : flat::TM) != 0) return false;
   if (f.W < 8) return false;
   if ((long long)f.N * f.C * f.W * 4 >= (1LL << 32) - 4096) return false;
   return (reinterpret_cast<uintptr_t>(src) & 3) == 0;

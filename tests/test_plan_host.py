@@ -37,7 +37,8 @@ CASES = [geom(N, C, H, H, k, s, p, b)
           (7, 33, 17, 3, 3, 0, 1), (2, 5, 300, 11, 4, 5, 0), (3, 700, 5, 1, 1, 0, 0), (3, 37, 28, 1, 1, 0, 0),
           (3, 37, 1, 1, 1, 0, 0), (2, 37, 9, 1, 2, 0, 0),
           # DenseNet widths (64 + 32 k channels): the LDS-DMA kernel with a ragged last tile row / column
-          (8, 96, 56, 1, 1, 0, 0), (8, 224, 28, 1, 1, 0, 0), (3, 992, 7, 1, 1, 0, 0), (8, 160, 14, 1, 1, 0, 0)]]
+          (8, 96, 56, 1, 1, 0, 0), (8, 224, 28, 1, 1, 0, 0), (3, 992, 7, 1, 1, 0, 0), (8, 160, 14, 1, 1, 0, 0),
+          (8, 336, 28, 1, 1, 0, 0), (5, 144, 9, 1, 1, 0, 0)]]
 
 
 @pytest.mark.parametrize("d", CASES)
@@ -79,10 +80,10 @@ def test_plan_respects_budgets(d):
     assert p["direct"] == int(p["TM"] == 128 and p["nslices"] == 1)
     assert p["nsub"] == (0 if p["direct"] else p["ntiles"] * (p["TM"] // 64) ** 2)
     if p["dma"]:
-        # LDS-DMA kernel (syrk_flat.hip): flattened factor, 128-row tiles (the last one may be ragged: widths of 32 k
+        # LDS-DMA kernel (syrk_flat.hip): flattened factor, 128-row tiles (the last one may be ragged: widths of 16 k
         # channels from 96 on), no bias row; K in stages of at most 16 pixels of one sample, ceil(ceil(HW / 8) / 2) stages
         # per sample
-        assert flat and not d["has_bias"] and p["dim"] % 32 == 0 and p["dim"] >= 96 and p["TM"] == 128
+        assert flat and not d["has_bias"] and p["dim"] % 16 == 0 and p["dim"] >= 96 and p["TM"] == 128
         steps = -(-(Ho * Wo) // 8)
         assert p["nchunks"] == d["N"] * -(-steps // 2)
         P = -(-p["dim"] // 128)
@@ -121,9 +122,9 @@ def test_plan_respects_budgets(d):
 
 
 def test_densenet_widths_take_the_lds_dma_kernel():
-    for C in (96, 160, 224, 480, 992):
+    for C in (96, 144, 160, 224, 336, 480, 992):
         assert plan([geom(8, C, 14, 14, 1, 1, 0, 0)])[0]["dma"] == 1
-    for C in (64, 37, 100):          # narrower than 96 / no multiple of 32: the register-staged kernel
+    for C in (64, 37, 100):          # narrower than 96 / no multiple of 16: the register-staged kernel
         assert plan([geom(8, C, 14, 14, 1, 1, 0, 0)])[0]["dma"] == 0
 
 

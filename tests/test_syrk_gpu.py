@@ -63,6 +63,8 @@ CONV_CASES = [
     (8, 992, 7, 7, 1, 1, 0, False),     # block 4, last unit
     (8, 192, 28, 28, 3, 1, 1, False),   # DenseNet-161's 3x3
     (8, 336, 28, 28, 1, 1, 0, False),   # DenseNet-161 block 2: C = 192 + 3 * 48
+    (5, 144, 9, 13, 1, 1, 0, False),    # DenseNet-161 block 1: C = 96 + 48 (a ragged tile whose edge cuts a 32 x 32 MFMA block)
+    (3, 1104, 7, 7, 1, 1, 0, False),    # DenseNet-161 block 4
 ]
 
 
