@@ -163,6 +163,41 @@ PEAK_HBM = 8.0e12             # MI355X_MICROARCH.md: HBM3E spec (6.3e12 achievab
 PEAK_F64_MFMA = 78.6e12       # datasheet; reachable: profiles/r04_micro_mfma_f64.txt (rounds 2-3 priced against a mis-measured 48e12)
 
 
+def inf_rooflines(shapes, update_ms, invert_ms, sample_ms):
+    """Roofline of the three INF phases from closed-form counts (curvatures.py:487-507, 538-600), a reader can
+    recompute every figure from `shapes` = [(n, m, a, b)] per layer:
+      invert   V_s^T V_s in closed form on distinct column pairs, fp64: a(a+1) n m + a(a+1) m b(b+1)/2 flops; then with
+               q = a b:  chol(vtv)^-1 (2/3) q^3  +  T = A^-1 - chol(vtv + I)^-1 A^-1 by forward substitution inside the
+               second sweep (2/3) q^3  +  P_c = diag(s) A^-T T diag(s) (upper x lower) (2/3) q^3 = 2 q^3, all on the
+               fp64 MFMA (78.6 TFLOP/s).  Never the reference's 2 n m q^2.
+      update   index selection + gathers + sif_diag = (U_A^2) Lam_lr (U_G^2)^T: 2 n a b + 2 n b m flops, against
+               HBM: lambda, diags read, the correction written, 4 B each (12 B per parameter)
+      sample   five skinny products 2 b m n + 2 b n a + 2 q^2 + 2 m b a + 2 n a m flops; HBM: X, r, r^2, Y read / written
+               and the weight read-modify-written (24 B per parameter) + P_c (4 q^2 B)."""
+    vtv = sum(a * (a + 1.0) * n * m + a * (a + 1.0) * m * b * (b + 1.0) / 2.0 for n, m, a, b in shapes)
+    chain = sum(2.0 * (float(a) * b) ** 3 for n, m, a, b in shapes)
+    inv_flops = vtv + chain
+    upd_flops = sum(2.0 * n * a * b + 2.0 * n * b * m for n, m, a, b in shapes)
+    upd_bytes = sum(12.0 * n * m for n, m, a, b in shapes)
+    smp_flops = sum(2.0 * b * m * n + 2.0 * b * n * a + 2.0 * (float(a) * b) ** 2 + 2.0 * m * b * a + 2.0 * n * a * m
+                    for n, m, a, b in shapes)
+    smp_bytes = sum(24.0 * n * m + 4.0 * (float(a) * b) ** 2 for n, m, a, b in shapes)
+    return {
+        "inf_invert": {"bound": "mfma (fp64)", "gflop": inv_flops / 1e9, "gflop_vtv": vtv / 1e9, "gflop_chain": chain / 1e9,
+                       "sum_q3": sum((float(a) * b) ** 3 for n, m, a, b in shapes),
+                       "peak": PEAK_F64_MFMA / 1e12, "unit": "TFLOP/s", "achieved": inv_flops / (invert_ms * 1e-3) / 1e12,
+                       "roof_ms": inv_flops / PEAK_F64_MFMA * 1e3, "frac": inv_flops / (invert_ms * 1e-3) / PEAK_F64_MFMA},
+        "inf_update": {"bound": "hbm", "gbyte": upd_bytes / 1e9, "gflop": upd_flops / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                       "achieved": upd_bytes / (update_ms * 1e-3) / 1e9, "roof_ms": upd_bytes / PEAK_HBM * 1e3,
+                       "frac": upd_bytes / (update_ms * 1e-3) / PEAK_HBM,
+                       "note": "54 layers x (selection read-back + gathers + two small products): launch- and host-bound, not a bandwidth figure"},
+        "inf_sample": {"bound": "hbm", "gbyte": smp_bytes / 1e9, "gflop": smp_flops / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                       "achieved": smp_bytes / (sample_ms * 1e-3) / 1e9, "roof_ms": smp_bytes / PEAK_HBM * 1e3,
+                       "frac": smp_bytes / (sample_ms * 1e-3) / PEAK_HBM,
+                       "note": "five dependent stages of skinny products (K = a, b <= rank): stage latency, not bytes"},
+    }
+
+
 def _timed_gpu(fn, reps=3, warm=1):
     import statistics
     for _ in range(warm):
@@ -325,18 +360,45 @@ def other_configs_gpu(dev, model50, kfac50, batch):
     c5["inf_sample_and_replace_ms"] = _timed_gpu(inf.sample_and_replace)
     c5["efb_invert_ms"] = _timed_gpu(lambda: e5.invert(1.0, 1000.0))
     c5["efb_sample_and_replace_ms"] = _timed_gpu(e5.sample_and_replace)
+    shapes5 = [(int(ua.shape[0]), int(ug.shape[0]), int(ua.shape[1]), int(ug.shape[1])) for ua, ug, _, _ in inf.state.values()]
+    c5["inf_shapes_n_m_a_b"] = shapes5
+    c5["roofline_phases"] = inf_rooflines(shapes5, c5["inf_update_rank100_ms"], c5["inf_invert_1_1000_ms"],
+                                          c5["inf_sample_and_replace_ms"])
+    del inf, e5
+    torch.cuda.empty_cache()
+    # the eigensolver on FULL-RANK factors: everything above decomposes factors of ONE batch (K = N L = 1568 < 4608 for
+    # the three widest: numerical rank 1568, taken through their range), the favourable case.  Factors accumulated over
+    # a dataset (scripts/factors.py:46-61) are full rank: four DIFFERENT batches here (K = 6272 > 4608)
+    kfac50.restart_accumulation()
+    for b in range(4):
+        model50.load_state_dict(kfac50.model_state)
+        torch.manual_seed(1000 + b)
+        _backward_once(model50, torch.randn(batch, 3, 224, 224, device=dev))
+        kfac50.update(batch_size=batch)
+    for key in ("eigenvectors_full_rank_first_call_ms", "eigenvectors_full_rank_ms"):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e5f = EFB(model50, kfac50.state)
+        torch.cuda.synchronize()
+        c5[key] = (time.perf_counter() - t0) * 1e3
+    full = _efb_eig_fracs(kfac50.state, 1.0, c5["eigenvectors_full_rank_ms"], int(getattr(ops.eigh, "last_sweeps", 0)), "",
+                          dict(getattr(ops.eigh, "last_ranks", {})))
+    c5["eigensolver_full_rank"] = {"batches_accumulated": 4, "sweeps": int(getattr(ops.eigh, "last_sweeps", 0)),
+                                   **{k: v for k, v in full.items() if k.startswith("eigensolver")}}
+    del e5f
     out["config5_resnet50_efb_inf_chain"] = c5
     # the same INF.invert on ONE synthetic layer of the stem's size, the only size at which the reference's explicit
     # (n m) x (a b) Kronecker chain can be timed on the host (cpu_oracle.inf_invert_anchor_ms)
-    import oracle.curvature_oracle as o
+    # built through the estimator itself (INF.update on this GPU selects the low-rank part): nothing of oracle/ runs in this leg
     U_A, U_G, lam, diag = _inf_anchor_layer()
-    ua, ug, lam_lr, corr, _, _ = o.inf_update(U_A, U_G, lam, diag, 100)
-    sigma = (1000.0 * lam_lr).sqrt().to(dev)
-    r = torch.reciprocal(1000.0 * corr.clamp(min=0) + 1.0).sqrt().to(dev)
-    from curvature_amd.curvatures import INF
-    ua_d, ug_d = ua.to(dev).contiguous(), ug.to(dev).contiguous()
-    out["inf_invert_anchor"] = {"layer": "synthetic n=147, m=64 (ResNet-50 stem size), rank 100: a x b = %d x %d" % (ua.shape[1], ug.shape[1]),
-                                "gpu_ms": _timed_gpu(lambda: INF.pre_sampler(ua_d, ug_d, sigma, r), reps=5)}
+    stem = torch.nn.Sequential(torch.nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)).to(dev)
+    conv = stem[0]
+    anchor = INF(stem, {conv: diag.to(dev)}, {conv: [U_A.to(dev), U_G.to(dev)]}, {conv: lam.to(dev)},
+                 eigvecs={conv: (U_A.to(dev), U_G.to(dev))})
+    anchor.update(rank=100)
+    ua_d, ug_d = anchor.state[conv][0], anchor.state[conv][1]
+    out["inf_invert_anchor"] = {"layer": "synthetic n=147, m=64 (ResNet-50 stem size), rank 100: a x b = %d x %d" % (ua_d.shape[1], ug_d.shape[1]),
+                                "gpu_ms": _timed_gpu(lambda: anchor.invert(1.0, 1000.0), reps=5)}
     return out
 
 

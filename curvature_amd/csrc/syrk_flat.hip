@@ -30,12 +30,6 @@ namespace curv {
 #ifndef CURV_FLAT_KC
 #define CURV_FLAT_KC 16
 #endif
-// Diagnostic builds only (tools/make_flat_ablate.py; results are WRONG by construction): what the kernel's time owes to
-//   1: half of its LDS operand reads (a1 <- a0, b1 <- b0)     2: all operand reads behind a stage's first step
-//   4: half of its LDS-DMA pieces (the odd ones)               8: half of its MFMAs (the lower quadrant row)
-#ifndef CURV_FLAT_ABLATE
-#define CURV_FLAT_ABLATE 0
-#endif
 
 namespace flat {
 constexpr int TM = 128;
@@ -90,8 +84,8 @@ __device__ __forceinline__ void flat_mfma_step(const f32x4& a0, const f32x4& a1,
     if (e < ne) {
       if (PART != 3) c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], c00, 0, 0, 0);
       if (PART != 2) c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], c01, 0, 0, 0);
-      if ((PART == 0 || PART == 2) && !(CURV_FLAT_ABLATE & 8)) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], c10, 0, 0, 0);
-      if (PART != 2 && !(CURV_FLAT_ABLATE & 8)) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], c11, 0, 0, 0);
+      if ((PART == 0 || PART == 2)) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], c10, 0, 0, 0);
+      if (PART != 2) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], c11, 0, 0, 0);
     }
     hook(e);                      // one LDS-DMA piece behind a group of MFMAs: its issue cost hides under them
   }
@@ -171,7 +165,6 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
   };
   auto piece = [&](int i) {
     const int p = i / PIECES, slot = i % PIECES;
-    if ((CURV_FLAT_ABLATE & 4) && (i & 1)) return;
     if (p < n_panels && g_lane < n_gmax) {
       const unsigned lbase = (p ? 2u * PANEL_B : 0u) + n_buf + (unsigned)(RPP * wave + 4 * RPP * slot) * ROW_B;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lbase), 16, voff,
@@ -194,16 +187,15 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
     // software pipeline over the stage's steps: operands of step j + 1 are read while the MFMAs of step j issue;
     // the DMA pieces of stage t + 1 go out during the first half of the stage, each behind a group of MFMAs, so
     // that the last one still has half of the stage's MFMA time to land before the wait at the top
-    f32x4 a0 = rd(0, 0), a1 = (CURV_FLAT_ABLATE & 1) ? a0 : rd(1, 0), b0 = rd(2, 0), b1 = (CURV_FLAT_ABLATE & 1) ? b0 : rd(3, 0);
+    f32x4 a0 = rd(0, 0), a1 = rd(1, 0), b0 = rd(2, 0), b1 = rd(3, 0);
     int next_piece = 0;
 #pragma unroll
     for (int j = 0; j < STEPS; ++j) {
       if (j < nsteps) {
         f32x4 na0, na1, nb0, nb1;
-        if (CURV_FLAT_ABLATE & 2) { na0 = a0; na1 = a1; nb0 = b0; nb1 = b1; }
-        else if (j + 1 < STEPS && j + 1 < nsteps) {
+        if (j + 1 < STEPS && j + 1 < nsteps) {
           na0 = rd(0, j + 1); nb0 = rd(2, j + 1);
-          na1 = (CURV_FLAT_ABLATE & 1) ? na0 : rd(1, j + 1); nb1 = (CURV_FLAT_ABLATE & 1) ? nb0 : rd(3, j + 1);
+          na1 = rd(1, j + 1); nb1 = rd(3, j + 1);
         }
         int ne = 4;
         if (last && j == nsteps - 1 && nv_last < 8) {
@@ -282,259 +274,9 @@ syrk_flat_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_items
   else flat_body<3>(d, local, slabs, l3);
 }
 
-#ifdef CURV_FLAT2
-// ------------------------------------------------------------------------------------------------
-// A/B variant, compiled only with -DCURV_FLAT2 (tools/make_variant.py syrk_flat.hip flat2 -DCURV_FLAT2; selected at run time
-// with CURV_FLAT_WAVES=2): the same tile on TWO waves, each with a 128 x 64 share (six operand reads per 32
-// MFMAs instead of four per 16; the stage barrier joins two waves instead of four).  Off-diagonal tile: wave w owns the
-// column half w (both row halves).  Diagonal tile of a symmetric factor: wave w owns the upper blocks of quadrant
-// (w, w) and the column w of quadrant (0, 1)'s 32-blocks - five blocks each.  Items, slabs, stages, DMA images and
-// accumulation order are those of flat_body.  Measured (profiles/r05_flat_ablation.txt): all 93 factor-build parity tests
-// green, update() 6.17-6.25 -> 6.29-6.32 ms - slower, as the ablation of the operand reads had predicted no gain.
-// ------------------------------------------------------------------------------------------------
-namespace flat2 {
-constexpr int THREADS = 128;
-constexpr int PIECES = flat::TM / flat::RPP / 2;     // pieces per panel per wave
-constexpr int NP = 2 * PIECES;                       // per stage per wave
-}
-
-template <bool DIAG>
-__device__ __forceinline__ void flat2_body(const FactorDev& d, int local, float* __restrict__ slabs, lds_char* lds) {
-  using namespace flat;
-  constexpr int NPW = flat2::NP, PCS = flat2::PIECES;
-  constexpr int NA = 4, NB_ = DIAG ? 1 : 2, NACC = DIAG ? 5 : 8;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r32 = lane & 31, h = lane >> 5;
-  const int slice = local / d.n_tiles, tile = local - slice * d.n_tiles;
-  int ti, tj;
-  decode_tile_of(d, tile, ti, tj);
-  const int i0 = ti * TM, j0 = tj * TM;
-  const int HW = d.W, C = d.C, pitch = d.pitch;
-  const int TS = (HW + 7) >> 3;
-  const int SPS = (TS + STEPS - 1) / STEPS;
-  const int base_steps = TS / SPS, rem_steps = TS - base_steps * SPS;
-  const int nv_last = HW - 8 * (TS - 1);
-
-  const int rsub = RPP * wave + (lane >> LANES_PER_ROW_SHIFT);
-  const int g_lane = (lane & (SLOTS - 1)) ^ ((rsub >> KEY_SHIFT) & (SLOTS - 1));
-  const int voff = (rsub * pitch + 4 * g_lane) * 4;
-  const unsigned total_b = (unsigned)((long long)d.N * C * pitch * 4);
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.src, 0, total_b, 0x00020000);
-
-  // operand row blocks (32 rows each) - off-diagonal: A = blocks 0..3 of panel i, B = blocks 2 w, 2 w + 1 of panel j;
-  // diagonal (one panel): A = {X0, X1, R0, R1} = own diagonal blocks 2 w, 2 w + 1 and blocks 0, 1; B = {Z} = block 2 + w
-  unsigned addr_a[NA][STEPS], addr_b[NB_][STEPS];
-  auto block_addr = [&](int blk, bool panel_j, int j) -> unsigned {
-    const int R = 32 * blk + r32;
-    const unsigned pbase = panel_j ? 2u * PANEL_B : 0u;
-    const int rkey = (R >> KEY_SHIFT) & (SLOTS - 1);
-    return pbase + R * ROW_B + (((2 * j + h) ^ rkey) << 4);
-  };
-#pragma unroll
-  for (int j = 0; j < STEPS; ++j) {
-    if (DIAG) {
-      addr_a[0][j] = block_addr(2 * wave, false, j);
-      addr_a[1][j] = block_addr(2 * wave + 1, false, j);
-      addr_a[2][j] = block_addr(0, false, j);
-      addr_a[3][j] = block_addr(1, false, j);
-      addr_b[0][j] = block_addr(2 + wave, false, j);
-    } else {
-#pragma unroll
-      for (int o = 0; o < 4; ++o) addr_a[o][j] = block_addr(o, false, j);
-      addr_b[0][j] = block_addr(2 * wave, true, j);
-      addr_b[NB_ - 1][j] = block_addr(2 * wave + 1, true, j);
-    }
-  }
-  f32x16 c[NACC];
-#pragma unroll
-  for (int k = 0; k < NACC; ++k) c[k] = 0.0f;
-  const int nseg = d.direct;
-  const int t0 = nseg ? 0 : slice * d.cpi, t1 = nseg ? d.n_chunks : min(t0 + d.cpi, d.n_chunks);
-  int seg = 0, seg_end = nseg ? min(d.cpi, t1) : t1 + 1;
-  const int n_panels = DIAG ? 1 : 2;
-
-  auto stage_geo = [&](int t, int& s_, int& px0, int& nsteps, bool& last) {
-    s_ = t / SPS;
-    const int q = t - s_ * SPS;
-    nsteps = base_steps + (q < rem_steps ? 1 : 0);
-    px0 = 8 * (q * base_steps + min(q, rem_steps));
-    last = (q == SPS - 1);
-  };
-  int n_soff[2] = {0, 0};
-  const int hadj[2] = {d.half ? (d.off_i2 - d.off_i - 64 * pitch) * 4 : 0, d.half ? (d.off_j2 - d.off_j - 64 * pitch) * 4 : 0};
-  int n_gmax = 0;
-  unsigned n_buf = 0;
-  auto plan_next = [&](int t) {
-    int s_, px0, nsteps; bool last;
-    stage_geo(t, s_, px0, nsteps, last);
-    n_gmax = last ? (HW - px0 + 3) / 4 : 2 * nsteps;
-    n_buf = (unsigned)(t & 1) * PANEL_B;
-    n_soff[0] = ((s_ * C + i0) * pitch + d.off_i + px0) * 4;
-    n_soff[1] = ((s_ * C + j0) * pitch + d.off_j + px0) * 4;
-  };
-  // piece i of this wave: panel i / PCS, rows RPP (wave + 2 slot) .. + RPP
-  auto piece = [&](int i) {
-    const int p = i / PCS, slot = i % PCS;
-    if (p < n_panels && g_lane < n_gmax) {
-      const unsigned lbase = (p ? 2u * PANEL_B : 0u) + n_buf + (unsigned)(RPP * wave + 2 * RPP * slot) * ROW_B;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lbase), 16, voff,
-                                               n_soff[p] + slot * 2 * RPP * pitch * 4 + (slot * 2 * RPP >= 64 ? hadj[p] : 0), 0, 0);
-    }
-  };
-  auto flush = [&](bool first_seg, bool last_seg) {
-    if (DIAG) {
-      // quadrant (w, w): upper blocks; quadrant (0, 1): its 32-column w
-      direct_store_quadrant(d, 1, i0 + 64 * wave, j0 + 64 * wave, r32, h, c[0], c[1], c[1], c[2], first_seg, last_seg);
-      if (wave == 0) direct_store_quadrant(d, 2, i0, j0 + 64, r32, h, c[3], c[3], c[4], c[4], first_seg, last_seg);
-      else direct_store_quadrant(d, 3, i0, j0 + 64, r32, h, c[3], c[3], c[4], c[4], first_seg, last_seg);
-    } else {
-      direct_store_quadrant(d, 0, i0, j0 + 64 * wave, r32, h, c[0], c[1], c[2], c[3], first_seg, last_seg);
-      direct_store_quadrant(d, 0, i0 + 64, j0 + 64 * wave, r32, h, c[4], c[5], c[6], c[NACC - 1], first_seg, last_seg);
-    }
-  };
-
-  plan_next(t0);
-#pragma unroll
-  for (int i = 0; i < NPW; ++i) piece(i);
-  for (int t = t0; t < t1; ++t) {
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();
-    const bool more = t + 1 < t1;
-    if (more) plan_next(t + 1);
-    int s_, px0, nsteps; bool last;
-    stage_geo(t, s_, px0, nsteps, last);
-    const unsigned buf = (unsigned)(t & 1) * PANEL_B;
-    auto rd = [&](unsigned a) { return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lds + a + buf); };
-    f32x4 a[NA], b[NB_];
-#pragma unroll
-    for (int o = 0; o < NA; ++o) a[o] = rd(addr_a[o][0]);
-#pragma unroll
-    for (int o = 0; o < NB_; ++o) b[o] = rd(addr_b[o][0]);
-    int next_piece = 0;
-#pragma unroll
-    for (int j = 0; j < STEPS; ++j) {
-      if (j < nsteps) {
-        f32x4 na[NA], nb[NB_];
-        if (j + 1 < STEPS && j + 1 < nsteps) {
-#pragma unroll
-          for (int o = 0; o < NA; ++o) na[o] = rd(addr_a[o][j + 1]);
-#pragma unroll
-          for (int o = 0; o < NB_; ++o) nb[o] = rd(addr_b[o][j + 1]);
-        }
-        int ne = 4;
-        if (last && j == nsteps - 1 && nv_last < 8) {
-          ne = min(4, nv_last);
-          asm volatile("; sample tail" ::: "memory");
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const bool ok = (4 * h + e) < nv_last;
-#pragma unroll
-            for (int o = 0; o < NA; ++o) a[o][e] = ok ? a[o][e] : 0.0f;
-#pragma unroll
-            for (int o = 0; o < NB_; ++o) b[o][e] = ok ? b[o][e] : 0.0f;
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (e < ne) {
-            if (DIAG) {
-              c[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][e], a[0][e], c[0], 0, 0, 0);
-              c[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][e], a[1][e], c[1], 0, 0, 0);
-              c[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][e], a[1][e], c[2], 0, 0, 0);
-              c[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][e], b[0][e], c[3], 0, 0, 0);
-            } else {
-              c[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][e], b[0][e], c[0], 0, 0, 0);
-              c[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][e], b[NB_ - 1][e], c[1], 0, 0, 0);
-              c[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][e], b[0][e], c[2], 0, 0, 0);
-              c[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][e], b[NB_ - 1][e], c[3], 0, 0, 0);
-            }
-          }
-          if (more && 2 * (4 * j + e) < NPW) piece(2 * (4 * j + e));
-          if (e < ne) {
-            if (DIAG) {
-              c[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3][e], b[0][e], c[4], 0, 0, 0);
-            } else {
-              c[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][e], b[0][e], c[4], 0, 0, 0);
-              c[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][e], b[NB_ - 1][e], c[5], 0, 0, 0);
-              c[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3][e], b[0][e], c[6], 0, 0, 0);
-              c[NACC - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3][e], b[NB_ - 1][e], c[NACC - 1], 0, 0, 0);
-            }
-          }
-          if (more && 2 * (4 * j + e) + 1 < NPW) piece(2 * (4 * j + e) + 1);
-        }
-        next_piece = min(NPW, 8 * (j + 1));
-        if (j + 1 < STEPS && j + 1 < nsteps) {
-#pragma unroll
-          for (int o = 0; o < NA; ++o) a[o] = na[o];
-#pragma unroll
-          for (int o = 0; o < NB_; ++o) b[o] = nb[o];
-        }
-      }
-    }
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < NPW; ++i) if (i >= next_piece) piece(i);
-    }
-    if (t + 1 == seg_end) {
-      flush(seg == 0, t + 1 == t1);
-#pragma unroll
-      for (int k = 0; k < NACC; ++k) c[k] = 0.0f;
-      ++seg;
-      seg_end = min(seg_end + d.cpi, t1);
-    }
-  }
-  if (nseg) return;
-  gfloat_t* slab = (gfloat_t*)slabs + d.slab_base + (long long)local * (TM * TM);
-  auto put = [&](int qi, int qj, int bi, int bj, const f32x16& acc) {      // 32 x 32 block (bi, bj) of quadrant (qi, qj)
-    gfloat_t* q = slab + (64 * qi + 32 * bi) * 128 + 64 * qj + 32 * bj;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) q[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 128 + r32] = acc[reg];
-  };
-  if (DIAG) {
-    put(wave, wave, 0, 0, c[0]); put(wave, wave, 0, 1, c[1]); put(wave, wave, 1, 0, c[1]); put(wave, wave, 1, 1, c[2]);
-    put(0, 1, 0, wave, c[3]); put(0, 1, 1, wave, c[4]);
-  } else {
-    put(0, wave, 0, 0, c[0]); put(0, wave, 0, 1, c[1]); put(0, wave, 1, 0, c[2]); put(0, wave, 1, 1, c[3]);
-    put(1, wave, 0, 0, c[4]); put(1, wave, 0, 1, c[5]); put(1, wave, 1, 0, c[6]); put(1, wave, 1, 1, c[NACC - 1]);
-  }
-}
-
-__global__ void __launch_bounds__(flat2::THREADS, 2)
-syrk_flat2_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_items, float* __restrict__ slabs) {
-  __shared__ __attribute__((aligned(1024))) char smem[flat::LDS_B];
-  const int item = xcd_item(blockIdx.x);
-  if (item >= n_items) return;
-  int f = find_segment(descs, n_factors, item, false);
-  int local = item - descs[f].item_base;
-  if (descs[f].group_n > 0) {
-    const int head = f - descs[f].group_pos;
-    const int gi = item - descs[head].item_base, nt = descs[head].n_tiles, gt = descs[head].group_n * nt;
-    const int slice = gi / gt, rem = gi - slice * gt, member = rem / nt;
-    f = head + member;
-    local = slice * nt + (rem - member * nt);
-  }
-  const FactorDev& d = descs[f];
-  const int tile = local % d.n_tiles;
-  int ti, tj;
-  decode_tile_of(d, tile, ti, tj);
-  lds_char* l3 = (lds_char*)smem;
-  if (ti == tj && !d.nonsym) flat2_body<true>(d, local, slabs, l3);
-  else flat2_body<false>(d, local, slabs, l3);
-}
-#endif   // CURV_FLAT2
-
 int launch_syrk_flat(hipStream_t stream, const FactorDev* table, int n_factors, int n_items, float* slabs) {
   if (n_items <= 0) return CURV_OK;
   const int grid = cdiv(n_items, 8 * XCD_GROUP) * 8 * XCD_GROUP;
-#ifdef CURV_FLAT2
-  static const int waves = getenv("CURV_FLAT_WAVES") ? atoi(getenv("CURV_FLAT_WAVES")) : 4;
-  if (waves == 2) {
-    hipLaunchKernelGGL(syrk_flat2_kernel, dim3(grid), dim3(flat2::THREADS), 0, stream, table, n_factors, n_items, slabs);
-    CURV_LAUNCH_CHECK();
-    return CURV_OK;
-  }
-#endif
   hipLaunchKernelGGL(syrk_flat_kernel, dim3(grid), dim3(SYRK_THREADS), 0, stream, table, n_factors, n_items, slabs);
   CURV_LAUNCH_CHECK();
   return CURV_OK;

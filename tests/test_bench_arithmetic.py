@@ -66,3 +66,18 @@ def test_traffic_file_is_tied_to_the_factor_build_sources(bench):
     # the committed counter file belongs to the committed factor-build sources: otherwise `roofline.traffic` is withheld
     assert rec.get("source_sha16") == bench.syrk_source_sha16(), "re-run tools/collect_profiles.sh: the factor-build sources changed"
     assert 3.9e9 < rec["hbm_bytes_per_launch"] < 3.0e10
+
+
+def test_roofline_of_the_inf_phases(bench):
+    """vtv in closed form + 2 q^3 for the fp64 chain (q = a b), never the reference's 2 n m q^2."""
+    shapes = [(147, 64, 30, 20), (4608, 512, 50, 40)]
+    out = bench.inf_rooflines(shapes, update_ms=10.0, invert_ms=50.0, sample_ms=2.0)
+    vtv = sum(a * (a + 1.0) * n * m + a * (a + 1.0) * m * b * (b + 1.0) / 2 for n, m, a, b in shapes)
+    chain = sum(2.0 * (a * b) ** 3 for n, m, a, b in shapes)
+    inv = out["inf_invert"]
+    assert inv["gflop_vtv"] == pytest.approx(vtv / 1e9) and inv["gflop_chain"] == pytest.approx(chain / 1e9)
+    assert inv["frac"] == pytest.approx((vtv + chain) / 50e-3 / 78.6e12)
+    assert inv["gflop"] * 1e9 < sum(2.0 * n * m * (a * b) ** 2 for n, m, a, b in shapes)      # far below the explicit form
+    assert out["inf_update"]["gbyte"] == pytest.approx(sum(12.0 * n * m for n, m, a, b in shapes) / 1e9)
+    assert out["inf_update"]["frac"] == pytest.approx(out["inf_update"]["gbyte"] * 1e9 / 10e-3 / 8.0e12)
+    assert out["inf_sample"]["frac"] == pytest.approx(out["inf_sample"]["gbyte"] * 1e9 / 2e-3 / 8.0e12)

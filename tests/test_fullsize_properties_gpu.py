@@ -143,6 +143,56 @@ def test_invert_and_sample_properties(gpu, resnet50_kfac):
     assert changed == 54 + 1                      # 54 weights and the one bias (fc); BatchNorm tensors restored
 
 
+def _fp64_oracle_L(F, add, mul):
+    """oracle.chol_of_inverse on the matrix the reference hands to LAPACK: the damping formed in fp32 exactly as
+    curvatures.py:368-375 forms it, everything behind it in fp64 on the host cores."""
+    import oracle.curvature_oracle as o
+    Fc = F.detach().cpu()
+    reg = torch.tensor(mul ** 0.5, dtype=torch.float32) * Fc + torch.diag(Fc.new_full((Fc.shape[0],), add ** 0.5))
+    M = ((reg + reg.t()) / 2.0).double()
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, threads))
+    try:
+        return o.chol_of_inverse(M)
+    finally:
+        torch.set_num_threads(threads)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("add,mul", [(1.0, 1000.0), (69.0, 25771.0)])
+def test_forward_error_of_L_on_the_wide_resnet50_factors(gpu, resnet50_kfac, add, mul):
+    """Entry-wise parity of ``L = chol_lower((sqrt(s) F + sqrt(n) I)^-1)`` (curvatures.py:378-379) for the factors that
+    carry the headline workload: the three 4608-wide A factors, one 2304-wide and the classifier's 2049-wide one, at
+    the bench's (1, 1000) and at the README's ResNet-50 pair (69, 25771; README.rst:262), against the fp64 oracle
+    on the CPU, through BOTH launch forms of the sweep: the whole model in one call (per-step launches, outer panels
+    of 6 block columns) and a call with at most 64 factors (block squares swept by one launch).  The triangular
+    inverse outside the block squares is accumulated in fp32 over up to 72 block steps (supd32_kernel); the bar is
+    1e-6 relative Frobenius, two orders below the north star's 1e-4."""
+    from curvature_amd import ops
+    model, kfac = resnet50_kfac
+    layers = kfac._layers()
+    wide = [l for l in layers if kfac.state[l][0].shape[0] == 4608]
+    mid = next(l for l in layers if kfac.state[l][0].shape[0] == 2304)
+    fc = layers[53]
+    assert len(wide) == 3 and kfac.state[fc][0].shape[0] == 2049
+    picks = wide + [mid, fc]
+    kfac.invert(add=add, multiply=mul)                                        # whole model: 108 factors in one sweep
+    factors = [kfac.state[l][0] for l in picks]
+    chain = ops.chol_inv_lower(factors, [add] * len(factors), [mul] * len(factors))   # <= 64 factors: chain form
+    torch.cuda.synchronize()
+    worst = 0.0
+    for layer, F, L_chain in zip(picks, factors, chain):
+        exact = _fp64_oracle_L(F, add, mul)
+        L_model = kfac.inv_state[layer][0]
+        for form, L in (("model", L_model), ("chain", L_chain)):
+            assert torch.equal(L, torch.tril(L))
+            err = rel_fro(L, exact)
+            worst = max(worst, err)
+            print(f"n = {F.shape[0]} ({add}, {mul}) {form} sweep: forward error of L {err:.2e}")
+            assert err < 1e-6, (F.shape[0], form, err)
+    kfac.invert(add=1.0, multiply=1000.0)                                     # what the tests below expect
+
+
 @pytest.mark.gpu
 def test_a_rank_share_inverts_like_the_whole_model(gpu, resnet50_kfac):
     """Layer sharding at full size: the factors of one rank's layers (here the largest layer alone, and a nine-layer

@@ -63,9 +63,11 @@ def test_kfac_update_invert_sample(gpu):
     kfac.invert(add=g3["c_add"].tolist(), multiply=g3["c_mul"].tolist())
     for li, layer in enumerate(layers):
         LA, LG = kfac.inv_state[layer]
-        # judged against the reference's fp64 twin where its own fp32 noise exceeds the tolerance
-        assert rel_fro(LA, g3[f"c_LA_l{li}"]) < 5e-4
-        assert rel_fro(LG, g3[f"c_LG_l{li}"]) < 5e-4
+        # judged against the reference's fp64 twin ("c64_*": its own code on float64 factors): the reference's fp32
+        # LAPACK chain is up to 4e-5 away from it on these factors, the north star's bar is 1e-4
+        assert rel_fro(LA, g3[f"c64_LA_l{li}"]) < TOL, (li, rel_fro(LA, g3[f"c64_LA_l{li}"]))
+        assert rel_fro(LG, g3[f"c64_LG_l{li}"]) < TOL, (li, rel_fro(LG, g3[f"c64_LG_l{li}"]))
+        assert rel_fro(LA, g3[f"c_LA_l{li}"]) < 5e-4 and rel_fro(LG, g3[f"c_LG_l{li}"]) < 5e-4
 
     # sample with the reference's noise: use the reference's inverse factors to isolate the sampler
     kfac.invert(add=0.5, multiply=1)

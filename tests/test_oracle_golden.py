@@ -75,7 +75,7 @@ def test_kfac_invert(tag):
         # path (up to ~1e-4 here between machines): the fp64 twin below is what pins the algorithm
         assert rel_fro(LA, g3[f"{tag}_LA_l{li}"]) < 1e-3
         assert rel_fro(LG, g3[f"{tag}_LG_l{li}"]) < 1e-3
-        if tag in ("a", "b"):
+        if True:                                     # every set has an fp64 twin since round 6 ("c64_*")
             LA64, LG64 = o.kfac_invert(A.double(), G.double(), n, s)
             assert rel_fro(LA64, g3[f"{tag}64_LA_l{li}"]) < 1e-6
             assert rel_fro(LG64, g3[f"{tag}64_LG_l{li}"]) < 1e-6

@@ -132,10 +132,10 @@ def gen_lenet():
         for li, layer in enumerate(layers_of(kfac)):
             inv[f"{tag}_LA_l{li}"] = npf(kfac.inv_state[layer][0])
             inv[f"{tag}_LG_l{li}"] = npf(kfac.inv_state[layer][1])
-    # fp64 twin of set "a" and "b": the reference's own code run on float64 factors
+    # fp64 twin of sets "a", "b" and "c": the reference's own code run on float64 factors
     state32 = kfac.state
     kfac.state = {l: [A.double(), G.double()] for l, (A, G) in state32.items()}
-    for tag, (add, mul) in {"a": (0.5, 1), "b": (1.0, 1000.0)}.items():
+    for tag, (add, mul) in {"a": (0.5, 1), "b": (1.0, 1000.0), "c": (per_layer_add, per_layer_mul)}.items():
         kfac.inv_state = {}
         kfac.invert(add=add, multiply=mul)
         for li, layer in enumerate(layers_of(kfac)):
