@@ -30,44 +30,82 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _compiler_id(hipcc: str) -> str:
+    try:
+        return subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    except OSError as exc:
+        raise RuntimeError(f"cannot run {hipcc}: {exc}")
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into ``csrc/libcurv_hip.so``; returns the library path.  Each source is
-    compiled to an object of its own under ``csrc/build/`` (in parallel, only when it or a header is newer than its
-    object unless ``force``), then linked."""
+    compiled to an object of its own under ``csrc/build/`` (in parallel), then linked.  An object is reused only while
+    the stamp beside it - a hash over compiler version, flags, the source and every header - still matches (an mtime
+    comparison would link stale objects after a change of flags, ``$HIPCC`` or ROCm).  Objects and the library are
+    written to temporary names and moved into place, under a file lock on ``csrc/build``: several ranks of a torchrun
+    job may call this at once on a fresh checkout."""
     if not force and not _stale():
         return LIB_PATH
+    import fcntl
+    import hashlib
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "hipcc")
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "curv_hip.h")]
-    t_headers = max(os.path.getmtime(h) for h in headers)
+    headers = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "curv_hip.h")])
     compile_flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-ldl")] + ["-c"]
+    base = hashlib.sha256()
+    base.update(_compiler_id(hipcc).encode())
+    base.update(" ".join(compile_flags).encode())
+    for h in headers:
+        base.update(open(h, "rb").read())
 
     def compile_one(src):
         path = os.path.join(CSRC, src)
         obj = os.path.join(objdir, src + ".o")
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), t_headers):
+        key = base.copy()
+        key.update(open(path, "rb").read())
+        stamp, want = obj + ".stamp", key.hexdigest()
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
             return obj, 0, ""
-        cmd = [hipcc] + compile_flags + ["-o", obj, path]
+        tmp = f"{obj}.{os.getpid()}.tmp"
+        cmd = [hipcc] + compile_flags + ["-o", tmp, path]
         if verbose:
-            print(" ".join(cmd), flush=True)
+            print(" ".join(cmd[:-3] + ["-o", obj, path]), flush=True)
         proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if proc.returncode == 0:
+            os.replace(tmp, obj)
+            with open(stamp + ".tmp", "w") as fh:
+                fh.write(want)
+            os.replace(stamp + ".tmp", stamp)
+        elif os.path.exists(tmp):
+            os.remove(tmp)
         return obj, proc.returncode, proc.stdout
 
-    with ThreadPoolExecutor(max_workers=int(os.environ.get("CURV_BUILD_JOBS", "6"))) as pool:
-        results = list(pool.map(compile_one, SOURCES))
-    for obj, rc, out in results:
-        if rc != 0:
-            raise RuntimeError("hipcc failed:\n" + out)
-        if verbose and out:
-            print(out)
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + [r[0] for r in results] + ["-ldl"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if proc.returncode != 0:
-        raise RuntimeError("hipcc (link) failed:\n" + proc.stdout)
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():                 # another process built it while this one waited
+                return LIB_PATH
+            with ThreadPoolExecutor(max_workers=int(os.environ.get("CURV_BUILD_JOBS", "6"))) as pool:
+                results = list(pool.map(compile_one, SOURCES))
+            for obj, rc, out in results:
+                if rc != 0:
+                    raise RuntimeError("hipcc failed:\n" + out)
+                if verbose and out:
+                    print(out)
+            tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+            cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + [r[0] for r in results] + ["-ldl"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if proc.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("hipcc (link) failed:\n" + proc.stdout)
+            os.replace(tmp, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
@@ -148,6 +186,7 @@ SIGNATURES = {
     "curv_comm_destroy": (_i, [_vp]),
     "curv_kfac_workspace_bytes": (_sz, [ctypes.POINTER(curv_factor_desc), _i]),
     "curv_kfac_plan_info": (_i, [ctypes.POINTER(curv_factor_desc), _i, ctypes.POINTER(ctypes.c_longlong)]),
+    "curv_kfac_path_for": (_i, [ctypes.POINTER(curv_factor_desc), _i]),
     "curv_kfac_accumulate": (_i, [_vp, ctypes.POINTER(curv_factor_desc), _i, _vp, _sz]),
     "curv_kfac_accumulate_timed": (_i, [_vp, ctypes.POINTER(curv_factor_desc), _i, _vp, _sz, _vp, _vp]),
     "curv_kfac_accumulate_ex": (_i, [_vp, ctypes.POINTER(curv_factor_desc), _i, _vp, _sz, ctypes.c_uint, _vp, _vp]),
@@ -191,7 +230,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 8                     # CURV_ABI_VERSION of include/curv_hip.h
+ABI_VERSION = 9                     # CURV_ABI_VERSION of include/curv_hip.h
 KFAC_TABLE_RESIDENT = 1             # CURV_KFAC_TABLE_RESIDENT
 PATH_AUTO, PATH_SMALL, PATH_GROUPED = 0, 1, 2     # CURV_PATH_* (curv_factor_desc.path_hint)
 SMALL_MAX_FLOP = 2.0e9              # CURV_SMALL_MAX_FLOP

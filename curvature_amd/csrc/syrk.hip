@@ -1353,6 +1353,11 @@ extern "C" size_t curv_kfac_workspace_bytes(const curv_factor_desc* descs, int n
   return std::max(grouped, kfac_small_workspace_bytes(descs, n_factors));      // (either path may take the call)
 }
 
+extern "C" int curv_kfac_path_for(const curv_factor_desc* descs, int n_factors) {
+  if (descs == nullptr || n_factors <= 0) return CURV_PATH_GROUPED;
+  return kfac_path_for(descs, n_factors);
+}
+
 extern "C" int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors, long long* out) {
   Plan plan;
   int rc = plan_without_pointers(descs, n_factors, plan);

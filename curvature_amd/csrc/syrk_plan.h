@@ -206,6 +206,7 @@ __device__ __forceinline__ void direct_store_quadrant(const FactorDev& d, int pa
 // not a small one; kfac_accumulate_small: CURV_ERR_WORKSPACE (no error text) if it is not, or if the workspace does not
 // hold its slabs - the caller then takes the grouped path.
 size_t kfac_small_workspace_bytes(const curv_factor_desc* descs, int n);
+int kfac_path_for(const curv_factor_desc* descs, int n);
 int kfac_accumulate_small(hipStream_t stream, const curv_factor_desc* descs, int n, void* workspace, size_t workspace_bytes,
                           void* ev_start, void* ev_stop);
 

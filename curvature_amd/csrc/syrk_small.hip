@@ -287,6 +287,15 @@ static bool small_plan(const curv_factor_desc* descs, int n, SmallPlan& plan) {
   return true;
 }
 
+// which form a launch of exactly these factors takes on its own (path hints ignored): every gate of small_plan - flops,
+// job count, slice length, workgroup count - evaluated on the UNSHARDED model, for the ranks of a layer-sharded run
+int kfac_path_for(const curv_factor_desc* descs, int n) {
+  std::vector<curv_factor_desc> plain(descs, descs + n);
+  for (curv_factor_desc& d : plain) d.path_hint = CURV_PATH_AUTO;
+  SmallPlan plan;
+  return small_plan(plain.data(), n, plan) ? CURV_PATH_SMALL : CURV_PATH_GROUPED;
+}
+
 // bytes of workspace the small path needs for these factors; 0: the launch is not a small one
 size_t kfac_small_workspace_bytes(const curv_factor_desc* descs, int n) {
   SmallPlan plan;

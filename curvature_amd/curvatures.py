@@ -782,24 +782,26 @@ class KFAC(Curvature):
         if self.shard is not None and self.shard.world > 1:
             # the launch form is a property of the MODEL, not of this rank's share: a share under the small-launch threshold
             # would otherwise sum its factors in another order than the unsharded run (which is over it)
-            total = 0.0
+            # (decided by the library itself - curv_kfac_path_for evaluates every gate of the small form, not only the
+            # flops - on the geometry of ALL selected layers: the hooks record every layer on every rank)
+            geoms, known = [], True
             for layer in self._layers():
                 forward, backward = self.record[layer]
-                ref = forward if forward is not None else backward
-                if ref is None:
-                    total = float("inf")
+                if (inputs and forward is None) or (grads and backward is None):
+                    known = False
                     break
                 if layer.__class__.__name__ == 'Conv2d':
-                    n_ = layer.in_channels * layer.kernel_size[0] * layer.kernel_size[1] + int(layer.bias is not None)
-                    m_ = layer.out_channels
-                    Ho = (forward.shape[2] + 2 * layer.padding[0] - layer.kernel_size[0]) // layer.stride[0] + 1 if forward is not None else backward.shape[2]
-                    Wo = (forward.shape[3] + 2 * layer.padding[1] - layer.kernel_size[1]) // layer.stride[1] + 1 if forward is not None else backward.shape[3]
-                    K_ = ref.shape[0] * Ho * Wo
+                    if inputs:
+                        geoms.append((*forward.shape, layer.kernel_size, layer.stride, layer.padding, layer.bias is not None))
+                    if grads:
+                        geoms.append((*backward.shape, (1, 1), (1, 1), (0, 0), False))
                 else:
-                    n_, m_ = layer.in_features + int(layer.bias is not None), layer.out_features
-                    K_ = ref.numel() // ref.shape[-1]
-                total += (ops.small_path_flop(n_, K_) if inputs else 0.0) + (ops.small_path_flop(m_, K_) if grads else 0.0)
-            hint = _lib.PATH_SMALL if total <= _lib.SMALL_MAX_FLOP else _lib.PATH_GROUPED
+                    if inputs:
+                        geoms.append((forward.numel() // forward.shape[-1], forward.shape[-1], 1, 1, (1, 1), (1, 1), (0, 0),
+                                      layer.bias is not None))
+                    if grads:
+                        geoms.append((backward.numel() // backward.shape[-1], backward.shape[-1], 1, 1, (1, 1), (1, 1), (0, 0), False))
+            hint = ops.kfac_path_for(geoms) if known else _lib.PATH_GROUPED
             for job in jobs:
                 job.path_hint = hint
         if getattr(self, "_count_flops", False):                 # bench.py: what the launch plan executes

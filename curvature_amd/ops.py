@@ -101,6 +101,24 @@ def _factor_descs(jobs: Sequence[FactorJob]):
     return arr
 
 
+def kfac_path_for(geometries) -> int:
+    """The launch form (``_lib.PATH_SMALL`` / ``_lib.PATH_GROUPED``) a factor build of exactly these factors takes on its
+    own, decided by the library (curv_kfac_path_for: flops, factor count, slice length, workgroup count).
+    `geometries`: one ``(N, C, H, W, kernel, stride, padding, has_bias)`` per factor of the UNSHARDED model; host only."""
+    geometries = list(geometries)
+    n = len(geometries)
+    if n == 0:
+        return _lib.PATH_GROUPED
+    arr = (curv_factor_desc * n)()
+    for d, (N, C, H, W, kernel, stride, padding, has_bias) in zip(arr, geometries):
+        d.N, d.C, d.H, d.W = int(N), int(C), int(H), int(W)
+        d.kh, d.kw = kernel
+        d.sh, d.sw = stride
+        d.ph, d.pw = padding
+        d.has_bias, d.first, d.scale, d.path_hint = int(has_bias), 1, 1.0, 0
+    return int(_lib.lib().curv_kfac_path_for(arr, n))
+
+
 PLAN_INFO_FIELDS = 25                 # CURV_PLAN_INFO_FIELDS
 
 

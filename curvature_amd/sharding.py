@@ -257,11 +257,9 @@ class Shard:
         ready = self.__dict__.get("_rccl_ok")
         if ready is None:
             import os
-            if os.environ.get("CURV_RCCL_ALLGATHER", "0") in ("", "0"):
-                # same environment on every rank of a torchrun job; no collective step needed for "off"
-                self.__dict__["_rccl_ok"] = False
-                return False
-            ok = 1
+            # the environment is read per process and a multi-node launcher need not propagate it: a rank without the
+            # variable still takes part in the all-reduce below (with ok = 0), so that every rank takes the same branch
+            ok = int(os.environ.get("CURV_RCCL_ALLGATHER", "0") not in ("", "0"))
             if ok:
                 # can THIS rank reach RCCL through the library at all (dlopen, symbols)?  A local probe without side effects
                 # (curv_rccl_available: no ncclGetUniqueId, whose bootstrap listener would stay behind on every rank): the

@@ -13,7 +13,11 @@
  *   - return value 0 = ok, otherwise a CURV_ERR_* code with text in curv_last_error();
  *     numerical failure ("not positive definite") is reported through caller-provided device
  *     `info` words so that a whole model can be processed without a host round trip per layer;
- *   - re-entrant, no global mutable state besides the thread-local error string.
+ *   - re-entrant; results never depend on library state.  What the library keeps per calling thread (and device)
+ *     besides the error string: a set of internal HIP streams and events (curv_init_streams below) on which the
+ *     whole-model sweeps of curv_chol_inv_lower* / curv_kfac_accumulate fork and join the caller's stream.  They
+ *     carry no data between calls; when they are created relative to the process's other streams can change the
+ *     TIME of the unchecked inversion entry points (see curv_init_streams), never a result bit.
  */
 #ifndef CURV_HIP_H
 #define CURV_HIP_H
@@ -25,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CURV_ABI_VERSION 8
+#define CURV_ABI_VERSION 9
 
 #define CURV_OK 0
 #define CURV_ERR_NOT_PD 1
@@ -86,6 +90,14 @@ typedef struct curv_factor_desc {
 /* executed multiply-add flops (32 x 32 blocks on and above the diagonal, 2 * 1024 * pairs * K per factor) up to which a
  * launch takes the two-launch small form (csrc/syrk_small.hip) */
 #define CURV_SMALL_MAX_FLOP 2.0e9
+
+/* Host-only: the launch form (CURV_PATH_SMALL or CURV_PATH_GROUPED) a curv_kfac_accumulate call with exactly these
+ * factors takes on its own - every gate of the small form (executed flops, number of factors, slice length, workgroup
+ * count) evaluated by the library itself; `src` / `dst` are not read and any path_hint in `descs` is ignored.  A
+ * layer-sharded caller passes the geometry of ALL factors of the model once and puts the answer into the path_hint
+ * of its own share's descriptors (curvature/curvatures.py:20-21: layers are independent, so a rank's results must not
+ * depend on what else the rank holds). */
+int curv_kfac_path_for(const curv_factor_desc* descs, int n_factors);
 
 /* Device scratch needed by curv_kfac_accumulate for this set of factors (bytes). */
 size_t curv_kfac_workspace_bytes(const curv_factor_desc* descs, int n_factors);

@@ -152,3 +152,27 @@ def test_invalid_geometry_is_rejected():
         setattr(arr[0], k, v)
     out = (ctypes.c_longlong * NF)()
     assert _lib.lib().curv_kfac_plan_info(arr, 1, out) == 2   # CURV_ERR_INVALID
+
+
+def test_launch_form_of_the_unsharded_model_is_decided_by_the_library():
+    """curv_kfac_path_for: the form a launch of exactly these factors takes on its own, with EVERY gate of the small
+    form (csrc/syrk_small.hip: small_plan), not only the flop bound a caller could restate: a deep, cheap model
+    (more than 96 factors) runs grouped when unsharded, so its layer-sharded ranks must be told GROUPED although each
+    share is tiny.  Host only."""
+    from curvature_amd import ops
+    tiny = (4, 16, 1, 1, (1, 1), (1, 1), (0, 0), True)              # Linear(15, .) with bias at N = 4
+    assert ops.kfac_path_for([tiny] * 10) == _lib.PATH_SMALL
+    assert ops.kfac_path_for([tiny] * 96) == _lib.PATH_SMALL
+    assert ops.kfac_path_for([tiny] * 98) == _lib.PATH_GROUPED       # more than 4 argument blocks of 24 factors
+    lenet = [(100, 1, 28, 28, (5, 5), (1, 1), (2, 2), True), (100, 6, 28, 28, (1, 1), (1, 1), (0, 0), False),
+             (100, 6, 14, 14, (5, 5), (1, 1), (0, 0), True), (100, 16, 10, 10, (1, 1), (1, 1), (0, 0), False),
+             (100, 400, 1, 1, (1, 1), (1, 1), (0, 0), True), (100, 120, 1, 1, (1, 1), (1, 1), (0, 0), False)]
+    assert ops.kfac_path_for(lenet) == _lib.PATH_SMALL
+    resnet_layer = [(32, 256, 56, 56, (1, 1), (1, 1), (0, 0), False)]   # 2 * 256^2 * 100 352: far over the flop bound
+    assert ops.kfac_path_for(lenet + resnet_layer) == _lib.PATH_GROUPED
+    # a hint in the descriptors does not leak into the decision
+    arr = (_lib.curv_factor_desc * 98)()
+    for d in arr:
+        d.N, d.C, d.H, d.W, d.kh, d.kw, d.sh, d.sw, d.has_bias, d.path_hint = 4, 16, 1, 1, 1, 1, 1, 1, 1, _lib.PATH_SMALL
+    assert _lib.lib().curv_kfac_path_for(arr, 98) == _lib.PATH_GROUPED
+    assert ops.kfac_path_for([]) == _lib.PATH_GROUPED
