@@ -1122,10 +1122,9 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
       f.TM = 128;
       f.P = cdiv(f.dim, 128);             // (the last tile row / column may be ragged: syrk_flat_eligible)
       f.n_tiles = f.P * (f.P + 1) / 2;
-      const int sps = syrk_flat_stages(f.W);
-      f.n_chunks = f.N * sps;
-      chunk_cost[i] = (double)f.W / sps * 32.0 * 4.0 + 800.0;     // 128x128xk = 128 k CU-cycles; + barrier / DMA wait
-      chunk_px[i] = (double)f.W / sps;
+      f.n_chunks = syrk_flat_chunks(f.N, f.W);
+      chunk_cost[i] = 16.0 * 32.0 * 4.0 + 800.0;                  // 128x128x16 = 2048 CU-cycles; + barrier / DMA wait
+      chunk_px[i] = 16.0;
       total_cost += chunk_cost[i] * f.n_tiles * f.n_chunks;
       continue;
     }
@@ -1191,12 +1190,11 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
     plan.corr.push_back(layer);
     for (int k = 0; k < layer.n_vf; ++k) {
       const FactorDev& v = plan.f[layer.vf0 + k];
-      const int sps = syrk_flat_stages(v.W);
       // (scaled by 1.5 / 2.0, i.e. dispatched earlier and sliced finer: flat kernel 4.06 -> 3.95 / 3.99 ms, pre-tiled kernel
       // 1.30 -> 1.39 / 1.38 ms - the target item length moves with the total: a wash)
-      const double cost = (double)v.W / sps * 32.0 * 4.0 + 800.0;
+      const double cost = 16.0 * 32.0 * 4.0 + 800.0;
       chunk_cost.push_back(cost);
-      chunk_px.push_back((double)v.W / sps);
+      chunk_px.push_back(16.0);
       total_cost += cost * v.n_tiles * v.n_chunks;
     }
   }

@@ -256,7 +256,7 @@ static void syrk_corr_expand_half(const curv_factor_desc& s, std::vector<FactorD
     v.pitch = pitch; v.nonsym = 1; v.half = 1;
     v.off_i = lead + a1; v.off_i2 = lead + a2; v.off_j = lead; v.off_j2 = lead - 1;
     v.TM = 128; v.P = 1; v.n_tiles = 1;
-    v.n_chunks = samples * syrk_flat_stages(K);
+    v.n_chunks = syrk_flat_chunks(samples, K);
     v.src = reinterpret_cast<const float*>(src_off);
     v.dst = reinterpret_cast<float*>(L.comp_off + (long long)tile * 128 * 128);
     f.push_back(v);
@@ -299,7 +299,7 @@ static void syrk_corr_expand_half(const curv_factor_desc& s, std::vector<FactorD
     v.dma = 1;
     v.pitch = L.pt_pitch;
     v.TM = 128; v.P = 1; v.n_tiles = 1;
-    v.n_chunks = syrk_flat_stages(s.N);
+    v.n_chunks = syrk_flat_chunks(1, s.N);
     v.src = reinterpret_cast<const float*>(L.pt_off + (long long)k * 64 * L.pt_pitch);
     v.dst = reinterpret_cast<float*>(L.comp_off + (long long)tile * 128 * 128);
     f.push_back(v);
@@ -351,7 +351,7 @@ void syrk_corr_expand(const curv_factor_desc& s, int user, std::vector<FactorDev
     v.TM = 128;
     v.P = s.C / 128;
     v.n_tiles = nonsym ? v.P * v.P : v.P * (v.P + 1) / 2;
-    v.n_chunks = samples * syrk_flat_stages(K);
+    v.n_chunks = syrk_flat_chunks(samples, K);
     // src / dst: offsets into the correlation area for now (syrk_corr_bind turns them into pointers)
     v.src = reinterpret_cast<const float*>(src_off);
     v.dst = reinterpret_cast<float*>(L.comp_off + (long long)comp * s.C * s.C);

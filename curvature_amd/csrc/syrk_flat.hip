@@ -56,15 +56,19 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(1))) float gfloat_t;
 
-// stages per sample: TS = ceil(HW / 8) steps, split evenly over ceil(TS / STEPS) stages
-int syrk_flat_stages(int HW) {
-  const int TS = (HW + 7) / 8;
-  return (TS + flat::STEPS - 1) / flat::STEPS;
+// The K range of a factor is the stream of its 4-pixel GROUPS: gps = ceil(W / 4) per (sample, channel) row, sample after
+// sample, N gps in all; a stage takes four consecutive groups of the stream (16 pixels) - also across a sample boundary -
+// so that every stage but the factor's last is full, whatever W is (round 5 cut every sample into its own stages: 49
+// pixels = 2 + 2 + 2 + 1 steps of eight, each count a run-time condition inside the MFMA sequence).
+int syrk_flat_chunks(int N, int W) {
+  const long long groups = (long long)N * ((W + 3) / 4);
+  return (int)((groups + flat::SLOTS - 1) / flat::SLOTS);
 }
 
 bool syrk_flat_eligible(const FactorDev& f, const void* src) {
   // flattened per-pixel factor (1x1, stride 1, no padding: H = 1, W = pixels per (sample, channel) row), no bias row, and
-  // the whole tensor addressable by one buffer descriptor (32-bit byte offsets).  The last tile row / column of a factor
+  // the whole tensor addressable by one buffer descriptor with 31-bit byte offsets (bit 31 of a lane's offset marks "no
+  // fetch": flat_body).  The last tile row / column of a factor
   // may be ragged (DenseNet-121 / 161: 64 + 32 k / 96 + 48 k channels; any multiple of 16 from 96 on): the panel rows behind the factor's edge are the next sample's first
   // channels (zeros behind the tensor's end: the descriptor's range check) - finite values whose products land in tile rows
   // and columns that neither epilogue stores (direct_store_block masks them, syrk_reduce_kernel does not read them)
@@ -72,28 +76,26 @@ bool syrk_flat_eligible(const FactorDev& f, const void* src) {
   if (!(f.compact && f.H == 1 && f.kh == 1 && f.kw == 1 && f.sh == 1 && f.sw == 1 && f.ph == 0 && f.pw == 0)) return false;
   if (f.has_bias || f.dim < (ragged ? 96 : flat::TM) || f.dim % (ragged ? 16 : flat::TM) != 0) return false;
   if (f.W < 8) return false;
-  if ((long long)f.N * f.C * f.W * 4 >= (1LL << 32) - 4096) return false;
+  if ((long long)f.N * f.C * f.W * 4 >= (1LL << 31) - 4096) return false;
   return (reinterpret_cast<uintptr_t>(src) & 3) == 0;
 }
 
-template <int PART, typename Hook>
+template <int PART>
 __device__ __forceinline__ void flat_mfma_step(const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1,
-                                               f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, int ne, Hook hook) {
+                                               f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    if (e < ne) {
-      if (PART != 3) c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], c00, 0, 0, 0);
-      if (PART != 2) c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], c01, 0, 0, 0);
-      if ((PART == 0 || PART == 2)) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], c10, 0, 0, 0);
-      if (PART != 2) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], c11, 0, 0, 0);
-    }
-    hook(e);                      // one LDS-DMA piece behind a group of MFMAs: its issue cost hides under them
+    if (PART != 3) c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], c00, 0, 0, 0);
+    if (PART != 2) c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], c01, 0, 0, 0);
+    if (PART == 0 || PART == 2) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], c10, 0, 0, 0);
+    if (PART != 2) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], c11, 0, 0, 0);
   }
 }
 
 template <int PART>
 __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* __restrict__ slabs, lds_char* lds) {
   using namespace flat;
+  static_assert(KC == 16 && STEPS == 2 && PIECES == 2, "the straight-line stage below is written for 16-pixel stages");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, h = lane >> 5;
@@ -106,24 +108,25 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
   int wm = wave >> 1, wn = wave & 1;
   if (PART >= 2) { wm = 0; wn = 1; }
   const int i0 = ti * TM, j0 = tj * TM;
-  const int HW = d.W, C = d.C, pitch = d.pitch;
+  const int W = d.W, C = d.C, pitch = d.pitch;
+  const int gps = (W + 3) >> 2;                             // groups per (sample, channel) row
+  const int nvl = W - 4 * (gps - 1);                        // pixels of a row's last group: 1 .. 4
+  const int g_tot = d.N * gps;                              // groups of the whole K range
 
-  // stage geometry of a sample: TS steps of 8 pixels in SPS stages of base (+1 for the first rem) steps
-  const int TS = (HW + 7) >> 3;
-  const int SPS = (TS + STEPS - 1) / STEPS;
-  const int base_steps = TS / SPS, rem_steps = TS - base_steps * SPS;
-  const int nv_last = HW - 8 * (TS - 1);                  // pixels of a sample's last step: 1 .. 8
-
-  // ---- DMA lane geometry: piece `slot` of this wave covers panel rows 32 slot + 8 wave + (lane >> 3); the lane's
-  // physical 16-byte slot (lane & 7) holds logical pixel group g = slot ^ ((row >> 1) & 7), which does not depend on
-  // the piece index (pieces of a wave are 32 rows apart)
+  // ---- DMA lane geometry: piece `slot` of this wave covers panel rows 64 slot + 16 wave + (lane >> 2); the lane's
+  // physical 16-byte slot (lane & 3) holds the stage's logical group g_lane = slot ^ ((row >> 2) & 3), which does not
+  // depend on the piece index (pieces of a wave are 64 rows apart).  Group G of the stream = (sample G / gps, group G % gps):
+  // a lane follows its own group from stage to stage (G += 4) and carries the (sample, row, pixel) part of the address in
+  // its voffset; tile row, panel offset and piece are scalars that do not change within an item.  A lane with nothing
+  // to fetch - its group lies behind the K range, or the item has no further stage - carries an out-of-range voffset
+  // instead of a cleared exec bit (the range check of the descriptor drops the fetch): no predicate, no branch.
+  constexpr int OOB = (int)0x80000000;                      // + soffset < 2^31 (syrk_flat_eligible) stays out of range
   const int rsub = RPP * wave + (lane >> LANES_PER_ROW_SHIFT);
   const int g_lane = (lane & (SLOTS - 1)) ^ ((rsub >> KEY_SHIFT) & (SLOTS - 1));
-  const int voff = (rsub * pitch + 4 * g_lane) * 4;
   const unsigned total_b = (unsigned)((long long)d.N * C * pitch * 4);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.src, 0, total_b, 0x00020000);
 
-  // ---- operand addresses: row R of a panel, step j: R * 128 + ((2 j + h) ^ ((R >> 1) & 7)) * 16
+  // ---- operand addresses: row R of a panel, step j: R * 64 + ((2 j + h) ^ ((R >> 2) & 3)) * 16
   unsigned addr[4][STEPS];
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
@@ -140,85 +143,84 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
   const int nseg = d.direct;
   const int t0 = nseg ? 0 : slice * d.cpi, t1 = nseg ? d.n_chunks : min(t0 + d.cpi, d.n_chunks);
   int seg = 0, seg_end = nseg ? min(d.cpi, t1) : t1 + 1;
-  const int n_panels = diag ? 1 : 2;
+  constexpr int N_PANELS = PART == 0 ? 2 : 1;               // PART != 0 <=> diagonal tile of a symmetric factor: one panel
 
-  auto stage_geo = [&](int t, int& s, int& px0, int& nsteps, bool& last) {
-    s = t / SPS;
-    const int q = t - s * SPS;
-    nsteps = base_steps + (q < rem_steps ? 1 : 0);
-    px0 = 8 * (q * base_steps + min(q, rem_steps));
-    last = (q == SPS - 1);
-  };
-  // next stage's DMA geometry (scalars) and the issue of one piece: piece i = (panel i / PIECES, row group i % PIECES)
-  int n_soff[2] = {0, 0};
   // packed pair tile (d.half): rows 64 .. 127 of a panel are the 64 channel rows again, at the panel's second offset
   const int hadj[2] = {d.half ? (d.off_i2 - d.off_i - 64 * pitch) * 4 : 0, d.half ? (d.off_j2 - d.off_j - 64 * pitch) * 4 : 0};
-  int n_gmax = 0;
-  unsigned n_buf = 0;
-  auto plan_next = [&](int t) {
-    int s, px0, nsteps; bool last;
-    stage_geo(t, s, px0, nsteps, last);
-    n_gmax = last ? (HW - px0 + 3) / 4 : 2 * nsteps;               // pixel groups this stage needs
-    n_buf = (unsigned)(t & 1) * PANEL_B;
-    n_soff[0] = ((s * C + i0) * pitch + d.off_i + px0) * 4;
-    n_soff[1] = ((s * C + j0) * pitch + d.off_j + px0) * 4;
+  const int soff[2] = {(i0 * pitch + d.off_i) * 4, (j0 * pitch + d.off_j) * 4};
+  // this lane's group at stage t0 (one division per item), then incrementally
+  int G = SLOTS * t0 + g_lane;
+  int smp = G / gps, gi = G - smp * gps;
+  auto lane_voff = [&](bool live) { return (live && G < g_tot) ? ((smp * C + rsub) * pitch + 4 * gi) * 4 : OOB; };
+  const bool short_rows = gps < SLOTS;                      // rows of fewer than 13 pixels (strips of the smallest images)
+  auto advance = [&]() {
+    G += SLOTS; gi += SLOTS;
+    if (short_rows) { smp = G / gps; gi = G - smp * gps; }
+    else if (gi >= gps) { gi -= gps; ++smp; }
   };
-  auto piece = [&](int i) {
+  auto piece = [&](int i, int voff, unsigned buf) {        // piece i = (panel i / PIECES, row group i % PIECES)
     const int p = i / PIECES, slot = i % PIECES;
-    if (p < n_panels && g_lane < n_gmax) {
-      const unsigned lbase = (p ? 2u * PANEL_B : 0u) + n_buf + (unsigned)(RPP * wave + 4 * RPP * slot) * ROW_B;
+    if (p < N_PANELS) {
+      const unsigned lbase = (p ? 2u * PANEL_B : 0u) + buf + (unsigned)(RPP * wave + 4 * RPP * slot) * ROW_B;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lbase), 16, voff,
-                                               n_soff[p] + slot * 4 * RPP * pitch * 4 + (slot * 4 * RPP >= 64 ? hadj[p] : 0), 0, 0);
+                                               soff[p] + slot * 4 * RPP * pitch * 4 + (slot * 4 * RPP >= 64 ? hadj[p] : 0), 0, 0);
     }
   };
-
-  plan_next(t0);
+  // ---- the reader's view of the stream: at step j this lane half multiplies group Gr = 4 t + 2 j + h.  Operand values
+  // that are not part of the sum - the pixels behind the end of a row in its last group (W not a multiple of 4: what the
+  // DMA fetched there belongs to the next row) and whole groups behind the K range (LDS keeps what an earlier stage left
+  // there) - are zeroed in the operand registers.  rr[j] = Gr mod gps.
+  const bool ragged = nvl < 4;
+  int rr[STEPS];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) piece(i);
+  for (int j = 0; j < STEPS; ++j) rr[j] = (SLOTS * t0 + 2 * j + h) % gps;
+  const int t_end = (g_tot - 1) / SLOTS;                   // the stage that holds the stream's last group
+  const bool short_end = (g_tot & (SLOTS - 1)) != 0;
+
+  {
+    const int v0 = lane_voff(true);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) piece(i, v0, (unsigned)(t0 & 1) * PANEL_B);
+    advance();
+  }
   for (int t = t0; t < t1; ++t) {
     __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's DMA of stage t has landed
     __syncthreads();                           // everyone's has; everyone is done reading the other buffer
-    const bool more = t + 1 < t1;
-    if (more) plan_next(t + 1);
-    int s, px0, nsteps; bool last;
-    stage_geo(t, s, px0, nsteps, last);
-    const unsigned buf = (unsigned)(t & 1) * PANEL_B;
+    const int voff_n = lane_voff(t + 1 < t1);  // stage t + 1 (all lanes out of range behind the item's last stage)
+    advance();
+    const unsigned buf = (unsigned)(t & 1) * PANEL_B, nbuf = PANEL_B - buf;
     auto rd = [&](int o, int j) { return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lds + addr[o][j] + buf); };
-    // software pipeline over the stage's steps: operands of step j + 1 are read while the MFMAs of step j issue;
-    // the DMA pieces of stage t + 1 go out during the first half of the stage, each behind a group of MFMAs, so
-    // that the last one still has half of the stage's MFMA time to land before the wait at the top
+    // straight line: the operands of both steps, then 2 x 16 MFMAs with the four pieces of stage t + 1 behind the first
+    // MFMA groups (the last piece has more than half of the stage's MFMA time to land before the wait at the top)
     f32x4 a0 = rd(0, 0), a1 = rd(1, 0), b0 = rd(2, 0), b1 = rd(3, 0);
-    int next_piece = 0;
+    f32x4 na0 = rd(0, 1), na1 = rd(1, 1), nb0 = rd(2, 1), nb1 = rd(3, 1);
+    if (ragged || (short_end && t == t_end)) {
+      asm volatile("; stream tail" ::: "memory");          // keeps this a branch around a VALU-only block
 #pragma unroll
-    for (int j = 0; j < STEPS; ++j) {
-      if (j < nsteps) {
-        f32x4 na0, na1, nb0, nb1;
-        if (j + 1 < STEPS && j + 1 < nsteps) {
-          na0 = rd(0, j + 1); nb0 = rd(2, j + 1);
-          na1 = rd(1, j + 1); nb1 = rd(3, j + 1);
-        }
-        int ne = 4;
-        if (last && j == nsteps - 1 && nv_last < 8) {
-          // the sample's final step: only nv_last of its 8 pixels exist (what the DMA fetched beyond them belongs to
-          // the next row): lane half h holds pixels 4 h + e
-          ne = min(4, nv_last);
-          asm volatile("; sample tail" ::: "memory");      // keeps this a branch: if-converted, its 16 selects ran at every step
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const bool ok = (4 * h + e) < nv_last;
-            a0[e] = ok ? a0[e] : 0.0f; a1[e] = ok ? a1[e] : 0.0f;
-            b0[e] = ok ? b0[e] : 0.0f; b1[e] = ok ? b1[e] : 0.0f;
-          }
-        }
-        flat_mfma_step<PART>(a0, a1, b0, b1, c00, c01, c10, c11, ne,
-                             [&](int k) { if (more && k < PPS && PPS * j + k < NP) piece(PPS * j + k); });
-        next_piece = min(NP, PPS * j + PPS);
-        if (j + 1 < STEPS && j + 1 < nsteps) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
+      for (int e = 0; e < 4; ++e) {
+        const bool k0 = (rr[0] == gps - 1 && e >= nvl) || SLOTS * t + h >= g_tot;
+        const bool k1 = (rr[1] == gps - 1 && e >= nvl) || SLOTS * t + 2 + h >= g_tot;
+        a0[e] = k0 ? 0.0f : a0[e]; a1[e] = k0 ? 0.0f : a1[e];
+        na0[e] = k1 ? 0.0f : na0[e]; na1[e] = k1 ? 0.0f : na1[e];
+        // (the B side too: 0 x Inf would put a NaN into sums the stray value has no part in)
+        b0[e] = k0 ? 0.0f : b0[e]; b1[e] = k0 ? 0.0f : b1[e];
+        nb0[e] = k1 ? 0.0f : nb0[e]; nb1[e] = k1 ? 0.0f : nb1[e];
       }
     }
-    if (more) {
 #pragma unroll
-      for (int i = 0; i < NP; ++i) if (i >= next_piece) piece(i);      // short stages: the rest
+    for (int e = 0; e < 4; ++e) {
+      if (PART != 3) c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], c00, 0, 0, 0);
+      if (PART != 2) c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], c01, 0, 0, 0);
+      if (PART == 0 || PART == 2) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], c10, 0, 0, 0);
+      if (PART != 2) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], c11, 0, 0, 0);
+      piece(e, voff_n, nbuf);                  // one LDS-DMA piece behind a group of MFMAs: its issue cost hides under them
+    }
+    flat_mfma_step<PART>(na0, na1, nb0, nb1, c00, c01, c10, c11);
+#pragma unroll
+    for (int j = 0; j < STEPS; ++j) {
+      rr[j] += SLOTS;
+      if (short_rows) rr[j] %= gps;
+      else if (rr[j] >= gps) rr[j] -= gps;
     }
     if (t + 1 == seg_end) {
       // end of a segment of an unsliced item: scale, add into the factor, (last segment) write the mirror tile; the

@@ -217,7 +217,7 @@ int curv_internal_side_stream(hipStream_t* out);
 int launch_syrk_flat(hipStream_t stream, const FactorDev* table, int n_factors, int n_items, float* slabs);
 // host-side eligibility / stage count of the LDS-DMA kernel
 bool syrk_flat_eligible(const FactorDev& f, const void* src);
-int syrk_flat_stages(int HW);
+int syrk_flat_chunks(int N, int W);     // stages of 16 pixels over the factor's stream of 4-pixel groups
 
 __device__ __forceinline__ void decode_tile_of(const FactorDev& d, int t, int& ti, int& tj) {
   if (d.nonsym) { ti = t / d.P; tj = t - ti * d.P; }

@@ -81,11 +81,11 @@ def test_plan_respects_budgets(d):
     assert p["nsub"] == (0 if p["direct"] else p["ntiles"] * (p["TM"] // 64) ** 2)
     if p["dma"]:
         # LDS-DMA kernel (syrk_flat.hip): flattened factor, 128-row tiles (the last one may be ragged: widths of 16 k
-        # channels from 96 on), no bias row; K in stages of at most 16 pixels of one sample, ceil(ceil(HW / 8) / 2) stages
-        # per sample
+        # channels from 96 on), no bias row; K = the stream of the factor's 4-pixel groups (ceil(HW / 4) per sample, sample
+        # after sample), in stages of four groups
         assert flat and not d["has_bias"] and p["dim"] % 16 == 0 and p["dim"] >= 96 and p["TM"] == 128
-        steps = -(-(Ho * Wo) // 8)
-        assert p["nchunks"] == d["N"] * -(-steps // 2)
+        groups = d["N"] * -(-(Ho * Wo) // 4)
+        assert p["nchunks"] == -(-groups // 4)
         P = -(-p["dim"] // 128)
         assert p["ntiles"] == P * (P + 1) // 2 and p["nitems"] == p["ntiles"] * p["nslices"]
         assert p["cpi"] * p["nslices"] >= p["nchunks"] and p["cpi"] * (p["nslices"] - 1) < p["nchunks"]

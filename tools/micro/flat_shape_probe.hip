@@ -220,9 +220,11 @@ static double run(int N, int C, int HW, int target_items, float* src, const std:
 
 int main(int argc, char** argv) {
   const int target = argc > 1 ? atoi(argv[1]) : 4096;
-  const int cases[3][2] = {{1024, 784}, {2048, 192}, {512, 3136}};
-  for (auto& cs : cases) {
-    const int N = 32, C = cs[0], HW = cs[1];
+  // {C, HW, N}: N = 32 keeps the inputs (50 - 205 MB) inside the 256 MB MALL across launches; larger N streams them from HBM
+  const int cases[][3] = {{1024, 784, 32}, {2048, 192, 32}, {512, 3136, 32}, {1024, 784, 128}, {1024, 784, 512}, {2048, 192, 512}, {512, 3136, 128}};
+  const int first = argc > 2 ? atoi(argv[2]) : 0, last = argc > 3 ? atoi(argv[3]) : 7;
+  for (int ci = first; ci < last && ci < 7; ++ci) {
+    const int C = cases[ci][0], HW = cases[ci][1], N = cases[ci][2];
     const size_t elems = (size_t)N * C * HW;
     std::vector<float> h(elems);
     unsigned st = 12345u + C * 7 + HW;
@@ -230,9 +232,10 @@ int main(int argc, char** argv) {
     float* src;
     hipMalloc(&src, elems * 4);
     hipMemcpy(src, h.data(), elems * 4, hipMemcpyHostToDevice);
+    printf("inputs %.0f MB\n", elems * 4 / 1e6);
     for (int rep = 0; rep < 2; ++rep) {
-      run<0>(N, C, HW, target, src, h);
-      run<1>(N, C, HW, target, src, h);
+      run<0>(N, C, HW, target * (N / 32), src, h);
+      run<1>(N, C, HW, target * (N / 32), src, h);
     }
     hipFree(src);
   }
