@@ -854,7 +854,7 @@ syrk_reduce_kernel(const FactorDev* __restrict__ descs, int n_factors, const flo
 
 // The descriptor table travels as kernel arguments (copied by the runtime at launch time), so the
 // call is fully asynchronous and needs neither pinned staging memory nor a stream synchronisation.
-constexpr int UPLOAD_CHUNK = 14;
+constexpr int UPLOAD_CHUNK = 13;
 constexpr int ZERO_PAD_FLOATS = 64;    // dummy load target of masked staging slots
 struct TableChunk { FactorDev f[UPLOAD_CHUNK]; };
 static_assert(sizeof(TableChunk) <= 3840, "kernel argument block must stay below 4 KB");
@@ -1115,7 +1115,24 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
       chunk_cost[i] = 0.0;
       continue;
     }
-    if (flattened && syrk_flat_eligible(f, s.src)) {
+    if (!flattened && f.compact && s.ph == 0 && s.pw == 0 && !syrk_corr_eligible(s)) {
+      // 1x1 with a stride: X = src[:, :, ::sh, ::sw] is a flattened factor of the sampled pixels - which lie sh * sw apart
+      // in memory, nothing an LDS-DMA piece can fetch.  A pass of its own gathers them into a compact (N, C, Ho Wo) copy
+      // (ResNet-50's three down-sampling convolutions: 45 MB) and the factor joins the LDS-DMA work list; on the
+      // register-staged kernel these items ran at a few percent of the matrix pipe and kept it resident - holding half of
+      // their CUs' registers - for 5 ms beside the LDS-DMA kernel (round 5: 5 GFLOP of its 30)
+      static const int sub_on = getenv("CURV_FLAT_SUB") ? atoi(getenv("CURV_FLAT_SUB")) : 1;
+      FactorDev g = f;
+      g.H = 1; g.W = f.Ho * f.Wo; g.sh = g.sw = 1;
+      if (sub_on && (long long)f.Ho * f.Wo < (1LL << 30) && syrk_flat_eligible(g, reinterpret_cast<const void*>(16))) {
+        f.sub = 1;
+        f.H = 1; f.W = g.W; f.Ho = 1; f.Wo = g.W; f.sh = f.sw = 1;
+        f.xq_off = plan.area_floats;
+        plan.area_floats += ((long long)f.N * f.C * f.W + 63) & ~63LL;
+        flattened = true;
+      }
+    }
+    if (flattened && (f.sub || syrk_flat_eligible(f, s.src))) {
       // LDS-DMA kernel: whole 128-row tiles, K in stages of <= 32 pixels of one sample (syrk_flat.hip)
       f.dma = 1;
       f.pitch = f.W;
@@ -1458,7 +1475,7 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
     memset(&chunk, 0, sizeof(chunk));
     for (int k = 0; k < count; ++k) {
       chunk.f[k] = plan.f[all[b + k]];
-      if (chunk.f[k].pre) chunk.f[k].src = area + chunk.f[k].xq_off;        // the kernel stages from the pre-tiled copy
+      if (chunk.f[k].pre || chunk.f[k].sub) chunk.f[k].src = area + chunk.f[k].xq_off;   // the kernel stages from the pre-tiled / compact copy
       chunk.f[k].xq_off = 0;
     }
     if (resident && memcmp(&shadow.rows[b], chunk.f, (size_t)count * sizeof(FactorDev)) == 0) continue;
@@ -1478,6 +1495,10 @@ static int kfac_accumulate_impl(void* stream_, const curv_factor_desc* descs, in
   if (n2 > 0) {
     const int rcq = launch_patch_prep(stream, plan.f, plan.order[2], area);
     if (rcq != CURV_OK) return rcq;
+  }
+  {
+    const int rcs = launch_sub_prep(stream, plan.f, plan.n_user, descs, area);
+    if (rcs != CURV_OK) return rcs;
   }
   // the register-staged kernel starts beside the MFMA kernels, behind the two HBM-bound passes (beside those it
   // slowed them down by more than it gained)

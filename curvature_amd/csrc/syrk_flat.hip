@@ -23,6 +23,9 @@
 //     slower: 1.45 -> 1.55 ms per sample, so that kernel keeps its 32-wide stages).
 // Work items, slabs and the wave roles on diagonal tiles are those of syrk.hip; syrk_reduce_kernel sums the slabs.
 #include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <vector>
 #include "syrk_plan.h"
 
 namespace curv {
@@ -274,6 +277,70 @@ syrk_flat_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_items
   else if (part == 1) flat_body<1>(d, local, slabs, l3);
   else if (part == 2) flat_body<2>(d, local, slabs, l3);
   else flat_body<3>(d, local, slabs, l3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// compact copies of the sources of `sub` factors: out[n][c][oh][ow] = src[n][c][oh sh][ow sw]
+// ------------------------------------------------------------------------------------------------
+struct SubDev {
+  const float* src;
+  float* out;
+  int H, W, sh, sw, Ho, Wo;
+  int planes;            // N * C
+  int wg_base;           // first workgroup of this factor in the grid
+};
+constexpr int SUB_CHUNK = 16;
+constexpr int SUB_ROWS = 16;   // (plane, output row) pairs per workgroup
+struct SubChunk { SubDev f[SUB_CHUNK]; };
+
+__global__ void __launch_bounds__(256) sub_prep_kernel(SubChunk chunk, int count) {
+  int l = 0;
+  while (l + 1 < count && chunk.f[l + 1].wg_base <= (int)blockIdx.x) ++l;
+  const SubDev& d = chunk.f[l];
+  const int Wo = d.Wo, Ho = d.Ho;
+  const long long rows = (long long)d.planes * Ho;                 // output rows of the copy
+  const long long r0 = (long long)(blockIdx.x - d.wg_base) * SUB_ROWS;
+  const gfloat_t* src = (const gfloat_t*)d.src;
+  gfloat_t* out = (gfloat_t*)d.out;
+  // a wave per output row at a time: lanes along ow (the source pixels of a row lie sw floats apart: every fetched
+  // 64-byte line gives 16 / sw of them)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = wave; k < SUB_ROWS; k += 4) {
+    const long long r = r0 + k;
+    if (r >= rows) break;
+    const long long plane = r / Ho;
+    const int oh = (int)(r - plane * Ho);
+    const gfloat_t* s = src + (plane * d.H + (long long)oh * d.sh) * d.W;
+    gfloat_t* o = out + r * Wo;
+    for (int ow = lane; ow < Wo; ow += 64) o[ow] = s[ow * d.sw];
+  }
+}
+
+int launch_sub_prep(hipStream_t stream, const std::vector<FactorDev>& f, int n_user, const curv_factor_desc* descs, float* area) {
+  std::vector<int> which;
+  for (int i = 0; i < n_user; ++i) if (f[i].sub) which.push_back(i);
+  for (size_t b = 0; b < which.size(); b += SUB_CHUNK) {
+    SubChunk chunk;
+    memset(&chunk, 0, sizeof(chunk));
+    const int count = (int)std::min<size_t>(SUB_CHUNK, which.size() - b);
+    long long wgs = 0;
+    for (int k = 0; k < count; ++k) {
+      const int i = which[b + k];
+      const curv_factor_desc& s = descs[i];
+      SubDev& d = chunk.f[k];
+      d.src = s.src;
+      d.out = area + f[i].xq_off;
+      d.H = s.H; d.W = s.W; d.sh = s.sh; d.sw = s.sw;
+      d.Ho = (s.H - 1) / s.sh + 1; d.Wo = (s.W - 1) / s.sw + 1;
+      d.planes = s.N * s.C;
+      d.wg_base = (int)wgs;
+      wgs += cdivll((long long)d.planes * d.Ho, SUB_ROWS);
+      CURV_REQUIRE(wgs < (1LL << 31), "curv_kfac: too many rows in a strided 1x1 source");
+    }
+    hipLaunchKernelGGL(sub_prep_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, chunk, count);
+    CURV_LAUNCH_CHECK();
+  }
+  return CURV_OK;
 }
 
 int launch_syrk_flat(hipStream_t stream, const FactorDev* table, int n_factors, int n_items, float* slabs) {

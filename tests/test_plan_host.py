@@ -48,6 +48,11 @@ def test_plan_respects_budgets(d):
     Ho = (d["H"] + 2 * d["ph"] - d["kh"]) // d["sh"] + 1
     Wo = (d["W"] + 2 * d["pw"] - d["kw"]) // d["sw"] + 1
     flat = compact and d["sh"] == 1 and d["ph"] == 0
+    # 1x1 with a stride: flattened too - through a compact copy of the sampled pixels - when the LDS-DMA kernel takes it
+    sub = compact and d["sh"] > 1 and d["ph"] == 0 and p["dma"] == 1
+    if sub:
+        assert not d["has_bias"] and p["dim"] % 16 == 0 and p["dim"] >= 96
+    flat = flat or sub
     assert p["dim"] == d["C"] * d["kh"] * d["kw"] + d["has_bias"]
     assert (p["Ho"], p["Wo"]) == ((1, Ho * Wo) if flat else (Ho, Wo))
     K = d["N"] * Ho * Wo

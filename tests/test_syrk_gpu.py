@@ -65,6 +65,14 @@ CONV_CASES = [
     (8, 336, 28, 28, 1, 1, 0, False),   # DenseNet-161 block 2: C = 192 + 3 * 48
     (5, 144, 9, 13, 1, 1, 0, False),    # DenseNet-161 block 1: C = 96 + 48 (a ragged tile whose edge cuts a 32 x 32 MFMA block)
     (3, 1104, 7, 7, 1, 1, 0, False),    # DenseNet-161 block 4
+    # 1x1 with a stride and at least 96 channels: compact copy of the sampled pixels, then the LDS-DMA kernel
+    (3, 128, 9, 11, 1, 2, 0, False),    # odd sizes: Ho x Wo = 5 x 6 = 30 pixels (rows of 7.5 groups: ragged row ends)
+    (2, 256, 14, 14, 1, 2, 0, False),   # ResNet down-sampling shape, 49 pixels per row
+    (4, 96, 10, 13, (1, 1), (2, 3), (0, 0), False),   # anisotropic stride, ragged tile
+    (5, 64, 9, 9, 1, 2, 0, False),      # 64 channels: stays on the register-staged kernel
+    # exactly 64 channels, flattened (a pair-tile form of the LDS-DMA kernel was built and measured slower, LAB_NOTEBOOK R6)
+    (5, 64, 9, 9, 1, 1, 0, False),      # odd sample count, 81 pixels per row
+    (3, 64, 7, 7, 1, 1, 0, False),      # 49 pixels
 ]
 
 
