@@ -64,7 +64,7 @@ typedef __attribute__((address_space(1))) float gfloat_t;
 // so that every stage but the factor's last is full, whatever W is (round 5 cut every sample into its own stages: 49
 // pixels = 2 + 2 + 2 + 1 steps of eight, each count a run-time condition inside the MFMA sequence).
 int syrk_flat_chunks(int N, int W) {
-  const long long groups = (long long)N * ((W + 3) / 4);
+  const long long groups = (long long)N * std::max((W + 3) / 4, flat::SLOTS);   // (rows shorter than a stage: flat_body)
   return (int)((groups + flat::SLOTS - 1) / flat::SLOTS);
 }
 
@@ -112,10 +112,10 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
   if (PART >= 2) { wm = 0; wn = 1; }
   const int i0 = ti * TM, j0 = tj * TM;
   const int W = d.W, C = d.C, pitch = d.pitch;
-  const int gps = (W + 3) >> 2;                             // groups per (sample, channel) row
-  const int nvl = W - 4 * (gps - 1);                        // pixels of a row's last group: 1 .. 4
+  // groups per (sample, channel) row of the stream: ceil(W / 4), at least four (rows of fewer than 13 pixels - strips of the
+  // smallest images - get phantom groups behind their end: a stage then never wraps more than once)
+  const int gps = max((W + 3) >> 2, SLOTS);
   const int g_tot = d.N * gps;                              // groups of the whole K range
-
   // ---- DMA lane geometry: piece `slot` of this wave covers panel rows 64 slot + 16 wave + (lane >> 2); the lane's
   // physical 16-byte slot (lane & 3) holds the stage's logical group g_lane = slot ^ ((row >> 2) & 3), which does not
   // depend on the piece index (pieces of a wave are 64 rows apart).  Group G of the stream = (sample G / gps, group G % gps):
@@ -151,15 +151,21 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
   // packed pair tile (d.half): rows 64 .. 127 of a panel are the 64 channel rows again, at the panel's second offset
   const int hadj[2] = {d.half ? (d.off_i2 - d.off_i - 64 * pitch) * 4 : 0, d.half ? (d.off_j2 - d.off_j - 64 * pitch) * 4 : 0};
   const int soff[2] = {(i0 * pitch + d.off_i) * 4, (j0 * pitch + d.off_j) * 4};
-  // this lane's group at stage t0 (one division per item), then incrementally
-  int G = SLOTS * t0 + g_lane;
-  int smp = G / gps, gi = G - smp * gps;
-  auto lane_voff = [&](bool live) { return (live && G < g_tot) ? ((smp * C + rsub) * pitch + 4 * gi) * 4 : OOB; };
-  const bool short_rows = gps < SLOTS;                      // rows of fewer than 13 pixels (strips of the smallest images)
+  // this lane's group at stage t0 (one division per item), then incrementally: four groups on, or - behind a row's last
+  // groups - into the next sample's row
+  int G = SLOTS * t0 + g_lane, gi, voff_l;
+  {
+    const int smp = G / gps;
+    gi = G - smp * gps;
+    voff_l = ((smp * C + rsub) * pitch + 4 * gi) * 4;
+  }
+  const int wrap_b = (C * pitch + 4 * (SLOTS - gps)) * 4;
+  auto lane_voff = [&](bool live) { return (live && G < g_tot) ? voff_l : OOB; };
   auto advance = [&]() {
     G += SLOTS; gi += SLOTS;
-    if (short_rows) { smp = G / gps; gi = G - smp * gps; }
-    else if (gi >= gps) { gi -= gps; ++smp; }
+    const bool w = gi >= gps;
+    gi -= w ? gps : 0;
+    voff_l += w ? wrap_b : SLOTS * 16;
   };
   auto piece = [&](int i, int voff, unsigned buf) {        // piece i = (panel i / PIECES, row group i % PIECES)
     const int p = i / PIECES, slot = i % PIECES;
@@ -169,14 +175,17 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
                                                soff[p] + slot * 4 * RPP * pitch * 4 + (slot * 4 * RPP >= 64 ? hadj[p] : 0), 0, 0);
     }
   };
-  // ---- the reader's view of the stream: at step j this lane half multiplies group Gr = 4 t + 2 j + h.  Operand values
-  // that are not part of the sum - the pixels behind the end of a row in its last group (W not a multiple of 4: what the
-  // DMA fetched there belongs to the next row) and whole groups behind the K range (LDS keeps what an earlier stage left
-  // there) - are zeroed in the operand registers.  rr[j] = Gr mod gps.
-  const bool ragged = nvl < 4;
+  // ---- the reader's view of the stream: at step j this lane half multiplies group Gr = 4 t + 2 j + h, which is group
+  // rr[j] = Gr mod gps of its row.  Operand values that are not part of the sum - pixels behind the end of a row (W not a
+  // multiple of 4, phantom groups: what the DMA fetched there belongs to the next row) and whole groups behind the K range
+  // (LDS keeps what an earlier stage left there) - are zeroed in the operand registers, in a block that only the stages
+  // holding such a group enter (ru = 4 t mod gps, scalar: the stage's first group).
+  const bool maskable = (W & 3) != 0 || gps != ((W + 3) >> 2);
+  const int g_full = W >> 2;                               // groups of a row whose four pixels all exist
   int rr[STEPS];
 #pragma unroll
   for (int j = 0; j < STEPS; ++j) rr[j] = (SLOTS * t0 + 2 * j + h) % gps;
+  int ru = (SLOTS * t0) % gps;
   const int t_end = (g_tot - 1) / SLOTS;                   // the stage that holds the stream's last group
   const bool short_end = (g_tot & (SLOTS - 1)) != 0;
 
@@ -197,12 +206,12 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
     // MFMA groups (the last piece has more than half of the stage's MFMA time to land before the wait at the top)
     f32x4 a0 = rd(0, 0), a1 = rd(1, 0), b0 = rd(2, 0), b1 = rd(3, 0);
     f32x4 na0 = rd(0, 1), na1 = rd(1, 1), nb0 = rd(2, 1), nb1 = rd(3, 1);
-    if (ragged || (short_end && t == t_end)) {
+    if ((maskable && ru + SLOTS > g_full) || (short_end && t == t_end)) {
       asm volatile("; stream tail" ::: "memory");          // keeps this a branch around a VALU-only block
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const bool k0 = (rr[0] == gps - 1 && e >= nvl) || SLOTS * t + h >= g_tot;
-        const bool k1 = (rr[1] == gps - 1 && e >= nvl) || SLOTS * t + 2 + h >= g_tot;
+        const bool k0 = 4 * rr[0] + e >= W || SLOTS * t + h >= g_tot;
+        const bool k1 = 4 * rr[1] + e >= W || SLOTS * t + 2 + h >= g_tot;
         a0[e] = k0 ? 0.0f : a0[e]; a1[e] = k0 ? 0.0f : a1[e];
         na0[e] = k1 ? 0.0f : na0[e]; na1[e] = k1 ? 0.0f : na1[e];
         // (the B side too: 0 x Inf would put a NaN into sums the stray value has no part in)
@@ -219,11 +228,12 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
       piece(e, voff_n, nbuf);                  // one LDS-DMA piece behind a group of MFMAs: its issue cost hides under them
     }
     flat_mfma_step<PART>(na0, na1, nb0, nb1, c00, c01, c10, c11);
+    ru += SLOTS;
+    ru -= ru >= gps ? gps : 0;
 #pragma unroll
     for (int j = 0; j < STEPS; ++j) {
       rr[j] += SLOTS;
-      if (short_rows) rr[j] %= gps;
-      else if (rr[j] >= gps) rr[j] -= gps;
+      rr[j] -= rr[j] >= gps ? gps : 0;
     }
     if (t + 1 == seg_end) {
       // end of a segment of an unsliced item: scale, add into the factor, (last segment) write the mirror tile; the

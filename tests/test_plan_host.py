@@ -89,7 +89,7 @@ def test_plan_respects_budgets(d):
         # channels from 96 on), no bias row; K = the stream of the factor's 4-pixel groups (ceil(HW / 4) per sample, sample
         # after sample), in stages of four groups
         assert flat and not d["has_bias"] and p["dim"] % 16 == 0 and p["dim"] >= 96 and p["TM"] == 128
-        groups = d["N"] * -(-(Ho * Wo) // 4)
+        groups = d["N"] * max(-(-(Ho * Wo) // 4), 4)
         assert p["nchunks"] == -(-groups // 4)
         P = -(-p["dim"] // 128)
         assert p["ntiles"] == P * (P + 1) // 2 and p["nitems"] == p["ntiles"] * p["nslices"]
