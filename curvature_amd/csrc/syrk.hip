@@ -1115,18 +1115,24 @@ static int build_plan(const curv_factor_desc* descs, int n, Plan& plan) {
       chunk_cost[i] = 0.0;
       continue;
     }
-    if (!flattened && f.compact && s.ph == 0 && s.pw == 0 && !syrk_corr_eligible(s)) {
-      // 1x1 with a stride: X = src[:, :, ::sh, ::sw] is a flattened factor of the sampled pixels - which lie sh * sw apart
-      // in memory, nothing an LDS-DMA piece can fetch.  A pass of its own gathers them into a compact (N, C, Ho Wo) copy
-      // (ResNet-50's three down-sampling convolutions: 45 MB) and the factor joins the LDS-DMA work list; on the
-      // register-staged kernel these items ran at a few percent of the matrix pipe and kept it resident - holding half of
-      // their CUs' registers - for 5 ms beside the LDS-DMA kernel (round 5: 5 GFLOP of its 30)
+    if (!flattened && !f.has_bias && !syrk_corr_eligible(s)) {
+      // Everything else without a bias row whose width suits the LDS-DMA kernel - 1x1 with a stride (X = src[:, :, ::sh,
+      // ::sw]: the sampled pixels lie sh * sw apart in memory, nothing an LDS-DMA piece can fetch) and kh x kw > 1
+      // convolutions that the shifted correlations do not cover (stride 2: ResNet-50's layer2-4.0.conv2) - is UNFOLDED once:
+      // a pass of its own writes X = unfold(src) as a compact (N, C kh kw, Ho Wo) copy into the workspace area
+      // (curvature/curvatures.py:329 materialises the same matrix; ResNet-50: 45 + 202 MB) and the factor joins the LDS-DMA
+      // work list as a flattened factor of C kh kw rows.  On the register-staged kernel the strided 1x1 items ran at a few
+      // percent of the matrix pipe and kept it resident - holding half of their CUs' registers - for 5 ms beside the LDS-DMA
+      // kernel; the implicit-im2col kernel gathers every MFMA operand from the LDS image by 4-byte reads between scalar
+      // branches (0.60 of the pipe, round 6: 1.24 ms for what the LDS-DMA kernel does in 0.9).
       static const int sub_on = getenv("CURV_FLAT_SUB") ? atoi(getenv("CURV_FLAT_SUB")) : 1;
       FactorDev g = f;
-      g.H = 1; g.W = f.Ho * f.Wo; g.sh = g.sw = 1;
-      if (sub_on && (long long)f.Ho * f.Wo < (1LL << 30) && syrk_flat_eligible(g, reinterpret_cast<const void*>(16))) {
+      g.C = f.rows; g.H = 1; g.W = f.Ho * f.Wo; g.kh = g.kw = g.sh = g.sw = 1; g.ph = g.pw = 0; g.compact = 1;
+      if (sub_on && (long long)f.Ho * f.Wo < (1LL << 30) && (long long)f.N * f.rows * f.Ho * f.Wo < (1LL << 29) &&
+          syrk_flat_eligible(g, reinterpret_cast<const void*>(16))) {
         f.sub = 1;
-        f.H = 1; f.W = g.W; f.Ho = 1; f.Wo = g.W; f.sh = f.sw = 1;
+        f.C = g.C; f.H = 1; f.W = g.W; f.Ho = 1; f.Wo = g.W;
+        f.kh = f.kw = f.sh = f.sw = 1; f.ph = f.pw = 0; f.khkw = 1; f.compact = 1;
         f.xq_off = plan.area_floats;
         plan.area_floats += ((long long)f.N * f.C * f.W + 63) & ~63LL;
         flattened = true;

@@ -290,39 +290,53 @@ syrk_flat_kernel(const FactorDev* __restrict__ descs, int n_factors, int n_items
 }
 
 // ------------------------------------------------------------------------------------------------
-// compact copies of the sources of `sub` factors: out[n][c][oh][ow] = src[n][c][oh sh][ow sw]
+// unfolded copies of the sources of `sub` factors (curvature/curvatures.py:329, F.unfold: rows (c, kh, kw), columns (oh, ow)):
+//   out[n][(c, i, j)][oh][ow] = src[n][c][oh sh + i - ph][ow sw + j - pw]   (0 outside the image)
 // ------------------------------------------------------------------------------------------------
 struct SubDev {
   const float* src;
   float* out;
-  int H, W, sh, sw, Ho, Wo;
-  int planes;            // N * C
+  int C, H, W, kh, kw, sh, sw, ph, pw, Ho, Wo;
   int wg_base;           // first workgroup of this factor in the grid
+  long long words;       // N * C kh kw * Ho * Wo
 };
 constexpr int SUB_CHUNK = 16;
-constexpr int SUB_ROWS = 16;   // (plane, output row) pairs per workgroup
+constexpr int SUB_SEG = 2048;  // output words per workgroup: 8 per thread, stores coalesced
 struct SubChunk { SubDev f[SUB_CHUNK]; };
+static_assert(sizeof(SubChunk) <= 3840, "kernel argument block must stay below 4 KB");
 
-__global__ void __launch_bounds__(256) sub_prep_kernel(SubChunk chunk, int count) {
+__global__ void __launch_bounds__(256) unfold_prep_kernel(SubChunk chunk, int count) {
   int l = 0;
   while (l + 1 < count && chunk.f[l + 1].wg_base <= (int)blockIdx.x) ++l;
   const SubDev& d = chunk.f[l];
-  const int Wo = d.Wo, Ho = d.Ho;
-  const long long rows = (long long)d.planes * Ho;                 // output rows of the copy
-  const long long r0 = (long long)(blockIdx.x - d.wg_base) * SUB_ROWS;
+  const int Wo = d.Wo, Ho = d.Ho, kk = d.kh * d.kw, rows = d.C * kk;
+  const long long e0 = (long long)(blockIdx.x - d.wg_base) * SUB_SEG;
   const gfloat_t* src = (const gfloat_t*)d.src;
   gfloat_t* out = (gfloat_t*)d.out;
-  // a wave per output row at a time: lanes along ow (the source pixels of a row lie sw floats apart: every fetched
-  // 64-byte line gives 16 / sw of them)
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int k = wave; k < SUB_ROWS; k += 4) {
-    const long long r = r0 + k;
-    if (r >= rows) break;
-    const long long plane = r / Ho;
-    const int oh = (int)(r - plane * Ho);
-    const gfloat_t* s = src + (plane * d.H + (long long)oh * d.sh) * d.W;
-    gfloat_t* o = out + r * Wo;
-    for (int ow = lane; ow < Wo; ow += 64) o[ow] = s[ow * d.sw];
+  // eight elements per thread, all eight loads issued before the first store (the nine rows of a channel read the same
+  // input lines: the source is fetched from HBM once)
+  constexpr int U = SUB_SEG / 256;
+  float v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long long e = e0 + threadIdx.x + 256 * u;
+    v[u] = 0.0f;
+    if (e < d.words) {
+      const long long r = e / Wo;                      // (sample, row of X, oh)
+      const int ow = (int)(e - r * Wo);
+      const long long q = r / Ho;                      // (sample, row of X)
+      const int oh = (int)(r - q * Ho);
+      const long long n = q / rows;
+      const int row = (int)(q - n * rows);
+      const int c = row / kk, ij = row - c * kk, i = ij / d.kw, j = ij - i * d.kw;
+      const int ih = oh * d.sh + i - d.ph, iw = ow * d.sw + j - d.pw;
+      if (ih >= 0 && ih < d.H && iw >= 0 && iw < d.W) v[u] = src[((n * d.C + c) * d.H + ih) * d.W + iw];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long long e = e0 + threadIdx.x + 256 * u;
+    if (e < d.words) out[e] = v[u];
   }
 }
 
@@ -340,14 +354,14 @@ int launch_sub_prep(hipStream_t stream, const std::vector<FactorDev>& f, int n_u
       SubDev& d = chunk.f[k];
       d.src = s.src;
       d.out = area + f[i].xq_off;
-      d.H = s.H; d.W = s.W; d.sh = s.sh; d.sw = s.sw;
-      d.Ho = (s.H - 1) / s.sh + 1; d.Wo = (s.W - 1) / s.sw + 1;
-      d.planes = s.N * s.C;
+      d.C = s.C; d.H = s.H; d.W = s.W; d.kh = s.kh; d.kw = s.kw; d.sh = s.sh; d.sw = s.sw; d.ph = s.ph; d.pw = s.pw;
+      d.Ho = (s.H + 2 * s.ph - s.kh) / s.sh + 1; d.Wo = (s.W + 2 * s.pw - s.kw) / s.sw + 1;
+      d.words = (long long)s.N * s.C * s.kh * s.kw * d.Ho * d.Wo;
       d.wg_base = (int)wgs;
-      wgs += cdivll((long long)d.planes * d.Ho, SUB_ROWS);
-      CURV_REQUIRE(wgs < (1LL << 31), "curv_kfac: too many rows in a strided 1x1 source");
+      wgs += cdivll(d.words, SUB_SEG);
+      CURV_REQUIRE(wgs < (1LL << 31), "curv_kfac: unfolded sources too large for one pass");
     }
-    hipLaunchKernelGGL(sub_prep_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, chunk, count);
+    hipLaunchKernelGGL(unfold_prep_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, chunk, count);
     CURV_LAUNCH_CHECK();
   }
   return CURV_OK;

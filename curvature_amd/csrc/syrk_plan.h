@@ -61,9 +61,9 @@ struct FactorDev {
   // shifted correlations of a layer - are then neighbours in launch order and meet in an XCD's L2.  The range starts
   // at the first member's item_base; member j carries item_base + j only to keep the table's bases ascending.
   int group_n, group_pos;
-  // sub: a 1x1 convolution with stride > 1 (X = src[:, :, ::sh, ::sw]): the LDS-DMA kernel reads a compact copy of the
-  // sampled pixels (sub_prep_kernel writes it into the workspace area at xq_off; `src` of the device table entry points
-  // there, N / C / W describe the copy)
+  // sub: a strided 1x1 or a kh x kw > 1 convolution whose unfolded matrix X (C kh kw rows of Ho Wo pixels per sample) is
+  // written out once (unfold_prep_kernel, into the workspace area at xq_off) and then built by the LDS-DMA kernel as a
+  // flattened factor: `src` of the device table entry points at the copy, N / C (= rows) / W (= Ho Wo) describe it
   int sub, pad2;
   long long slab_base;     // in floats
   long long xq_off;        // pre: offset of the pre-tiled copy in the workspace area, in floats (host side only)
@@ -219,7 +219,7 @@ int curv_internal_side_stream(hipStream_t* out);
 
 // syrk_flat.hip: host launcher of the LDS-DMA kernel over a device table of dma factors
 int launch_syrk_flat(hipStream_t stream, const FactorDev* table, int n_factors, int n_items, float* slabs);
-// the compact copies of `sub` factors (one pass in front of the LDS-DMA kernel): descs = the caller's descriptors
+// the unfolded copies of `sub` factors (one pass in front of the LDS-DMA kernel): descs = the caller's descriptors
 int launch_sub_prep(hipStream_t stream, const std::vector<FactorDev>& f, int n_user, const curv_factor_desc* descs, float* area);
 // host-side eligibility / stage count of the LDS-DMA kernel
 bool syrk_flat_eligible(const FactorDev& f, const void* src);

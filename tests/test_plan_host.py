@@ -48,8 +48,8 @@ def test_plan_respects_budgets(d):
     Ho = (d["H"] + 2 * d["ph"] - d["kh"]) // d["sh"] + 1
     Wo = (d["W"] + 2 * d["pw"] - d["kw"]) // d["sw"] + 1
     flat = compact and d["sh"] == 1 and d["ph"] == 0
-    # 1x1 with a stride: flattened too - through a compact copy of the sampled pixels - when the LDS-DMA kernel takes it
-    sub = compact and d["sh"] > 1 and d["ph"] == 0 and p["dma"] == 1
+    # a strided 1x1 or a kh x kw > 1 convolution that the LDS-DMA kernel takes: flattened too - through its unfolded copy
+    sub = not flat and p["dma"] == 1
     if sub:
         assert not d["has_bias"] and p["dim"] % 16 == 0 and p["dim"] >= 96
     flat = flat or sub
