@@ -243,10 +243,12 @@ static void syrk_corr_expand_half(const curv_factor_desc& s, std::vector<FactorD
   L.comp_off = take(10LL * 128 * 128);
   for (int k = 0; k < CORR_COMPONENTS; ++k) L.comp_at[k] = -1;
   int tile = 0;
-  auto pair_tile = [&](long long src_off, int samples, int pitch, int K, int lead, int a1, int a2) {
+  auto pair_tile = [&](long long src_off, int samples, int pitch, int K, int lead, int a1, int a2, bool pad_k = false) {
     FactorDev v;
     memset(&v, 0, sizeof(v));
-    v.N = samples; v.C = 64; v.H = 1; v.W = K;
+    // (the rows the whole-image tiles read end in a zero tail: K rounded up to whole 4-pixel groups adds zeros to the sums
+    // and spares the LDS-DMA kernel its row-end masks; Wo keeps the true K for the flop count)
+    v.N = samples; v.C = 64; v.H = 1; v.W = pad_k ? (int)round_up4(K) : K;
     v.kh = v.kw = v.sh = v.sw = 1;
     v.Ho = 1; v.Wo = K; v.khkw = 1;
     v.rows = v.dim = 128;
@@ -256,7 +258,7 @@ static void syrk_corr_expand_half(const curv_factor_desc& s, std::vector<FactorD
     v.pitch = pitch; v.nonsym = 1; v.half = 1;
     v.off_i = lead + a1; v.off_i2 = lead + a2; v.off_j = lead; v.off_j2 = lead - 1;
     v.TM = 128; v.P = 1; v.n_tiles = 1;
-    v.n_chunks = syrk_flat_chunks(samples, K);
+    v.n_chunks = syrk_flat_chunks(samples, v.W);
     v.src = reinterpret_cast<const float*>(src_off);
     v.dst = reinterpret_cast<float*>(L.comp_off + (long long)tile * 128 * 128);
     f.push_back(v);
@@ -266,7 +268,7 @@ static void syrk_corr_expand_half(const curv_factor_desc& s, std::vector<FactorD
   // whole-image correlations
   const int rows8[4][2] = {{0, 1}, {Wp - 2, Wp}, {Wp + 1, 2 * Wp - 2}, {2 * Wp, 2 * Wp + 1}};
   for (int t4 = 0; t4 < 4; ++t4) {
-    const int t = pair_tile(L.xp_off, s.N, L.xp_pitch, plane, XP_LEAD, rows8[t4][0], rows8[t4][1]);
+    const int t = pair_tile(L.xp_off, s.N, L.xp_pitch, plane, XP_LEAD, rows8[t4][0], rows8[t4][1], true);
     f.back().group_n = 4; f.back().group_pos = t4;
     for (int hi = 0; hi < 2; ++hi)
       for (int hj = 0; hj < 2; ++hj) {
@@ -323,7 +325,9 @@ void syrk_corr_expand(const curv_factor_desc& s, int user, std::vector<FactorDev
   L.pt_pitch = (int)round_up4(s.N) + 4;
   auto take = [&](long long n) { const long long o = area_floats; area_floats += round_up4(n) + 64; return o; };
   // 64 channels: rows with a zero tail of two image rows (+ DMA slack) and XP_LEAD zeros in front of the array
-  const int xp_pitch = s.C == 64 ? (int)round_up4((long long)s.H * L.Wp + 2 * L.Wp + 12) : s.H * L.Wp;
+  // (128 channels and more: a zero tail of one group behind every row, so that a correlation's K = plane - delta rounds up to
+  // whole 4-pixel groups: the shifted panel reads zeros there and the LDS-DMA kernel needs no row-end masks)
+  const int xp_pitch = s.C == 64 ? (int)round_up4((long long)s.H * L.Wp + 2 * L.Wp + 12) : (int)round_up4((long long)s.H * L.Wp + 4);
   L.xp_off = take((long long)s.N * s.C * xp_pitch + (s.C == 64 ? XP_LEAD : 0));
   L.rowb_off = take((long long)s.C * L.row_pitch);
   L.rowt_off = take((long long)s.C * L.row_pitch);
@@ -332,15 +336,15 @@ void syrk_corr_expand(const curv_factor_desc& s, int user, std::vector<FactorDev
   L.pt_off = take(4LL * s.C * L.pt_pitch);
   if (s.C == 64) { syrk_corr_expand_half(s, f, L, area_floats); return; }
   L.n_vf = CORR_COMPONENTS;
-  L.xp_pitch = s.H * L.Wp;
+  L.xp_pitch = xp_pitch;
   L.comp_pitch = s.C;
   for (int k = 0; k < CORR_COMPONENTS; ++k) L.comp_at[k] = k * s.C * s.C;
   L.comp_off = take((long long)CORR_COMPONENTS * s.C * s.C);
 
-  auto add = [&](int comp, long long src_off, int samples, int pitch, int K, int off_i, int off_j, bool nonsym) {
+  auto add = [&](int comp, long long src_off, int samples, int pitch, int K, int off_i, int off_j, bool nonsym, bool pad_k = false) {
     FactorDev v;
     memset(&v, 0, sizeof(v));
-    v.N = samples; v.C = s.C; v.H = 1; v.W = K;
+    v.N = samples; v.C = s.C; v.H = 1; v.W = pad_k ? (int)round_up4(K) : K;
     v.kh = v.kw = v.sh = v.sw = 1;
     v.Ho = 1; v.Wo = K; v.khkw = 1;
     v.rows = v.dim = s.C;
@@ -351,7 +355,7 @@ void syrk_corr_expand(const curv_factor_desc& s, int user, std::vector<FactorDev
     v.TM = 128;
     v.P = s.C / 128;
     v.n_tiles = nonsym ? v.P * v.P : v.P * (v.P + 1) / 2;
-    v.n_chunks = syrk_flat_chunks(samples, K);
+    v.n_chunks = syrk_flat_chunks(samples, v.W);
     // src / dst: offsets into the correlation area for now (syrk_corr_bind turns them into pointers)
     v.src = reinterpret_cast<const float*>(src_off);
     v.dst = reinterpret_cast<float*>(L.comp_off + (long long)comp * s.C * s.C);
@@ -363,7 +367,7 @@ void syrk_corr_expand(const curv_factor_desc& s, int user, std::vector<FactorDev
     int dh, dw;
     if (k < 3) { dh = 0; dw = -k; } else { dh = -1 - (k - 3) / 5; dw = (k - 3) % 5 - 2; }
     const int delta = -(dh * L.Wp + dw);
-    add(f_index(dh, dw), L.xp_off, s.N, plane, plane - delta, delta, 0, delta != 0);
+    add(f_index(dh, dw), L.xp_off, s.N, L.xp_pitch, plane - delta, delta, 0, delta != 0, true);
     if (k >= 1) { f.back().group_n = 12; f.back().group_pos = k - 1; }      // the 12 non-symmetric ones: one item range
   }
   for (int a = 0; a < 3; ++a) add(RB0 + a, L.rowb_off, 1, L.row_pitch, s.N * L.Wp, LEAD, LEAD - a, a != 0);

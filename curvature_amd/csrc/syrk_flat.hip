@@ -202,23 +202,29 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
     advance();
     const unsigned buf = (unsigned)(t & 1) * PANEL_B, nbuf = PANEL_B - buf;
     auto rd = [&](int o, int j) { return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lds + addr[o][j] + buf); };
-    // straight line: the operands of both steps, then 2 x 16 MFMAs with the four pieces of stage t + 1 behind the first
-    // MFMA groups (the last piece has more than half of the stage's MFMA time to land before the wait at the top)
-    f32x4 a0 = rd(0, 0), a1 = rd(1, 0), b0 = rd(2, 0), b1 = rd(3, 0);
-    f32x4 na0 = rd(0, 1), na1 = rd(1, 1), nb0 = rd(2, 1), nb1 = rd(3, 1);
-    if ((maskable && ru + SLOTS > g_full) || (short_end && t == t_end)) {
-      asm volatile("; stream tail" ::: "memory");          // keeps this a branch around a VALU-only block
+    // straight line: per step four operand reads and 16 MFMAs, the four pieces of stage t + 1 behind the first step's MFMA
+    // groups (the last piece has more than half of the stage's MFMA time to land before the wait at the top).  A step
+    // whose lane halves hold a row end (or lie behind the stream's end) zeroes those operand values first - a VALU-only
+    // block per step, so that the second step's reads still issue under the first step's MFMAs (one block for the whole
+    // stage put all eight reads in front of the first MFMA: DenseNet-121 update() 7.6 -> 8.2 ms)
+    const bool tail_stage = (maskable && ru + SLOTS > g_full) || (short_end && t == t_end);
+    auto mask_step = [&](int j, f32x4& xa0, f32x4& xa1, f32x4& xb0, f32x4& xb1) {
+      if (tail_stage) {
+        asm volatile("; stream tail" ::: "memory");        // keeps this a branch around a VALU-only block
+        const bool gone = SLOTS * t + 2 * j + h >= g_tot;  // the whole group lies behind the K range
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool k0 = 4 * rr[0] + e >= W || SLOTS * t + h >= g_tot;
-        const bool k1 = 4 * rr[1] + e >= W || SLOTS * t + 2 + h >= g_tot;
-        a0[e] = k0 ? 0.0f : a0[e]; a1[e] = k0 ? 0.0f : a1[e];
-        na0[e] = k1 ? 0.0f : na0[e]; na1[e] = k1 ? 0.0f : na1[e];
-        // (the B side too: 0 x Inf would put a NaN into sums the stray value has no part in)
-        b0[e] = k0 ? 0.0f : b0[e]; b1[e] = k0 ? 0.0f : b1[e];
-        nb0[e] = k1 ? 0.0f : nb0[e]; nb1[e] = k1 ? 0.0f : nb1[e];
+        for (int e = 0; e < 4; ++e) {
+          const bool k = 4 * rr[j] + e >= W || gone;
+          xa0[e] = k ? 0.0f : xa0[e]; xa1[e] = k ? 0.0f : xa1[e];
+          // the B side only where LDS may hold anything (behind the stream's end nothing was fetched); behind a row's end
+          // it holds the next row's pixels, whose products with the A side's zeros vanish
+          xb0[e] = gone ? 0.0f : xb0[e]; xb1[e] = gone ? 0.0f : xb1[e];
+        }
       }
-    }
+    };
+    f32x4 a0 = rd(0, 0), a1 = rd(1, 0), b0 = rd(2, 0), b1 = rd(3, 0);
+    mask_step(0, a0, a1, b0, b1);
+    f32x4 na0 = rd(0, 1), na1 = rd(1, 1), nb0 = rd(2, 1), nb1 = rd(3, 1);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (PART != 3) c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], c00, 0, 0, 0);
@@ -227,6 +233,7 @@ __device__ __forceinline__ void flat_body(const FactorDev& d, int local, float* 
       if (PART != 2) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], c11, 0, 0, 0);
       piece(e, voff_n, nbuf);                  // one LDS-DMA piece behind a group of MFMAs: its issue cost hides under them
     }
+    mask_step(1, na0, na1, nb0, nb1);
     flat_mfma_step<PART>(na0, na1, nb0, nb1, c00, c01, c10, c11);
     ru += SLOTS;
     ru -= ru >= gps ? gps : 0;
