@@ -647,6 +647,109 @@ outer_update_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int 
   outer_update_body<2>(t, nf, k0, kend, lo, hi, strip, n_items, As, Bs);
   if (!strip) KT_END(255)
 }
+// ------------------------------------------------------------------------------------------------
+// The far update of KFAC.invert's sweeps (trailing tiles only: their inverse is accumulated elsewhere, in fp32) with
+// LDS-DMA staging (round 6).  outer_update_kernel stages its operands through registers: per K step of 16 a burst of
+// global loads, a pass of LDS stores, two barriers, and operand reads of 8 bytes issued right in front of the MFMAs that
+// wait for them (0.51 of the fp64 pipe inside a whole-model sweep, 47 TFLOP/s on one panel of three 4608-wide factors).
+// Here (tools/micro/far_update_forms.hip: 58 TFLOP/s on the same panel, the same bits):
+//   * buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, into a double-buffered image [64 rows][8 x 16 B] per operand
+//     (16 k per stage); the 16-byte slots XOR-swizzled by (row >> 1) & 7 on the SOURCE side (the DMA writes lane-linear
+//     bytes), so that the 16 rows x one slot of an operand read cover all 64 banks;
+//   * operands by ds_read_b128: two k per read; lane quarter kq multiplies k = 8 h + 2 kq + d at MFMA (h, d) of a stage -
+//     a product only needs both operands to agree on the order of its k;
+//   * one barrier per stage, no staging registers, no LDS stores: 66 registers, 32 KiB of LDS, four workgroups per CU.
+// Tiles, super-block order and the read-modify-write epilogue are outer_update_body's; fp64 sums of the same products in
+// another order (the K order inside a stage differs): results agree to rounding, not bit for bit, with the register-staged
+// form - every launch form of a sweep uses this kernel for its far updates, so sharded and unsharded runs still agree.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+namespace fard {
+constexpr int ROW_B = 128, TILE_B = NB * ROW_B, KS = 16;
+}
+__global__ void __launch_bounds__(INV_THREADS, 4)
+outer_update_dma_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int row0, int n_items) {
+  using namespace fard;
+  __shared__ __attribute__((aligned(1024))) char smem[4 * TILE_B];     // [A buf0][A buf1][B buf0][B buf1]
+  lds_char* lds = (lds_char*)smem;
+  int item;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3;           // whole super-blocks per XCD (see outer_update_body)
+    item = ((jj / (SB * SB)) * 8 + xcd) * (SB * SB) + (jj % (SB * SB));
+  }
+  if (item >= n_items) return;
+  int f, local;
+  if (!locate(t, nf, item, [kend, row0](const InvDev& d) { return (int)outer_tiles(d.P, kend, row0, false); }, f, local)) return;
+  const InvDev& d = t[f];
+  int i, j;
+  {
+    const int r = d.P - row0;
+    const int sb = local / (SB * SB), in = local - sb * (SB * SB);
+    const int di = in / SB, dj = in - di * SB;
+    int a = 0, tl = sb;
+    while (tl > a) { tl -= a + 1; ++a; }
+    const int ri = a * SB + di, rj = tl * SB + dj;                      // relative to row0
+    if (ri >= r || rj > ri) return;
+    i = row0 + ri; j = row0 + rj;
+  }
+  const int np = d.np;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const bool same = i == j;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.W, 0, (unsigned)((long long)np * np * 8), 0x00020000);
+  // DMA lane geometry: piece p (8 rows x 128 B) of an operand = rows 8 p ..; this wave moves pieces `wave` and `wave + 4`
+  // (32 rows apart: the same swizzle key)
+  const int drow = 8 * wave + (lane >> 3);
+  const int voff = (drow * np) * 8 + (((lane & 7) ^ ((drow >> 1) & 7)) << 4);
+  const int soff_a = (i * NB * np) * 8, soff_b = (j * NB * np) * 8, half_b = 32 * np * 8;
+  auto issue = [&](int ke, unsigned buf) {
+    const int kb = ke * 8;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + buf + wave * 1024), 16, voff, soff_a + kb, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + buf + (wave + 4) * 1024), 16, voff, soff_a + half_b + kb, 0, 0);
+    if (!same) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + 2 * TILE_B + buf + wave * 1024), 16, voff, soff_b + kb, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + 2 * TILE_B + buf + (wave + 4) * 1024), 16, voff, soff_b + half_b + kb, 0, 0);
+    }
+  };
+  // operand addresses: block m (16 rows), half h: row * 128 + ((kq + 4 h) ^ key) * 16
+  unsigned addr_a[2], addr_b[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int ra = 32 * wm + 16 * m + r16, rb = 32 * wn + 16 * m + r16;
+    addr_a[m] = ra * ROW_B + ((kq ^ ((ra >> 1) & 7)) << 4);
+    addr_b[m] = (same ? 0 : 2 * TILE_B) + rb * ROW_B + ((kq ^ ((rb >> 1) & 7)) << 4);
+  }
+  f64x4 acc[2][2] = {};
+  const int ke0 = k0 * NB, n_st = (kend - k0) * NB / KS;
+  issue(ke0, 0);
+  for (int st = 0; st < n_st; ++st) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's pieces of stage st have landed
+    __syncthreads();                           // everyone's have; everyone is done reading the other buffer
+    const unsigned buf = (st & 1) * TILE_B;
+    if (st + 1 < n_st) issue(ke0 + KS * (st + 1), TILE_B - buf);
+    f64x2 av[2][2], bv[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        av[m][h] = *reinterpret_cast<const __attribute__((address_space(3))) f64x2*>(lds + buf + (addr_a[m] ^ (h << 6)));
+        bv[m][h] = *reinterpret_cast<const __attribute__((address_space(3))) f64x2*>(lds + buf + (addr_b[m] ^ (h << 6)));
+      }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m][h][dd], bv[n][h][dd], acc[m][n], 0, 0, 0);
+  }
+  store_acc((gdouble*)d.W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);
+}
+
 __global__ void __launch_bounds__(1024)
 outer_update_wide_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int lo, int hi, int strip, int n_items) {
   __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
@@ -2001,9 +2104,11 @@ struct GroupSweep {
     // "mid" strip so that a far update has two chain periods before anything waits for it was measured
     // 2-4 % slower: the far updates are throughput-bound, not waited for.)
     long long near_tiles = 0, far_tiles = 0;
+    bool any_s_part = false;
     for (const InvDev& d : tab) {
       near_tiles += strip_tiles(d.P, kend, kend, row0, s_in_sweep(d));
       far_tiles += outer_tiles(d.P, kend, row0, s_in_sweep(d));
+      any_s_part = any_s_part || s_in_sweep(d);
     }
     static const int near_side = getenv("CURV_NEAR_SIDE") ? atoi(getenv("CURV_NEAR_SIDE")) : 0;
     static const int inv_stream = getenv("CURV_INV_STREAM") ? atoi(getenv("CURV_INV_STREAM")) : 0;
@@ -2054,8 +2159,14 @@ struct GroupSweep {
       const long long grid = cdivll(far_tiles, 8 * SB * SB) * 8 * SB * SB;
       const bool ride = ext_events != 0 && !capturing && !near_side;
       const InvDev* tb = table;
-      hipExtLaunchKernelGGL(outer_update_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, side->stream, nullptr,
-                            ride ? side->ev_side[panel & 1] : nullptr, 0, tb, n_factors, k0, kend, row0, 0, 0, (int)far_tiles);
+      // trailing tiles only (KFAC.invert: the inverse is accumulated in fp32 off the chain): the LDS-DMA form
+      static const int far_dma = getenv("CURV_FAR_DMA") ? atoi(getenv("CURV_FAR_DMA")) : 1;
+      if (far_dma && !any_s_part)
+        hipExtLaunchKernelGGL(outer_update_dma_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, side->stream, nullptr,
+                              ride ? side->ev_side[panel & 1] : nullptr, 0, tb, n_factors, k0, kend, row0, (int)far_tiles);
+      else
+        hipExtLaunchKernelGGL(outer_update_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, side->stream, nullptr,
+                              ride ? side->ev_side[panel & 1] : nullptr, 0, tb, n_factors, k0, kend, row0, 0, 0, (int)far_tiles);
       CURV_LAUNCH_CHECK();
       if (!near_side) {
         if (!ride) CURV_HIP_CHECK(hipEventRecord(side->ev_side[panel & 1], side->stream));
