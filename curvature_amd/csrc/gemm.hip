@@ -661,8 +661,8 @@ static bool gemv_eligible(const curv_gemm_desc& s) {
 
 static bool nt_eligible(const curv_gemm_desc& s) {
   const long long a_ext = ((long long)(s.M - 1) * s.a_rs + s.K) * 4, b_ext = ((long long)(s.N - 1) * s.b_cs + s.K) * 4;
-  return s.a_cs == 1 && s.b_rs == 1 && s.M >= 64 && s.N >= 64 && s.K >= 8 && a_ext < (1LL << 32) - 64 &&
-         b_ext < (1LL << 32) - 64;
+  return s.a_cs == 1 && s.b_rs == 1 && s.M >= 64 && s.N >= 64 && s.K >= 8 && a_ext < (1LL << 31) - 64 &&   // (31 bits: bit 31 of a lane offset marks "no fetch", gemm_nt.h)
+         b_ext < (1LL << 31) - 64;
 }
 static long long nt_tiles_of(const curv_gemm_desc* descs, int n_desc) {
   long long t = 0;

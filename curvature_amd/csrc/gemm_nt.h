@@ -102,9 +102,10 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmDev& d, int local, lds_ch
     inner = kb + d.kslice < K;
     K = min(K, kb + d.kslice);
   }
-  const int TS = (K - kb + 7) >> 3;                  // steps of 8 k
-  const int n_stages = (TS + STEPS - 1) / STEPS;
-  const int nv_last = (cut || inner) ? 8 : K - kb - 8 * (TS - 1);   // k values of the last step that exist (beyond a cut: stored zeros)
+  (void)cut; (void)inner;
+  const int n_stages = (K - kb + KC - 1) / KC;
+  // the last stage holds k values at or behind K when the range is no multiple of KC (never behind a triangular cut or
+  // inside a split: those end on whole tiles / slices): what the DMA leaves there is zeroed in the operand registers
 
   // DMA lane geometry (see syrk_flat.hip): piece `slot` of this wave covers panel rows 32 slot + 8 wave + (lane >> 3)
   const int rsub = RPP * wave + (lane >> LANES_PER_ROW_SHIFT);
@@ -131,71 +132,59 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmDev& d, int local, lds_ch
   }
   f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
 
-  int n_k0 = 0, n_gmax = 0;
-  unsigned n_buf = 0;
-  auto plan_next = [&](int t) {
-    n_k0 = kb + t * KC;
-    n_gmax = min(SLOTS, (K - n_k0 + 3) >> 2);      // 16-byte groups this stage needs
-    n_buf = (unsigned)(t & 1) * PANEL_B;
-  };
-  auto piece = [&](int i) {
+  // Every stage runs as straight-line code (round 6, as syrk_flat.hip: the round-5 form carried step counts, the k tail and
+  // the DMA predicate as run-time conditions, i.e. a scalar branch around every group of MFMAs and an exec-mask change
+  // around every piece).  A lane whose 16-byte group lies at or behind K - or any lane behind the item's last stage -
+  // carries an out-of-range voffset instead (the descriptor's range check drops the fetch; operand extents stay below
+  // 2^31 bytes: launch_gemm_nt's eligibility).
+  constexpr int OOB = (int)0x80000000;
+  auto issue = [&](int i, bool live, int k0n, unsigned nbuf) {
     const int p = i / PIECES, slot = i % PIECES;
-    if (g_lane < n_gmax) {
-      const unsigned lbase = (p ? 2u * PANEL_B : 0u) + n_buf + (unsigned)(RPP * wave + 4 * RPP * slot) * ROW_B;
-      if (p == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_void_t*)(lds + lbase), 16, voff_a[slot], n_k0 * 4, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_void_t*)(lds + lbase), 16, voff_b[slot], n_k0 * 4, 0, 0);
-    }
+    const unsigned lbase = (p ? 2u * PANEL_B : 0u) + nbuf + (unsigned)(RPP * wave + 4 * RPP * slot) * ROW_B;
+    if (p == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_void_t*)(lds + lbase), 16, live ? voff_a[slot] : OOB, k0n * 4, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_void_t*)(lds + lbase), 16, live ? voff_b[slot] : OOB, k0n * 4, 0, 0);
   };
-
   if (n_stages > 0) {
-    plan_next(0);
+    const bool live = kb + 4 * g_lane < K;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) piece(i);
+    for (int i = 0; i < NP; ++i) issue(i, live, kb, 0u);
   }
   for (int t = 0; t < n_stages; ++t) {
     __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's DMA of stage t has landed
     __syncthreads();
     const bool more = t + 1 < n_stages;
-    if (more) plan_next(t + 1);
-    const int nsteps = min(STEPS, TS - t * STEPS);
-    const bool last = !more;
-    const unsigned buf = (unsigned)(t & 1) * PANEL_B;
+    const int k0n = kb + (t + 1) * KC;
+    const bool live_n = more && k0n + 4 * g_lane < K;
+    const unsigned buf = (unsigned)(t & 1) * PANEL_B, nbuf = PANEL_B - buf;
+    const int kbase = kb + t * KC;
+    const bool tail_stage = kbase + KC > K;    // (the last stage of a range that is no multiple of KC)
     auto rd = [&](int o, int j) { return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lds + addr[o][j] + buf); };
-    f32x4 a0 = rd(0, 0), a1 = rd(1, 0), b0 = rd(2, 0), b1 = rd(3, 0);
-    int next_piece = 0;
-#pragma unroll
-    for (int j = 0; j < STEPS; ++j) {
-      if (j < nsteps) {
-        f32x4 na0, na1, nb0, nb1;
-        if (j + 1 < STEPS && j + 1 < nsteps) { na0 = rd(0, j + 1); na1 = rd(1, j + 1); nb0 = rd(2, j + 1); nb1 = rd(3, j + 1); }
-        int ne = 4;
-        if (last && j == nsteps - 1 && nv_last < 8) {
-          ne = min(4, nv_last);
-          asm volatile("; k tail" ::: "memory");             // keeps this a branch (see syrk_flat.hip)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const bool ok = (4 * h + e) < nv_last;
-            a0[e] = ok ? a0[e] : 0.0f; a1[e] = ok ? a1[e] : 0.0f;
-            b0[e] = ok ? b0[e] : 0.0f; b1[e] = ok ? b1[e] : 0.0f;
-          }
-        }
+    auto mask_step = [&](int j, f32x4& xa0, f32x4& xa1, f32x4& xb0, f32x4& xb1) {
+      if (tail_stage) {
+        asm volatile("; k tail" ::: "memory");             // keeps this a branch around a VALU-only block
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (e < ne) {
-            c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], c00, 0, 0, 0);
-            c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], c01, 0, 0, 0);
-            c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], c10, 0, 0, 0);
-            c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], c11, 0, 0, 0);
-          }
-          if (more && e < PPS && PPS * j + e < NP) piece(PPS * j + e);
+          const bool gone = kbase + 4 * (2 * j + h) + e >= K;
+          xa0[e] = gone ? 0.0f : xa0[e]; xa1[e] = gone ? 0.0f : xa1[e];
+          xb0[e] = gone ? 0.0f : xb0[e]; xb1[e] = gone ? 0.0f : xb1[e];
         }
-        next_piece = min(NP, PPS * j + PPS);
-        if (j + 1 < STEPS && j + 1 < nsteps) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
       }
-    }
-    if (more) {
+    };
+    f32x4 a0 = rd(0, 0), a1 = rd(1, 0), b0 = rd(2, 0), b1 = rd(3, 0);
 #pragma unroll
-      for (int i = 0; i < NP; ++i) if (i >= next_piece) piece(i);
+    for (int j = 0; j < STEPS; ++j) {
+      mask_step(j, a0, a1, b0, b1);
+      f32x4 na0, na1, nb0, nb1;
+      if (j + 1 < STEPS) { na0 = rd(0, j + 1); na1 = rd(1, j + 1); nb0 = rd(2, j + 1); nb1 = rd(3, j + 1); }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], c11, 0, 0, 0);
+        if (e < PPS && PPS * j + e < NP) issue(PPS * j + e, live_n, k0n, nbuf);     // one piece behind a group of MFMAs
+      }
+      if (j + 1 < STEPS) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
     }
   }
 
