@@ -575,7 +575,8 @@ __device__ __forceinline__ void outer_update_body(const InvDev* __restrict__ t, 
                                                   int strip, int n_items, double* __restrict__ As, double* __restrict__ Bs) {
   bool trailing;
   int i, j, f, local;
-  if (strip) {
+  const bool s_only = strip == 2;            // far launch of the S tiles alone (the trailing tiles went to outer_update_dma_kernel)
+  if (strip == 1) {
     // strip: block columns / rows [lo, hi)
     if (!locate(t, nf, blockIdx.x, [kend, lo, hi](const InvDev& d) { return (int)strip_tiles(d.P, kend, lo, hi, s_in_sweep(d)); }, f, local))
       return;
@@ -601,12 +602,14 @@ __device__ __forceinline__ void outer_update_body(const InvDev* __restrict__ t, 
       item = ((jj / (SB * SB)) * 8 + xcd) * (SB * SB) + (jj % (SB * SB));
     }
     if (item >= n_items) return;
-    if (!locate(t, nf, item, [kend, row0](const InvDev& d) { return (int)outer_tiles(d.P, kend, row0, s_in_sweep(d)); }, f, local)) return;
+    if (!locate(t, nf, item, [kend, row0, s_only](const InvDev& d) {
+          const int all = (int)outer_tiles(d.P, kend, row0, s_in_sweep(d));
+          return s_only ? all - (int)outer_tiles(d.P, kend, row0, false) : all; }, f, local)) return;
     const int r = t[f].P - row0;
     const int nsb = (r + SB - 1) / SB;
-    const int sb = local / (SB * SB), in = local - sb * (SB * SB);
-    const int di = in / SB, dj = in - di * SB;
     const int n_trail_sb = nsb * (nsb + 1) / 2;
+    const int sb = local / (SB * SB) + (s_only ? n_trail_sb : 0), in = local % (SB * SB);
+    const int di = in / SB, dj = in - di * SB;
     if (sb < n_trail_sb) {
       int a = 0, tl = sb;
       while (tl > a) { tl -= a + 1; ++a; }
@@ -2164,7 +2167,24 @@ struct GroupSweep {
       if (far_dma && !any_s_part)
         hipExtLaunchKernelGGL(outer_update_dma_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, side->stream, nullptr,
                               ride ? side->ev_side[panel & 1] : nullptr, 0, tb, n_factors, k0, kend, row0, (int)far_tiles);
-      else
+      else if (far_dma) {
+        // a sweep that accumulates its inverse itself (curv_chol_factor_inverse, INF's fp64 chain): the trailing tiles on the
+        // LDS-DMA form, the S tiles (B operand as [k][col]) on the register-staged one, one launch each
+        long long trail = 0;
+        for (const InvDev& d : tab) trail += outer_tiles(d.P, kend, row0, false);
+        const long long s_tiles = far_tiles - trail;
+        if (trail > 0) {
+          const long long g1 = cdivll(trail, 8 * SB * SB) * 8 * SB * SB;
+          hipExtLaunchKernelGGL(outer_update_dma_kernel, dim3((unsigned)g1), dim3(INV_THREADS), 0, side->stream, nullptr,
+                                (ride && s_tiles == 0) ? side->ev_side[panel & 1] : nullptr, 0, tb, n_factors, k0, kend, row0, (int)trail);
+          CURV_LAUNCH_CHECK();
+        }
+        if (s_tiles > 0) {
+          const long long g2 = cdivll(s_tiles, 8 * SB * SB) * 8 * SB * SB;
+          hipExtLaunchKernelGGL(outer_update_kernel, dim3((unsigned)g2), dim3(INV_THREADS), 0, side->stream, nullptr,
+                                ride ? side->ev_side[panel & 1] : nullptr, 0, tb, n_factors, k0, kend, row0, 0, 2, (int)s_tiles);
+        }
+      } else
         hipExtLaunchKernelGGL(outer_update_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, side->stream, nullptr,
                               ride ? side->ev_side[panel & 1] : nullptr, 0, tb, n_factors, k0, kend, row0, 0, 0, (int)far_tiles);
       CURV_LAUNCH_CHECK();
