@@ -38,11 +38,12 @@ def rank_cost(dims: Sequence[Sequence[float]], estimator: str = "kfac", rank: in
 
     Not additive: the factors of a rank are inverted in one batched sweep, so the serial chains of 64-column steps
     overlap and only the longest one counts, and every phase pays a fixed price for its launches however little work
-    they carry (a rank with ten small layers is bound by that, not by flops).  Calibrated on one MI355X
-    (tools/emulate_sharding.py, profiles/r03_emulate_sharding.txt): single 4608^2 factor 2.65 ms = 72 steps x 37 us
-    when the call has at most 64 factors (the library then sweeps a panel's block square in one launch), 48 us per step
-    otherwise; three of them 5.2 ms, all 108 ResNet-50 factors 8.4 ms; grouped factor build 95 TFLOP/s executed for a whole
-    model, ~60 for a rank's share; sampling GEMMs 95 TFLOP/s.
+    they carry (a rank with ten small layers is bound by that, not by flops).  Calibrated on one MI355X with the round-6
+    kernels (tools/emulate_sharding.py, profiles/r06_emulate_sharding.txt): a single 4608^2 factor inverts in 2.48 ms =
+    72 steps x 34.5 us when the call has at most 64 factors (the library then sweeps a panel's block square in one
+    launch), 40 us per step otherwise (the 108 ResNet-50 factors: 6.45 ms); grouped factor build 100 TFLOP/s executed for
+    a whole model (5.6 ms for 526 GFLOP) on top of ~0.3 ms of fixed passes; sampling products 0.96 ms for the model's
+    156 GFLOP (dense count; half of it is cut away by the triangles), 0.32 ms for one 4608 x 512 layer.
 
     `estimator`: "kfac" prices update + invert + sample_and_replace of KFAC; "efb" adds the eigendecomposition of the
     rank's factors (HBM-bound block-Jacobi: ~2.8e-12 s per n^3, and never faster than the serial chain of the
@@ -52,11 +53,12 @@ def rank_cost(dims: Sequence[Sequence[float]], estimator: str = "kfac", rank: in
     if not dims:
         return 0.0
     flops = sum(d[3] if len(d) > 3 else (d[0] * (d[0] + 1.0) + d[1] * (d[1] + 1.0)) * d[2] for d in dims)
-    build = 0.25e-3 + 0.035e-3 * min(len(dims), 10) + flops / 70e12
-    sample = 0.15e-3 + sum(2.0 * (d[0] * d[0] * d[1] + d[0] * d[1] * d[1]) for d in dims) / 95e12 + 6e-6 * len(dims)
-    chain = max(max(d[0], d[1]) for d in dims) / 64.0 * (37e-6 if 2 * len(dims) <= 64 else 48e-6)
-    # (round 5: the triangular inverse runs in fp32 off the chain - 6.8 ms for the 108 ResNet-50 factors, 2.7 ms for one 4608^2)
-    invert = 0.3e-3 + 0.7 * chain + sum((2.0 / 3.0) * (d[0] ** 3 + d[1] ** 3) for d in dims) / 50e12 + 6e-6 * len(dims)
+    build = 0.25e-3 + 0.035e-3 * min(len(dims), 10) + flops / 100e12
+    sample = 0.2e-3 + sum(2.0 * (d[0] * d[0] * d[1] + d[0] * d[1] * d[1]) for d in dims) / 200e12 + 2e-6 * len(dims)
+    chain = max(max(d[0], d[1]) for d in dims) / 64.0 * (34.5e-6 if 2 * len(dims) <= 64 else 40e-6)
+    # (the triangular inverse runs in fp32 off the chain, the far updates through LDS-DMA: 6.45 ms for the 108 ResNet-50
+    # factors, 2.48 ms for one 4608^2)
+    invert = 0.2e-3 + 0.7 * chain + sum((2.0 / 3.0) * (d[0] ** 3 + d[1] ** 3) for d in dims) / 75e12 + 6e-6 * len(dims)
     total = build + invert + sample
     if estimator in ("efb", "inf"):
         n3 = sum(float(d[0]) ** 3 + float(d[1]) ** 3 for d in dims)

@@ -104,11 +104,42 @@ def main():
             for h in kfac.hooks:
                 h.remove()
             del kfac
+        copies_ms = 0.0
+        if world > 1 and not chain:
+            # the device copies around the collective, MEASURED (the collective itself cannot run on one GPU): rank 0's
+            # batched pack of its own parameters into the flat vector, the padded staging copies of the default
+            # (torch all_gather_into_tensor) path, and the batched unpack of the other ranks' segments
+            from curvature_amd import ops
+            params = [[p.detach().reshape(-1) for p in (l.weight, l.bias) if p is not None] for l in layers]
+            sizes = [0] * world
+            for i, ps in enumerate(params):
+                sizes[owner[i]] += sum(p.numel() for p in ps)
+            displs = [sum(sizes[:r]) for r in range(world)]
+            flat = torch.zeros(sum(sizes), device=dev)
+            cursor, pack, unpack = list(displs), [], []
+            for i, ps in enumerate(params):
+                for p in ps:
+                    seg = flat[cursor[owner[i]]:cursor[owner[i]] + p.numel()]
+                    (pack if owner[i] == 0 else unpack).append((seg, p) if owner[i] == 0 else (p, seg))
+                    cursor[owner[i]] += p.numel()
+            pack_plan = ops.CopyPlan([d for d, _ in pack], [s_ for _, s_ in pack])
+            unpack_plan = ops.CopyPlan([d for d, _ in unpack], [s_ for _, s_ in unpack])
+            cap = max(sizes)
+            mine, gathered = torch.zeros(cap, device=dev), torch.empty(world * cap, device=dev)
+
+            def copies():
+                pack_plan.run()
+                mine[:sizes[0]].copy_(flat[:sizes[0]])
+                for r in range(1, world):
+                    flat[displs[r]:displs[r] + sizes[r]].copy_(gathered[r * cap:r * cap + sizes[r]])
+                unpack_plan.run()
+            copies_ms = timed(copies, 10)
         mx = max(times)
         n_params = sum(n * m for n, m, *_ in dims)
         gather_ms = 0.0 if world == 1 else (4.0 * n_params * (world - 1) / world / 300e9 + 20e-6 * world) * 1e3
         print(f"world {world}: per-rank ms " + " ".join(f"{t:.1f}" for t in times) + f" -> slowest rank {mx:.1f} ms + MODELLED "
-              f"all-gather {gather_ms:.2f} ms ({4.0 * n_params / 1e6:.0f} MB vector, variable counts, unpadded) = {mx + gather_ms:.1f} ms")
+              f"all-gather {gather_ms:.2f} ms ({4.0 * n_params / 1e6:.0f} MB vector, variable counts, unpadded) + MEASURED pack / "
+              f"staging / unpack copies {copies_ms:.2f} ms = {mx + gather_ms + copies_ms:.1f} ms")
 
 
 if __name__ == "__main__":
