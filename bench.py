@@ -823,7 +823,7 @@ def main():
     # The figure is only reported while the factor-build sources are the ones it was measured on (`source_sha16` of the
     # file = sha256 over csrc/syrk*.hip + syrk_plan.h, written by tools/collect_profiles.sh); otherwise null.
     traffic, traffic_source = None, None
-    for name in ("r05_syrk_pmc.json",):
+    for name in ("r06_syrk_pmc.json",):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if world == 1 and args.batch == 32 and os.path.exists(pmc_path):
             try:

@@ -61,7 +61,7 @@ def test_cpu_leg_takes_the_smallest_thread_count_near_the_fastest_probe(bench):
 
 
 def test_traffic_file_is_tied_to_the_factor_build_sources(bench):
-    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_syrk_pmc.json")))
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r06_syrk_pmc.json")))
     assert len(bench.syrk_source_sha16()) == 16
     # the committed counter file belongs to the committed factor-build sources: otherwise `roofline.traffic` is withheld
     assert rec.get("source_sha16") == bench.syrk_source_sha16(), "re-run tools/collect_profiles.sh: the factor-build sources changed"

@@ -4,7 +4,7 @@
 # 2) PMC passes of bench.py (separate passes: TCC slots; the program itself after `--`)
 #      FETCH_SIZE | WRITE_SIZE | SQ instruction / MFMA counters | SQ wait counters  -> gpurun_out/<round>_kernels_pmc.json
 # 3) the same passes for the eigensolver (the 108 ResNet-50 factors, tools/eigh_r50.py) -> gpurun_out/<round>_eigh_pmc.json
-R=${1:-r05}
+R=${1:-r06}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT

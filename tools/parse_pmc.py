@@ -12,7 +12,7 @@ import glob
 import json
 import sys
 
-DEFAULT = ["syrk_pre_kernel", "syrk_patch_kernel", "syrk_flat_kernel", "patch_prep_kernel", "syrk_reduce_kernel", "gemv_rows_kernel", "outer_update_kernel", "outer_update_wide_kernel",
+DEFAULT = ["syrk_pre_kernel", "syrk_patch_kernel", "syrk_flat_kernel", "patch_prep_kernel", "unfold_prep_kernel", "syrk_reduce_kernel", "gemv_rows_kernel", "outer_update_kernel", "outer_update_dma_kernel", "outer_update_wide_kernel",
            "inner_update_kernel", "panel_product_kernel", "panel_product_wide_kernel", "chol_diag_kernel", "chol_panel_kernel",
            "supd32_kernel", "xrows32_kernel",
            "gemm_f32_kernel", "gemm_nt_kernel", "gemm_f64_kernel", "corr_prep_kernel", "corr_assemble_kernel", "jacobi_pair_kernel", "jacobi_rows_kernel", "jacobi_cols_kernel"]
@@ -89,8 +89,8 @@ def main():
         # bench.py's `roofline.traffic`: HBM bytes of ONE update(), everything inside the timed window: the padding /
         # pre-tiling passes, the three MFMA kernels, the k-slice reductions and the 3x3 assembly.  Per kernel: average
         # bytes per launch x launches per update (= its launches / the launches of syrk_flat_kernel, one per update)
-        names = ("corr_prep_kernel", "patch_prep_kernel", "syrk_pre_kernel", "syrk_patch_kernel", "syrk_flat_kernel",
-                 "syrk_reduce_kernel", "corr_assemble_kernel")
+        names = ("corr_prep_kernel", "patch_prep_kernel", "unfold_prep_kernel", "syrk_pre_kernel", "syrk_patch_kernel",
+                 "syrk_flat_kernel", "syrk_reduce_kernel", "corr_assemble_kernel")
         parts = {k: summarise(root, k) for k in names}
         parts = {k: v for k, v in parts.items() if v}
         updates = max(parts.get("syrk_flat_kernel", {}).get("launches_profiled", 1), 1)
