@@ -1,10 +1,11 @@
-// KFAC factor build for FLATTENED per-pixel factors on gfx950 (1x1 stride-1 convolutions' A side and every G side,
-// curvature/curvatures.py:329-350 with kernel 1x1: X_s = src[s] is a (C x HW) row-major matrix per sample and
+// KFAC factor build for factors whose rows are CONTIGUOUS in memory on gfx950 - flattened per-pixel factors (1x1 stride-1
+// convolutions' A side and every G side, curvature/curvatures.py:329-350 with kernel 1x1: X_s = src[s] is a (C x HW)
+// row-major matrix per sample), the components of the shifted correlations (syrk_corr.hip) and, since round 6, the unfolded
+// copies of stride-2 3x3 and strided 1x1 convolutions (unfold_prep_kernel below) -
 //   slab(tile, slice) = sum over the slice's (sample, pixel) of X[rows_i][k] X[rows_j][k]
-// for every upper-triangular 128x128 tile.  About a third of a ResNet's factor-build flops, and the class the
-// implicit-im2col kernel of syrk.hip serves worst: there is no im2col reuse, so a tile streams 2 x 128 rows x K
-// floats, and staging them through registers (load burst, LDS store pass, barrier) left the matrix pipe idle two
-// thirds of the time.  Here:
+// for every upper-triangular 128x128 tile: five sixths of a ResNet-50's factor-build window.  There is no im2col reuse in
+// such a factor: a tile streams 2 x 128 rows x K floats, and staging them through registers (load burst, LDS store pass,
+// barrier) left the matrix pipe idle two thirds of the time.  Here:
 //   * LDS-DMA staging: buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, straight from global memory into a
 //     double-buffered LDS image - no staging registers, no store pass, no vector-ALU work; the pieces of stage t + 1 are
 //     issued behind the first MFMA groups of stage t and have the rest of the stage to land;
@@ -14,8 +15,9 @@
 //     read back with conflict-free ds_read_b128 (one read = one operand row x 4 pixels = the A or B input of 4 MFMAs);
 //   * the k order inside a stage is whatever suits the reads (lane half h takes pixel group 2 j + h): a SYRK only
 //     needs both operands to agree on it;
-//   * every lane's four read addresses per operand are computed once per work item (16 registers); the steady state
-//     has no vector-ALU instructions besides the MFMAs;
+//   * every stage is full and straight-line code (the K range is the stream of the factor's 4-pixel groups, flat_body);
+//     every lane's read addresses are computed once per work item, the steady state carries a dozen vector-ALU
+//     instructions per 32 MFMAs (the lane's place in the stream);
 //   * 32 KiB of LDS and <= 128 registers: FOUR workgroups per CU, each covering the others' barriers and DMA waits
 //     (round 3: 32-pixel stages, 64 KiB, two per CU -> 16-pixel stages, four per CU: the MFMA kernels of a ResNet-50
 //     update() 5.89 -> 5.75 ms on one box; the stand-alone prototype's trend - 64-pixel stages at one per CU 0.42-0.50

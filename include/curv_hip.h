@@ -120,9 +120,9 @@ size_t curv_kfac_workspace_bytes(const curv_factor_desc* descs, int n_factors);
 int curv_kfac_plan_info(const curv_factor_desc* descs, int n_factors, long long* out);
 
 /* Grouped build of all factors of a model: a fixed, small number of launches whatever the number of factors (the
- * implicit-im2col kernel, the LDS-DMA kernel for flattened factors and the shifted correlations of 3x3 / stride 1 /
- * padding 1 factors, one reduce launch for each, plus a padding pass and an assembly pass when such 3x3 factors are
- * present).  A launch that is small as a whole (LeNet scale: at most 2 GFLOP) takes a two-launch build of its own
+ * implicit-im2col kernel, the LDS-DMA kernel for flattened factors, for the shifted correlations of 3x3 / stride 1 /
+ * padding 1 factors and for the unfolded copies of stride-2 3x3 / strided 1x1 ones, one reduce launch for each, plus a
+ * padding pass and an assembly pass when such 3x3 factors are present and an unfold pass for the strided ones).  A launch that is small as a whole (LeNet scale: at most 2 GFLOP) takes a two-launch build of its own
  * instead (32 x 32 blocks x K slices gathered straight from the tensors, then a reduce pass; CURV_KFAC_SMALL=0 in the
  * environment keeps such a launch on the grouped kernels).  `descs` is a host array; it may be reused as soon as the call
  * returns. */
