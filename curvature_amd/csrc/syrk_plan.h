@@ -84,10 +84,46 @@ __device__ __forceinline__ int find_segment(const FactorDev* __restrict__ descs,
   return __builtin_amdgcn_readfirstlane(count - 1);
 }
 
+// Tile t of a factor's upper triangle (ti <= tj) of P x P tiles.  Order: blocks of TB_H x TB_W tiles, block row by block
+// row, row-major inside a block - so that XCD_GROUP = 32 consecutive work items of one k-slice (one XCD, launched together)
+// stream TB_H + TB_W = 12 different operand panels instead of the ~33 of a plain row-major walk over a wide triangle: an
+// XCD's L2 is filled with every panel once per block, not once per tile row (round 6; factors of at most 8 tile rows keep
+// their old order).  Scalar loops over at most P^2 / 32 blocks per work item.
+constexpr int TB_H = 4, TB_W = 8;
 __device__ __forceinline__ void decode_tile(int t, int P, int& ti, int& tj) {
-  ti = 0;
-  while (t >= P - ti) { t -= P - ti; ++ti; }
-  tj = ti + t;
+  for (int r0 = 0; r0 < P; r0 += TB_H) {
+    const int r1 = min(r0 + TB_H, P);
+    for (int c0 = (r0 / TB_W) * TB_W; c0 < P; c0 += TB_W) {
+      const int c1 = min(c0 + TB_W, P);
+      int cnt = 0;                                   // tiles of the block on or above the diagonal
+      for (int r = r0; r < r1; ++r) cnt += max(0, c1 - max(c0, r));
+      if (t < cnt) {
+        for (int r = r0; r < r1; ++r) {
+          const int lo = max(c0, r), w = max(0, c1 - lo);
+          if (t < w) { ti = r; tj = lo + t; return; }
+          t -= w;
+        }
+      }
+      t -= cnt;
+    }
+  }
+  ti = tj = 0;                                       // (t < P (P + 1) / 2: not reached)
+}
+// ... and of a full P x P grid (a correlation between differently shifted rows), in the same blocks
+__device__ __forceinline__ void decode_tile_full(int t, int P, int& ti, int& tj) {
+  const int ncb = (P + TB_W - 1) / TB_W;
+  for (int r0 = 0; r0 < P; r0 += TB_H) {
+    const int h = min(TB_H, P - r0), row_tiles = h * P;
+    if (t < row_tiles) {
+      for (int cb = 0; cb < ncb; ++cb) {
+        const int c0 = cb * TB_W, w = min(TB_W, P - c0), cnt = h * w;
+        if (t < cnt) { ti = r0 + t / w; tj = c0 + t % w; return; }
+        t -= cnt;
+      }
+    }
+    t -= row_tiles;
+  }
+  ti = tj = 0;
 }
 
 
@@ -226,7 +262,7 @@ bool syrk_flat_eligible(const FactorDev& f, const void* src);
 int syrk_flat_chunks(int N, int W);     // stages of 16 pixels over the factor's stream of 4-pixel groups
 
 __device__ __forceinline__ void decode_tile_of(const FactorDev& d, int t, int& ti, int& tj) {
-  if (d.nonsym) { ti = t / d.P; tj = t - ti * d.P; }
+  if (d.nonsym) decode_tile_full(t, d.P, ti, tj);
   else decode_tile(t, d.P, ti, tj);
 }
 
