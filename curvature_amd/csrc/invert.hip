@@ -322,109 +322,6 @@ inner_update_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int ken
   }
 }
 
-// The panel solve FUSED into the inner update (per-step sweeps of a whole model): a step's launches were
-// chol_panel (A[i][k] <- A[i][k] X_kk^T for the rows of the square; row k of the square's inverse) and inner_update, i.e.
-// two boundaries per 64 columns on the critical path.  Nothing but this step's inner update ever reads the solved tiles
-// of the square (the rows below it come from the panel product at the end of the panel, the far updates and the fp32
-// inverse read those), so every tile recomputes the one or two solves it needs in LDS - the same products, the same bits -
-// and the solved tiles are never stored.  Row k of the square's inverse, X[k][jj] = -X_kk S[k][jj], is formed in LDS where
-// a tile needs it and stored by xsq_rows_kernel once per panel: S[k][jj] stays in place until then (the right-looking
-// accumulation touches row k of S only before step k), and other tiles of the launch still read it.
-__global__ void __launch_bounds__(INV_THREADS)
-inner_fused_kernel(const InvDev* __restrict__ t, int nf, int k, int k0, int kend) {
-  __shared__ double As[NB * LDA], Bs[NB * LDA], Xs[NB * LDA];
-  int f, local;
-  if (!locate(t, nf, blockIdx.x, [k, k0, kend](const InvDev& d) { return (int)inner_tiles(d.P, k, k0, kend); }, f, local)) return;
-  const InvDev& d = t[f];
-  const int np = d.np, P = d.P, ke = kend < P ? kend : P;
-  gdouble* W = (gdouble*)d.W;
-  gdouble* X = (gdouble*)d.X;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-  f64x4 acc[2][2] = {}, c1[2][2] = {}, c2[2][2] = {};
-  int j = k + 1;
-  bool trailing = false;
-  for (; j < ke; ++j) {
-    if (local < ke - j) { trailing = true; break; }
-    local -= ke - j;
-  }
-  load_block(X + (long long)k * NB * np + k * NB, np, Xs);         // X_kk
-  if (trailing) {
-    const int i = j + local;                                       // A[i][j] -= C[i][k] C[j][k]^T,  C[r][k] = A[r][k] X_kk^T
-    load_block(W + (long long)i * NB * np + k * NB, np, As);
-    if (i != j) load_block(W + (long long)j * NB * np + k * NB, np, Bs);
-    __syncthreads();
-    mma_64<true>(As, Xs, wm, wn, lane, c1);
-    if (i != j) mma_64<true>(Bs, Xs, wm, wn, lane, c2);
-    __syncthreads();                                               // every wave is done reading A_ik / A_jk
-    acc_to_lds(c1, wm, wn, lane, As);
-    if (i != j) acc_to_lds(c2, wm, wn, lane, Bs);
-    __syncthreads();
-    mma_64<true>(As, (i != j) ? Bs : As, wm, wn, lane, acc);
-    if (i == j && j == k + 1) {
-      // next diagonal block: A_jj - acc is final.  Factorise it here (As/Bs become the two work tiles).
-      __shared__ int bad;
-      __syncthreads();                                             // all waves are done reading As
-      if (threadIdx.x == 0) bad = 0;
-      load_block(W + (long long)j * NB * np + j * NB, np, As);
-      __syncthreads();
-      lds_sub_acc(As, acc, wm, wn, lane);
-      __syncthreads();
-      factor_invert_64(As, Bs, &bad, j * NB, d.pivot_min);
-      store_block(X + (long long)j * NB * np + j * NB, np, Bs);
-      if (threadIdx.x == 0 && bad != 0) atomicCAS(d.info, 0, bad);
-    } else {
-      store_sub(W + (long long)i * NB * np + j * NB, np, acc, wm, wn, lane, 0);
-    }
-  } else {
-    const int w = k - k0 + 1;                                      // S[i][jj] (+)= C[i][k] X[k][jj], k0 <= jj <= k
-    const int a = local / w, jj = k0 + local - a * w;
-    const int i = k + 1 + a;
-    load_block(W + (long long)i * NB * np + k * NB, np, As);
-    if (jj != k) load_block(X + (long long)k * NB * np + jj * NB, np, Bs);      // S[k][jj]
-    __syncthreads();
-    mma_64<true>(As, Xs, wm, wn, lane, c1);                        // C[i][k]
-    if (jj != k) mma_64<false>(Xs, Bs, wm, wn, lane, c2);          // X_kk S[k][jj]
-    __syncthreads();
-    acc_to_lds(c1, wm, wn, lane, As);
-    if (jj != k) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) c2[m][n] = -c2[m][n];
-      acc_to_lds(c2, wm, wn, lane, Bs);                            // X[k][jj]
-    }
-    __syncthreads();
-    mma_64<false>(As, jj == k ? Xs : Bs, wm, wn, lane, acc);
-    store_sub(X + (long long)i * NB * np + jj * NB, np, acc, wm, wn, lane, jj == k ? 1 : 2);
-  }
-}
-// the rows of the square's inverse left of its diagonal, once per panel (see inner_fused_kernel):
-//   X[k][jj] = -X_kk S[k][jj]      k0 <= jj < k < min(kend, P)
-__device__ __host__ __forceinline__ int xsq_row_tiles(int P, int k0, int kend) {
-  if (P <= k0) return 0;
-  const int nb = (kend < P ? kend : P) - k0;
-  return nb * (nb - 1) / 2;
-}
-__global__ void __launch_bounds__(INV_THREADS)
-xsq_rows_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
-  __shared__ double As[NB * LDA], Bs[NB * LDA];
-  int f, local;
-  if (!locate(t, nf, blockIdx.x, [k0, kend](const InvDev& d) { return xsq_row_tiles(d.P, k0, kend); }, f, local)) return;
-  const InvDev& d = t[f];
-  const int np = d.np;
-  gdouble* X = (gdouble*)d.X;
-  int r = 1;
-  while (local >= r) { local -= r; ++r; }                          // row r of the square (1 ..), column local < r
-  const int k = k0 + r, jj = k0 + local;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-  f64x4 acc[2][2] = {};
-  load_block(X + (long long)k * NB * np + k * NB, np, As);          // X_kk as [row][kk]
-  load_block(X + (long long)k * NB * np + jj * NB, np, Bs);         // S_k,jj as [kk][col]
-  __syncthreads();
-  mma_64<false>(As, Bs, wm, wn, lane, acc);
-  store_acc(X + (long long)k * NB * np + jj * NB, np, acc, wm, wn, lane, 3);
-}
-
 // (2o)/(4o) once per outer panel [k0, kend): everything beyond the panel, K = (kend - k0) * 64.
 // K advances in short steps through two small LDS operand tiles; the next step is fetched into registers while
 // the MFMAs of the current one run.  What this latency-bound streaming kernel is short of is workgroups per CU
@@ -442,7 +339,7 @@ struct TileJob {                        // everything wave-uniform
   gdouble* C;                           // output tile, pitch np
   int np, ke0, ke1, mode;               // K range in elements; mode of store_acc
   bool bt, same;                        // same: B is A (diagonal tile of a symmetric update)
-  gfloat* C32 = nullptr;                // F32 = false: also store the tile as fp32 here (pitch np); F32 = true: THE output
+  gfloat* C32 = nullptr;                // also store the tile as fp32 here (pitch np)
 };
 // fp32 twin of store_acc: tile (pitch ld floats) = sign * acc
 __device__ __forceinline__ void store_acc_f32(gfloat* __restrict__ C, int ld, const f64x4 (&acc)[2][2], int wm, int wn, int lane,
@@ -469,11 +366,8 @@ __device__ __forceinline__ void store_acc_f32(gfloat* __restrict__ C, int ld, co
 // flags tested inside it, every step carried ~13 scalar branches, 9 v_cndmask and 16 v_mov next to its 16 MFMAs,
 // and VALU instructions do not overlap with another wave's MFMAs on this chip (tools/micro/f64_mfma_overlap.hip:
 // a wave issuing MFMAs back to back starves the VALU work of the other wave of its SIMD completely).
-// F32 (MODE 2 only, the columns-left product of the fp32 inverse): B is an fp32 matrix (pitch np floats, converted on the
-// way into LDS) and the output goes to o.C32 as -acc in fp32.
-template <int WV, int MODE, bool F32 = false>
+template <int WV, int MODE>
 __device__ __forceinline__ void tile_product_impl(const TileJob& o, double* __restrict__ As, double* __restrict__ Bs) {
-  static_assert(!F32 || MODE == 2, "fp32 B operand: [k][col] form only");
   constexpr int THREADS = 64 * WV * WV, T = 4 / WV, LPT = NB * OKS / THREADS;   // MFMA tiles per wave edge, loads per thread
   const int np = o.np;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WV, wn = wave % WV;
@@ -481,7 +375,7 @@ __device__ __forceinline__ void tile_product_impl(const TileJob& o, double* __re
   const int r16 = lane & 15, kq = lane >> 4;
   double ra[LPT], rb[LPT];
   const unsigned voff_k = (unsigned)(((long long)(tid / OKS) * np + (tid % OKS)) * 8);   // [rows][OKS k] operands
-  constexpr int BE = F32 ? 4 : 8;                                                      // bytes per element of the [k][col] operand
+  constexpr int BE = 8;                                                                // bytes per element of the [k][col] operand
   const unsigned voff_n = (unsigned)(((long long)(tid >> 6) * np + (tid & 63)) * BE);   // [OKS k][64 cols] operand
   const long long step_k = (long long)(THREADS / OKS) * np * 8, step_n = (long long)(THREADS / 64) * np * BE;
   auto fetch = [&](int ke) __attribute__((always_inline)) {                            // ke: first K element of the step
@@ -491,7 +385,6 @@ __device__ __forceinline__ void tile_product_impl(const TileJob& o, double* __re
     for (int u = 0; u < LPT; ++u) {
       ra[u] = *(const gdouble*)(ga + u * step_k + voff_k);
       if (trailing) rb[u] = same ? 0.0 : *(const gdouble*)(gb + u * step_k + voff_k);
-      else if (F32) rb[u] = (double)*(const gfloat*)(gb + u * step_n + voff_n);
       else rb[u] = *(const gdouble*)(gb + u * step_n + voff_n);
     }
   };
@@ -525,17 +418,7 @@ __device__ __forceinline__ void tile_product_impl(const TileJob& o, double* __re
     }
     __syncthreads();
   }
-  if constexpr (F32) {
-    if constexpr (WV == 2) {
-      store_acc_f32(o.C32, np, acc, wm, wn, lane, -1.0f);
-    } else {
-      const int c16 = lane & 15, rq = lane >> 4;
-      gbyte* base = (gbyte*)o.C32;
-      const unsigned voff = (unsigned)(((long long)(16 * wm + rq) * np + 16 * wn + c16) * 4);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) *(gfloat*)(base + (long long)(4 * q) * np * 4 + voff) = -(float)acc[0][0][q];
-    }
-  } else if constexpr (WV == 2) {
+  if constexpr (WV == 2) {
     store_acc(o.C, np, acc, wm, wn, lane, o.mode);
     if (o.C32 != nullptr) store_acc_f32(o.C32, np, acc, wm, wn, lane, 1.0f);
   } else {
@@ -1322,20 +1205,18 @@ chol_square_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int* 
 // doing these rows step by step (nb panel solves + nb (nb - 1) / 2 rank-64 updates, each a read-modify-
 // write of 64x64 tiles) the row panel is read and written once.
 // ------------------------------------------------------------------------------------------------
-// Jobs of a panel product launch per factor (kind: s_kind).  part 0 (the chain): the block rows below the square; for the
-// factors that carry their inverse in the sweep also the block columns left of the square (right-hand side mode: the
-// block columns of Zm).  part 1 (off the chain): the block columns left of the square of the fp32 inverse.
-__device__ __host__ __forceinline__ int panel_jobs(int P, int kind, int k0, int kend, int part) {
+// Jobs of a panel product launch per factor (kind: s_kind): the block rows below the square; for the factors that carry
+// their inverse in the sweep also the block columns left of the square (right-hand side mode: the block columns of Zm).
+// (The columns left of the square of KFAC.invert's fp32 inverse are xrows32_kernel's, off the chain.)
+__device__ __host__ __forceinline__ int panel_jobs(int P, int kind, int k0, int kend) {
   if (P <= k0) return 0;
-  if (part == 1) return kind == 0 ? k0 : 0;
   return (P > kend ? P - kend : 0) + (kind == 2 ? (kend < P ? kend : P) : kind == 1 ? k0 : 0);
 }
 template <int WV>
-__device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t, int nf, int k0, int kend, int part,
+__device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t, int nf, int k0, int kend,
                                                    double* __restrict__ As, double* __restrict__ Bs) {
   int f, local;
-  if (!locate(t, nf, blockIdx.x,
-              [k0, kend, part](const InvDev& d) { return panel_jobs(d.P, s_kind(d), k0, kend, part); }, f, local))
+  if (!locate(t, nf, blockIdx.x, [k0, kend](const InvDev& d) { return panel_jobs(d.P, s_kind(d), k0, kend); }, f, local))
     return;
   const InvDev& d = t[f];
   const int np = d.np, nb = (kend < d.P ? kend : d.P) - k0;
@@ -1345,22 +1226,6 @@ __device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t,
   o.np = np;
   o.same = false;
   o.ke0 = 0;
-  if (part == 1) {
-    // fp32 inverse: X32[k0 + c][j] <- - sum_{k <= c} X_sq[c][k] S32[k0 + k][j], in place (descending c)
-    const int j = local;
-    gfloat* S = (gfloat*)d.X32;
-    o.bt = false;
-    o.mode = 3;
-    for (int c = nb - 1; c >= 0; --c) {
-      o.a0 = (const gbyte*)(X + (long long)(k0 + c) * NB * np + k0 * NB);
-      o.b0 = (const gbyte*)(S + (long long)k0 * NB * np + j * NB);
-      o.C = nullptr;
-      o.C32 = S + (long long)(k0 + c) * NB * np + j * NB;
-      o.ke1 = (c + 1) * NB;
-      tile_product_impl<WV, 2, true>(o, As, Bs);
-    }
-    return;
-  }
   const int n_below = d.P > kend ? d.P - kend : 0;
   const bool below = local < n_below;
   const int i = kend + local, j = local - n_below;
@@ -1396,11 +1261,9 @@ __device__ __forceinline__ void panel_product_body(const InvDev* __restrict__ t,
 constexpr int PQ_PITCH = 4 * NB + 1;                 // [16][257]: rows of the workgroup's slice of W
 constexpr int PQ_OWN = 16 * PQ_PITCH > 4 * NB * 17 ? 16 * PQ_PITCH : 4 * NB * 17;   // or [256][17]: columns of S
 // `below` is a template parameter: tested inside the K loop it put a scalar branch in front of every operand read
-// F32 (columns-left form only): S is read from / the result written to the fp32 matrix X32 (fp32 inverse, off the chain)
-template <bool below, bool F32 = false>
+template <bool below>
 __device__ __forceinline__ void panel_quarter_body(const InvDev& d, int k0, int nb, int i, int j, int q,
                                                    double* __restrict__ Own, double* __restrict__ Ts) {
-  static_assert(!(below && F32), "fp32 form: columns left of the square only");
   const int np = d.np;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
   PQT(240)
@@ -1419,14 +1282,12 @@ __device__ __forceinline__ void panel_quarter_body(const InvDev& d, int k0, int 
     }
   } else {
     // S[k0*64 + k][j*64 + 16 q + c], k < 64 nb, c < 16: element (k = tid / 16 + 16 u, c = tid % 16)
-    constexpr int SE = F32 ? 4 : 8;
-    const gbyte* g = (F32 ? (const gbyte*)d.X32 : Xb) + ((long long)k0 * NB * np + (long long)j * NB + 16 * q) * SE;
+    const gbyte* g = Xb + ((long long)k0 * NB * np + (long long)j * NB + 16 * q) * 8;
     for (int v = 0; v < nb; ++v) {
       double x[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const gbyte* e = g + ((long long)((tid >> 4) + 16 * u + 64 * v) * np + (tid & 15)) * SE;
-        x[u] = F32 ? (double)*(const gfloat*)e : *(const gdouble*)e;
+        x[u] = *(const gdouble*)(g + ((long long)((tid >> 4) + 16 * u + 64 * v) * np + (tid & 15)) * 8);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) Own[((tid >> 4) + 16 * u + 64 * v) * 17 + (tid & 15)] = x[u];
@@ -1472,18 +1333,16 @@ __device__ __forceinline__ void panel_quarter_body(const InvDev& d, int k0, int 
       // 16x16 tile of output block c: rows 16 wm + rq + 4 qq, column 16 wn + c16
       const int wm = below ? q : wave, wn = below ? wave : q;
       const int c16 = lane & 15, rq = lane >> 4;
-      constexpr int OE = F32 ? 4 : 8;
       gbyte* base = below ? (gbyte*)d.W + (((long long)i * NB) * np + (long long)(k0 + c) * NB) * 8
-                          : (F32 ? (gbyte*)d.X32 : (gbyte*)d.X) + (((long long)(k0 + c) * NB) * np + (long long)j * NB) * OE;
-      const unsigned voff = (unsigned)(((long long)(16 * wm + rq) * np + 16 * wn + c16) * OE);
+                          : (gbyte*)d.X + (((long long)(k0 + c) * NB) * np + (long long)j * NB) * 8;
+      const unsigned voff = (unsigned)(((long long)(16 * wm + rq) * np + 16 * wn + c16) * 8);
       // (below) the fp32 copy of C for the off-chain inverse
       gbyte* base32 = (below && d.C32 != nullptr) ? (gbyte*)d.C32 + (((long long)i * NB) * np + (long long)(k0 + c) * NB) * 4 : nullptr;
       const unsigned voff32 = (unsigned)(((long long)(16 * wm + rq) * np + 16 * wn + c16) * 4);
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const double v = (acc[0][qq] + acc[1][qq]) + (acc[2][qq] + acc[3][qq]);
-        if (F32) *(gfloat*)(base + (long long)(4 * qq) * np * 4 + voff) = -(float)v;
-        else *(gdouble*)(base + (long long)(4 * qq) * np * 8 + voff) = below ? v : -v;
+        *(gdouble*)(base + (long long)(4 * qq) * np * 8 + voff) = below ? v : -v;
         if (below && base32 != nullptr) *(gfloat*)(base32 + (long long)(4 * qq) * np * 4 + voff32) = (float)v;
       }
 #pragma unroll
@@ -1502,38 +1361,35 @@ __device__ __forceinline__ void panel_quarter_body(const InvDev& d, int k0, int 
   }
 }
 __global__ void __launch_bounds__(INV_THREADS)
-panel_product_quarter_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int part) {
+panel_product_quarter_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
   __shared__ double Own[PQ_OWN], Ts[NB * LDA];
   const int job = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7), q = (blockIdx.x >> 3) & 3;   // the four quarters of a job on one XCD
   int f, local;
   KT_BEGIN(236)
-  if (!locate(t, nf, job,
-              [k0, kend, part](const InvDev& d) { return panel_jobs(d.P, s_kind(d), k0, kend, part); }, f, local))
-    return;
+  if (!locate(t, nf, job, [k0, kend](const InvDev& d) { return panel_jobs(d.P, s_kind(d), k0, kend); }, f, local)) return;
   const InvDev& d = t[f];
   const int nb = (kend < d.P ? kend : d.P) - k0;
-  const int n_below = part == 1 ? 0 : (d.P > kend ? d.P - kend : 0);
-  if (part == 1) panel_quarter_body<false, true>(d, k0, nb, 0, local, q, Own, Ts);
-  else if (local < n_below) panel_quarter_body<true>(d, k0, nb, kend + local, 0, q, Own, Ts);
+  const int n_below = d.P > kend ? d.P - kend : 0;
+  if (local < n_below) panel_quarter_body<true>(d, k0, nb, kend + local, 0, q, Own, Ts);
   else panel_quarter_body<false>(d, k0, nb, 0, local - n_below, q, Own, Ts);
   KT_END(237)
 }
 __global__ void __launch_bounds__(INV_THREADS, 3)
-panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int part) {
+panel_product_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
   __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
-  panel_product_body<2>(t, nf, k0, kend, part, As, Bs);
+  panel_product_body<2>(t, nf, k0, kend, As, Bs);
 }
 __global__ void __launch_bounds__(1024)
-panel_product_wide_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend, int part) {
+panel_product_wide_kernel(const InvDev* __restrict__ t, int nf, int k0, int kend) {
   __shared__ double As[NB * OPA], Bs[NB * OPA > OKS * LDA ? NB * OPA : OKS * LDA];
-  panel_product_body<4>(t, nf, k0, kend, part, As, Bs);
+  panel_product_body<4>(t, nf, k0, kend, As, Bs);
 }
 
 // ------------------------------------------------------------------------------------------------
 // (4') The triangular inverse X = C^-1 OUTSIDE the block squares, for KFAC.invert: in fp32 and off the chain.
 //     S32[i][j] (+)= C32[i][panel] X[panel][j]      for block rows i below the panel, block columns j <= panel
 // (the forward substitution of C X = I, right-looking, one K = 256 product per tile and panel), followed one panel later
-// by the columns-left product with the square's fp64 inverse (panel_product, part 1), which turns the S rows of the next
+// by the columns-left product with the square's fp64 inverse (xrows32_kernel), which turns the S rows of the next
 // panel into rows of X.  Everything the chain computes - the Cholesky factor, the inverses of the 256 x 256 block squares -
 // stays fp64; only these sums, n^3 / 3 of the sweep's (2/3) n^3 flops, run on v_mfma_f32_32x32x2_f32 at twice the fp64
 // rate and half the bytes.  Forward substitution is far better conditioned than the factorisation: on damped ResNet
@@ -1774,8 +1630,6 @@ struct SideStream {
   hipEvent_t ev_main[2] = {nullptr, nullptr};
   hipEvent_t ev_side[2] = {nullptr, nullptr};
   hipEvent_t ev_tail = nullptr;          // the last row panel of the triangular inverse is done
-  hipStream_t inv = nullptr;             // the fp32 inverse (xrows32 / supd32): CU-masked like `stream`
-  hipEvent_t ev_near[2] = {nullptr, nullptr};   // the near update of a panel is done (when it runs on `stream`)
 };
 struct StreamSet {
   SideStream side[2];
@@ -1847,9 +1701,9 @@ static int stream_set(StreamSet** out) {
     CURV_HIP_CHECK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio_low));
     return CURV_OK;
   };
-  // EXPERIMENT (CURV_STREAM_ORDER, LAB_NOTEBOOK R5.6): creation order of the set's streams with dummies between them: a = large
-  // chain, m = small chain, 0 / 1 = far-update streams, i / j = their fp32-inverse streams (CURV_INV_STREAM=1), x / p / h / l =
-  // unused CU-masked / plain / high-priority / low-priority stream
+  // Test hook (CURV_STREAM_ORDER; tests/test_invert_gpu.py, tools/stream_sensitivity.py, LAB_NOTEBOOK R5.6): creation order of
+  // the set's streams with dummies between them: a = large chain, m = small chain, 0 / 1 = far-update streams, x / p / h / l =
+  // unused CU-masked / plain / high-priority / low-priority stream (the dummies live as long as the process)
   if (const char* order = getenv("CURV_STREAM_ORDER")) {
     for (const char* c = order; *c; ++c) {
       hipStream_t dummy = nullptr;
@@ -1858,8 +1712,6 @@ static int stream_set(StreamSet** out) {
         case 'm': CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.masked, hipStreamNonBlocking)); break;
         case '0': { const int rc = wide_stream(&s.side[0].stream); if (rc != CURV_OK) return rc; } break;
         case '1': { const int rc = wide_stream(&s.side[1].stream); if (rc != CURV_OK) return rc; } break;
-        case 'i': { const int rc = wide_stream(&s.side[0].inv); if (rc != CURV_OK) return rc; } break;
-        case 'j': { const int rc = wide_stream(&s.side[1].inv); if (rc != CURV_OK) return rc; } break;
         case 'x': { const int rc = wide_stream(&dummy); if (rc != CURV_OK) return rc; } break;
         case 'p': CURV_HIP_CHECK(hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking)); break;
         case 'h': CURV_HIP_CHECK(hipStreamCreateWithPriority(&dummy, hipStreamNonBlocking, phi)); break;
@@ -1870,39 +1722,15 @@ static int stream_set(StreamSet** out) {
   }
   if (s.aux == nullptr) CURV_HIP_CHECK(hipStreamCreateWithPriority(&s.aux, hipStreamNonBlocking, aux_prio ? phi : plo));
   // The small group's chain: a plain stream.  Measured alternatives (round 5, ResNet-50 factors): CU-masked like the far
-  // updates' streams (CURV_SMALL_MASKED=1; the reserved CUs then belong to the large group's chain alone) 7.5 -> 8.5 ms -
+  // updates' streams (the reserved CUs then belong to the large group's chain alone) 7.5 -> 8.5 ms -
   // the small group's own chain starves beside the far updates; on the LOW priority level (the runtime keeps a pool of
   // hardware queues per level, so the stream would not share a queue with normal streams the process created earlier):
   // no effect on the creation-order sensitivity, 6.9 / 6.9 / 11.0 ms for none / three streams after / three before the
   // set, as with a normal stream.  What the four busy streams of a sweep need is four different hardware pipes; a
   // fifth busy stream of any kind (CU-masked, low priority, shared between the groups) costs 4-5 ms.
-  static const int small_masked = getenv("CURV_SMALL_MASKED") ? atoi(getenv("CURV_SMALL_MASKED")) : 0;
-  static const int small_full = getenv("CURV_SMALL_FULLMASK") ? atoi(getenv("CURV_SMALL_FULLMASK")) : 0;
-  if (s.masked != nullptr) {}
-  else if (small_masked) { const int rc = wide_stream(&s.masked); if (rc != CURV_OK) return rc; }
-  else if (small_full) {
-    // a CU-masked stream with every CU in its mask: a hardware queue of its own (the runtime pools the queues of plain streams)
-    hipDeviceProp_t prop;
-    int dev_id = 0;
-    CURV_HIP_CHECK(hipGetDevice(&dev_id));
-    CURV_HIP_CHECK(hipGetDeviceProperties(&prop, dev_id));
-    std::vector<uint32_t> mask((size_t)cdiv(prop.multiProcessorCount, 32), 0u);
-    for (int c = 0; c < prop.multiProcessorCount; ++c) mask[c >> 5] |= 1u << (c & 31);
-    CURV_HIP_CHECK(hipExtStreamCreateWithCUMask(&s.masked, (uint32_t)mask.size(), mask.data()));
-    std::lock_guard<std::mutex> lock(g_masked_mutex);
-    if (g_masked_streams.empty()) atexit(destroy_masked_streams);
-    g_masked_streams.emplace_back(dev_id, s.masked);
-  }
-  else CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.masked, hipStreamNonBlocking));
+  if (s.masked == nullptr) CURV_HIP_CHECK(hipStreamCreateWithFlags(&s.masked, hipStreamNonBlocking));
   for (int g = 0; g < 2; ++g) {
     if (s.side[g].stream == nullptr) { const int rc = wide_stream(&s.side[g].stream); if (rc != CURV_OK) return rc; }
-    // (a stream of its own for the fp32 inverse only on request: every additional hardware queue of the process slows
-    // the whole sweep down - two more CU-masked streams, even unused: invert() of the ResNet-50 factors 7.5 -> 11.1 ms)
-    static const int inv_stream = getenv("CURV_INV_STREAM") ? atoi(getenv("CURV_INV_STREAM")) : 0;
-    if (s.side[g].inv != nullptr) {}
-    else if (inv_stream == 1 || (inv_stream == 2 && g == 0)) { const int rc = wide_stream(&s.side[g].inv); if (rc != CURV_OK) return rc; }
-    else if (inv_stream == 2) s.side[g].inv = s.side[0].inv;
-    for (int i = 0; i < 2; ++i) CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_near[i], hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) {
       CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_main[i], hipEventDisableTiming));
       CURV_HIP_CHECK(hipEventCreateWithFlags(&s.side[g].ev_side[i], hipEventDisableTiming));
@@ -1961,6 +1789,11 @@ extern "C" size_t curv_chol_inv_workspace_bytes(const curv_inv_desc* descs, int 
 // after a whole sweep has been enqueued waits for that stream's tail, not for the event's position in it (measured: the
 // second group of a whole-model inversion started when the first one's last panels ran, whatever event it waited for;
 // tools/trace_buckets.py), so a group that is to start beside another one must be enqueued beside it.
+// block columns per outer panel (GroupSweep::begin has the measurements)
+static int sweep_nbo(bool latency_bound) {
+  static const int nbo_env = getenv("CURV_NBO") ? atoi(getenv("CURV_NBO")) : 0;
+  return latency_bound ? 4 : (nbo_env > 0 ? nbo_env : 6);
+}
 struct GroupSweep {
   hipStream_t stream;
   SideStream* side;
@@ -1999,12 +1832,11 @@ struct GroupSweep {
     }
     hipLaunchKernelGGL(inv_prepare_kernel, dim3((unsigned)prep_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, flags);
     CURV_LAUNCH_CHECK();
-    static const int nbo_env = getenv("CURV_NBO") ? atoi(getenv("CURV_NBO")) : 0;
     // outer panel: 4 block columns = 256 for the chain-bound forms (the square kernel is built for 4); 6 = 384 for the
     // per-step launches of a whole model - same-box sweeps on the ResNet-50 factors, two rounds each: NBO 4 / 5 / 6 / 7 =
     // 7.5 / 7.2 / 6.8 / 7.3 ms (8: 7.4, 12: 7.3): fewer panel products, near updates and cross-stream hand-offs per block
     // step, and 72 = 12 x 6, 36 = 6 x 6: the widest factors end on a full panel
-    NBO = latency_bound ? 4 : (nbo_env > 0 ? nbo_env : 6);
+    NBO = sweep_nbo(latency_bound);
     return CURV_OK;
   }
 
@@ -2036,7 +1868,6 @@ struct GroupSweep {
                          flags, panel + 1);
       CURV_LAUNCH_CHECK();
     }
-    static const int fused_step = getenv("CURV_FUSED_STEP") ? atoi(getenv("CURV_FUSED_STEP")) : 0;   // measured: 6.85-6.93 ms without, 6.81-7.14 with
     for (int k = k0; !use_square && k < std::min(kend, Pmax); ++k) {
       long long diag_tiles = 0, panel_tiles = 0, upd_tiles = 0;
       for (const InvDev& d : tab) {
@@ -2047,13 +1878,6 @@ struct GroupSweep {
         hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)diag_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k);
         CURV_LAUNCH_CHECK();
       }
-      if (fused_step) {   // one launch per step: the panel solves are recomputed inside the inner update (inner_fused_kernel)
-        if (upd_tiles > 0) {
-          hipLaunchKernelGGL(inner_fused_kernel, dim3((unsigned)upd_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, k0, kend);
-          CURV_LAUNCH_CHECK();
-        }
-        continue;
-      }
       if (panel_tiles > 0) {
         hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)panel_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k, k0, kend);
         CURV_LAUNCH_CHECK();
@@ -2063,34 +1887,26 @@ struct GroupSweep {
         CURV_LAUNCH_CHECK();
       }
     }
-    if (!use_square && fused_step) {   // ... and the rows of the squares' inverses once per panel
-      long long row_tiles = 0;
-      for (const InvDev& d : tab) row_tiles += xsq_row_tiles(d.P, k0, kend);
-      if (row_tiles > 0) {
-        hipLaunchKernelGGL(xsq_rows_kernel, dim3((unsigned)row_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0, kend);
-        CURV_LAUNCH_CHECK();
-      }
-    }
-    // the launch form of a panel product by its number of jobs; part 0 on the chain, part 1 (fp32 inverse) on the side stream
+    // the launch form of a panel product by its number of jobs
     // `done` (optional): recorded as the launch's own completion (hipExtLaunchKernelGGL's stop event) - no marker packet
     // of its own in the chain's queue
-    auto launch_product = [&](hipStream_t st, long long jobs, int part, hipEvent_t done) -> int {
+    auto launch_product = [&](hipStream_t st, long long jobs, hipEvent_t done) -> int {
       const InvDev* tb = table;
       if (jobs <= quarter_prod)
         hipExtLaunchKernelGGL(panel_product_quarter_kernel, dim3((unsigned)(cdivll(jobs, 8) * 32)), dim3(INV_THREADS), 0, st,
-                              nullptr, done, 0, tb, n_factors, k0, kend, part);
+                              nullptr, done, 0, tb, n_factors, k0, kend);
       else if (jobs <= wide_prod)
         hipExtLaunchKernelGGL(panel_product_wide_kernel, dim3((unsigned)jobs), dim3(1024), 0, st, nullptr, done, 0, tb, n_factors,
-                              k0, kend, part);
+                              k0, kend);
       else
         hipExtLaunchKernelGGL(panel_product_kernel, dim3((unsigned)jobs), dim3(INV_THREADS), 0, st, nullptr, done, 0, tb,
-                              n_factors, k0, kend, part);
+                              n_factors, k0, kend);
       CURV_LAUNCH_CHECK();
       return CURV_OK;
     };
     long long inv_jobs = 0, inv_tiles = 0;    // fp32 inverse: columns-left products of this panel, then its S update
     for (const InvDev& d : tab) {
-      prod_tiles += panel_jobs(d.P, s_kind(d), k0, kend, 0);
+      prod_tiles += panel_jobs(d.P, s_kind(d), k0, kend);
       inv_jobs += xrow_tiles(d.P, s_kind(d), k0, kend);
       inv_tiles += supd_tiles(d.P, s_kind(d), kend);
     }
@@ -2098,7 +1914,7 @@ struct GroupSweep {
     bool fork_recorded = false;           // ev_main rides on the panel product's completion
     if (prod_tiles > 0) {   // rows below the square (right-hand side mode: and the columns of Zm): one triangular product each
       fork_recorded = ext_events != 0 && !capturing;
-      const int rc = launch_product(stream, prod_tiles, 0, fork_recorded ? side->ev_main[panel & 1] : nullptr);
+      const int rc = launch_product(stream, prod_tiles, fork_recorded ? side->ev_main[panel & 1] : nullptr);
       if (rc != CURV_OK) return rc;
     }
     // Outer update of this panel in two parts: near = the strip the next chain touches (this stream, on the
@@ -2113,54 +1929,43 @@ struct GroupSweep {
       far_tiles += outer_tiles(d.P, kend, row0, s_in_sweep(d));
       any_s_part = any_s_part || s_in_sweep(d);
     }
-    static const int near_side = getenv("CURV_NEAR_SIDE") ? atoi(getenv("CURV_NEAR_SIDE")) : 0;
-    static const int inv_stream = getenv("CURV_INV_STREAM") ? atoi(getenv("CURV_INV_STREAM")) : 0;
-    hipStream_t inv_st = inv_stream ? side->inv : side->stream;
-    // CURV_NEAR_SIDE=1: near update on the side stream, in front of the far update (a wide launch on the chain's unmasked
-    // stream fills the CUs the mask keeps free, and the small chain launches of this and of the OTHER group then wait for
-    // it to drain).  Measured slower: ResNet-50 factors 7.75 -> 8.66 ms, one 4608^2 2.69 -> 3.10 ms - the chain pays two
-    // cross-stream waits per panel instead of one.  CURV_INV_STREAM: the fp32 inverse on a stream of its own - every
-    // additional hardware queue costs far more than it brings (7.5 -> 11.1 ms with one more CU-masked stream)
-    const bool near_on_side = near_side != 0 && near_tiles > 0;
-    const bool side_work = far_tiles > 0 || near_on_side || (!inv_stream && (inv_jobs > 0 || inv_tiles > 0));
+    hipStream_t inv_st = side->stream;
+    // (Measured and removed, LAB_NOTEBOOK R5.3 / R5.7: the near update on the side stream in front of the far update -
+    // ResNet-50 factors 7.75 -> 8.66 ms, the chain pays two cross-stream waits per panel; the fp32 inverse on a stream of
+    // its own - every additional busy hardware queue costs far more than it brings, 7.5 -> 11.1 ms.)
     const bool inv_work = inv_jobs > 0 || inv_tiles > 0;
-    // fork: the other streams' work needs this panel's chain.  CURV_FORK_AFTER_NEAR=1 forks BEHIND the near update (a far
+    const bool side_work = far_tiles > 0 || inv_work;
+    // fork: the side stream's work needs this panel's chain.  CURV_FORK_AFTER_NEAR=1 forks BEHIND the near update (a far
     // update launched beside it takes every CU but the reserved ones and the near update then runs in rounds on those: one
     // 4608^2 40 -> 14 us per panel) - measured neutral: the side stream's work moves 25 us later and lands on the next panel
     // product instead (17 -> 45 us); one 4608^2 2.63 vs 2.66 ms, whole model 6.87 vs 6.84 ms over six pairs
     static const int fork_late_env = getenv("CURV_FORK_AFTER_NEAR") ? atoi(getenv("CURV_FORK_AFTER_NEAR")) : 0;
-    const bool fork_late = fork_late_env != 0 && !near_on_side;
+    const bool fork_late = fork_late_env != 0;
     auto fork = [&]() -> int {
-      if (side_work || inv_work) {
+      if (side_work) {
         if (!fork_recorded || fork_late) CURV_HIP_CHECK(hipEventRecord(side->ev_main[panel & 1], stream));
-        if (side_work) CURV_HIP_CHECK(hipStreamWaitEvent(side->stream, side->ev_main[panel & 1], 0));
-        if (inv_work && inv_stream) CURV_HIP_CHECK(hipStreamWaitEvent(side->inv, side->ev_main[panel & 1], 0));
+        CURV_HIP_CHECK(hipStreamWaitEvent(side->stream, side->ev_main[panel & 1], 0));
       }
       return CURV_OK;
     };
     if (!fork_late) { const int rc = fork(); if (rc != CURV_OK) return rc; }
     if (near_tiles > 0) {
-      hipStream_t near_st = near_on_side ? side->stream : stream;
-      if (far_pending && !near_on_side) {        // join: the previous far part wrote the tiles updated here
+      if (far_pending) {                         // join: the previous far part wrote the tiles updated here
         CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_side[(panel + 1) & 1], 0));
       }
-      far_pending = false;                       // (near on the side stream: ordered behind the previous far part there)
+      far_pending = false;
       if (near_tiles <= wide_near)
-        hipLaunchKernelGGL(outer_update_wide_kernel, dim3((unsigned)near_tiles), dim3(1024), 0, near_st, table, n_factors,
+        hipLaunchKernelGGL(outer_update_wide_kernel, dim3((unsigned)near_tiles), dim3(1024), 0, stream, table, n_factors,
                            k0, kend, kend, row0, 1, (int)near_tiles);
       else
-        hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)near_tiles), dim3(INV_THREADS), 0, near_st, table, n_factors, k0,
+        hipLaunchKernelGGL(outer_update_kernel, dim3((unsigned)near_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, k0,
                            kend, kend, row0, 1, (int)near_tiles);
       CURV_LAUNCH_CHECK();
-      if (near_on_side) {                        // the next panel's chain starts behind it
-        CURV_HIP_CHECK(hipEventRecord(side->ev_near[panel & 1], side->stream));
-        CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_near[panel & 1], 0));
-      }
     }
     if (fork_late) { const int rc = fork(); if (rc != CURV_OK) return rc; }
     if (far_tiles > 0) {
       const long long grid = cdivll(far_tiles, 8 * SB * SB) * 8 * SB * SB;
-      const bool ride = ext_events != 0 && !capturing && !near_side;
+      const bool ride = ext_events != 0 && !capturing;
       const InvDev* tb = table;
       // trailing tiles only (KFAC.invert: the inverse is accumulated in fp32 off the chain): the LDS-DMA form
       static const int far_dma = getenv("CURV_FAR_DMA") ? atoi(getenv("CURV_FAR_DMA")) : 1;
@@ -2188,10 +1993,8 @@ struct GroupSweep {
         hipExtLaunchKernelGGL(outer_update_kernel, dim3((unsigned)grid), dim3(INV_THREADS), 0, side->stream, nullptr,
                               ride ? side->ev_side[panel & 1] : nullptr, 0, tb, n_factors, k0, kend, row0, 0, 0, (int)far_tiles);
       CURV_LAUNCH_CHECK();
-      if (!near_side) {
-        if (!ride) CURV_HIP_CHECK(hipEventRecord(side->ev_side[panel & 1], side->stream));
-        far_pending = true;
-      }
+      if (!ride) CURV_HIP_CHECK(hipEventRecord(side->ev_side[panel & 1], side->stream));
+      far_pending = true;
     }
     // the fp32 inverse on its stream: the rows of this panel x X_sq (needs the square, i.e. this panel's chain, and the S
     // updates of all earlier panels: stream order), then this panel's S update of the rows below
@@ -2217,9 +2020,7 @@ struct GroupSweep {
     if (chain_done != nullptr) CURV_HIP_CHECK(hipEventRecord(chain_done, stream));
     if (far_pending) CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_side[(panel + 1) & 1], 0));
     if (inv_pending) {
-      static const int inv_stream = getenv("CURV_INV_STREAM") ? atoi(getenv("CURV_INV_STREAM")) : 0;
-      hipStream_t inv_st = inv_stream ? side->inv : side->stream;
-      CURV_HIP_CHECK(hipEventRecord(side->ev_tail, inv_st));
+      CURV_HIP_CHECK(hipEventRecord(side->ev_tail, side->stream));
       CURV_HIP_CHECK(hipStreamWaitEvent(stream, side->ev_tail, 0));
     }
     hipLaunchKernelGGL(inv_finalize_kernel, dim3((unsigned)fin_tiles), dim3(INV_THREADS), 0, stream, table, n_factors, NBO * NB);
@@ -2359,22 +2160,17 @@ static int chol_sweep(hipStream_t stream, std::vector<InvDev>& tab, void* worksp
   // `start_panel` panels, so that its throughput work fills the large group's chain-bound tail.
   static const int start_frac = getenv("CURV_SMALL_START") ? atoi(getenv("CURV_SMALL_START")) : 30;  // percent of the panels
   // (ResNet-50: 0 -> 9.25 ms, 20 -> 9.2, 30 -> 9.0, 40 -> 9.2, 50 -> 9.5)
-  static const int nbo_env2 = getenv("CURV_NBO") ? atoi(getenv("CURV_NBO")) : 0;
-  const int n_panels = cdiv(Pmax, latency_bound ? 4 : (nbo_env2 > 0 ? nbo_env2 : 6));
+  const int n_panels = cdiv(Pmax, sweep_nbo(latency_bound));
   long long far0 = 0;                          // far tiles of the large group's first panel
   for (const InvDev& d : big) far0 += outer_tiles(d.P, 4, 8, s_in_sweep(d));
   // only a far-bound large group has such a tail to fill (a chain step is ~54 us, a far tile ~0.04 us of the
   // whole GPU): with [2048 | 1024, 512, 256] the delay costs 8 %
   const int start_panel = far0 >= 5000 ? std::min(n_panels - 1, n_panels * start_frac / 100) : 0;
-  // the large group of a whole model (a handful of factors with the longest chain) may take the chain-bound forms too
-  static const int square_big = getenv("CURV_SQUARE_BIG") ? atoi(getenv("CURV_SQUARE_BIG")) : 0;
-  bool big_rhs = false;
-  for (const InvDev& d : big) big_rhs = big_rhs || d.R != nullptr;
-  const bool big_latency = latency_bound || (square_big != 0 && (int)big.size() <= square_big && !big_rhs);
+  // (the chain-bound forms for the large group of a whole model: 6.7-7.0 vs 6.7-6.8 ms, LAB_NOTEBOOK R5.3 - not kept)
   // The two sweeps are enqueued panel by panel, the small group's panel t - start_panel behind the large group's panel t:
   // the event the small group's stream waits for (the large group has done `start_panel` panels) is then the large
   // group's stream TAIL at the moment of the wait, which is what hipStreamWaitEvent effectively waits for.
-  GroupSweep gb(ss->aux, &ss->side[0], big, table0, flags0, big_latency);
+  GroupSweep gb(ss->aux, &ss->side[0], big, table0, flags0, latency_bound);
   // CURV_SMALL_ONE_STREAM=1: the small group's far updates and fp32 inverse on its chain's stream (three busy streams)
   static const int small_one = getenv("CURV_SMALL_ONE_STREAM") ? atoi(getenv("CURV_SMALL_ONE_STREAM")) : 0;
   SideStream side_small = ss->side[1];
