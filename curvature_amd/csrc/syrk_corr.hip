@@ -59,88 +59,125 @@ struct CorrDev {
   float scale;
   long long prep_base;       // first workgroup of this layer in the prep grid
   int tile_base;             // first workgroup of this layer in the assembly grid
-  unsigned wp_magic, h_magic, c_magic;      // ceil(2^32 / d) for W + 2, H, C
+  unsigned g_magic, h_magic, c_magic;       // ceil(2^32 / d) for W / G, H, C
+  int G, pad_;               // source floats per access of the padding pass (4 / 2 / 1)
 };
-constexpr int CORR_CHUNK = 14;
+constexpr int CORR_CHUNK = 13;
 struct CorrChunk { CorrDev l[CORR_CHUNK]; };
 static_assert(sizeof(CorrChunk) <= 3840, "kernel argument block must stay below 4 KB");
 
 typedef __attribute__((address_space(1))) float gfl;
 
-// one workgroup per PREP_SEG consecutive elements of a layer's Xp (one exact division per workgroup, multiply-high
-// arithmetic per element); the border rows / columns / corners are scattered from the same value
-constexpr int PREP_SEG = 4096;
+// one workgroup per PREP_SEG consecutive access groups of a layer's source (one exact division per workgroup, multiply-high
+// arithmetic per group); the border rows / columns / corners are scattered from the same values
+constexpr int PREP_SEG = 2048;
 __device__ __forceinline__ int corr_divu(int x, int d, unsigned magic) { return d == 1 ? x : (int)__umulhi((unsigned)x, magic); }
 static unsigned corr_magic(int d) { return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
 
+// G consecutive floats of a SOURCE row per thread and access (G = 4 / 2 / 1: the widest that divides W and the source
+// alignment allows - 16-byte loads for the 56- and 28-wide images that make up three quarters of the bytes), U groups per
+// thread and pass with all loads issued before the first store; the thread that holds a row's last group also writes the
+// row's two zero columns and its share of the zero tail.  (Round 5: one 4-byte element of Xp per thread and access, 2.6 TB/s.)
+template <int G>
+__device__ __forceinline__ void corr_prep_body(const CorrDev& d, long long g_first, int n_groups) {
+  constexpr int U = 4;             // (segments of 1024-8192 groups, 4 or 8 groups per pass: the same update() within 0.5 %)
+  const int Wp = d.Wp, H = d.H, W = d.W, C = d.C;
+  const int gpr = W / G;                                     // groups per source row
+  const unsigned g_magic = d.g_magic, h_magic = d.h_magic, c_magic = d.c_magic;
+  gfl* xp = (gfl*)d.xp;
+  const int plane = H * Wp, tail = d.xp_pitch - plane;
+  const gfl* __restrict__ src = (const gfl*)d.src;
+  typedef float fg __attribute__((ext_vector_type(G == 1 ? 2 : G)));      // (G = 1: scalar accesses below)
+  typedef __attribute__((address_space(1))) fg gfg;
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) f2 gf2;
+  const long long row_first = g_first / gpr;                 // one exact division per workgroup
+  const int goff0 = (int)(g_first - row_first * gpr);
+  // everything but the Xp store of one element (n, c, u, v) - a pixel or one of the two zero columns behind its row:
+  // the gathered border rows / columns / corners and the zero leads, as the factor's strips read them
+  auto emit = [&](int sc, int n, int c, int u, int v, float val) {
+    if (tail > 0 && v >= W) {
+      // packed pair tiles read every row up to two image rows past its end: zero tail, written by the 2 H elements
+      // that are the row's padding columns
+      for (int q = 2 * u + (v - W); q < tail; q += 2 * H) xp[(long long)sc * d.xp_pitch + plane + q] = 0.0f;
+      if (sc == 0 && u == 0) for (int q = v - W; q < d.xp_lead; q += 2) xp[q - d.xp_lead] = 0.0f;
+    }
+    if (u == H - 1) d.rowb[(long long)c * d.row_pitch + corr::LEAD + n * Wp + v] = val;
+    if (u == 0) d.rowt[(long long)c * d.row_pitch + corr::LEAD + n * Wp + v] = val;
+    if (v == W - 1 || v == 0) {
+      float* col = (v == 0 ? d.coll : d.colr) + (long long)c * d.col_pitch + corr::LEAD + n * d.Hq;
+      col[u] = val;
+      if (u == H - 1) { col[H] = 0.0f; col[H + 1] = 0.0f; }
+    }
+    if ((u == 0 || u == H - 1) && (v == 0 || v == W - 1)) {
+      const int kk = (u == 0 ? 2 : 0) + (v == 0 ? 1 : 0);           // BR, BL, TR, TL
+      d.pt[((long long)kk * C + c) * d.pt_pitch + n] = val;
+    }
+    if (n == 0 && u == 0 && v < corr::LEAD) {
+      d.rowb[(long long)c * d.row_pitch + v] = 0.0f;
+      d.rowt[(long long)c * d.row_pitch + v] = 0.0f;
+      d.colr[(long long)c * d.col_pitch + v] = 0.0f;
+      d.coll[(long long)c * d.col_pitch + v] = 0.0f;
+    }
+  };
+  for (int t0 = threadIdx.x; t0 < n_groups; t0 += 256 * U) {
+    int r_[U], v_[U];
+    float val_[U][G];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int off = goff0 + min(t0 + 256 * k, n_groups - 1);      // (passes beyond the segment repeat its last group)
+      const int drow = gpr == 1 ? off : (int)__umulhi((unsigned)off, g_magic);
+      v_[k] = (off - drow * gpr) * G;
+      r_[k] = (int)row_first + drow;                                // (n * C + c) * H + u
+      const gfl* sp = src + (long long)r_[k] * W + v_[k];
+      if (G == 1) val_[k][0] = *sp;
+      else {
+        const fg x = *(const gfg*)sp;
+#pragma unroll
+        for (int e = 0; e < G; ++e) val_[k][e] = x[e];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (t0 + 256 * k >= n_groups) break;
+      const int r = r_[k], v = v_[k];
+      const int sc = corr_divu(r, H, h_magic), u = r - sc * H;
+      const int n = corr_divu(sc, C, c_magic), c = sc - n * C;
+      gfl* row = xp + (long long)sc * d.xp_pitch + u * Wp;
+      // (Wp = W + 2 and v are even for G >= 2, the pitch a multiple of four: 8-byte stores)
+      if (G == 1) row[v] = val_[k][0];
+      else {
+#pragma unroll
+        for (int e = 0; e < G; e += 2) *(gf2*)(row + v + e) = f2{val_[k][e], val_[k][e + 1]};
+      }
+      const bool edge = v == 0 || v + G == W || u == 0 || u == H - 1;
+      if (edge) {
+#pragma unroll
+        for (int e = 0; e < G; ++e) emit(sc, n, c, u, v + e, val_[k][e]);
+      }
+      if (v + G == W) {                                             // the row's last group: its two zero columns
+        if (G == 1) { row[W] = 0.0f; row[W + 1] = 0.0f; }
+        else *(gf2*)(row + W) = f2{0.0f, 0.0f};
+        emit(sc, n, c, u, W, 0.0f);
+        emit(sc, n, c, u, W + 1, 0.0f);
+      }
+    }
+  }
+}
 __global__ void __launch_bounds__(256) corr_prep_kernel(CorrChunk chunk, int count, long long total) {
   (void)total;
   int l = 0;
   while (l + 1 < count && chunk.l[l + 1].prep_base <= (long long)blockIdx.x) ++l;
   const CorrDev& d = chunk.l[l];
-  const int Wp = d.Wp, H = d.H, W = d.W, C = d.C;
-  const long long words = (long long)d.N * C * H * Wp;
-  const long long e0 = ((long long)blockIdx.x - d.prep_base) * PREP_SEG;
-  const int row0 = (int)(e0 / Wp);
-  const int v0 = (int)(e0 - (long long)row0 * Wp);
-  const int cnt = (int)min((long long)PREP_SEG, words - e0);
-  const unsigned wp_magic = d.wp_magic, h_magic = d.h_magic, c_magic = d.c_magic;
-  gfl* xp = (gfl*)d.xp;
-  const int plane = H * Wp, tail = d.xp_pitch - plane;
-  // four elements per thread and pass, all four loads issued before the first store: with one element per pass the
-  // kernel kept 1 KB per workgroup in flight and ran at 2.2-2.5 TB/s
-  const gfl* __restrict__ src = (const gfl*)d.src;
-#ifndef CURV_PREP_U
-#define CURV_PREP_U 4
-#endif
-  constexpr int U = CURV_PREP_U;
-  for (int t0 = threadIdx.x; t0 < cnt; t0 += 256 * U) {
-    int r_[U], v_[U], sc_[U], u_[U];
-    float val_[U];
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      const int off = v0 + min(t0 + 256 * k, cnt - 1);      // < PREP_SEG + Wp (passes beyond cnt repeat its last element)
-      const int drow = (int)__umulhi((unsigned)off, wp_magic);
-      v_[k] = off - drow * Wp;
-      r_[k] = row0 + drow;                                  // (n * C + c) * H + u
-      sc_[k] = corr_divu(r_[k], H, h_magic);
-      u_[k] = r_[k] - sc_[k] * H;
-      val_[k] = v_[k] < W ? src[(long long)r_[k] * W + v_[k]] : 0.0f;
-    }
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      if (t0 + 256 * k >= cnt) break;
-      const int v = v_[k], sc = sc_[k], u = u_[k];
-      const float val = val_[k];
-      const int n = corr_divu(sc, C, c_magic);
-      const int c = sc - n * C;
-      xp[(long long)sc * d.xp_pitch + u * Wp + v] = val;
-      if (tail > 0 && v >= W) {
-        // packed pair tiles read every row up to two image rows past its end: zero tail, written by the 2 H threads
-        // that hold the row's padding columns
-        for (int q = 2 * u + (v - W); q < tail; q += 2 * H) xp[(long long)sc * d.xp_pitch + plane + q] = 0.0f;
-        if (sc == 0 && u == 0) for (int q = v - W; q < d.xp_lead; q += 2) xp[q - d.xp_lead] = 0.0f;
-      }
-      if (u == H - 1) d.rowb[(long long)c * d.row_pitch + corr::LEAD + n * Wp + v] = val;
-      if (u == 0) d.rowt[(long long)c * d.row_pitch + corr::LEAD + n * Wp + v] = val;
-      if (v == W - 1 || v == 0) {
-        float* col = (v == 0 ? d.coll : d.colr) + (long long)c * d.col_pitch + corr::LEAD + n * d.Hq;
-        col[u] = val;
-        if (u == H - 1) { col[H] = 0.0f; col[H + 1] = 0.0f; }
-      }
-      if ((u == 0 || u == H - 1) && (v == 0 || v == W - 1)) {
-        const int kk = (u == 0 ? 2 : 0) + (v == 0 ? 1 : 0);           // BR, BL, TR, TL
-        d.pt[((long long)kk * C + c) * d.pt_pitch + n] = val;
-      }
-      if (n == 0 && u == 0 && v < corr::LEAD) {
-        d.rowb[(long long)c * d.row_pitch + v] = 0.0f;
-        d.rowt[(long long)c * d.row_pitch + v] = 0.0f;
-        d.colr[(long long)c * d.col_pitch + v] = 0.0f;
-        d.coll[(long long)c * d.col_pitch + v] = 0.0f;
-      }
-    }
-  }
+  const int G = d.G;
+  const long long groups = (long long)d.N * d.C * d.H * (d.W / G);
+  const long long g0 = ((long long)blockIdx.x - d.prep_base) * PREP_SEG;
+  const int cnt = (int)min((long long)PREP_SEG, groups - g0);
+  if (G == 4) corr_prep_body<4>(d, g0, cnt);
+  else if (G == 2) corr_prep_body<2>(d, g0, cnt);
+  else corr_prep_body<1>(d, g0, cnt);
 }
+
 
 // dst tile (OUT x OUT) of channel tile (cb, cb2): rows (c, p), columns (c', q).  p >= q reads the components at
 // [c][c'], p < q is the transposed block (q, p) and reads them at [c'][c] (the mirrored channel tile).
@@ -158,58 +195,84 @@ __global__ void __launch_bounds__(256) corr_assemble_kernel(CorrChunk chunk, int
   int t = blockIdx.x - d.tile_base;
   if (t < ((nct * nct) & ~31)) { const int w = t & 31; t = (t & ~31) + ((w & 7) << 2) + (w >> 3); }
   const int cb = t / nct, cb2 = t - cb * nct;
-  for (int e = threadIdx.x; e < 29 * CT * CT; e += 256) {
-    const int k = e / (CT * CT), rc = e - k * (CT * CT), r = rc / CT, c = rc - r * CT;
-    const float* m = d.comp + d.comp_at[k];
-    ta[k][r][c] = m[(long long)(cb * CT + r) * d.comp_pitch + cb2 * CT + c];
-    tb[k][r][c] = m[(long long)(cb2 * CT + r) * d.comp_pitch + cb * CT + c];
+  {
+    // component tiles: 8-float rows = two 16-byte loads (component offsets, pitches and tile columns are multiples of four
+    // floats), all of a thread's loads issued before its first LDS store
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) f4 gf4;
+    constexpr int HALVES = 29 * CT * 2, PER = (HALVES + 255) / 256;      // 16-byte pieces per operand side
+    f4 va[PER], vb[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = min((int)threadIdx.x + 256 * i, HALVES - 1);
+      const int k = e / (CT * 2), rc = e - k * (CT * 2), r = rc >> 1, c = (rc & 1) * 4;
+      const gfl* m = (const gfl*)d.comp + d.comp_at[k];
+      va[i] = *(const gf4*)(m + (long long)(cb * CT + r) * d.comp_pitch + cb2 * CT + c);
+      vb[i] = *(const gf4*)(m + (long long)(cb2 * CT + r) * d.comp_pitch + cb * CT + c);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = (int)threadIdx.x + 256 * i;
+      if (e < HALVES) {
+        const int k = e / (CT * 2), rc = e - k * (CT * 2), r = rc >> 1, c = (rc & 1) * 4;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { ta[k][r][c + x] = va[i][x]; tb[k][r][c + x] = vb[i][x]; }
+      }
+    }
   }
   __syncthreads();
   const int dim = 9 * C;
   const float scale = d.scale;
   const bool first = d.first != 0;
   gfl* dst = (gfl*)d.dst;
-  // four elements per thread and pass: the loads of the accumulated factor are issued first and land while the components
-  // are combined (one element per pass waited for its own load - 20 dependent round trips per thread: 268 -> 213 us)
-#ifndef CURV_ASM_U
-#define CURV_ASM_U 4
-#endif
-  constexpr int U = CURV_ASM_U;
-  for (int e0 = threadIdx.x; e0 < OUT * OUT; e0 += 256 * U) {
+  // four CONSECUTIVE columns per thread (one 16-byte access to the accumulated factor each way: tile rows are 288 bytes,
+  // 16-byte aligned since 9 C and 72 are multiples of four), three such groups per thread and pass, the loads of the
+  // accumulated factor issued first so that they land while the components are combined (round 5: one 4-byte element
+  // per access, 20 dependent round trips per thread: 229-266 us for 0.8 GB)
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) f4 gf4;
+  constexpr int GROUPS = OUT * OUT / 4, GPR = OUT / 4;      // 16-byte groups per tile / per tile row
+  static_assert(OUT % 4 == 0, "tile rows in whole 16-byte groups");
+  auto element = [&](int R, int Q) -> float {
+    int c = R / 9, p = R - 9 * c, c2 = Q / 9, q = Q - 9 * c2;
+    const bool lower = p >= q;
+    const float (*T)[CT][CT + 1] = lower ? ta : tb;
+    if (!lower) { int s_ = p; p = q; q = s_; s_ = c; c = c2; c2 = s_; }      // block (q, p) transposed
+    const int kh = p / 3, kw = p - 3 * kh, kh2 = q / 3, kw2 = q - 3 * kh2;
+    const int dh = kh2 - kh, dw = kw2 - kw;
+    float v = T[f_index(dh, dw)][c][c2];
+    if (dh == 0) {
+      if (kh == 0) v -= T[RB0 - dw][c][c2];
+      if (kh == 2) v -= T[RT0 - dw][c][c2];
+    }
+    if (dw == 0) {
+      if (kw == 0) v -= T[CR0 - dh][c][c2];
+      if (kw == 2) v -= T[CL0 - dh][c][c2];
+    }
+    if (dh == 0 && dw == 0 && kh != 1 && kw != 1) v += T[PT0 + (kh == 2 ? 2 : 0) + (kw == 2 ? 1 : 0)][c][c2];
+    return v * scale;
+  };
+  constexpr int U = 3;
+  for (int g0 = threadIdx.x; g0 < GROUPS; g0 += 256 * U) {
     long long o_[U];
-    float old_[U], v_[U];
+    f4 old_[U], v_[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int e = min(e0 + 256 * u, OUT * OUT - 1);
-      const int R = e / OUT, Q = e - R * OUT;
+      const int g = min(g0 + 256 * u, GROUPS - 1);
+      const int R = g / GPR, Q = 4 * (g - R * GPR);
       o_[u] = (long long)(cb * OUT + R) * dim + cb2 * OUT + Q;
-      old_[u] = first ? 0.0f : dst[o_[u]];
+      old_[u] = first ? f4{0.0f, 0.0f, 0.0f, 0.0f} : *(const gf4*)(dst + o_[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int e = min(e0 + 256 * u, OUT * OUT - 1);
-      const int R = e / OUT, Q = e - R * OUT;
-      int c = R / 9, p = R - 9 * c, c2 = Q / 9, q = Q - 9 * c2;
-      const bool lower = p >= q;
-      const float (*T)[CT][CT + 1] = lower ? ta : tb;
-      if (!lower) { int s_ = p; p = q; q = s_; s_ = c; c = c2; c2 = s_; }      // block (q, p) transposed
-      const int kh = p / 3, kw = p - 3 * kh, kh2 = q / 3, kw2 = q - 3 * kh2;
-      const int dh = kh2 - kh, dw = kw2 - kw;
-      float v = T[f_index(dh, dw)][c][c2];
-      if (dh == 0) {
-        if (kh == 0) v -= T[RB0 - dw][c][c2];
-        if (kh == 2) v -= T[RT0 - dw][c][c2];
-      }
-      if (dw == 0) {
-        if (kw == 0) v -= T[CR0 - dh][c][c2];
-        if (kw == 2) v -= T[CL0 - dh][c][c2];
-      }
-      if (dh == 0 && dw == 0 && kh != 1 && kw != 1) v += T[PT0 + (kh == 2 ? 2 : 0) + (kw == 2 ? 1 : 0)][c][c2];
-      v_[u] = v * scale;
+      const int g = min(g0 + 256 * u, GROUPS - 1);
+      const int R = g / GPR, Q = 4 * (g - R * GPR);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) v_[u][x] = element(R, Q + x);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (e0 + 256 * u < OUT * OUT) dst[o_[u]] = first ? v_[u] : old_[u] + v_[u];
+      if (g0 + 256 * u < GROUPS) *(gf4*)(dst + o_[u]) = first ? v_[u] : old_[u] + v_[u];
   }
 }
 
@@ -401,7 +464,9 @@ static void fill_dev(const CorrLayer& L, const FactorDev& user, float* area, Cor
   d.N = L.N; d.C = L.C; d.H = L.H; d.W = L.W; d.Wp = L.Wp; d.Hq = L.Hq;
   d.row_pitch = L.row_pitch; d.col_pitch = L.col_pitch; d.pt_pitch = L.pt_pitch;
   d.first = user.first; d.scale = user.scale;
-  d.wp_magic = corr_magic(L.Wp); d.h_magic = corr_magic(L.H); d.c_magic = corr_magic(L.C);
+  d.G = ((L.W & 3) == 0 && (reinterpret_cast<uintptr_t>(user.src) & 15) == 0) ? 4
+        : ((L.W & 1) == 0 && (reinterpret_cast<uintptr_t>(user.src) & 7) == 0) ? 2 : 1;
+  d.g_magic = corr_magic(L.W / d.G); d.h_magic = corr_magic(L.H); d.c_magic = corr_magic(L.C);
 }
 
 int launch_corr_prep(hipStream_t stream, const std::vector<CorrLayer>& layers, const std::vector<FactorDev>& f,
@@ -415,7 +480,7 @@ int launch_corr_prep(hipStream_t stream, const std::vector<CorrLayer>& layers, c
       const CorrLayer& L = layers[b + k];
       fill_dev(L, f[L.user], area, chunk.l[k]);
       chunk.l[k].prep_base = total;
-      total += ((long long)L.N * L.C * L.H * L.Wp + PREP_SEG - 1) / PREP_SEG;
+      total += ((long long)L.N * L.C * L.H * (L.W / chunk.l[k].G) + PREP_SEG - 1) / PREP_SEG;
     }
     CURV_REQUIRE(total < (1LL << 31), "curv_kfac: too many padding segments");
     hipLaunchKernelGGL(corr_prep_kernel, dim3((unsigned)total), dim3(256), 0, stream, chunk, count, total);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """One source of the library recompiled with extra -D flags and linked with the product's other objects (csrc/build/, run
 build() first) into tools/micro/libcurv_<tag>.so - for same-box A/B runs (tools/ab_libs.sh, tools/ab_update.py):
-    python tools/make_variant.py syrk_corr.hip asm1 -DCURV_ASM_U=1"""
+    python tools/make_variant.py syrk_flat.hip kc32 -DCURV_FLAT_KC=32"""
 import glob
 import os
 import subprocess
