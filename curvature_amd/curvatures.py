@@ -1105,6 +1105,17 @@ class EFB(Curvature):
             for layer, (gw, gb), tmp in zip(layers, grads, tmps):
                 n0 = gw.numel() // gw.shape[0]
                 U_A, U_G = self.eigvecs[layer]
+                if gb is None and min(gw.shape[0], n0) >= 64:
+                    # bias-free layer: both products in the "rows times rows" form the LDS-DMA GEMM kernel takes (every operand
+                    # contiguous along the summation index) - the eigenvectors are constants, their transposes are kept:
+                    #   T^T = U_A^T W.grad^T  (n0 x m),   Lambda += (U_G^T T)**2 = (U_G^T (T^T)^T)**2
+                    U_At, U_Gt = self._eigvecs_t(layer)
+                    tmp_t = tmp.view(-1)[:n0 * gw.shape[0]].view(n0, gw.shape[0])
+                    stage1.append(ops.Gemm(U_At, views[vi].t(), tmp_t))
+                    staged.append(views[vi])
+                    vi += 1
+                    stage2.append(ops.Gemm(U_Gt, tmp_t.t(), self.state[layer], beta=1.0, epilogue=ops.EPI_SQUARE))
+                    continue
                 stage1.append(ops.Gemm(U_G.t(), views[vi], tmp[:, :n0]))              # U_G^T [W.grad | b.grad]
                 staged.append(views[vi])
                 vi += 1
@@ -1127,6 +1138,16 @@ class EFB(Curvature):
                                        for layer, (gw, gb) in zip(layers, grads)], batch_size)      # one launch
         for layer, st in zip(layers, done):
             self.diags[layer] = st
+
+    def _eigvecs_t(self, layer):
+        """(U_A^T, U_G^T) as contiguous tensors, formed once per layer (the eigenvectors are constants of the estimator)."""
+        cache = self.__dict__.setdefault("_eigvecs_t_cache", {})
+        U_A, U_G = self.eigvecs[layer]
+        hit = cache.get(layer)
+        if hit is None or hit[0] != (U_A.data_ptr(), U_G.data_ptr()):
+            hit = ((U_A.data_ptr(), U_G.data_ptr()), U_A.t().contiguous(), U_G.t().contiguous())
+            cache[layer] = hit
+        return hit[1], hit[2]
 
     def invert(self, add: Union[float, list, tuple] = 0., multiply: Union[float, list, tuple] = 1.):
         assert self.state, "State dict is empty. Did you call 'update' prior to this?"
@@ -1160,10 +1181,10 @@ class EFB(Curvature):
         if z is None:
             z = self._randn(n, m, device=first.device)
         zt = ops.mul2d(z.t(), lambdas)                                    # (m, n)
-        tmp = torch.empty(m, n, dtype=torch.float32, device=first.device)
+        pt = torch.empty(n, m, dtype=torch.float32, device=first.device)
         out = torch.empty(m, n, dtype=torch.float32, device=first.device)
-        ops.gemm_batched([ops.Gemm(second, zt, tmp)])
-        ops.gemm_batched([ops.Gemm(tmp, first.t(), out)])
+        ops.gemm_batched([ops.Gemm(first, zt.t(), pt)])                   # P^T = U_A zt^T (see sample_and_replace)
+        ops.gemm_batched([ops.Gemm(second, pt.t(), out)])                 # U_G P
         return out
 
     def sample_and_replace(self, noise: Optional[Dict[Module, Tensor]] = None):
@@ -1191,16 +1212,19 @@ class EFB(Curvature):
             for layer, zt, tmp in zip(layers, zts, tmps):
                 first, second = self.eigvecs[layer]
                 n, m = first.size(0), second.size(0)
-                stage1.append(ops.Gemm(second, zt, tmp))
+                # U_G zt U_A^T as  P^T = U_A zt^T (n x m),  out = U_G P: both products "rows times rows" (every operand
+                # contiguous along the summation index - the form the LDS-DMA GEMM kernel takes), no transposed copies
+                pt = tmp.view(-1).view(n, m)
+                stage1.append(ops.Gemm(first, zt.t(), pt))
                 n0 = n - int(layer.bias is not None)
                 w = layer.weight.data.view(m, n0)
                 w_mean = self.model_state_of(layer, 'weight').view(m, n0)
-                ua_t = first.t()
-                stage2.append(ops.Gemm(tmp, ua_t[:, :n0], w, epilogue=ops.EPI_ADD_E, E=w_mean))
+                p = pt.t()                                                          # (m, n) view of P
+                stage2.append(ops.Gemm(second, p[:, :n0], w, epilogue=ops.EPI_ADD_E, E=w_mean))
                 if layer.bias is not None:
                     b = layer.bias.data.view(m, 1)
                     b_mean = self.model_state_of(layer, 'bias').view(m, 1)
-                    stage2.append(ops.Gemm(tmp, ua_t[:, n0:], b, epilogue=ops.EPI_ADD_E, E=b_mean))
+                    stage2.append(ops.Gemm(second, p[:, n0:], b, epilogue=ops.EPI_ADD_E, E=b_mean))
             stage1.sort(key=lambda j: -(j.A.shape[0] * j.A.shape[1] * j.B.shape[1]))
             stage2.sort(key=lambda j: -(j.A.shape[0] * j.A.shape[1] * j.B.shape[1]))
             inv_flat = getattr(self, "_inv_flat", None)
