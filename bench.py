@@ -565,7 +565,7 @@ def _efb_eig_fracs(state, efb_update_ms, eig_ms, sweeps, prefix, ranks=None):
     n / 32 - 1 rounds, and a round of the fp32 phase moves 14 n^2 bytes (the symmetric two-sided pass over A32: 6 n^2, the
     column pass over V32: 8 n^2; DESIGN K4).  Every matrix is priced at the sweep count of the slowest one and at the fp32
     phase's bytes (the two or three fp64 sweeps move twice as much): the fraction is an estimate, good to ~20 %.  A wide
-    rank-deficient factor that went through its range (ops._eigh_lowrank; `ranks` = position -> k) is priced at the k x k
+    rank-deficient factor that went through its range (csrc/eigh_lowrank.hip; `ranks` = position -> k) is priced at the k x k
     problem the iteration ran on - the range finder's products are not counted."""
     flops = sum(2.0 * (G.shape[0] ** 2 * A.shape[0] + G.shape[0] * A.shape[0] ** 2) for A, G in state.values())
     widths = [n for A, G in state.values() for n in (A.shape[0], G.shape[0])]

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(_HERE, "..", "include"))
 LIB_PATH = os.path.join(CSRC, "libcurv_hip.so")
-SOURCES = ["api.cpp", "collective.cpp", "elementwise.hip", "syrk.hip", "syrk_flat.hip", "syrk_corr.hip", "syrk_pre.hip", "syrk_small.hip", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip"]
+SOURCES = ["api.cpp", "collective.cpp", "elementwise.hip", "syrk.hip", "syrk_flat.hip", "syrk_corr.hip", "syrk_pre.hip", "syrk_small.hip", "invert.hip", "gemm.hip", "inf.hip", "eigh.hip", "eigh_lowrank.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall",
                "-Wno-unused-function", "-ldl"]
 
@@ -202,6 +202,8 @@ SIGNATURES = {
     "curv_gemm_f64_batched": (_i, [_vp, ctypes.POINTER(curv_gemm64_desc), _i]),
     "curv_syevd_workspace_bytes": (_sz, [ctypes.POINTER(curv_eigh_desc), _i]),
     "curv_syevd": (_i, [_vp, ctypes.POINTER(curv_eigh_desc), _i, _vp, _sz, _i, _d, ctypes.POINTER(ctypes.c_int)]),
+    "curv_syevd_ex": (_i, [_vp, ctypes.POINTER(curv_eigh_desc), _i, _vp, _sz, _i, _d, ctypes.POINTER(ctypes.c_int),
+                          ctypes.POINTER(ctypes.c_int)]),
     "curv_inf_select": (_i, [_vp, ctypes.POINTER(curv_select_desc), _i]),
     "curv_colpairs": (_i, [_vp, _vp, _i, _i, _ll, _vp]),
     "curv_inf_vtv_assemble": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -230,7 +232,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 9                     # CURV_ABI_VERSION of include/curv_hip.h
+ABI_VERSION = 10                     # CURV_ABI_VERSION of include/curv_hip.h
 KFAC_TABLE_RESIDENT = 1             # CURV_KFAC_TABLE_RESIDENT
 PATH_AUTO, PATH_SMALL, PATH_GROUPED = 0, 1, 2     # CURV_PATH_* (curv_factor_desc.path_hint)
 SMALL_MAX_FLOP = 2.0e9              # CURV_SMALL_MAX_FLOP

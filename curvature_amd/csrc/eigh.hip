@@ -860,15 +860,16 @@ static bool eigh_layout(const curv_eigh_desc* descs, int n, EighLayout& L) {
 
 using namespace curv;
 
-extern "C" size_t curv_syevd_workspace_bytes(const curv_eigh_desc* descs, int n_mats) {
+// The block-Jacobi iteration on whole matrices: curv_syevd (eigh_lowrank.hip) is this, behind the projection of wide
+// rank-deficient matrices onto their range.
+size_t curv::syevd_jacobi_workspace_bytes(const curv_eigh_desc* descs, int n_mats) {
   EighLayout L;
   if (!eigh_layout(descs, n_mats, L)) return 0;
   return L.total;
 }
 
-extern "C" int curv_syevd(void* stream_, const curv_eigh_desc* descs, int n_mats, void* workspace,
-                          size_t workspace_bytes, int max_sweeps, double tol, int* sweeps_done) {
-  hipStream_t stream = (hipStream_t)stream_;
+int curv::syevd_jacobi(hipStream_t stream, const curv_eigh_desc* descs, int n_mats, void* workspace,
+                       size_t workspace_bytes, int max_sweeps, double tol, int* sweeps_done) {
   if (n_mats == 0) return CURV_OK;
   CURV_REQUIRE(descs != nullptr, "curv_syevd: null descriptor array");
   EighLayout L;

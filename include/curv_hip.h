@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CURV_ABI_VERSION 9
+#define CURV_ABI_VERSION 10
 
 #define CURV_OK 0
 #define CURV_ERR_NOT_PD 1
@@ -363,6 +363,18 @@ typedef struct curv_eigh_desc {
 size_t curv_syevd_workspace_bytes(const curv_eigh_desc* descs, int n_mats);
 int curv_syevd(void* stream, const curv_eigh_desc* descs, int n_mats, void* workspace, size_t workspace_bytes,
                int max_sweeps, double tol, int* sweeps_done);
+/* With the defaults (max_sweeps <= 0 and tol <= 0) a matrix at least 2048 wide whose numerical rank is below half its width
+ * - the Kronecker factor of a layer with more rows than samples went into it (a 4608-wide ResNet-50 factor at N = 32: rank
+ * 1568) - is decomposed through its RANGE (csrc/eigh_lowrank.hip, ABI 10; round 5 did this in the Python mirror only): Gaussian range
+ * finder, rank from a pivoted Cholesky of its Gram matrix, Cholesky-QR, the iteration on the k x k projected matrix only, an
+ * orthonormal basis of the complement for the zero eigenvalues; accepted iff ||F - P F P|| <= 3e-6 ||F||, otherwise the matrix
+ * takes the iteration on the whole matrix like all others.  Same outputs, same order.  The workspace size above includes
+ * what the projection needs (about 1.2 GB per 4608-wide matrix).  CURV_EIGH_LOWRANK=0 in the environment, an explicit
+ * max_sweeps or an explicit tol select the plain iteration.
+ * curv_syevd_ex: the same call; `ranks` (optional host array, n_mats ints) receives per matrix the rank k of the projected
+ * problem, or 0 for a matrix that went through the plain iteration. */
+int curv_syevd_ex(void* stream, const curv_eigh_desc* descs, int n_mats, void* workspace, size_t workspace_bytes,
+                  int max_sweeps, double tol, int* sweeps_done, int* ranks);
 
 /* ------------------------------------------------------------------------------------------------
  * INF (sparse information form), curvature/curvatures.py:463-672

@@ -431,7 +431,7 @@ def test_chol_factor_inverse_with_right_hand_side(gpu, count):
 
 @pytest.mark.gpu
 def test_eigh_low_rank_path_and_its_fallback(gpu):
-    """Wide matrices whose numerical rank is below half their width are decomposed through their range (ops._eigh_lowrank:
+    """Wide matrices whose numerical rank is below half their width are decomposed through their range (csrc/eigh_lowrank.hip behind curv_syevd:
     Gaussian range finder, rank from a thresholded Cholesky of the Gram matrix, three Cholesky-QR passes, the iteration on
     the projected k x k matrix, an orthonormal complement for the null space); a wide matrix of full rank must fall back to
     the iteration on the whole matrix.  Same bars as the iteration: residual, orthogonality, ascending order, eigenvalues
@@ -469,7 +469,7 @@ def test_eigh_low_rank_path_sharp_rank(gpu):
     X = torch.cat([torch.relu(torch.randn(2048, 32, device=gpu)), torch.ones(1, 32, device=gpu)])
     F = (X @ X.t() / 32).contiguous()
     (U,), (w,) = ops.eigh([F], with_values=True)
-    assert ops.eigh.last_lowrank == 1, ops.eigh.lowrank_log
+    assert ops.eigh.last_lowrank == 1 and ops.eigh.last_ranks == {0: 32}
     Fd, Ud, wd = F.double(), U.double(), w.double()
     assert float(torch.linalg.norm(Fd @ Ud - Ud * wd)) < 5e-6 * float(torch.linalg.norm(Fd))
     assert float(torch.linalg.norm(Ud.t() @ Ud - torch.eye(2049, device=gpu, dtype=torch.float64))) < 1e-5 * 2049 ** 0.5
@@ -493,3 +493,31 @@ def test_eigh_low_rank_path_does_not_depend_on_the_batch(gpu):
     U_many, w_many = ops.eigh([small[0], other, big, small[1], small[2]], with_values=True)
     assert ops.eigh.last_lowrank == 2 and sorted(ops.eigh.last_ranks) == [1, 2]
     assert torch.equal(U_alone, U_many[2]) and torch.equal(w_alone, w_many[2])
+
+
+@pytest.mark.gpu
+def test_lowrank_path_of_the_library_matches_the_python_glue(gpu):
+    """The projection path lives behind `curv_syevd` since round 6 (csrc/eigh_lowrank.hip); round 5's Python glue over the same
+    entry points is kept as its checker (tools/eigh_lowrank_reference.py): same Gaussian matrices, same products, same
+    factorisations, same order - the eigenvectors and eigenvalues must agree bit for bit, on a rank-deficient matrix, on one
+    whose rank is hit exactly, and on a full-rank one that both leave to the iteration on the whole matrix."""
+    import os
+    import sys
+    from curvature_amd import ops
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import eigh_lowrank_reference as ref
+    torch.manual_seed(11)
+    X = torch.relu(torch.randn(2304, 500, device=gpu) + 0.3)
+    low = (X @ X.t() / 500).contiguous()
+    Z = torch.cat([torch.relu(torch.randn(2048, 32, device=gpu)), torch.ones(1, 32, device=gpu)])
+    sharp = (Z @ Z.t() / 32).contiguous()
+    Y = torch.randn(2048, 4096, device=gpu)
+    full = (Y @ Y.t() / 4096).contiguous()
+    mats = [low, sharp, full]
+    want = ref.eigh_lowrank(mats, [0, 1, 2])
+    assert sorted(want) == [0, 1]                                     # the full-rank matrix is left to the iteration
+    vecs, vals = ops.eigh(mats, with_values=True)
+    assert ops.eigh.last_ranks == {i: k for i, (_, _, k) in want.items()}
+    for i, (U, w, _) in want.items():
+        assert torch.equal(U, vecs[i]) and torch.equal(w, vals[i]), i
+
