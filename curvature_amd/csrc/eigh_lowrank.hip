@@ -270,8 +270,8 @@ static int lowrank_cholqr(hipStream_t stream, std::vector<LowRank*>& live, const
   return CURV_OK;
 }
 
-template <typename T>
-static void keep_live(std::vector<LowRank*>& live, const std::vector<char>& ok, T) {
+// the matrices that passed the last test stay on the path; the others are left to the iteration on the whole matrix
+static void keep_live(std::vector<LowRank*>& live, const std::vector<char>& ok) {
   std::vector<LowRank*> next;
   for (size_t i = 0; i < live.size(); ++i) {
     if (ok[i]) next.push_back(live[i]);
@@ -349,7 +349,7 @@ static int lowrank_run(hipStream_t stream, std::vector<LowRank>& ms, char* ws, i
   if (rc != CURV_OK) return rc;
   // (the current basis of a matrix is Qa, the other buffer Qb; swapped after every pass)
   auto pass = [&]() -> int {
-    keep_live(live, ok, 0);
+    keep_live(live, ok);
     if (live.empty()) return CURV_OK;
     const int r2 = lowrank_cholqr(stream, live, vec([](LowRank& q) { return (const double*)q.Qa; }), vec([](LowRank& q) { return (long long)q.k; }),
                                   vec([](LowRank& q) { return q.k; }), vec([](LowRank& q) { return q.gram; }),
@@ -363,7 +363,7 @@ static int lowrank_run(hipStream_t stream, std::vector<LowRank>& ms, char* ws, i
     if (rc != CURV_OK) return rc;
     if (live.empty()) return CURV_OK;
   }
-  keep_live(live, ok, 0);
+  keep_live(live, ok);
   if (live.empty()) return CURV_OK;
   // one step of subspace iteration, Q <- orth(S Q): without it the basis of a matrix whose rank was hit exactly (no
   // oversampling: a sharp drop of the pivots) is only as good as the k x k Gaussian mixing matrix is conditioned
@@ -377,7 +377,7 @@ static int lowrank_run(hipStream_t stream, std::vector<LowRank>& ms, char* ws, i
     rc = pass();
     if (rc != CURV_OK) return rc;
     if (live.empty()) return CURV_OK;
-    keep_live(live, ok, 0);
+    keep_live(live, ok);
     if (live.empty()) return CURV_OK;
     ok.assign(live.size(), 1);
   }
@@ -404,7 +404,7 @@ static int lowrank_run(hipStream_t stream, std::vector<LowRank>& ms, char* ws, i
     const double res2 = live[i]->nS2 - nb2[i], bar = live[i]->nS2 * (LOWRANK_RESIDUAL * LOWRANK_RESIDUAL);
     ok[i] = res2 <= bar;
   }
-  keep_live(live, ok, 0);
+  keep_live(live, ok);
   if (live.empty()) return CURV_OK;
   // the small problems: the block-Jacobi iteration (they have full rank by construction)
   {
@@ -440,7 +440,7 @@ static int lowrank_run(hipStream_t stream, std::vector<LowRank>& ms, char* ws, i
                         vec([](LowRank& q) { return q.n - q.k; }), vec([](LowRank& q) { return q.gramZ; }),
                         vec([](LowRank& q) { return q.XZ; }), vec([](LowRank& q) { return q.Za; }), false, info_dev, chol_ws, sh.chol_bytes, ok);
     if (rc != CURV_OK) return rc;
-    keep_live(live, ok, 0);
+    keep_live(live, ok);
     if (live.empty()) return CURV_OK;
   }
   // U = [ Z | Q W ] in ascending order of [ 0 | lam ] (stable: the order torch.sort(stable=True) gives)
