@@ -102,16 +102,35 @@ __device__ __forceinline__ void corr_prep_body(const CorrDev& d, long long g_fir
       for (int q = 2 * u + (v - W); q < tail; q += 2 * H) xp[(long long)sc * d.xp_pitch + plane + q] = 0.0f;
       if (sc == 0 && u == 0) for (int q = v - W; q < d.xp_lead; q += 2) xp[q - d.xp_lead] = 0.0f;
     }
-    if (u == H - 1) d.rowb[(long long)c * d.row_pitch + corr::LEAD + n * Wp + v] = val;
-    if (u == 0) d.rowt[(long long)c * d.row_pitch + corr::LEAD + n * Wp + v] = val;
+    // The gathered arrays are padded to their pitch (a multiple of four floats + 4): the LDS-DMA kernel reads whole 4-pixel
+    // groups, i.e. up to three floats behind a row's last element, and zeroes only ONE operand side there (flat_body) - the
+    // other side must be finite, so whoever writes a row's last element also zeroes the gap behind it (round 6: these gaps
+    // were left as the workspace held them, and a NaN bit pattern from an earlier fp64 use turned 0 * x into NaN)
+    const bool last = n == d.N - 1;
+    if (u == H - 1) {
+      float* row = d.rowb + (long long)c * d.row_pitch;
+      row[corr::LEAD + n * Wp + v] = val;
+      if (last && v == W + 1) for (int q = corr::LEAD + d.N * Wp; q < d.row_pitch; ++q) row[q] = 0.0f;
+    }
+    if (u == 0) {
+      float* row = d.rowt + (long long)c * d.row_pitch;
+      row[corr::LEAD + n * Wp + v] = val;
+      if (last && v == W + 1) for (int q = corr::LEAD + d.N * Wp; q < d.row_pitch; ++q) row[q] = 0.0f;
+    }
     if (v == W - 1 || v == 0) {
-      float* col = (v == 0 ? d.coll : d.colr) + (long long)c * d.col_pitch + corr::LEAD + n * d.Hq;
+      float* colbase = (v == 0 ? d.coll : d.colr) + (long long)c * d.col_pitch;
+      float* col = colbase + corr::LEAD + n * d.Hq;
       col[u] = val;
-      if (u == H - 1) { col[H] = 0.0f; col[H + 1] = 0.0f; }
+      if (u == H - 1) {
+        col[H] = 0.0f; col[H + 1] = 0.0f;
+        if (last) for (int q = corr::LEAD + d.N * d.Hq; q < d.col_pitch; ++q) colbase[q] = 0.0f;
+      }
     }
     if ((u == 0 || u == H - 1) && (v == 0 || v == W - 1)) {
       const int kk = (u == 0 ? 2 : 0) + (v == 0 ? 1 : 0);           // BR, BL, TR, TL
-      d.pt[((long long)kk * C + c) * d.pt_pitch + n] = val;
+      float* prow = d.pt + ((long long)kk * C + c) * d.pt_pitch;
+      prow[n] = val;
+      if (last) for (int q = d.N; q < d.pt_pitch; ++q) prow[q] = 0.0f;
     }
     if (n == 0 && u == 0 && v < corr::LEAD) {
       d.rowb[(long long)c * d.row_pitch + v] = 0.0f;

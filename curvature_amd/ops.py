@@ -45,7 +45,15 @@ def workspace(nbytes: int, device: torch.device, tag: str = "default") -> torch.
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
             _workspaces[key] = buf
+    if _POISON:
+        buf.fill_(0xFF)
     return buf
+
+
+# CURV_DEBUG_POISON=1 (diagnostics, tests/test_poisoned_workspace_gpu.py): every scratch buffer is filled with NaN bit patterns
+# each time it is handed to the library, and no descriptor table is assumed to have survived in it - a kernel that reads
+# scratch it has not written shows up as a non-finite result instead of depending on what the buffer held before
+_POISON = os.environ.get("CURV_DEBUG_POISON", "0") not in ("", "0")
 
 
 def release_workspaces() -> None:
@@ -151,7 +159,7 @@ def kfac_accumulate(jobs: Sequence[FactorJob], events=None) -> None:
     # its head still holds the descriptor table of that call and unchanged argument blocks need no second upload
     # (a ResNet-50 update() is 26 of them)
     me = threading.get_ident()
-    flags = _lib.KFAC_TABLE_RESIDENT if _kfac_last.get(me) is ws else 0
+    flags = _lib.KFAC_TABLE_RESIDENT if (_kfac_last.get(me) is ws and not _POISON) else 0
     _kfac_last[me] = ws
     ev0, ev1 = events if events is not None else (None, None)
     rc = L.curv_kfac_accumulate_ex(_lib.stream_ptr(), arr, n, ws.data_ptr(), ws.numel(), flags, ev0, ev1)
