@@ -392,6 +392,8 @@ class GemmPlan:
             # launches per call otherwise).  Slab space is shared scratch in effect - only this plan's launches use it.
             nbytes = int(L.curv_gemm_workspace_bytes_for(self.descs, self.n))
             self._ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.jobs[0].C.device)
+            if _POISON:
+                self._ws.fill_(0xFF)
             self._resident_on = None
         stream = _lib.stream_ptr()
         # (the table is written by launches on a stream: only replays on that same stream may rely on it)
