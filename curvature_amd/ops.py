@@ -54,6 +54,23 @@ def workspace(nbytes: int, device: torch.device, tag: str = "default") -> torch.
 # each time it is handed to the library, and no descriptor table is assumed to have survived in it - a kernel that reads
 # scratch it has not written shows up as a non-finite result instead of depending on what the buffer held before
 _POISON = os.environ.get("CURV_DEBUG_POISON", "0") not in ("", "0")
+if _POISON:
+    # ... and every GPU tensor that torch.empty / torch.empty_like hands out in this process starts as NaNs (integers: all
+    # bits set): an output a kernel only partly writes cannot pass a test on what the allocator happened to return
+    _torch_empty, _torch_empty_like = torch.empty, torch.empty_like
+
+    def _poisoned(t):
+        if isinstance(t, torch.Tensor) and t.is_cuda and t.numel() > 0:
+            if t.is_floating_point():
+                t.fill_(float("nan"))
+            elif t.dtype == torch.uint8:
+                t.fill_(0xFF)
+            elif t.dtype in (torch.int8, torch.int16, torch.int32, torch.int64):
+                t.fill_(-1)
+        return t
+
+    torch.empty = lambda *a, **k: _poisoned(_torch_empty(*a, **k))
+    torch.empty_like = lambda *a, **k: _poisoned(_torch_empty_like(*a, **k))
 
 
 def release_workspaces() -> None:
