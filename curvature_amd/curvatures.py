@@ -1362,6 +1362,7 @@ class INF(Curvature):
                 reg_lr_lambda = ops.sqrt_scale(lr_lambda, s)
                 ops.rsqrt_affine(correction, n, s, out=r)
                 regs.append((lr_frst_eigvecs, lr_scnd_eigvecs, reg_lr_lambda, r))
+        self._r_version = getattr(self, "_r_version", 0) + 1            # (the sampler's cached r**2 is stale)
         prev = [self.inv_state[l][3] if l in self.inv_state else None for l in layers]
         pre_samples = self.pre_sampler_many(regs, outs=prev)
         for layer, (ua, ug, _, r), pre_sample in zip(layers, regs, pre_samples):
@@ -1528,9 +1529,9 @@ class INF(Curvature):
             r_whole = _is_arena(getattr(self, "_r_flat", None), [self.inv_state[l][2] for l in layers]) and \
                 sum(self.inv_state[l][2].numel() for l in layers) == xflat.numel()
             plan = (key, xflat, Xs, yflat, Ys, r2flat, r2s, [ops.GemmPlan(st) for st in stages],
-                    self._r_flat if r_whole else None)
+                    self._r_flat if r_whole else None, [None])         # (last: the inversion whose r**2 `r2flat` holds)
             self._keep_plan(key, plan)
-        _, xflat, Xs, yflat, Ys, r2flat, r2s, gemms, r_flat = plan
+        _, xflat, Xs, yflat, Ys, r2flat, r2s, gemms, r_flat, r2_of = plan
         if noise is None:
             self._randn(xflat.numel(), device=xflat.device, out=xflat)
         else:
@@ -1538,7 +1539,9 @@ class INF(Curvature):
         if r_flat is not None:                                  # Y_l = r * X and r^2 for the whole model
             rf = r_flat[:xflat.numel()]
             ops.mul(rf, xflat, out=yflat)
-            ops.mul(rf, rf, out=r2flat)
+            if r2_of[0] != getattr(self, "_r_version", 0):       # r changes with invert() only: r^2 once per inversion
+                ops.mul(rf, rf, out=r2flat)
+                r2_of[0] = getattr(self, "_r_version", 0)
         else:
             for layer, X, Y_l, r2 in zip(layers, Xs, Ys, r2s):
                 r = self.inv_state[layer][2]

@@ -135,6 +135,17 @@ def test_inf_end_to_end_own_chain(gpu):
                        ref[:, :-1].reshape(layer.weight.shape)) < TOL
         assert rel_fro(layer.bias.data - inf.model_state_of(layer, 'bias'), ref[:, -1]) < TOL
     print(f"INF own chain vs reference sample: worst relative Frobenius error {worst:.2e}")
+    # a second inversion with other hyper-parameters, then back: the fused sampler keeps r**2 between samples and must
+    # refresh it when invert() changed r (round 6) - the same noise must land on the same parameters as before
+    first = {l: (l.weight.data.clone(), l.bias.data.clone()) for l in layers}
+    noise = {l: g9[f"X_l{li}"].to(gpu) for li, l in enumerate(layers)}
+    inf.invert(add=3.0, multiply=7.0)
+    inf.sample_and_replace(noise=noise)
+    assert any(not torch.equal(l.weight.data, first[l][0]) for l in layers)
+    inf.invert(add=float(g8["add"]), multiply=float(g8["mul"]))
+    inf.sample_and_replace(noise=noise)
+    for l in layers:
+        assert torch.equal(l.weight.data, first[l][0]) and torch.equal(l.bias.data, first[l][1])
 
 
 def test_inf_pc_accuracy_floor(gpu):
