@@ -180,9 +180,10 @@ def test_inf_invert_and_sample(gpu):
         assert rel_fro(vtv, g8[f"vtv_l{li}"]) < TOL
         # P_c: the reference's fp32 chain is itself noisy (2 Cholesky + 3 inverses in fp32); the bar is the
         # reference code run in fp64 (golden Pc64), and the fp32 reference within its own noise
-        assert rel_fro(Pc, g8[f"Pc64_l{li}"]) < 1e-3, rel_fro(Pc, g8[f"Pc64_l{li}"])
+        # (measured on these fixtures: 6e-8 .. 1e-7 against the fp64 twin; the reference's own fp32 result sits 2e-7 .. 9e-7 from it)
+        assert rel_fro(Pc, g8[f"Pc64_l{li}"]) < 1e-5, rel_fro(Pc, g8[f"Pc64_l{li}"])
         noise = rel_fro(g8[f"Pc_l{li}"], g8[f"Pc64_l{li}"])
-        assert rel_fro(Pc, g8[f"Pc_l{li}"]) < max(1e-3, 3 * noise)
+        assert rel_fro(Pc, g8[f"Pc_l{li}"]) < max(1e-5, 3 * noise)
         assert not torch.allclose(Pc, Pc.t())                                   # non-symmetric, as in the reference
     # sampler with the reference's inverse state and noise
     for li, layer in enumerate(layers):
